@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — MC energy-evaluations/sec of the MI355X backend on the BASELINE.json workload.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one lock-step energy+force evaluation of every resident chain: neighbor list +
+3-model PaiNN ensemble forward + reverse pass (what one BFGS step costs in the reference,
+mcmc/calculators/calculators.py:484).  Workload at N=1: BASELINE configs[3] — 256 independent chains of
+the SrTiO3(001) 2x2 slab tiled 2x2 in-plane (240 atoms) plus 8..32 seeded adsorbates,
+inputs resident in HBM before the timed region.  N > 1: every rank owns 256 more chains (weak scaling,
+BASELINE configs[4]); the only collective is the RCCL all_gather of per-chain energies.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHAINS_PER_GPU = 256
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F = 128
+
+
+def load_golden():
+    g = os.path.join(ROOT, "tests", "golden")
+    blobs = [np.fromfile(os.path.join(g, "weights", f"SrTiO3_painn_model0{m}.f32"), dtype="<f4") for m in (1, 2, 3)]
+    S = np.load(os.path.join(g, "structures.npz"))
+    with open(os.path.join(g, "offset_data.json")) as fh:
+        offset_data = json.load(fh)
+    return blobs, S, offset_data
+
+
+def build_chains(S, first, count):
+    from surface_sampling_amd import structures
+
+    k = "SrTiO3_2x2_pristine"
+    base = structures.Structure(S[f"{k}.numbers"], S[f"{k}.positions"], S[f"{k}.cell"], S[f"{k}.pbc"])
+    big = base.repeat((2, 2, 1))
+    return [structures.synth_chain(big, c) for c in range(first, first + count)]
+
+
+def neighbor_sum_bytes(n_atoms, n_edges, n_models, layer0):
+    """Algorithmic bytes of ONE neighbor-sum (edge_message_fwd) launch, SURVEY.md §8(d):
+    read phi [N,3F], v [N,3,F], s [N,F] + 16 B per edge; write s' [N,F], v' [N,3,F].
+    Layer 0 has v = 0 and no a-section: read phi b,c [N,2F] + s, write s', v'."""
+    per_atom = (2 * F + F + F + 3 * F) * 4 if layer0 else (3 * F + 3 * F + F + F + 3 * F) * 4
+    return n_models * (per_atom * n_atoms + 16 * n_edges)
+
+
+def cpu_baseline(blobs, chains, table, const, budget_s=20.0):
+    """Time the CPU oracle (a port: the reference's CPU path is not installable) on a bounded
+    sample of the same workload.  The oracle is only the reported baseline / checker, never the product."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+
+    oracle.build()
+    n, t0 = 0, time.perf_counter()
+    s = chains[0]
+    oracle.ensemble(blobs, s.numbers, s.positions, s.cell, s.pbc, 32, table, const)  # warm-up (page-in, threads)
+    t0 = time.perf_counter()
+    while n < len(chains) and (time.perf_counter() - t0 < budget_s or n < 4):
+        s = chains[n]
+        oracle.ensemble(blobs, s.numbers, s.positions, s.cell, s.pbc, 32, table, const)
+        n += 1
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": n / dt, "unit": "evaluations/s", "cores": cores, "kind": "port",
+            "sample": f"{n} chains of the same workload (fp32 oracle, OpenMP, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    from surface_sampling_amd import backend
+    from surface_sampling_amd.calculators import stoich_offset_table
+    from surface_sampling_amd.sharding import chain_range
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    blobs, S, offset_data = load_golden()
+    table, const = stoich_offset_table(offset_data)
+    B = args.chains_per_gpu
+    first, count = chain_range(world * B, world, rank)   # block partition of the global chain list
+    chains = build_chains(S, first, count)
+
+    eng = backend.PainnEngine(blobs, device=local_rank, offset_per_z=table, offset_const=const)
+    eng.upload([(s.numbers, s.positions, s.cell, s.pbc) for s in chains])   # inputs resident in HBM
+    want = backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD
+    dev = torch.device("cuda", local_rank)
+    gathered = torch.empty(world * count * 2, dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        eng.run(want)
+        if world > 1:   # the path's only exchange: per-chain (E_mean, E_std) to every rank
+            res = eng.download(backend.WANT_ENERGY | backend.WANT_STD)
+            mine = torch.from_numpy(np.concatenate([res["energy"], res["energy_std"]])).to(dev)
+            dist.all_gather_into_tensor(gathered, mine)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_enable(True)
+    eng.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    stats = eng.stats()
+    res = eng.download(want)
+    if not (np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()):
+        raise SystemExit("non-finite results in the timed region")
+
+    if rank == 0:
+        total_evals = world * count * args.steps
+        value = total_evals / elapsed
+        M = len(blobs)
+        ns = prof.get("edge_message_fwd", {"launches": 0, "total_ms": 0.0})
+        n_launch = max(1, ns["launches"])
+        layers = 3
+        bytes_per_step = sum(neighbor_sum_bytes(stats["atoms"], stats["edges"], M, l == 0) for l in range(layers))
+        bytes_per_launch = bytes_per_step / layers
+        avg_ms = ns["total_ms"] / n_launch
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        step_ms = sum(v["total_ms"] for v in prof.values()) / args.steps
+        line = {
+            "metric": "MC energy-evaluations/sec (SrTiO3(001) ~250-atom slabs, 3-model PaiNN ensemble E+F incl. neighbor list)",
+            "value": value, "unit": "evaluations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SrTiO3(001) PaiNN x3, {count} batched independent chains per GPU "
+                                   f"(BASELINE configs[{3 if world == 1 else 4}]), 248-272 atoms/chain",
+                       "chains_per_gpu": count, "atoms_per_gpu": stats["atoms"], "edges_per_gpu": stats["edges"],
+                       "parallelism": f"chains sharded x{world}, RCCL all_gather of per-chain energies"},
+            "roofline": {"bound": "hbm", "kernel": "edge_message_fwd (neighbor-sum)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_launch_ms": avg_ms, "launches": ns["launches"]},
+            "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]},
+            "device_ms_per_step": step_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(blobs, chains, table, const)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

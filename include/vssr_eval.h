@@ -1,0 +1,168 @@
+/*
+ * vssr_eval.h — C ABI of the MI355X (gfx950) energy/force evaluation backend for VSSR-MC.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * has no FFI today: its ASE calculators call into nff/torch and LAMMPS.  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference repo):
+ *
+ *   vssr_create / vssr_destroy      <- EnsembleNFFSurface.__init__ + load_model x3
+ *                                      (mcmc/calculators/calculators.py:366-377,
+ *                                       scripts/sample_surface.py:164-175)
+ *   vssr_eval / vssr_eval_batch     <- EnsembleNFFSurface.calculate -> EnsembleNFF.calculate
+ *                                      (mcmc/calculators/calculators.py:468-489, :484) including
+ *                                      AtomsBatch.update_nbr_list (mcmc/dynamics.py:129,
+ *                                      mcmc/utils/misc.py:34-42)
+ *   vssr_batch_upload / _run / _download / _set_positions
+ *                                   <- the same call split into its H2D / compute / D2H parts so
+ *                                      a relaxation loop (mcmc/dynamics.py:133-143) can keep the
+ *                                      batch resident in HBM between force calls
+ *   vssr_tersoff_create / vssr_tersoff_eval_batch
+ *                                   <- LAMMMPSCalc.run_lammps_calc / run_lammps_energy with
+ *                                      pair_style tersoff (mcmc/calculators/calculators.py:507-640)
+ *
+ * Conventions
+ *   - All arrays are caller-allocated and borrowed only for the duration of the call.
+ *   - Positions are double [N][3] (Angstrom), cell is double[9] with rows = lattice vectors,
+ *     pbc is uint8[3].  Results are float32 (the model computes in fp32, like the reference).
+ *   - A batch is a list of independent configurations (Markov chains), concatenated:
+ *     n_atoms[B], then Z / pos / forces concatenated in chain order.
+ *   - Status codes: 0 ok, <0 error (see VSSR_E_*); vssr_last_error() gives the message.
+ *     Non-finite energies are returned, not raised (the +-1000 clamp is the caller's job,
+ *     mcmc/dynamics.py:159-168).
+ *   - A handle is not re-entrant; distinct handles are independent (one per GPU / stream).
+ *     Calls are synchronous unless stated.
+ *
+ * Weight blob layout (float32, little endian), F=feat_dim, R=n_rbf, H=readout_hidden:
+ *   embed [n_embed][F]
+ *   for l in 0..num_conv-1:
+ *     msg.W1 [F][F], msg.b1 [F], msg.W2 [3F][F], msg.b2 [3F], msg.Wd [3F][R], msg.bd [3F],
+ *     upd.U [F][F], upd.V [F][F], upd.W3 [F][2F], upd.b3 [F], upd.W4 [3F][F], upd.b4 [3F]
+ *   readout.W5 [H][F], readout.b5 [H], readout.w6 [H], readout.b6 [1]
+ * (torch Linear layout W[out][in]; nff state-dict keys in surface-sampling_amd/checkpoint.py).
+ */
+#ifndef VSSR_EVAL_H
+#define VSSR_EVAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSSR_ABI_VERSION 1
+
+enum {
+    VSSR_OK = 0,
+    VSSR_E_BADARG = -1,
+    VSSR_E_DEVICE = -2,   /* HIP runtime error */
+    VSSR_E_CAPACITY = -3, /* neighbor capacity exceeded even after regrow / LDS limits */
+    VSSR_E_NOMEM = -4,
+    VSSR_E_STATE = -5     /* call sequence error (e.g. run before upload) */
+};
+
+/* `want` bitmask */
+enum {
+    VSSR_WANT_ENERGY = 1u,
+    VSSR_WANT_FORCES = 2u,
+    VSSR_WANT_STD = 4u,       /* ensemble std of energy / forces */
+    VSSR_WANT_PER_MODEL = 8u, /* per-model energies */
+    VSSR_WANT_PER_ATOM = 16u  /* per-atom energies (Tersoff: pe/atom) */
+};
+
+typedef struct vssr_handle vssr_handle;
+
+typedef struct {
+    uint32_t struct_size; /* sizeof(vssr_painn_config), for forward compatibility */
+    int32_t device;       /* HIP device ordinal */
+    /* ensemble */
+    int32_t n_models;
+    const float *const *weights; /* n_models blobs in the layout above */
+    uint64_t weights_len;        /* floats per blob */
+    /* PaiNN hyper-parameters (params.json of the reference checkpoints) */
+    int32_t feat_dim;       /* 128 (the only compiled value) */
+    int32_t n_rbf;          /* 20 */
+    int32_t num_conv;       /* 3 */
+    int32_t n_embed;        /* rows of the embedding table, 100 */
+    int32_t readout_hidden; /* 64 */
+    float cutoff;           /* 5.0 A */
+    int32_t excl_vol;       /* 1 -> add sum_e (excl_sigma/d_e)^excl_power */
+    int32_t excl_power;     /* 12 */
+    float excl_sigma;       /* 1.5 A */
+    /* EnsembleNFF unit handling: E_eV = E_model / model_units_per_ev + offset */
+    double model_units_per_ev;  /* 23.0605 for kcal/mol models */
+    const double *offset_per_z; /* [n_embed] eV per atom of species Z, or NULL */
+    double offset_const;        /* eV per structure (applied only when offset_per_z != NULL) */
+} vssr_painn_config;
+
+typedef struct {
+    float *energy;        /* [B]            ensemble mean, eV (incl. offset)            */
+    float *energy_std;    /* [B]            population std over models (WANT_STD)       */
+    float *forces;        /* [sum N][3]     -mean gradient, eV/A (WANT_FORCES)          */
+    float *forces_std;    /* [sum N][3]     (WANT_FORCES|WANT_STD)                      */
+    float *energy_models; /* [B][n_models]  (WANT_PER_MODEL)                            */
+    float *energy_atoms;  /* [sum N]        per-atom energies where defined (PER_ATOM)  */
+} vssr_out;
+
+/* ---- PaiNN ensemble ------------------------------------------------------------------- */
+int vssr_abi_version(void);
+int vssr_create(const vssr_painn_config *cfg, vssr_handle **out);
+void vssr_destroy(vssr_handle *h);
+const char *vssr_last_error(const vssr_handle *h); /* h may be NULL: last create() error */
+
+/* One configuration (what one ASE calculate() call is). */
+int vssr_eval(vssr_handle *h, int32_t n_atoms, const int32_t *Z, const double *pos,
+              const double cell[9], const uint8_t pbc[3], uint32_t want, vssr_out *out);
+
+/* B independent configurations in one lock-step evaluation (upload + run + download). */
+int vssr_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, const int32_t *Z,
+                    const double *pos, const double *cell /*[B][9]*/, const uint8_t *pbc /*[B][3]*/,
+                    uint32_t want, vssr_out *out);
+
+/* The same, split: keep the batch resident in HBM across a relaxation loop. */
+int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, const int32_t *Z,
+                      const double *pos, const double *cell, const uint8_t *pbc);
+int vssr_batch_set_positions(vssr_handle *h, const double *pos /*[sum N][3]*/);
+int vssr_batch_run(vssr_handle *h, uint32_t want); /* asynchronous on the handle's stream */
+int vssr_batch_download(vssr_handle *h, uint32_t want, vssr_out *out); /* synchronises */
+int vssr_synchronize(vssr_handle *h);
+
+/* ---- introspection used by tests and bench (no effect on results) ---------------------- */
+/* Per-kernel timing with HIP events on the handle's own stream.  enable=1 starts recording;
+ * vssr_profile_read synchronises and returns, for each kernel class, the number of launches and
+ * the summed duration since the last reset.  names[i] points to a static string. */
+int vssr_profile_enable(vssr_handle *h, int enable);
+int vssr_profile_reset(vssr_handle *h);
+int vssr_profile_read(vssr_handle *h, int32_t cap, const char **names, int64_t *launches,
+                      double *total_ms, int32_t *n_out);
+/* Workload counters of the resident batch after a run: atoms, directed edges (unpadded),
+ * padded edge slots. */
+int vssr_batch_stats(vssr_handle *h, int64_t *n_atoms, int64_t *n_edges, int64_t *n_slots);
+/* Neighbor multigraph of the resident batch (after a run): for every directed edge its centre i,
+ * neighbor j (global atom indices) and image shift S.  Returns the edge count through n_edges;
+ * arrays may be NULL to query the size. */
+int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, int32_t *eS,
+                         float *er, int64_t *n_edges);
+/* Copy a named device intermediate of model m (fp32) to host; for parity debugging.
+ * Names: "phi<l>", "s_msg<l>", "v_msg<l>", "s_upd<l>", "v_upd<l>", "sbar_msg<l>", "vbar_msg<l>",
+ * "e_atom".  Layouts: s [N][F], v [N][3][F], phi [N][3F]. */
+int vssr_debug_read(vssr_handle *h, const char *name, int32_t model, float *dst, int64_t cap,
+                    int64_t *n_out);
+
+/* ---- Tersoff (GaN config) ---------------------------------------------------------------- */
+/* params: n_types^3 entries ordered [i][j][k], 14 doubles each, LAMMPS column order
+ * (m gamma lambda3 c d costheta0 n beta lambda2 B R D lambda1 A). */
+int vssr_tersoff_create(int32_t device, int32_t n_types, const double *params, vssr_handle **out);
+/* type[i] in [0,n_types).  Fills out->energy (total, eV), out->energy_atoms (WANT_PER_ATOM),
+ * out->forces (WANT_FORCES).  fp64 arithmetic on the device; results narrowed to fp32 in
+ * vssr_out, and returned exactly through the optional double arrays. */
+int vssr_tersoff_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms,
+                            const int32_t *type, const double *pos, const double *cell,
+                            const uint8_t *pbc, uint32_t want, vssr_out *out,
+                            double *energy_f64 /*[B] or NULL*/, double *energy_atoms_f64,
+                            double *forces_f64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSSR_EVAL_H */

@@ -1,0 +1,297 @@
+"""ctypes binding of ``libvssr_eval.so`` (the C ABI in ``include/vssr_eval.h``).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, every entry
+point raises.  The oracle under ``oracle/`` is test infrastructure and is never imported here.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvssr_eval.so")
+
+WANT_ENERGY, WANT_FORCES, WANT_STD, WANT_PER_MODEL, WANT_PER_ATOM = 1, 2, 4, 8, 16
+WANT_ALL = WANT_ENERGY | WANT_FORCES | WANT_STD | WANT_PER_MODEL | WANT_PER_ATOM
+
+EXPORTS = (
+    "vssr_abi_version", "vssr_create", "vssr_destroy", "vssr_last_error", "vssr_eval", "vssr_eval_batch",
+    "vssr_batch_upload", "vssr_batch_set_positions", "vssr_batch_run", "vssr_batch_download",
+    "vssr_synchronize", "vssr_profile_enable", "vssr_profile_reset", "vssr_profile_read",
+    "vssr_batch_stats", "vssr_batch_neighbors", "vssr_debug_read", "vssr_tersoff_create",
+    "vssr_tersoff_eval_batch",
+)
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+class PainnConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("n_models", C.c_int32),
+        ("weights", C.POINTER(C.POINTER(C.c_float))), ("weights_len", C.c_uint64),
+        ("feat_dim", C.c_int32), ("n_rbf", C.c_int32), ("num_conv", C.c_int32), ("n_embed", C.c_int32),
+        ("readout_hidden", C.c_int32), ("cutoff", C.c_float), ("excl_vol", C.c_int32),
+        ("excl_power", C.c_int32), ("excl_sigma", C.c_float), ("model_units_per_ev", C.c_double),
+        ("offset_per_z", C.POINTER(C.c_double)), ("offset_const", C.c_double),
+    ]
+
+
+class Out(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in
+                ("energy", "energy_std", "forces", "forces_std", "energy_models", "energy_atoms")]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libvssr_eval.so; raise BackendError (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). This backend has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp, fp, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float), \
+        C.POINTER(C.c_uint8)
+    i64p = C.POINTER(C.c_int64)
+    L.vssr_abi_version.restype = C.c_int
+    L.vssr_create.restype = C.c_int
+    L.vssr_create.argtypes = [C.POINTER(PainnConfig), C.POINTER(vp)]
+    L.vssr_destroy.restype = None
+    L.vssr_destroy.argtypes = [vp]
+    L.vssr_last_error.restype = C.c_char_p
+    L.vssr_last_error.argtypes = [vp]
+    L.vssr_eval.restype = C.c_int
+    L.vssr_eval.argtypes = [vp, C.c_int32, ip, dp, dp, u8p, C.c_uint32, C.POINTER(Out)]
+    L.vssr_eval_batch.restype = C.c_int
+    L.vssr_eval_batch.argtypes = [vp, C.c_int32, ip, ip, dp, dp, u8p, C.c_uint32, C.POINTER(Out)]
+    L.vssr_batch_upload.restype = C.c_int
+    L.vssr_batch_upload.argtypes = [vp, C.c_int32, ip, ip, dp, dp, u8p]
+    L.vssr_batch_set_positions.restype = C.c_int
+    L.vssr_batch_set_positions.argtypes = [vp, dp]
+    L.vssr_batch_run.restype = C.c_int
+    L.vssr_batch_run.argtypes = [vp, C.c_uint32]
+    L.vssr_batch_download.restype = C.c_int
+    L.vssr_batch_download.argtypes = [vp, C.c_uint32, C.POINTER(Out)]
+    L.vssr_synchronize.restype = C.c_int
+    L.vssr_synchronize.argtypes = [vp]
+    L.vssr_profile_enable.restype = C.c_int
+    L.vssr_profile_enable.argtypes = [vp, C.c_int]
+    L.vssr_profile_reset.restype = C.c_int
+    L.vssr_profile_reset.argtypes = [vp]
+    L.vssr_profile_read.restype = C.c_int
+    L.vssr_profile_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i64p, dp, ip]
+    L.vssr_batch_stats.restype = C.c_int
+    L.vssr_batch_stats.argtypes = [vp, i64p, i64p, i64p]
+    L.vssr_batch_neighbors.restype = C.c_int
+    L.vssr_batch_neighbors.argtypes = [vp, C.c_int64, ip, ip, ip, fp, i64p]
+    L.vssr_debug_read.restype = C.c_int
+    L.vssr_debug_read.argtypes = [vp, C.c_char_p, C.c_int32, fp, C.c_int64, i64p]
+    L.vssr_tersoff_create.restype = C.c_int
+    L.vssr_tersoff_create.argtypes = [C.c_int32, C.c_int32, dp, C.POINTER(vp)]
+    L.vssr_tersoff_eval_batch.restype = C.c_int
+    L.vssr_tersoff_eval_batch.argtypes = [vp, C.c_int32, ip, ip, dp, dp, u8p, C.c_uint32, C.POINTER(Out), dp, dp, dp]
+    if L.vssr_abi_version() != 1:
+        raise BackendError("libvssr_eval.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def pack_batch(structs):
+    """List of (numbers, positions, cell, pbc) -> concatenated ABI arrays."""
+    n_atoms = np.array([len(s[0]) for s in structs], dtype=np.int32)
+    Z = np.ascontiguousarray(np.concatenate([np.asarray(s[0]) for s in structs]), dtype=np.int32)
+    pos = np.ascontiguousarray(np.concatenate([np.asarray(s[1], dtype=np.float64).reshape(-1, 3) for s in structs]))
+    cell = np.ascontiguousarray(np.stack([np.asarray(s[2], dtype=np.float64).reshape(9) for s in structs]))
+    pbc = np.ascontiguousarray(np.stack([np.asarray(s[3]).astype(np.uint8).reshape(3) for s in structs]))
+    return n_atoms, Z, pos, cell, pbc
+
+
+class _Handle:
+    """Owns a vssr_handle*; shared plumbing for the PaiNN and Tersoff engines."""
+
+    def __init__(self):
+        self._lib = load_library()
+        self._h = C.c_void_p(None)
+        self.n_models = 1
+        self._n_cfg = 0
+        self._n_atoms = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.vssr_last_error(self._h)
+            raise BackendError(f"vssr error {rc}: {msg.decode() if msg else '?'}")
+
+    def close(self):
+        if self._h:
+            self._lib.vssr_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- resident-batch API ------------------------------------------------------------------
+    def upload(self, structs):
+        n_atoms, Z, pos, cell, pbc = pack_batch(structs)
+        self.upload_arrays(n_atoms, Z, pos, cell, pbc)
+
+    def upload_arrays(self, n_atoms, Z, pos, cell, pbc):
+        n_atoms = np.ascontiguousarray(n_atoms, dtype=np.int32)
+        Z = np.ascontiguousarray(Z, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        cell = np.ascontiguousarray(cell, dtype=np.float64)
+        pbc = np.ascontiguousarray(pbc, dtype=np.uint8)
+        if Z.shape[0] != int(n_atoms.sum()) or pos.size != 3 * Z.shape[0] or cell.size != 9 * len(n_atoms) \
+                or pbc.size != 3 * len(n_atoms):
+            raise ValueError("inconsistent batch arrays")
+        self._check(self._lib.vssr_batch_upload(self._h, len(n_atoms), _ptr(n_atoms, C.c_int32),
+                                                _ptr(Z, C.c_int32), _ptr(pos, C.c_double),
+                                                _ptr(cell, C.c_double), _ptr(pbc, C.c_uint8)))
+        self._n_cfg, self._n_atoms = len(n_atoms), int(Z.shape[0])
+        self._cfg_start = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
+
+    def set_positions(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        if pos.size != 3 * self._n_atoms:
+            raise ValueError("positions do not match the resident batch")
+        self._check(self._lib.vssr_batch_set_positions(self._h, _ptr(pos, C.c_double)))
+
+    def run(self, want=WANT_ALL):
+        self._check(self._lib.vssr_batch_run(self._h, int(want)))
+
+    def synchronize(self):
+        self._check(self._lib.vssr_synchronize(self._h))
+
+    def download(self, want=WANT_ALL):
+        B, N, M = self._n_cfg, self._n_atoms, self.n_models
+        res = {
+            "energy": np.zeros(B, np.float32), "energy_std": np.zeros(B, np.float32),
+            "forces": np.zeros((N, 3), np.float32), "forces_std": np.zeros((N, 3), np.float32),
+            "energy_models": np.zeros((B, M), np.float32), "energy_atoms": np.zeros(N, np.float32),
+        }
+        out = Out(*[_ptr(res[k], C.c_float) for k in
+                    ("energy", "energy_std", "forces", "forces_std", "energy_models", "energy_atoms")])
+        self._check(self._lib.vssr_batch_download(self._h, int(want), C.byref(out)))
+        res["cfg_start"] = self._cfg_start
+        return res
+
+    def evaluate(self, structs, want=WANT_ALL):
+        self.upload(structs)
+        self.run(want)
+        return self.download(want)
+
+    # -- introspection -----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._lib.vssr_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.vssr_profile_reset(self._h))
+
+    def profile_read(self):
+        cap = 32
+        names = (C.c_char_p * cap)()
+        launches = np.zeros(cap, np.int64)
+        ms = np.zeros(cap, np.float64)
+        n = C.c_int32(0)
+        self._check(self._lib.vssr_profile_read(self._h, cap, names, _ptr(launches, C.c_int64),
+                                                _ptr(ms, C.c_double), C.byref(n)))
+        return {names[k].decode(): {"launches": int(launches[k]), "total_ms": float(ms[k])}
+                for k in range(n.value)}
+
+    def stats(self):
+        a, e, s = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.vssr_batch_stats(self._h, C.byref(a), C.byref(e), C.byref(s)))
+        return {"atoms": a.value, "edges": e.value, "slots": s.value}
+
+    def neighbors(self):
+        n = C.c_int64(0)
+        self._check(self._lib.vssr_batch_neighbors(self._h, 0, None, None, None, None, C.byref(n)))
+        E = n.value
+        ei = np.zeros(E, np.int32); ej = np.zeros(E, np.int32)
+        eS = np.zeros((E, 3), np.int32); er = np.zeros((E, 3), np.float32)
+        self._check(self._lib.vssr_batch_neighbors(self._h, E, _ptr(ei, C.c_int32), _ptr(ej, C.c_int32),
+                                                   _ptr(eS, C.c_int32), _ptr(er, C.c_float), C.byref(n)))
+        return ei, ej, eS, er
+
+    def debug_read(self, name, model=0):
+        n = C.c_int64(0)
+        self._check(self._lib.vssr_debug_read(self._h, name.encode(), model, None, 0, C.byref(n)))
+        buf = np.zeros(n.value, np.float32)
+        self._check(self._lib.vssr_debug_read(self._h, name.encode(), model, _ptr(buf, C.c_float), n.value,
+                                              C.byref(n)))
+        return buf
+
+
+class PainnEngine(_Handle):
+    """PaiNN-ensemble evaluator on one GPU (one handle = one HIP stream)."""
+
+    def __init__(self, blobs, device=0, cutoff=5.0, model_units_per_ev=23.0605, offset_per_z=None,
+                 offset_const=0.0, hparams=None):
+        super().__init__()
+        hp = {"feat_dim": 128, "n_rbf": 20, "num_conv": 3, "n_embed": 100, "readout_hidden": 64,
+              "excl_vol": True, "V_ex_power": 12, "V_ex_sigma": 1.5}
+        hp.update(hparams or {})
+        self._blobs = [np.ascontiguousarray(b, dtype=np.float32) for b in blobs]
+        if not self._blobs:
+            raise ValueError("at least one model is required")
+        M = len(self._blobs)
+        ptrs = (C.POINTER(C.c_float) * M)(*[_ptr(b, C.c_float) for b in self._blobs])
+        off = None
+        if offset_per_z is not None:
+            off = np.ascontiguousarray(offset_per_z, dtype=np.float64)
+            if off.size != hp["n_embed"]:
+                raise ValueError("offset_per_z must have n_embed entries")
+        cfg = PainnConfig(
+            C.sizeof(PainnConfig), int(device), M, ptrs, self._blobs[0].size, hp["feat_dim"], hp["n_rbf"],
+            hp["num_conv"], hp["n_embed"], hp["readout_hidden"], float(cutoff), int(bool(hp["excl_vol"])),
+            int(hp["V_ex_power"]), float(hp["V_ex_sigma"]), float(model_units_per_ev),
+            _ptr(off, C.c_double), float(offset_const))
+        rc = self._lib.vssr_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.vssr_last_error(None)
+            raise BackendError(f"vssr_create failed ({rc}): {msg.decode() if msg else '?'}")
+        self.n_models = M
+        self.cutoff = float(cutoff)
+
+
+class TersoffEngine(_Handle):
+    """Tersoff evaluator (fp64 on device)."""
+
+    def __init__(self, params, device=0):
+        super().__init__()
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        if params.ndim != 4 or params.shape[3] != 14 or not (params.shape[0] == params.shape[1] == params.shape[2]):
+            raise ValueError("params must be [nt, nt, nt, 14]")
+        self.n_types = params.shape[0]
+        rc = self._lib.vssr_tersoff_create(int(device), self.n_types, _ptr(params, C.c_double), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.vssr_last_error(None)
+            raise BackendError(f"vssr_tersoff_create failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def evaluate_f64(self, structs, want=WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM):
+        """structs: list of (types, positions, cell, pbc). Returns fp64 energy [B], e_atom [N], forces [N,3]."""
+        n_atoms, T, pos, cell, pbc = pack_batch(structs)
+        B, N = len(n_atoms), len(T)
+        e = np.zeros(B); ea = np.zeros(N); f = np.zeros((N, 3))
+        self._check(self._lib.vssr_tersoff_eval_batch(
+            self._h, B, _ptr(n_atoms, C.c_int32), _ptr(T, C.c_int32), _ptr(pos, C.c_double),
+            _ptr(cell, C.c_double), _ptr(pbc, C.c_uint8), int(want), None, _ptr(e, C.c_double),
+            _ptr(ea, C.c_double), _ptr(f, C.c_double)))
+        self._n_cfg, self._n_atoms = B, N
+        self._cfg_start = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
+        return e, ea, f

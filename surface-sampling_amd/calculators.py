@@ -1,0 +1,436 @@
+"""ASE-Calculator-shaped front ends of the MI355X backend, mirroring the reference's classes.
+
+Reference interfaces mirrored (``mcmc/calculators/calculators.py``):
+  * ``EnsembleNFFSurface`` (:366-489)  -> :class:`EnsembleNFFSurface` here (same name, ctor kwargs
+    ``device, model_units, prediction_units, offset_units``, ``set(**kw)``, ``parameters``,
+    ``implemented_properties``, ``calculate``, ``get_surface_energy``, ``results`` keys/shapes,
+    ``atoms.results.update`` side effect, ``models`` list).
+  * ``LAMMPSSurfCalc`` / ``LAMMMPSCalc`` (:492-752) with ``pair_style tersoff``
+                                       -> :class:`TersoffSurfCalc` (``energy``, ``per_atom_energies``,
+    ``forces``, ``surface_energy``; no files, no LAMMPS process).
+Callers on the reference side: ``SurfaceSystem.get_surface_energy`` (``mcmc/system.py:450-470``),
+``optimize_slab`` (``mcmc/dynamics.py:83-170``), ``get_results_single`` (``calculators.py:34-47``).
+
+ASE is optional: with ASE installed the classes derive from ``ase.calculators.calculator.Calculator``;
+without it they derive from a small stand-in implementing the same caching protocol
+(``get_property`` / ``check_state`` / ``get_potential_energy`` / ``get_forces``).
+All numerical work happens in ``libvssr_eval.so``; there is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import copy
+import logging
+from collections import Counter
+
+import numpy as np
+
+from . import backend, checkpoint, structures, tersoff as tersoff_io
+
+EV_TO_KCAL_MOL = 23.0605   # nff/utils/constants.py
+HARTREE_TO_EV = 27.2114    # nff/utils/constants.py (reference import: calculators.py:21)
+
+all_changes = ["positions", "numbers", "cell", "pbc", "initial_charges", "initial_magmoms"]
+
+try:  # pragma: no cover - ASE is not installed in the build container
+    from ase.calculators.calculator import Calculator as _AseCalculator
+    from ase.calculators.calculator import all_changes as _ase_all_changes
+
+    all_changes = list(_ase_all_changes)
+    HAVE_ASE = True
+except Exception:  # ImportError or a broken ASE install
+    _AseCalculator = None
+    HAVE_ASE = False
+
+
+class _MiniCalculator:
+    """The part of ``ase.calculators.calculator.Calculator`` the reference's callers rely on."""
+
+    implemented_properties: tuple = ()
+    default_parameters: dict = {}
+    name = "calculator"
+
+    def __init__(self, restart=None, label=None, atoms=None, **kwargs):
+        self.atoms = None
+        self.results: dict = {}
+        self.parameters: dict = dict(self.default_parameters)
+        self.label = label
+        if atoms is not None:
+            atoms.calc = self
+        self.set(**kwargs)
+
+    def set(self, **kwargs) -> dict:
+        changed = {}
+        for key, value in kwargs.items():
+            old = self.parameters.get(key, None)
+            same = False
+            try:
+                same = key in self.parameters and bool(np.all(old == value))
+            except Exception:
+                same = False
+            if not same:
+                changed[key] = value
+                self.parameters[key] = value
+        if changed:
+            self.reset()
+        return changed
+
+    def reset(self):
+        self.atoms = None
+        self.results = {}
+
+    @staticmethod
+    def _snapshot(atoms):
+        Z, pos, cell, pbc = structures.as_arrays(atoms)
+        return structures.Structure(Z.copy(), pos.copy(), cell.copy(), pbc.astype(bool))
+
+    def check_state(self, atoms, tol=1e-15):
+        if self.atoms is None:
+            return list(all_changes)
+        old, new = structures.as_arrays(self.atoms), structures.as_arrays(atoms)
+        changes = []
+        for key, a, b in zip(("numbers", "positions", "cell", "pbc"), old, new):
+            if a.shape != b.shape or not np.allclose(a, b, rtol=0, atol=tol):
+                changes.append(key)
+        return changes
+
+    def calculate(self, atoms=None, properties=("energy",), system_changes=all_changes):
+        if atoms is not None:
+            self.atoms = self._snapshot(atoms)
+
+    def get_property(self, name, atoms=None, allow_calculation=True):
+        if name not in self.implemented_properties:
+            raise NotImplementedError(f"{name} property not implemented")
+        if atoms is None:
+            raise ValueError("atoms is required")
+        changes = self.check_state(atoms)
+        if changes:
+            self.results = {}
+        if name not in self.results:
+            if not allow_calculation:
+                return None
+            self.calculate(atoms, [name], changes)
+        result = self.results[name]
+        if isinstance(result, np.ndarray):
+            result = result.copy()
+        return result
+
+    def get_potential_energy(self, atoms=None, force_consistent=False):
+        return self.get_property("energy", atoms)
+
+    def get_forces(self, atoms=None):
+        return self.get_property("forces", atoms)
+
+    def calculation_required(self, atoms, properties):
+        if self.check_state(atoms):
+            return True
+        return any(p not in self.results for p in properties)
+
+
+_Base = _AseCalculator if HAVE_ASE else _MiniCalculator
+
+
+def _device_index(device) -> int:
+    """'cuda', 'cuda:1', 1 -> ordinal; 'cpu' is rejected (the product has no CPU path)."""
+    if isinstance(device, (int, np.integer)):
+        return int(device)
+    s = str(device).lower()
+    if s.startswith("cpu"):
+        raise backend.BackendError("device='cpu' requested: this backend only runs on an MI355X (HIP) device")
+    if ":" in s:
+        return int(s.split(":", 1)[1])
+    return 0
+
+
+def _units_per_ev(model_units: str, prediction_units: str) -> float:
+    mu, pu = model_units.lower(), prediction_units.lower()
+    if pu != "ev":
+        raise ValueError("prediction_units must be 'eV'")
+    if mu in ("kcal/mol", "kcal"):
+        return EV_TO_KCAL_MOL
+    if mu == "ev":
+        return 1.0
+    if mu in ("atomic", "hartree", "ha"):
+        return 1.0 / HARTREE_TO_EV
+    raise ValueError(f"unknown model_units {model_units!r}")
+
+
+def stoich_offset_table(offset_data: dict, n_embed: int = 100):
+    """``stoidict`` (Hartree) -> per-species eV table + constant, as EnsembleNFF adds it to every
+    prediction when ``offset_data`` is configured."""
+    stoidict = offset_data["stoidict"]
+    table = np.zeros(n_embed)
+    for sym, val in stoidict.items():
+        if sym == "offset":
+            continue
+        table[structures.ATOMIC_NUMBERS[sym]] = float(val) * HARTREE_TO_EV
+    return table, float(stoidict.get("offset", 0.0)) * HARTREE_TO_EV
+
+
+def surface_energy_from_energy(energy: float, symbols, chem_pots: dict, offset_data: dict,
+                               offset_units: str = "atomic") -> float:
+    """Bulk-reference and chemical-potential bookkeeping of
+    ``EnsembleNFFSurface.get_surface_energy`` (reference ``calculators.py:379-446``)."""
+    ads_count = Counter(symbols)
+    bulk_energies = offset_data["bulk_energies"]
+    stoics = offset_data["stoics"]
+    ref_formula = offset_data["ref_formula"]
+    ref_element = offset_data["ref_element"]
+    bulk_ref_en = ads_count[ref_element] * bulk_energies[ref_formula]
+    for ele in ads_count:
+        if ele != ref_element:
+            bulk_ref_en += (ads_count[ele] - stoics[ele] / stoics[ref_element] * ads_count[ref_element]) \
+                * bulk_energies[ele]
+    surface_energy = energy - (bulk_ref_en * HARTREE_TO_EV if offset_units == "atomic" else bulk_ref_en)
+    pot = 0.0
+    for ele in ads_count:
+        if ele != ref_element:
+            pot += (ads_count[ele] - stoics[ele] / stoics[ref_element] * ads_count[ref_element]) * chem_pots[ele]
+    return surface_energy - pot
+
+
+class EnsembleNFFSurface(_Base):
+    """PaiNN-ensemble surface calculator on MI355X (drop-in for the reference class of the same name).
+
+    Args:
+        models: list of checkpoints — paths to nff ``best_model`` files / canonical ``.f32`` blobs, or
+            float32 arrays already in the canonical layout (``include/vssr_eval.h``).
+        device: ``"cuda"``, ``"cuda:N"`` or an int ordinal.
+        model_units / prediction_units / offset_units: as in the reference (``"kcal/mol"``, ``"eV"``,
+            ``"atomic"``).
+        cutoff: neighbor cutoff in Å (the reference passes it through ``get_atoms_batch``).
+    """
+
+    implemented_properties = ("energy", "forces", "stress", "energy_std", "forces_std", "surface_energy")
+    name = "ensemble_nff_surface_mi355x"
+
+    def __init__(self, models, device="cuda", model_units="kcal/mol", prediction_units="eV",
+                 offset_units="atomic", cutoff=5.0, hparams=None, logger=None, **kwargs):
+        self.models = [self._load_model(m, hparams) for m in models]
+        self.device = device
+        self.model_units = model_units
+        self.prediction_units = prediction_units
+        self.offset_units = offset_units
+        self.cutoff = float(cutoff)
+        self.hparams = dict(hparams or {})
+        self.chem_pots: dict = {}
+        self.offset_data: dict = {}
+        self.logger = logger or logging.getLogger(__name__)
+        self._engine = None
+        self._engine_key = None
+        super().__init__(**kwargs)
+
+    @staticmethod
+    def _load_model(m, hparams):
+        if isinstance(m, (str, bytes)) or hasattr(m, "__fspath__"):
+            return checkpoint.load_painn_blob(str(m), hparams)
+        blob = np.ascontiguousarray(m, dtype=np.float32).reshape(-1)
+        checkpoint.blob_to_fields(blob, hparams)
+        return blob
+
+    # -- engine lifetime (lazy: created on first use, re-created when the offset config changes) ----
+    def _offset_config(self):
+        if self.parameters.get("offset", False) and self.offset_data and "stoidict" in self.offset_data:
+            table, const = stoich_offset_table(self.offset_data)
+            return table, const
+        return None, 0.0
+
+    def _get_engine(self):
+        table, const = self._offset_config()
+        key = (None if table is None else table.tobytes(), const, _device_index(self.device), self.cutoff)
+        if self._engine is None or key != self._engine_key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = backend.PainnEngine(
+                self.models, device=_device_index(self.device), cutoff=self.cutoff,
+                model_units_per_ev=_units_per_ev(self.model_units, self.prediction_units),
+                offset_per_z=table, offset_const=const, hparams=self.hparams)
+            self._engine_key = key
+        return self._engine
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_engine", "_engine_key"):
+                setattr(new, k, None)
+            elif k in ("models", "logger"):
+                setattr(new, k, v)  # weights are immutable: share
+            else:
+                setattr(new, k, copy.deepcopy(v, memo))
+        return new
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engine"] = None
+        state["_engine_key"] = None
+        state["logger"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        if self.logger is None:
+            self.logger = logging.getLogger(__name__)
+
+    # -- reference surface -----------------------------------------------------------------------------
+    def set(self, **kwargs) -> dict:
+        """Set parameters; ``chem_pots`` / ``offset_data`` are mirrored onto attributes
+        (reference ``calculators.py:448-466``)."""
+        changed = _Base.set(self, **kwargs)
+        if "chem_pots" in self.parameters:
+            self.chem_pots = self.parameters["chem_pots"]
+            self.logger.info("chemical potentials: %s are set from parameters", self.chem_pots)
+        if "offset_data" in self.parameters:
+            self.offset_data = self.parameters["offset_data"]
+            self.logger.info("offset data: %s is set from parameters", self.offset_data)
+        return changed
+
+    def get_surface_energy(self, atoms=None, chem_pots: dict | None = None, offset_data: dict | None = None) -> float:
+        """Surface energy = E_slab - bulk reference - chemical-potential deviation
+        (reference ``calculators.py:379-446``).  Raises ValueError when the chemical potentials or the
+        offset data are not set."""
+        if atoms is None:
+            atoms = self.atoms
+        if chem_pots is None:
+            chem_pots = self.chem_pots
+        if not chem_pots:
+            raise ValueError("chemical potentials are not set")
+        if offset_data is None:
+            offset_data = self.offset_data
+        if not offset_data:
+            raise ValueError("offset data is not set")
+        energy = self.get_potential_energy(atoms=atoms)
+        return surface_energy_from_energy(energy, atoms.get_chemical_symbols(), chem_pots, offset_data,
+                                          self.offset_units)
+
+    def _fill_results(self, res, b=0):
+        a0, a1 = int(res["cfg_start"][b]), int(res["cfg_start"][b + 1])
+        return {
+            "energy": res["energy"][b:b + 1].copy(),            # shape (1,), like the reference
+            "energy_std": res["energy_std"][b:b + 1].copy(),
+            "forces": res["forces"][a0:a1].copy(),
+            "forces_std": res["forces_std"][a0:a1].copy(),
+            "energy_models": res["energy_models"][b].copy(),
+        }
+
+    def calculate(self, atoms=None, properties=implemented_properties, system_changes=all_changes):
+        """One ensemble energy+force evaluation (reference ``calculators.py:468-489``)."""
+        if atoms is None:
+            atoms = self.atoms
+        _Base.calculate(self, atoms, properties, system_changes)
+        res = self._get_engine().evaluate([structures.as_arrays(atoms)])
+        self.results.update(self._fill_results(res, 0))
+        if "surface_energy" in properties:
+            self.results["surface_energy"] = surface_energy_from_energy(
+                self.results["energy"], atoms.get_chemical_symbols(), self._require(self.chem_pots, "chemical potentials"),
+                self._require(self.offset_data, "offset data"), self.offset_units)
+        if hasattr(atoms, "results") and isinstance(atoms.results, dict):
+            atoms.results.update(self.results)
+
+    @staticmethod
+    def _require(value, what):
+        if not value:
+            raise ValueError(f"{what} are not set" if what.endswith("s") else f"{what} is not set")
+        return value
+
+    # -- new capability: many independent chains in one lock-step evaluation ----------------------------
+    def calculate_batch(self, atoms_list, want_surface_energy: bool = False) -> list[dict]:
+        """Evaluate B independent configurations at once; returns one results dict per configuration."""
+        res = self._get_engine().evaluate([structures.as_arrays(a) for a in atoms_list])
+        out = []
+        for b, atoms in enumerate(atoms_list):
+            r = self._fill_results(res, b)
+            if want_surface_energy:
+                r["surface_energy"] = surface_energy_from_energy(
+                    r["energy"], atoms.get_chemical_symbols(), self._require(self.chem_pots, "chemical potentials"),
+                    self._require(self.offset_data, "offset data"), self.offset_units)
+            out.append(r)
+        return out
+
+
+class TersoffSurfCalc(_Base):
+    """Tersoff energy / per-atom energies / forces on MI355X (drop-in for ``LAMMPSSurfCalc`` with
+    ``pair_style tersoff``, reference ``calculators.py:492-752``): ``energy`` is the static energy,
+    ``per_atom_energies`` is LAMMPS' ``pe/atom``; periodic in all directions like the reference's
+    ``boundary p p p`` template."""
+
+    implemented_properties = ("energy", "forces", "per_atom_energies", "surface_energy")
+    name = "tersoff_mi355x"
+
+    def __init__(self, potential, species, device="cuda", all_periodic=True, logger=None, **kwargs):
+        """potential: path or text of a LAMMPS tersoff file, or a params array [nt,nt,nt,14];
+        species: symbols in LAMMPS type order (e.g. ["Ga", "N"])."""
+        if isinstance(potential, np.ndarray):
+            self.params = np.ascontiguousarray(potential, dtype=np.float64)
+        else:
+            text = potential
+            if "\n" not in str(potential):
+                with open(potential) as fh:
+                    text = fh.read()
+            self.params = tersoff_io.parse_tersoff(text, list(species))
+        self.species = list(species)
+        self.device = device
+        self.all_periodic = bool(all_periodic)
+        self.run_dir = None
+        self.relax_steps = 100
+        self.logger = logger or logging.getLogger(__name__)
+        self._engine = None
+        super().__init__(**kwargs)
+
+    def _get_engine(self):
+        if self._engine is None:
+            self._engine = backend.TersoffEngine(self.params, device=_device_index(self.device))
+        return self._engine
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, None if k == "_engine" else (v if k in ("params", "logger") else copy.deepcopy(v, memo)))
+        return new
+
+    def set(self, **kwargs) -> dict:
+        changed = _Base.set(self, **kwargs)
+        if "run_dir" in self.parameters:
+            self.run_dir = self.parameters["run_dir"]
+        if "relax_steps" in self.parameters:
+            self.relax_steps = self.parameters["relax_steps"]
+        return changed
+
+    def _pack(self, atoms):
+        Z, pos, cell, pbc = structures.as_arrays(atoms)
+        idx = {structures.ATOMIC_NUMBERS[s]: t for t, s in enumerate(self.species)}
+        try:
+            types = np.array([idx[int(z)] for z in Z], dtype=np.int32)
+        except KeyError as e:
+            raise ValueError(f"element Z={e.args[0]} is not covered by the potential {self.species}") from None
+        if self.all_periodic:
+            pbc = np.ones(3, np.uint8)
+        return types, pos, cell, pbc
+
+    def get_surface_energy(self, atoms=None) -> float:
+        """Currently the same as the potential energy (reference ``calculators.py:707-719``)."""
+        if atoms is None:
+            atoms = self.atoms
+        return self.get_potential_energy(atoms=atoms)
+
+    def calculate(self, atoms=None, properties=implemented_properties, system_changes=all_changes):
+        if atoms is None:
+            atoms = self.atoms
+        _Base.calculate(self, atoms, properties, system_changes)
+        e, ea, f = self._get_engine().evaluate_f64([self._pack(atoms)])
+        self.results["energy"] = float(e[0])
+        self.results["per_atom_energies"] = ea
+        self.results["forces"] = f
+        if "surface_energy" in properties:
+            self.results["surface_energy"] = self.results["energy"]
+
+    def calculate_batch(self, atoms_list) -> list[dict]:
+        packs = [self._pack(a) for a in atoms_list]
+        e, ea, f = self._get_engine().evaluate_f64(packs)
+        out, o = [], 0
+        for b, p in enumerate(packs):
+            n = len(p[0])
+            out.append({"energy": float(e[b]), "per_atom_energies": ea[o:o + n].copy(), "forces": f[o:o + n].copy()})
+            o += n
+        return out

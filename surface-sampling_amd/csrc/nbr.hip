@@ -1,0 +1,201 @@
+// nbr.hip — neighbor multigraph of a batch of independent configurations (gfx950).
+//
+// Replaces AtomsBatch.update_nbr_list (nff/io/ase.py; reference call sites
+// mcmc/dynamics.py:129, mcmc/utils/misc.py:34-42) + the per-call trim to d <= cutoff
+// (SURVEY.md Appendix A item 1).  Output: padded CSR by centre atom; every directed
+// (i, j, S) with 0 < |x_j + S.cell - x_i| <= cutoff is one slot; a pair reachable through
+// several periodic images occupies several slots.  Distances are decided in
+// fp64 from the caller's fp64 positions, so the edge SET equals the oracle's bit for bit;
+// the stored edge vector is narrowed to fp32 for the fp32 model.
+#include "vssr_internal.h"
+
+namespace vssr {
+
+__device__ inline int pack_shift(int s0, int s1, int s2) {
+    return ((s0 + 128) & 255) | (((s1 + 128) & 255) << 8) | (((s2 + 128) & 255) << 16);
+}
+__device__ inline void unpack_shift(int p, int &s0, int &s1, int &s2) {
+    s0 = (p & 255) - 128;
+    s1 = ((p >> 8) & 255) - 128;
+    s2 = ((p >> 16) & 255) - 128;
+}
+
+// wrap positions into the cell along periodic axes (fractional floor), like the oracle
+__global__ void k_wrap(int n, const double *__restrict__ pos, const int *__restrict__ atom_cfg,
+                       const double *__restrict__ cell, const double *__restrict__ invcell,
+                       const uint8_t *__restrict__ pbc, double *__restrict__ wpos, int *__restrict__ wrap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = atom_cfg[i];
+    const double *C = cell + 9 * c, *I = invcell + 9 * c;
+    double p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+    double q[3] = {p[0], p[1], p[2]};
+    for (int a = 0; a < 3; ++a) {
+        int w = 0;
+        if (pbc[3 * c + a]) {
+            double f = I[3 * a] * p[0] + I[3 * a + 1] * p[1] + I[3 * a + 2] * p[2];
+            w = (int)floor(f);
+            q[0] -= w * C[3 * a];
+            q[1] -= w * C[3 * a + 1];
+            q[2] -= w * C[3 * a + 2];
+        }
+        wrap[3 * i + a] = w;
+    }
+    wpos[3 * i] = q[0];
+    wpos[3 * i + 1] = q[1];
+    wpos[3 * i + 2] = q[2];
+}
+
+// FILL = false: count neighbors of each centre; FILL = true: write the slots.
+template <bool FILL>
+__global__ void k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
+                      const int *__restrict__ cfg_start, const double *__restrict__ cell,
+                      const int *__restrict__ nimg, double rc2, int *__restrict__ deg,
+                      const int *__restrict__ row_start, float4 *__restrict__ edge,
+                      int *__restrict__ edge_S, long long slot_cap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = atom_cfg[i];
+    int a0 = cfg_start[c], a1 = cfg_start[c + 1];
+    const double *C = cell + 9 * c;
+    int n0 = nimg[3 * c], n1 = nimg[3 * c + 1], n2 = nimg[3 * c + 2];
+    double px = wpos[3 * i], py = wpos[3 * i + 1], pz = wpos[3 * i + 2];
+    long long base = FILL ? (long long)row_start[i] : 0;
+    int cnt = 0;
+    for (int j = a0; j < a1; ++j) {
+        double bx = wpos[3 * j] - px, by = wpos[3 * j + 1] - py, bz = wpos[3 * j + 2] - pz;
+        for (int s0 = -n0; s0 <= n0; ++s0)
+            for (int s1 = -n1; s1 <= n1; ++s1)
+                for (int s2 = -n2; s2 <= n2; ++s2) {
+                    if (i == j && s0 == 0 && s1 == 0 && s2 == 0) continue;
+                    double rx = bx + s0 * C[0] + s1 * C[3] + s2 * C[6];
+                    double ry = by + s0 * C[1] + s1 * C[4] + s2 * C[7];
+                    double rz = bz + s0 * C[2] + s1 * C[5] + s2 * C[8];
+                    double d2 = rx * rx + ry * ry + rz * rz;
+                    if (d2 > rc2 || d2 <= 0.0) continue;
+                    if (FILL) {
+                        long long slot = base + cnt;
+                        if (slot < slot_cap) {
+                            edge[slot] = make_float4((float)rx, (float)ry, (float)rz, __int_as_float(j));
+                            edge_S[slot] = pack_shift(s0, s1, s2);
+                        }
+                    }
+                    ++cnt;
+                }
+    }
+    if (FILL) {
+        int padded = (cnt + 3) & ~3;
+        for (int k = cnt; k < padded; ++k) {
+            long long slot = base + k;
+            if (slot < slot_cap) {
+                edge[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+                edge_S[slot] = pack_shift(0, 0, 0);
+            }
+        }
+    } else {
+        deg[i] = cnt;
+    }
+}
+
+// exclusive scan of padded degrees -> row_start ; counters[0] = slots, [1] = real edges
+__global__ void k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start,
+                            int *__restrict__ counters, long long slot_cap) {
+    __shared__ long long part[1024];
+    __shared__ long long part_real[1024];
+    int t = threadIdx.x, nt = blockDim.x;
+    int chunk = (n + nt - 1) / nt;
+    int b = t * chunk, e = min(n, b + chunk);
+    long long s = 0, sr = 0;
+    for (int i = b; i < e; ++i) {
+        s += (deg[i] + 3) & ~3;
+        sr += deg[i];
+    }
+    part[t] = s;
+    part_real[t] = sr;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {  // inclusive Hillis-Steele
+        long long v = (t >= off) ? part[t - off] : 0;
+        long long vr = (t >= off) ? part_real[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        part_real[t] += vr;
+        __syncthreads();
+    }
+    long long run = part[t] - s;
+    for (int i = b; i < e; ++i) {
+        row_start[i] = (int)run;
+        run += (deg[i] + 3) & ~3;
+    }
+    if (t == nt - 1) {
+        long long total = part[t];
+        row_start[n] = (int)total;
+        counters[0] = (int)total;
+        counters[1] = (int)part_real[t];
+        counters[2] = (total > slot_cap || total > 2147483000LL) ? 1 : 0;
+    }
+}
+
+// reverse-edge slot: for slot (i -> j, S') find (j -> i, -S') in j's row
+__global__ void k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
+                      const int *__restrict__ edge_S, int *__restrict__ rev,
+                      const int *__restrict__ counters) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || counters[2]) return;
+    for (int e = row_start[i]; e < row_start[i + 1]; ++e) {
+        int j = __float_as_int(edge[e].w);
+        if (j < 0) {
+            rev[e] = -1;
+            continue;
+        }
+        int s0, s1, s2;
+        unpack_shift(edge_S[e], s0, s1, s2);
+        int want = pack_shift(-s0, -s1, -s2);
+        int found = -1;
+        for (int e2 = row_start[j]; e2 < row_start[j + 1]; ++e2) {
+            if (__float_as_int(edge[e2].w) == i && edge_S[e2] == want) {
+                found = e2;
+                break;
+            }
+        }
+        rev[e] = found;
+    }
+}
+
+// Enqueue the neighbor build on the handle's stream (no host synchronisation).  If the slot
+// capacity is exceeded, counters[2] is set on the device, every consumer kernel exits early on
+// that flag, and the host (vssr_batch_download / vssr_synchronize) grows the buffers and reruns.
+int build_neighbors(vssr_handle *h, double cutoff) {
+    const int n = h->n_atoms;
+    hipStream_t st = h->stream;
+    if (h->d_wpos.ensure(sizeof(double) * 3 * n) || h->d_wrap.ensure(sizeof(int) * 3 * n) ||
+        h->d_deg.ensure(sizeof(int) * n) || h->d_row_start.ensure(sizeof(int) * (n + 1)) ||
+        h->d_counters.ensure(sizeof(int) * 4))
+        return set_err(h, VSSR_E_NOMEM, "neighbor buffers: out of device memory");
+    if (h->slot_cap < (int64_t)n * 64 + 64) h->slot_cap = (int64_t)n * 64 + 64;
+    if (h->d_edge.ensure(sizeof(float4) * h->slot_cap) || h->d_edge_S.ensure(sizeof(int) * h->slot_cap) ||
+        h->d_rev.ensure(sizeof(int) * h->slot_cap))
+        return set_err(h, VSSR_E_NOMEM, "edge buffers: out of device memory");
+    h->prof.begin(KC_NBR, st);
+    dim3 blk(128), grd((n + 127) / 128);
+    hipLaunchKernelGGL(k_wrap, grd, blk, 0, st, n, h->d_pos.as<double>(), h->d_atom_cfg.as<int>(),
+                       h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_pbc.as<uint8_t>(),
+                       h->d_wpos.as<double>(), h->d_wrap.as<int>());
+    hipLaunchKernelGGL(k_nbr<false>, grd, blk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
+                       h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_nimg.as<int>(),
+                       cutoff * cutoff, h->d_deg.as<int>(), (const int *)nullptr, (float4 *)nullptr,
+                       (int *)nullptr, (long long)0);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, n, h->d_deg.as<int>(),
+                       h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap);
+    hipLaunchKernelGGL(k_nbr<true>, grd, blk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
+                       h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_nimg.as<int>(),
+                       cutoff * cutoff, h->d_deg.as<int>(), h->d_row_start.as<int>(),
+                       h->d_edge.as<float4>(), h->d_edge_S.as<int>(), (long long)h->slot_cap);
+    hipLaunchKernelGGL(k_rev, grd, blk, 0, st, n, h->d_row_start.as<int>(), h->d_edge.as<float4>(),
+                       h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>());
+    h->prof.end(st);
+    VSSR_HIP(h, hipMemcpyAsync(h->h_counters, h->d_counters.as<int>(), sizeof(int) * 4,
+                               hipMemcpyDeviceToHost, st));
+    return VSSR_OK;
+}
+
+}  // namespace vssr

@@ -1,0 +1,803 @@
+// painn.hip — PaiNN ensemble forward + hand-derived reverse pass on gfx950, batched over
+// independent configurations (Markov chains) and ensemble members.
+//
+// Replaces `for model in models: model(batch)` + torch.autograd.grad inside
+// EnsembleNFF.calculate (nff/io/ase_calcs.py; reference call site
+// mcmc/calculators/calculators.py:484) — math per SURVEY.md Appendix A items 2-10:
+//   message block  (nff/nn/modules/painn.py MessageBlock / InvariantMessage / DistanceEmbed)
+//   update block   (nff/nn/modules/painn.py UpdateBlock)
+//   readout + excluded volume + sum pool (nff/nn/models/painn.py)
+// The reverse pass is written out by hand (the reference gets it from autograd):
+// every edge quantity is accumulated by the workgroup that owns the CENTRE atom, so there are
+// no float atomics anywhere and results are run-to-run deterministic.
+//
+// Data layout in HBM (fp32): s [M][N][F], v [M][N][3][F] (Cartesian-major so that a wave reads
+// 64 consecutive features), phi [M][N][3F]; M = ensemble members, N = atoms of the whole batch.
+// grid.y = ensemble member for every kernel.
+#include "vssr_internal.h"
+
+namespace vssr {
+
+constexpr int T = NODE_TILE;
+constexpr int RB = 21;       // n_rbf (20) radial functions * envelope, + the envelope itself (bias column)
+constexpr int ECHUNK = 16;   // edges staged per step in the edge kernels
+constexpr float PI_F = 3.14159265358979323846f;
+
+__device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ inline float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ inline float dswishf_(float x) {
+    float sg = sigmoidf_(x);
+    return sg * (1.f + x * (1.f - sg));
+}
+
+// ---- embedding: s0 = Emb[Z], v0 = 0 ------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_embed(int N, const int *__restrict__ Z, const ModelW *__restrict__ MW,
+                                               float *__restrict__ s0, float *__restrict__ v0) {
+    int i = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
+    const ModelW &W = MW[m];
+    size_t a = (size_t)m * N + i;
+    s0[a * F + f] = W.embed[(size_t)Z[i] * F + f];
+    v0[(a * 3 + 0) * F + f] = 0.f;
+    v0[(a * 3 + 1) * F + f] = 0.f;
+    v0[(a * 3 + 2) * F + f] = 0.f;
+}
+
+// ---- message MLP: phi = W2 swish(W1 s + b1) + b2 -------------------------------------------------
+__global__ void __launch_bounds__(128) k_msg_mlp(int N, int l, const ModelW *__restrict__ MW,
+                                                 const float *__restrict__ s_in, float *__restrict__ phi) {
+    __shared__ float xs[F][T];
+    __shared__ float hs[F][T];
+    const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
+    const LayerW &W = MW[m].layer[l];
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        xs[tid][t] = atom < N ? s_in[((size_t)m * N + atom) * F + tid] : 0.f;
+    }
+    __syncthreads();
+    float acc[T];
+    {
+        float b = W.b1[tid];
+        for (int t = 0; t < T; ++t) acc[t] = b;
+        for (int k = 0; k < F; ++k) {
+            float w = W.W1t[k * F + tid];
+            for (int t = 0; t < T; ++t) acc[t] = fmaf(w, xs[k][t], acc[t]);
+        }
+        for (int t = 0; t < T; ++t) hs[tid][t] = swishf_(acc[t]);
+    }
+    __syncthreads();
+    for (int c = 0; c < 3; ++c) {
+        int o = tid + c * F;
+        float b = W.b2[o];
+        for (int t = 0; t < T; ++t) acc[t] = b;
+        for (int k = 0; k < F; ++k) {
+            float w = W.W2t[k * F3 + o];
+            for (int t = 0; t < T; ++t) acc[t] = fmaf(w, hs[k][t], acc[t]);
+        }
+        for (int t = 0; t < T; ++t) {
+            int atom = a0 + t;
+            if (atom < N) phi[((size_t)m * N + atom) * F3 + o] = acc[t];
+        }
+    }
+}
+
+// ---- per-chunk edge geometry shared by the two edge kernels ----------------------------------------
+struct EdgeChunk {
+    float rho[ECHUNK][RB_MAX];
+    float drho[ECHUNK][RB_MAX];
+    float u[ECHUNK][4];  // unit vector centre -> neighbor, [3] = distance
+    int j[ECHUNK];
+    float fc[ECHUNK], dfc[ECHUNK];
+};
+
+template <bool DERIV>
+__device__ inline void stage_chunk(EdgeChunk &S, const float4 *__restrict__ edge, int e0, int ne, float rc) {
+    const int tid = threadIdx.x;
+    if (tid < ECHUNK) {
+        int j = -1;
+        float d = 1.f, fc = 0.f, dfc = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
+        if (tid < ne) {
+            float4 ed = edge[e0 + tid];
+            j = __float_as_int(ed.w);
+            if (j >= 0) {
+                d = sqrtf(ed.x * ed.x + ed.y * ed.y + ed.z * ed.z);
+                float inv = 1.f / d;
+                ux = ed.x * inv; uy = ed.y * inv; uz = ed.z * inv;
+                if (d < rc) {
+                    fc = 0.5f * (cosf(PI_F * d / rc) + 1.f);
+                    dfc = -0.5f * PI_F / rc * sinf(PI_F * d / rc);
+                }
+            }
+        }
+        S.j[tid] = j;
+        S.u[tid][0] = ux; S.u[tid][1] = uy; S.u[tid][2] = uz; S.u[tid][3] = d;
+        S.fc[tid] = fc; S.dfc[tid] = dfc;
+        S.rho[tid][RB - 1] = fc;
+        if (DERIV) S.drho[tid][RB - 1] = dfc;
+    }
+    __syncthreads();
+    for (int p = tid; p < ECHUNK * (RB - 1); p += blockDim.x) {
+        int e = p / (RB - 1), k = p % (RB - 1);
+        float r = 0.f, dr = 0.f;
+        if (S.j[e] >= 0) {
+            float d = S.u[e][3], a = (float)(k + 1) * PI_F / rc;
+            float sn, cs;
+            sincosf(a * d, &sn, &cs);
+            float rb = sn / d;
+            r = rb * S.fc[e];
+            if (DERIV) dr = (a * cs / d - sn / (d * d)) * S.fc[e] + rb * S.dfc[e];
+        }
+        S.rho[e][k] = r;
+        if (DERIV) S.drho[e][k] = dr;
+    }
+    __syncthreads();
+}
+
+// ---- message block, forward: one workgroup per (centre atom, model); thread = feature --------------
+// s_msg_i = s_i + sum_e phi_j[b] w_e[b];  v_msg_i = v_i + sum_e (phi_j[c] w_e[c] u_e + phi_j[a] w_e[a] v_j)
+template <bool L0>
+__global__ void __launch_bounds__(128)
+k_edge_fwd(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *__restrict__ counters,
+           float rc, int excl_vol, float excl_sigma, int excl_power, const float *__restrict__ s_in,
+           const float *__restrict__ v_in, const float *__restrict__ phi, float *__restrict__ s_msg,
+           float *__restrict__ v_msg, float *__restrict__ e_excl) {
+    __shared__ EdgeChunk S;
+    __shared__ float exs[ECHUNK];
+    if (counters[2]) return;
+    const int i = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
+    const LayerW &W = MW[m].layer[l];
+    float wa[RB], wb[RB], wc[RB];
+    for (int k = 0; k < RB - 1; ++k) {
+        wa[k] = L0 ? 0.f : W.Wd[(size_t)(f) * (RB - 1) + k];
+        wb[k] = W.Wd[(size_t)(F + f) * (RB - 1) + k];
+        wc[k] = W.Wd[(size_t)(2 * F + f) * (RB - 1) + k];
+    }
+    wa[RB - 1] = L0 ? 0.f : W.bd[f];
+    wb[RB - 1] = W.bd[F + f];
+    wc[RB - 1] = W.bd[2 * F + f];
+
+    float acc_s = 0.f, ax = 0.f, ay = 0.f, az = 0.f, ex = 0.f;
+    const int e_begin = G.row_start[i], e_end = G.row_start[i + 1];
+    const size_t mN = (size_t)m * N;
+    for (int e0 = e_begin; e0 < e_end; e0 += ECHUNK) {
+        int ne = min(ECHUNK, e_end - e0);
+        stage_chunk<false>(S, G.edge, e0, ne, rc);
+        if (L0 && excl_vol && f < ne && S.j[f] >= 0) ex += powf(excl_sigma / S.u[f][3], (float)excl_power);
+        for (int e = 0; e < ne; ++e) {
+            int j = S.j[e];
+            if (j < 0) continue;
+            float wA = 0.f, wB = 0.f, wC = 0.f;
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                float r = S.rho[e][k];
+                if (!L0) wA = fmaf(wa[k], r, wA);
+                wB = fmaf(wb[k], r, wB);
+                wC = fmaf(wc[k], r, wC);
+            }
+            const float *pj = phi + (mN + j) * F3;
+            acc_s = fmaf(pj[F + f], wB, acc_s);
+            float mc = pj[2 * F + f] * wC;
+            ax = fmaf(mc, S.u[e][0], ax);
+            ay = fmaf(mc, S.u[e][1], ay);
+            az = fmaf(mc, S.u[e][2], az);
+            if (!L0) {
+                float ma = pj[f] * wA;
+                const float *vj = v_in + (mN + j) * 3 * F;
+                ax = fmaf(ma, vj[f], ax);
+                ay = fmaf(ma, vj[F + f], ay);
+                az = fmaf(ma, vj[2 * F + f], az);
+            }
+        }
+        __syncthreads();
+    }
+    size_t a = mN + i;
+    s_msg[a * F + f] = s_in[a * F + f] + acc_s;
+    if (L0) {
+        v_msg[(a * 3 + 0) * F + f] = ax;
+        v_msg[(a * 3 + 1) * F + f] = ay;
+        v_msg[(a * 3 + 2) * F + f] = az;
+        if (f < ECHUNK) exs[f] = ex;
+        __syncthreads();
+        if (f == 0) {
+            float tot = 0.f;
+            for (int k = 0; k < ECHUNK; ++k) tot += exs[k];
+            e_excl[a] = tot;
+        }
+    } else {
+        v_msg[(a * 3 + 0) * F + f] = v_in[(a * 3 + 0) * F + f] + ax;
+        v_msg[(a * 3 + 1) * F + f] = v_in[(a * 3 + 1) * F + f] + ay;
+        v_msg[(a * 3 + 2) * F + f] = v_in[(a * 3 + 2) * F + f] + az;
+    }
+}
+
+// ---- update block pieces shared by forward and reverse -----------------------------------------------
+struct UpdateLocals {
+    float Uv[3 * T], Vv[3 * T];  // [t*3+x]
+    float nrm[T], inner[T], s1[T], h3[T], avv[T], asv[T], ass[T];
+};
+
+// Computes the update block for feature `tid` of the T atoms of the tile.  vs: v_msg tile
+// [k][t*3+x]; hs/as: scratch.  Leaves hs = [s1; nrm], as_ = swish(h3).
+__device__ inline void update_forward_tile(const LayerW &W, int tid, float (*vs)[3 * T], float (*hs)[T],
+                                           float (*as_)[T], const float *__restrict__ s_msg, size_t mN,
+                                           int a0, int N, UpdateLocals &L) {
+    for (int r = 0; r < 3 * T; ++r) { L.Uv[r] = 0.f; L.Vv[r] = 0.f; }
+    for (int k = 0; k < F; ++k) {
+        float wu = W.Ut[k * F + tid], wv = W.Vt[k * F + tid];
+#pragma unroll
+        for (int r = 0; r < 3 * T; ++r) {
+            float x = vs[k][r];
+            L.Uv[r] = fmaf(wu, x, L.Uv[r]);
+            L.Vv[r] = fmaf(wv, x, L.Vv[r]);
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        float n2 = 0.f, in = 0.f;
+        for (int x = 0; x < 3; ++x) {
+            float vv = L.Vv[t * 3 + x];
+            n2 += vv * vv + 1e-15f;
+            in = fmaf(L.Uv[t * 3 + x], vv, in);
+        }
+        L.nrm[t] = sqrtf(n2);
+        L.inner[t] = in;
+        int atom = a0 + t;
+        L.s1[t] = atom < N ? s_msg[(mN + atom) * F + tid] : 0.f;
+        hs[tid][t] = L.s1[t];
+        hs[F + tid][t] = L.nrm[t];
+    }
+    __syncthreads();
+    {
+        float b = W.b3[tid];
+        for (int t = 0; t < T; ++t) L.h3[t] = b;
+        for (int k = 0; k < 2 * F; ++k) {
+            float w = W.W3t[k * F + tid];
+            for (int t = 0; t < T; ++t) L.h3[t] = fmaf(w, hs[k][t], L.h3[t]);
+        }
+        for (int t = 0; t < T; ++t) as_[tid][t] = swishf_(L.h3[t]);
+    }
+    __syncthreads();
+    {
+        float b0 = W.b4[tid], b1 = W.b4[F + tid], b2 = W.b4[2 * F + tid];
+        for (int t = 0; t < T; ++t) { L.avv[t] = b0; L.asv[t] = b1; L.ass[t] = b2; }
+        for (int k = 0; k < F; ++k) {
+            float w0 = W.W4t[k * F3 + tid], w1 = W.W4t[k * F3 + F + tid], w2 = W.W4t[k * F3 + 2 * F + tid];
+            for (int t = 0; t < T; ++t) {
+                float a = as_[k][t];
+                L.avv[t] = fmaf(w0, a, L.avv[t]);
+                L.asv[t] = fmaf(w1, a, L.asv[t]);
+                L.ass[t] = fmaf(w2, a, L.ass[t]);
+            }
+        }
+    }
+}
+
+__device__ inline void load_v_tile(float (*vs)[3 * T], const float *__restrict__ v, size_t mN, int a0, int N,
+                                   int tid) {
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        for (int x = 0; x < 3; ++x)
+            vs[tid][t * 3 + x] = atom < N ? v[((mN + atom) * 3 + x) * F + tid] : 0.f;
+    }
+}
+
+// ---- update block, forward ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+k_update_fwd(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
+             const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out) {
+    __shared__ float vs[F][3 * T];
+    __shared__ float hs[2 * F][T];
+    __shared__ float as_[F][T];
+    const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
+    const LayerW &W = MW[m].layer[l];
+    const size_t mN = (size_t)m * N;
+    load_v_tile(vs, v_msg, mN, a0, N, tid);
+    __syncthreads();
+    UpdateLocals L;
+    update_forward_tile(W, tid, vs, hs, as_, s_msg, mN, a0, N, L);
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        if (atom >= N) continue;
+        size_t a = mN + atom;
+        s_out[a * F + tid] = L.s1[t] + L.asv[t] * L.inner[t] + L.ass[t];
+        for (int x = 0; x < 3; ++x)
+            v_out[(a * 3 + x) * F + tid] = fmaf(L.avv[t], L.Uv[t * 3 + x], vs[tid][t * 3 + x]);
+    }
+}
+
+// ---- readout (+ its own reverse): e_i = w6.swish(W5 s + b5) + b6 ; sbar = W5^T (w6 * swish'(h5)) ---------
+__global__ void __launch_bounds__(128)
+k_readout(int N, int H, const ModelW *__restrict__ MW, const float *__restrict__ s, const float *__restrict__ e_excl,
+          int excl_vol, float *__restrict__ e_atom, float *__restrict__ sbar) {
+    __shared__ float xs[F][T];
+    __shared__ float hb[F][T];
+    __shared__ float es[F][T];
+    const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
+    const ModelW &W = MW[m];
+    const size_t mN = (size_t)m * N;
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        xs[tid][t] = atom < N ? s[(mN + atom) * F + tid] : 0.f;
+    }
+    __syncthreads();
+    float acc[T];
+    if (tid < H) {
+        float b = W.b5[tid], w6 = W.w6[tid];
+        for (int t = 0; t < T; ++t) acc[t] = b;
+        for (int k = 0; k < F; ++k) {
+            float w = W.W5t[k * H + tid];
+            for (int t = 0; t < T; ++t) acc[t] = fmaf(w, xs[k][t], acc[t]);
+        }
+        for (int t = 0; t < T; ++t) {
+            es[tid][t] = w6 * swishf_(acc[t]);
+            hb[tid][t] = w6 * dswishf_(acc[t]);
+        }
+    }
+    __syncthreads();
+    if (tid < T) {
+        int atom = a0 + tid;
+        if (atom < N) {
+            float e = W.b6[0];
+            for (int o = 0; o < H; ++o) e += es[o][tid];
+            if (excl_vol) e += e_excl[mN + atom];
+            e_atom[mN + atom] = e;
+        }
+    }
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    for (int o = 0; o < H; ++o) {
+        float w = W.W5[o * F + tid];
+        for (int t = 0; t < T; ++t) acc[t] = fmaf(w, hb[o][t], acc[t]);
+    }
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        if (atom < N) sbar[(mN + atom) * F + tid] = acc[t];
+    }
+}
+
+// ---- update block, reverse: (sbar, vbar) of the block outputs -> (sbar_msg, vbar_msg) of its inputs --------
+__global__ void __launch_bounds__(128)
+k_update_bwd(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
+             const float *__restrict__ v_msg, const float *__restrict__ sbar, const float *__restrict__ vbar,
+             float *__restrict__ sbar_msg, float *__restrict__ vbar_msg) {
+    __shared__ float vs[F][3 * T];
+    __shared__ float hs[2 * F][T];
+    __shared__ float as_[F][T];
+    __shared__ float qb[F3][T];
+    __shared__ float ub[F][3 * T];
+    __shared__ float vb[F][3 * T];
+    const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
+    const LayerW &W = MW[m].layer[l];
+    const size_t mN = (size_t)m * N;
+    load_v_tile(vs, v_msg, mN, a0, N, tid);
+    __syncthreads();
+    UpdateLocals L;
+    update_forward_tile(W, tid, vs, hs, as_, s_msg, mN, a0, N, L);
+
+    float Ub[3 * T], Vb[3 * T], vbo[3 * T], sb[T];
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        size_t a = mN + atom;
+        sb[t] = atom < N ? sbar[a * F + tid] : 0.f;
+        float abar_vv = 0.f;
+        for (int x = 0; x < 3; ++x) {
+            int r = t * 3 + x;
+            vbo[r] = (atom < N && !vbar_is_zero) ? vbar[(a * 3 + x) * F + tid] : 0.f;
+            abar_vv = fmaf(vbo[r], L.Uv[r], abar_vv);
+            Ub[r] = vbo[r] * L.avv[t] + sb[t] * L.asv[t] * L.Vv[r];
+            Vb[r] = sb[t] * L.asv[t] * L.Uv[r];
+        }
+        qb[tid][t] = abar_vv;
+        qb[F + tid][t] = sb[t] * L.inner[t];
+        qb[2 * F + tid][t] = sb[t];
+    }
+    __syncthreads();  // qb complete; as_ (swish(h3)) no longer needed
+    float acc[T];
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    for (int c = 0; c < F3; ++c) {
+        float w = W.W4[c * F + tid];
+        for (int t = 0; t < T; ++t) acc[t] = fmaf(w, qb[c][t], acc[t]);
+    }
+    for (int t = 0; t < T; ++t) as_[tid][t] = acc[t] * dswishf_(L.h3[t]);  // h3bar
+    __syncthreads();
+    float hs_s[T], hs_n[T];
+    for (int t = 0; t < T; ++t) { hs_s[t] = 0.f; hs_n[t] = 0.f; }
+    for (int o = 0; o < F; ++o) {
+        float w0 = W.W3[o * 2 * F + tid], w1 = W.W3[o * 2 * F + F + tid];
+        for (int t = 0; t < T; ++t) {
+            float g = as_[o][t];
+            hs_s[t] = fmaf(w0, g, hs_s[t]);
+            hs_n[t] = fmaf(w1, g, hs_n[t]);
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        if (atom < N) sbar_msg[(mN + atom) * F + tid] = sb[t] + hs_s[t];
+        float sc = hs_n[t] / L.nrm[t];
+        for (int x = 0; x < 3; ++x) {
+            int r = t * 3 + x;
+            Vb[r] = fmaf(sc, L.Vv[r], Vb[r]);
+            ub[tid][r] = Ub[r];
+            vb[tid][r] = Vb[r];
+        }
+    }
+    __syncthreads();
+    float out[3 * T];
+    for (int r = 0; r < 3 * T; ++r) out[r] = vbo[r];
+    for (int fo = 0; fo < F; ++fo) {
+        float wu = W.U[fo * F + tid], wv = W.V[fo * F + tid];
+#pragma unroll
+        for (int r = 0; r < 3 * T; ++r) {
+            out[r] = fmaf(wu, ub[fo][r], out[r]);
+            out[r] = fmaf(wv, vb[fo][r], out[r]);
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        if (atom >= N) continue;
+        for (int x = 0; x < 3; ++x) vbar_msg[((mN + atom) * 3 + x) * F + tid] = out[t * 3 + x];
+    }
+}
+
+// ---- message block, reverse: one workgroup per (atom c, model), c in its role as SOURCE j ------------------
+// For every neighbor n of c the edge (n -> c) carried phi_c, v_c into n.  Gathers the output
+// adjoints of n, accumulates phibar_c and vbar_c without scatter, and produces dE/d r for the
+// edge (n -> c), stored at the slot (c, n).
+template <bool L0>
+__global__ void __launch_bounds__(128)
+k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphView G,
+           const int *__restrict__ counters, float rc, int excl_vol, float excl_sigma, int excl_power,
+           const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
+           const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
+           float4 *__restrict__ gbar, long long gbar_stride) {
+    __shared__ EdgeChunk S;
+    __shared__ float red[ECHUNK][4][F + 1];
+    __shared__ float tots[ECHUNK][4];
+    if (counters[2]) return;
+    const int c = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
+    const LayerW &W = MW[m].layer[l];
+    float wa[RB], wb[RB], wc[RB];
+    for (int k = 0; k < RB - 1; ++k) {
+        wa[k] = L0 ? 0.f : W.Wd[(size_t)(f) * (RB - 1) + k];
+        wb[k] = W.Wd[(size_t)(F + f) * (RB - 1) + k];
+        wc[k] = W.Wd[(size_t)(2 * F + f) * (RB - 1) + k];
+    }
+    wa[RB - 1] = L0 ? 0.f : W.bd[f];
+    wb[RB - 1] = W.bd[F + f];
+    wc[RB - 1] = W.bd[2 * F + f];
+
+    const size_t mN = (size_t)m * N;
+    const size_t ac = mN + c;
+    const float pc_a = L0 ? 0.f : phi[ac * F3 + f];
+    const float pc_b = phi[ac * F3 + F + f];
+    const float pc_c = phi[ac * F3 + 2 * F + f];
+    float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
+    if (!L0) {
+        vc0 = v_in[(ac * 3 + 0) * F + f];
+        vc1 = v_in[(ac * 3 + 1) * F + f];
+        vc2 = v_in[(ac * 3 + 2) * F + f];
+    }
+    float accb = 0.f, accc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    float4 *gb = gbar + (size_t)m * gbar_stride;
+    const int e_begin = G.row_start[c], e_end = G.row_start[c + 1];
+    for (int e0 = e_begin; e0 < e_end; e0 += ECHUNK) {
+        int ne = min(ECHUNK, e_end - e0);
+        stage_chunk<true>(S, G.edge, e0, ne, rc);
+        for (int e = 0; e < ne; ++e) {
+            int n = S.j[e];
+            if (n < 0) {
+                red[e][0][f] = 0.f; red[e][1][f] = 0.f; red[e][2][f] = 0.f; red[e][3][f] = 0.f;
+                continue;
+            }
+            float wA = 0.f, wB = 0.f, wC = 0.f, dA = 0.f, dB = 0.f, dC = 0.f;
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                float r = S.rho[e][k], dr = S.drho[e][k];
+                if (!L0) { wA = fmaf(wa[k], r, wA); dA = fmaf(wa[k], dr, dA); }
+                wB = fmaf(wb[k], r, wB); dB = fmaf(wb[k], dr, dB);
+                wC = fmaf(wc[k], r, wC); dC = fmaf(wc[k], dr, dC);
+            }
+            const size_t an = mN + n;
+            float sbn = sbar_msg[an * F + f];
+            float vb0 = vbar_msg[(an * 3 + 0) * F + f];
+            float vb1 = vbar_msg[(an * 3 + 1) * F + f];
+            float vb2 = vbar_msg[(an * 3 + 2) * F + f];
+            // unit vector of the edge (n -> c) = -(c -> n)
+            float u0 = -S.u[e][0], u1 = -S.u[e][1], u2 = -S.u[e][2];
+            float p = vb0 * u0 + vb1 * u1 + vb2 * u2;
+            accb = fmaf(wB, sbn, accb);
+            accc = fmaf(wC, p, accc);
+            float dpart = pc_b * sbn * dB + pc_c * p * dC;
+            if (!L0) {
+                float q = vb0 * vc0 + vb1 * vc1 + vb2 * vc2;
+                ax = fmaf(wA, vb0, ax);
+                ay = fmaf(wA, vb1, ay);
+                az = fmaf(wA, vb2, az);
+                dpart = fmaf(pc_a * q, dA, dpart);
+            }
+            float mc = pc_c * wC;
+            red[e][0][f] = dpart;
+            red[e][1][f] = mc * vb0;
+            red[e][2][f] = mc * vb1;
+            red[e][3][f] = mc * vb2;
+        }
+        __syncthreads();
+        if (f < ne * 4) {
+            int e = f >> 2, comp = f & 3;
+            float tot = 0.f;
+            for (int k = 0; k < F; ++k) tot += red[e][comp][k];
+            tots[e][comp] = tot;
+        }
+        __syncthreads();
+        if (f < ne && S.j[f] >= 0) {
+            float d = S.u[f][3];
+            float u0 = -S.u[f][0], u1 = -S.u[f][1], u2 = -S.u[f][2];
+            float db = tots[f][0];
+            if (L0 && excl_vol) db -= (float)excl_power * powf(excl_sigma / d, (float)excl_power) / d;
+            float b0 = tots[f][1], b1 = tots[f][2], b2 = tots[f][3];
+            float dot = b0 * u0 + b1 * u1 + b2 * u2;
+            float g0 = db * u0 + (b0 - dot * u0) / d;
+            float g1 = db * u1 + (b1 - dot * u1) / d;
+            float g2 = db * u2 + (b2 - dot * u2) / d;
+            if (accumulate) {
+                float4 old = gb[e0 + f];
+                g0 += old.x; g1 += old.y; g2 += old.z;
+            }
+            gb[e0 + f] = make_float4(g0, g1, g2, 0.f);
+        }
+        __syncthreads();
+    }
+    if (!L0) {
+        phibar[ac * F3 + f] = vc0 * ax + vc1 * ay + vc2 * az;
+        phibar[ac * F3 + F + f] = accb;
+        phibar[ac * F3 + 2 * F + f] = accc;
+        vbar_in[(ac * 3 + 0) * F + f] = fmaf(pc_a, ax, vbar_msg[(ac * 3 + 0) * F + f]);
+        vbar_in[(ac * 3 + 1) * F + f] = fmaf(pc_a, ay, vbar_msg[(ac * 3 + 1) * F + f]);
+        vbar_in[(ac * 3 + 2) * F + f] = fmaf(pc_a, az, vbar_msg[(ac * 3 + 2) * F + f]);
+    }
+}
+
+// ---- message MLP, reverse: sbar_in = sbar_msg + W1^T [ (W2^T phibar) * swish'(W1 s + b1) ] -------------------
+__global__ void __launch_bounds__(128)
+k_msg_mlp_bwd(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
+              const float *__restrict__ phibar, const float *__restrict__ sbar_msg, float *__restrict__ sbar_in) {
+    __shared__ float xs[F][T];
+    __shared__ float pb[F3][T];
+    __shared__ float hb[F][T];
+    const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
+    const LayerW &W = MW[m].layer[l];
+    const size_t mN = (size_t)m * N;
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        bool ok = atom < N;
+        xs[tid][t] = ok ? s_in[(mN + atom) * F + tid] : 0.f;
+        for (int c = 0; c < 3; ++c) pb[c * F + tid][t] = ok ? phibar[(mN + atom) * F3 + c * F + tid] : 0.f;
+    }
+    __syncthreads();
+    float h1[T], acc[T];
+    {
+        float b = W.b1[tid];
+        for (int t = 0; t < T; ++t) h1[t] = b;
+        for (int k = 0; k < F; ++k) {
+            float w = W.W1t[k * F + tid];
+            for (int t = 0; t < T; ++t) h1[t] = fmaf(w, xs[k][t], h1[t]);
+        }
+    }
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    for (int c = 0; c < F3; ++c) {
+        float w = W.W2[c * F + tid];
+        for (int t = 0; t < T; ++t) acc[t] = fmaf(w, pb[c][t], acc[t]);
+    }
+    for (int t = 0; t < T; ++t) hb[tid][t] = acc[t] * dswishf_(h1[t]);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    for (int o = 0; o < F; ++o) {
+        float w = W.W1[o * F + tid];
+        for (int t = 0; t < T; ++t) acc[t] = fmaf(w, hb[o][t], acc[t]);
+    }
+    for (int t = 0; t < T; ++t) {
+        int atom = a0 + t;
+        if (atom < N) sbar_in[(mN + atom) * F + tid] = sbar_msg[(mN + atom) * F + tid] + acc[t];
+    }
+}
+
+// ---- ensemble reduction -----------------------------------------------------------------------------------------
+// forces: dE/dx_c = sum_{slots (c,n)} ( G[(n->c)] - G[(c->n)] ), G[(c->n)] lives at rev[slot].
+__global__ void k_finalize_forces(int N, int M, GraphView G, const int *__restrict__ counters,
+                                  const float4 *__restrict__ gbar, long long gbar_stride, double units_per_ev,
+                                  float *__restrict__ forces, float *__restrict__ forces_std) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N || counters[2]) return;
+    double fm[3] = {0, 0, 0}, f2[3] = {0, 0, 0};
+    for (int m = 0; m < M; ++m) {
+        const float4 *gb = gbar + (size_t)m * gbar_stride;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        for (int e = G.row_start[c]; e < G.row_start[c + 1]; ++e) {
+            int r = G.rev[e];
+            if (r < 0) continue;
+            float4 a = gb[e], b = gb[r];
+            g0 += a.x - b.x; g1 += a.y - b.y; g2 += a.z - b.z;
+        }
+        double f[3] = {-(double)g0 / units_per_ev, -(double)g1 / units_per_ev, -(double)g2 / units_per_ev};
+        for (int x = 0; x < 3; ++x) { fm[x] += f[x]; f2[x] += f[x] * f[x]; }
+    }
+    for (int x = 0; x < 3; ++x) {
+        double mu = fm[x] / M;
+        double var = f2[x] / M - mu * mu;
+        forces[3 * c + x] = (float)mu;
+        if (forces_std) forces_std[3 * c + x] = (float)sqrt(var > 0 ? var : 0.0);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_finalize_energy(int N, int M, const int *__restrict__ cfg_start, const int *__restrict__ Z,
+                  const float *__restrict__ e_atom, double units_per_ev, const double *__restrict__ offset_per_z,
+                  double offset_const, float *__restrict__ energy, float *__restrict__ energy_std,
+                  float *__restrict__ energy_models, float *__restrict__ e_atoms_mean) {
+    __shared__ double red[256];
+    __shared__ double em[MAX_MODELS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int a0 = cfg_start[b], a1 = cfg_start[b + 1];
+    double off = 0.0;
+    if (offset_per_z) {
+        for (int i = a0 + tid; i < a1; i += blockDim.x) off += offset_per_z[Z[i]];
+    }
+    red[tid] = off;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    double offset = offset_per_z ? red[0] + offset_const : 0.0;
+    __syncthreads();
+    for (int m = 0; m < M; ++m) {
+        double acc = 0.0;
+        for (int i = a0 + tid; i < a1; i += blockDim.x) acc += (double)e_atom[(size_t)m * N + i];
+        red[tid] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) em[m] = red[0] / units_per_ev + offset;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double mu = 0, var = 0;
+        for (int m = 0; m < M; ++m) mu += em[m];
+        mu /= M;
+        for (int m = 0; m < M; ++m) var += (em[m] - mu) * (em[m] - mu);
+        energy[b] = (float)mu;
+        energy_std[b] = (float)sqrt(var / M);
+        for (int m = 0; m < M; ++m) energy_models[(size_t)b * M + m] = (float)em[m];
+    }
+    for (int i = a0 + tid; i < a1; i += blockDim.x) {
+        double acc = 0;
+        for (int m = 0; m < M; ++m) acc += (double)e_atom[(size_t)m * N + i];
+        e_atoms_mean[i] = (float)(acc / M / units_per_ev);
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+int painn_alloc_state(vssr_handle *h) {
+    const size_t N = h->n_atoms, M = h->n_models, L = h->num_conv;
+    const size_t nS = M * N * F, nV = 3 * nS, nP = 3 * nS;
+    size_t floats = (L + 1) * (nS + nV) + L * nP + L * (nS + nV) + 2 * M * N  // forward
+                    + 2 * (nS + nV) + nP;                                          // reverse
+    if (h->d_state.ensure(floats * sizeof(float)))
+        return set_err(h, VSSR_E_NOMEM, "activation arena (%zu MB): out of device memory", floats * 4 >> 20);
+    float *p = h->d_state.as<float>();
+    StateView &sv = h->sv;
+    sv.n_atoms = (int)N;
+    sv.n_models = (int)M;
+    for (size_t l = 0; l <= L; ++l) { sv.s_in[l] = p; p += nS; sv.v_in[l] = p; p += nV; }
+    for (size_t l = 0; l < L; ++l) {
+        sv.phi[l] = p; p += nP;
+        sv.s_msg[l] = p; p += nS;
+        sv.v_msg[l] = p; p += nV;
+    }
+    sv.e_atom = p; p += M * N;
+    sv.e_excl = p; p += M * N;
+    sv.sbar = p; p += nS;
+    sv.vbar = p; p += nV;
+    sv.sbar_msg = p; p += nS;
+    sv.vbar_msg = p; p += nV;
+    sv.phibar = p; p += nP;
+    if (h->d_gbar.ensure(sizeof(float4) * M * (size_t)h->slot_cap))
+        return set_err(h, VSSR_E_NOMEM, "edge-gradient buffer: out of device memory");
+    sv.gbar = h->d_gbar.as<float4>();
+    if (h->d_energy.ensure(sizeof(float) * h->n_cfg) || h->d_energy_std.ensure(sizeof(float) * h->n_cfg) ||
+        h->d_energy_models.ensure(sizeof(float) * h->n_cfg * M) || h->d_forces.ensure(sizeof(float) * 3 * N) ||
+        h->d_forces_std.ensure(sizeof(float) * 3 * N) || h->d_e_atoms.ensure(sizeof(float) * N))
+        return set_err(h, VSSR_E_NOMEM, "result buffers: out of device memory");
+    return VSSR_OK;
+}
+
+int painn_run(vssr_handle *h, uint32_t want) {
+    const int N = h->n_atoms, M = h->n_models, L = h->num_conv, H = h->readout_hidden;
+    hipStream_t st = h->stream;
+    int rc = build_neighbors(h, (double)h->cutoff);
+    if (rc) return rc;
+    rc = painn_alloc_state(h);
+    if (rc) return rc;
+    StateView &sv = h->sv;
+    GraphView G;
+    G.n_atoms = N;
+    G.n_cfg = h->n_cfg;
+    G.atom_cfg = h->d_atom_cfg.as<int>();
+    G.cfg_start = h->d_cfg_start.as<int>();
+    G.row_start = h->d_row_start.as<int>();
+    G.deg = h->d_deg.as<int>();
+    G.edge = h->d_edge.as<float4>();
+    G.rev = h->d_rev.as<int>();
+    const ModelW *MW = h->model_table.as<ModelW>();
+    const int *counters = h->d_counters.as<int>();
+    const int *Z = h->d_Z.as<int>();
+    dim3 blk(128);
+    dim3 g_atom(N, M), g_tile((N + T - 1) / T, M);
+    Profiler &P = h->prof;
+
+    P.begin(KC_EMBED, st);
+    hipLaunchKernelGGL(k_embed, g_atom, blk, 0, st, N, Z, MW, sv.s_in[0], sv.v_in[0]);
+    P.end(st);
+    for (int l = 0; l < L; ++l) {
+        P.begin(KC_MSG_MLP, st);
+        hipLaunchKernelGGL(k_msg_mlp, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phi[l]);
+        P.end(st);
+        P.begin(KC_EDGE_FWD, st);
+        if (l == 0)
+            hipLaunchKernelGGL(k_edge_fwd<true>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
+                               h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
+                               sv.v_msg[l], sv.e_excl);
+        else
+            hipLaunchKernelGGL(k_edge_fwd<false>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
+                               h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
+                               sv.v_msg[l], sv.e_excl);
+        P.end(st);
+        P.begin(KC_UPDATE_FWD, st);
+        hipLaunchKernelGGL(k_update_fwd, g_tile, blk, 0, st, N, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1],
+                           sv.v_in[l + 1]);
+        P.end(st);
+    }
+    P.begin(KC_READOUT, st);
+    hipLaunchKernelGGL(k_readout, g_tile, blk, 0, st, N, H, MW, sv.s_in[L], sv.e_excl, h->excl_vol, sv.e_atom,
+                       sv.sbar);
+    P.end(st);
+
+    if (want & VSSR_WANT_FORCES) {
+        for (int l = L - 1; l >= 0; --l) {
+            P.begin(KC_UPDATE_BWD, st);
+            hipLaunchKernelGGL(k_update_bwd, g_tile, blk, 0, st, N, l, (int)(l == L - 1), MW, sv.s_msg[l],
+                               sv.v_msg[l], sv.sbar, sv.vbar, sv.sbar_msg, sv.vbar_msg);
+            P.end(st);
+            P.begin(KC_EDGE_BWD, st);
+            int accumulate = (l != L - 1);
+            if (l == 0)
+                hipLaunchKernelGGL(k_edge_bwd<true>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
+                                   h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
+                                   sv.sbar_msg, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap);
+            else
+                hipLaunchKernelGGL(k_edge_bwd<false>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
+                                   h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
+                                   sv.sbar_msg, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap);
+            P.end(st);
+            if (l > 0) {
+                P.begin(KC_MSG_MLP_BWD, st);
+                hipLaunchKernelGGL(k_msg_mlp_bwd, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phibar, sv.sbar_msg,
+                                   sv.sbar);
+                P.end(st);
+            }
+        }
+    }
+    P.begin(KC_FINALIZE, st);
+    if (want & VSSR_WANT_FORCES)
+        hipLaunchKernelGGL(k_finalize_forces, dim3((N + 127) / 128), dim3(128), 0, st, N, M, G, counters, sv.gbar,
+                           (long long)h->slot_cap, h->units_per_ev, h->d_forces.as<float>(),
+                           h->d_forces_std.as<float>());
+    hipLaunchKernelGGL(k_finalize_energy, dim3(h->n_cfg), dim3(256), 0, st, N, M, G.cfg_start, Z, sv.e_atom,
+                       h->units_per_ev, h->has_offset ? h->offset_per_z.as<double>() : (const double *)nullptr,
+                       h->offset_const, h->d_energy.as<float>(), h->d_energy_std.as<float>(),
+                       h->d_energy_models.as<float>(), h->d_e_atoms.as<float>());
+    P.end(st);
+    VSSR_HIP(h, hipGetLastError());
+    return VSSR_OK;
+}
+
+}  // namespace vssr

@@ -1,0 +1,541 @@
+// vssr_api.hip — extern "C" entry points declared in include/vssr_eval.h.
+#include <cmath>
+#include <cstdarg>
+
+#include "vssr_internal.h"
+
+namespace vssr {
+
+const char *const kKernelClassNames[KC_COUNT] = {
+    "neighbor_list", "embed", "message_mlp", "edge_message_fwd", "update_fwd", "readout",
+    "update_bwd", "edge_message_bwd", "message_mlp_bwd", "finalize", "tersoff"};
+
+static std::string g_create_error;
+
+int set_err(vssr_handle *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+// ---- profiler ------------------------------------------------------------------------------------------
+hipEvent_t Profiler::get_event() {
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void Profiler::begin(int kc, hipStream_t s) {
+    if (!enabled) return;
+    Rec r{kc, get_event(), get_event()};
+    (void)hipEventRecord(r.a, s);
+    pending.push_back(r);
+}
+void Profiler::end(hipStream_t s) {
+    if (!enabled) return;
+    (void)hipEventRecord(pending.back().b, s);
+}
+void Profiler::collect() {
+    for (auto &r : pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            total_ms[r.kc] += ms;
+            launches[r.kc] += 1;
+        }
+        pool.push_back(r.a);
+        pool.push_back(r.b);
+    }
+    pending.clear();
+}
+void Profiler::reset() {
+    collect();
+    for (int k = 0; k < KC_COUNT; ++k) { launches[k] = 0; total_ms[k] = 0; }
+}
+void Profiler::destroy() {
+    collect();
+    for (auto e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+}
+
+// ---- weights ------------------------------------------------------------------------------------------
+static void transpose(const float *src, int rows, int cols, float *dst) {  // dst[c][r] = src[r][c]
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) dst[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+}
+
+static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
+    const int M = cfg->n_models, L = cfg->num_conv, R = cfg->n_rbf, H = cfg->readout_hidden, NE = cfg->n_embed;
+    const size_t per_layer = (size_t)F * F + F + (size_t)F3 * F + F3 + (size_t)F3 * R + F3 + 2 * (size_t)F * F +
+                             (size_t)F * 2 * F + F + (size_t)F3 * F + F3;
+    const size_t blob_len = (size_t)NE * F + L * per_layer + (size_t)H * F + H + H + 1;
+    if (cfg->weights_len != blob_len)
+        return set_err(h, VSSR_E_BADARG, "weights_len %llu does not match the layout (%zu floats)",
+                       (unsigned long long)cfg->weights_len, blob_len);
+    // device image per model: [blob][transposed copies]
+    const size_t t_per_layer = (size_t)F * F + (size_t)F * F3 + 2 * (size_t)F * F + (size_t)2 * F * F + (size_t)F * F3;
+    const size_t img_len = blob_len + L * t_per_layer + (size_t)F * H;
+    std::vector<float> img(img_len * M);
+    std::vector<ModelW> table(M);
+    if (h->weights.ensure(img.size() * sizeof(float)))
+        return set_err(h, VSSR_E_NOMEM, "weights: out of device memory");
+    float *dbase = h->weights.as<float>();
+    for (int m = 0; m < M; ++m) {
+        float *hb = img.data() + (size_t)m * img_len;
+        float *db = dbase + (size_t)m * img_len;
+        memcpy(hb, cfg->weights[m], blob_len * sizeof(float));
+        for (size_t t = 0; t < blob_len; ++t)
+            if (!std::isfinite(hb[t])) return set_err(h, VSSR_E_BADARG, "model %d: non-finite weight", m);
+        ModelW &W = table[m];
+        size_t o = 0, to = blob_len;
+        auto take = [&](size_t n) { size_t r = o; o += n; return r; };
+        auto taket = [&](size_t n) { size_t r = to; to += n; return r; };
+        W.embed = db + take((size_t)NE * F);
+        for (int l = 0; l < L; ++l) {
+            LayerW &Lw = W.layer[l];
+            size_t w1 = take((size_t)F * F), b1 = take(F), w2 = take((size_t)F3 * F), b2 = take(F3);
+            size_t wd = take((size_t)F3 * R), bd = take(F3), u = take((size_t)F * F), v = take((size_t)F * F);
+            size_t w3 = take((size_t)F * 2 * F), b3 = take(F), w4 = take((size_t)F3 * F), b4 = take(F3);
+            size_t w1t = taket((size_t)F * F), w2t = taket((size_t)F * F3), ut = taket((size_t)F * F);
+            size_t vt = taket((size_t)F * F), w3t = taket((size_t)2 * F * F), w4t = taket((size_t)F * F3);
+            transpose(hb + w1, F, F, hb + w1t);
+            transpose(hb + w2, F3, F, hb + w2t);
+            transpose(hb + u, F, F, hb + ut);
+            transpose(hb + v, F, F, hb + vt);
+            transpose(hb + w3, F, 2 * F, hb + w3t);
+            transpose(hb + w4, F3, F, hb + w4t);
+            Lw.W1 = db + w1; Lw.W1t = db + w1t; Lw.b1 = db + b1;
+            Lw.W2 = db + w2; Lw.W2t = db + w2t; Lw.b2 = db + b2;
+            Lw.Wd = db + wd; Lw.bd = db + bd;
+            Lw.U = db + u; Lw.Ut = db + ut; Lw.V = db + v; Lw.Vt = db + vt;
+            Lw.W3 = db + w3; Lw.W3t = db + w3t; Lw.b3 = db + b3;
+            Lw.W4 = db + w4; Lw.W4t = db + w4t; Lw.b4 = db + b4;
+        }
+        size_t w5 = take((size_t)H * F), b5 = take(H), w6 = take(H), b6 = take(1);
+        size_t w5t = taket((size_t)F * H);
+        transpose(hb + w5, H, F, hb + w5t);
+        W.W5 = db + w5; W.W5t = db + w5t; W.b5 = db + b5; W.w6 = db + w6; W.b6 = db + b6;
+    }
+    VSSR_HIP(h, hipMemcpy(dbase, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (h->model_table.ensure(sizeof(ModelW) * M)) return set_err(h, VSSR_E_NOMEM, "model table");
+    VSSR_HIP(h, hipMemcpy(h->model_table.p, table.data(), sizeof(ModelW) * M, hipMemcpyHostToDevice));
+    return VSSR_OK;
+}
+
+static int common_init(vssr_handle *h, int device) {
+    h->device = device;
+    VSSR_HIP(h, hipSetDevice(device));
+    VSSR_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    VSSR_HIP(h, hipHostMalloc((void **)&h->h_counters, sizeof(int) * 4));
+    h->h_counters[0] = h->h_counters[1] = h->h_counters[2] = 0;
+    return VSSR_OK;
+}
+
+static void cell_host_setup(const double *cell, const uint8_t *pbc, double cutoff, double inv[9], int nimg[3],
+                            bool &ok) {
+    const double *a = cell, *b = cell + 3, *c = cell + 6;
+    double bc[3] = {b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]};
+    double ca[3] = {c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0]};
+    double ab[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    double vol = a[0] * bc[0] + a[1] * bc[1] + a[2] * bc[2];
+    ok = true;
+    for (int x = 0; x < 9; ++x) inv[x] = 0.0;
+    nimg[0] = nimg[1] = nimg[2] = 0;
+    if (!(pbc[0] || pbc[1] || pbc[2])) return;
+    if (std::fabs(vol) < 1e-12) { ok = false; return; }
+    for (int x = 0; x < 3; ++x) { inv[x] = bc[x] / vol; inv[3 + x] = ca[x] / vol; inv[6 + x] = ab[x] / vol; }
+    double hgt[3] = {std::fabs(vol) / std::sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]),
+                     std::fabs(vol) / std::sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]),
+                     std::fabs(vol) / std::sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2])};
+    for (int k = 0; k < 3; ++k)
+        if (pbc[k]) nimg[k] = (int)std::floor(cutoff / hgt[k]) + 1;
+}
+
+static double handle_cutoff(const vssr_handle *h) { return h->kind == 2 ? h->ters_cutmax : (double)h->cutoff; }
+
+static int run_any(vssr_handle *h, uint32_t want) {
+    return h->kind == 2 ? tersoff_run(h, want) : painn_run(h, want);
+}
+
+// synchronise; if the neighbor capacity overflowed, grow and rerun
+static int sync_and_check(vssr_handle *h, uint32_t want) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        VSSR_HIP(h, hipStreamSynchronize(h->stream));
+        h->prof.collect();
+        if (!h->ran || !h->h_counters[2]) return VSSR_OK;
+        if (h->h_counters[0] <= 0)
+            return set_err(h, VSSR_E_CAPACITY, "neighbor list exceeds 2^31 slots");
+        h->slot_cap = (int64_t)h->h_counters[0] + (int64_t)h->h_counters[0] / 8 + 64;
+        int rc = run_any(h, want);
+        if (rc) return rc;
+    }
+    return set_err(h, VSSR_E_CAPACITY, "neighbor list capacity could not be satisfied");
+}
+
+}  // namespace vssr
+
+using namespace vssr;
+
+extern "C" {
+
+int vssr_abi_version(void) { return VSSR_ABI_VERSION; }
+
+const char *vssr_last_error(const vssr_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
+    if (!cfg || !out) return set_err(nullptr, VSSR_E_BADARG, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(vssr_painn_config))
+        return set_err(nullptr, VSSR_E_BADARG, "vssr_painn_config size mismatch (%u vs %zu)", cfg->struct_size,
+                       sizeof(vssr_painn_config));
+    if (cfg->feat_dim != F || cfg->n_rbf != 20)
+        return set_err(nullptr, VSSR_E_BADARG, "only feat_dim=128, n_rbf=20 are compiled (got %d, %d)", cfg->feat_dim,
+                       cfg->n_rbf);
+    if (cfg->n_models < 1 || cfg->n_models > MAX_MODELS || cfg->num_conv < 1 || cfg->num_conv > MAX_LAYERS ||
+        cfg->readout_hidden < 1 || cfg->readout_hidden > F || cfg->n_embed < 1 || !cfg->weights ||
+        !(cfg->cutoff > 0) || !(cfg->model_units_per_ev > 0))
+        return set_err(nullptr, VSSR_E_BADARG, "bad PaiNN configuration");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_err(nullptr, VSSR_E_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return set_err(nullptr, VSSR_E_BADARG, "device %d out of range", cfg->device);
+    vssr_handle *h = new vssr_handle();
+    h->kind = 1;
+    h->n_models = cfg->n_models; h->n_rbf = cfg->n_rbf; h->num_conv = cfg->num_conv; h->n_embed = cfg->n_embed;
+    h->readout_hidden = cfg->readout_hidden; h->cutoff = cfg->cutoff; h->excl_vol = cfg->excl_vol;
+    h->excl_power = cfg->excl_power; h->excl_sigma = cfg->excl_sigma; h->units_per_ev = cfg->model_units_per_ev;
+    int rc = common_init(h, cfg->device);
+    if (!rc) rc = upload_weights(h, cfg);
+    if (!rc && cfg->offset_per_z) {
+        h->has_offset = true;
+        h->offset_const = cfg->offset_const;
+        if (h->offset_per_z.ensure(sizeof(double) * cfg->n_embed)) rc = set_err(h, VSSR_E_NOMEM, "offset table");
+        else if (hipMemcpy(h->offset_per_z.p, cfg->offset_per_z, sizeof(double) * cfg->n_embed,
+                           hipMemcpyHostToDevice) != hipSuccess)
+            rc = set_err(h, VSSR_E_DEVICE, "offset table upload failed");
+    }
+    if (rc) {
+        g_create_error = h->err;
+        vssr_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return VSSR_OK;
+}
+
+int vssr_tersoff_create(int32_t device, int32_t n_types, const double *params, vssr_handle **out) {
+    if (!params || !out || n_types < 1 || n_types > 8) return set_err(nullptr, VSSR_E_BADARG, "bad tersoff arguments");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_err(nullptr, VSSR_E_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_err(nullptr, VSSR_E_BADARG, "device %d out of range", device);
+    vssr_handle *h = new vssr_handle();
+    h->kind = 2;
+    h->n_types = n_types;
+    h->n_embed = n_types;
+    int rc = common_init(h, device);
+    const size_t np = (size_t)n_types * n_types * n_types;
+    double cutmax = 0;
+    for (size_t t = 0; t < np && !rc; ++t) {
+        const double *p = params + 14 * t;
+        if (!(p[0] == 1.0 || p[0] == 3.0) || !(p[11] > 0) || !(p[4] != 0)) rc = set_err(h, VSSR_E_BADARG, "bad tersoff entry %zu", t);
+        if (p[10] + p[11] > cutmax) cutmax = p[10] + p[11];
+    }
+    h->ters_cutmax = cutmax;
+    if (!rc && h->ters_params.ensure(sizeof(double) * 14 * np)) rc = set_err(h, VSSR_E_NOMEM, "tersoff params");
+    if (!rc && hipMemcpy(h->ters_params.p, params, sizeof(double) * 14 * np, hipMemcpyHostToDevice) != hipSuccess)
+        rc = set_err(h, VSSR_E_DEVICE, "tersoff params upload failed");
+    if (rc) {
+        g_create_error = h->err;
+        vssr_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return VSSR_OK;
+}
+
+void vssr_destroy(vssr_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->prof.destroy();
+    DevBuf *bufs[] = {&h->weights, &h->model_table, &h->offset_per_z, &h->ters_params, &h->d_pos, &h->d_wpos,
+                      &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
+                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters,
+                      &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
+                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f};
+    for (DevBuf *b : bufs) b->release();
+    if (h->h_counters) (void)hipHostFree(h->h_counters);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, const int32_t *Z, const double *pos,
+                      const double *cell, const uint8_t *pbc) {
+    if (!h) return VSSR_E_BADARG;
+    if (n_cfg < 1 || !n_atoms || !Z || !pos || !cell || !pbc) return set_err(h, VSSR_E_BADARG, "null or empty batch");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    VSSR_HIP(h, hipStreamSynchronize(h->stream));
+    h->batch_valid = false;
+    h->ran = false;
+    std::vector<int> start(n_cfg + 1, 0);
+    for (int b = 0; b < n_cfg; ++b) {
+        if (n_atoms[b] < 1) return set_err(h, VSSR_E_BADARG, "configuration %d has %d atoms", b, n_atoms[b]);
+        if ((int64_t)start[b] + n_atoms[b] > 2000000000LL) return set_err(h, VSSR_E_BADARG, "batch too large");
+        start[b + 1] = start[b] + n_atoms[b];
+    }
+    const int N = start[n_cfg];
+    std::vector<int> atom_cfg(N);
+    for (int b = 0; b < n_cfg; ++b)
+        for (int i = start[b]; i < start[b + 1]; ++i) atom_cfg[i] = b;
+    for (int i = 0; i < N; ++i)
+        if (Z[i] < 0 || Z[i] >= h->n_embed)
+            return set_err(h, VSSR_E_BADARG, "atom %d: species index %d outside [0,%d)", i, Z[i], h->n_embed);
+    for (size_t t = 0; t < (size_t)3 * N; ++t)
+        if (!std::isfinite(pos[t])) return set_err(h, VSSR_E_BADARG, "non-finite position");
+    std::vector<double> inv((size_t)9 * n_cfg);
+    std::vector<int> nimg((size_t)3 * n_cfg);
+    const double rc = handle_cutoff(h);
+    for (int b = 0; b < n_cfg; ++b) {
+        bool ok;
+        cell_host_setup(cell + 9 * b, pbc + 3 * b, rc, inv.data() + 9 * b, nimg.data() + 3 * b, ok);
+        if (!ok) return set_err(h, VSSR_E_BADARG, "configuration %d: periodic but singular cell", b);
+        for (int k = 0; k < 3; ++k)
+            if (nimg[3 * b + k] > 100) return set_err(h, VSSR_E_BADARG, "configuration %d: cell too thin for the cutoff", b);
+    }
+    if (h->d_pos.ensure(sizeof(double) * 3 * N) || h->d_Z.ensure(sizeof(int) * N) ||
+        h->d_atom_cfg.ensure(sizeof(int) * N) || h->d_cfg_start.ensure(sizeof(int) * (n_cfg + 1)) ||
+        h->d_cell.ensure(sizeof(double) * 9 * n_cfg) || h->d_invcell.ensure(sizeof(double) * 9 * n_cfg) ||
+        h->d_nimg.ensure(sizeof(int) * 3 * n_cfg) || h->d_pbc.ensure((size_t)3 * n_cfg))
+        return set_err(h, VSSR_E_NOMEM, "batch buffers: out of device memory");
+    VSSR_HIP(h, hipMemcpy(h->d_pos.p, pos, sizeof(double) * 3 * N, hipMemcpyHostToDevice));
+    VSSR_HIP(h, hipMemcpy(h->d_Z.p, Z, sizeof(int) * N, hipMemcpyHostToDevice));
+    VSSR_HIP(h, hipMemcpy(h->d_atom_cfg.p, atom_cfg.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+    VSSR_HIP(h, hipMemcpy(h->d_cfg_start.p, start.data(), sizeof(int) * (n_cfg + 1), hipMemcpyHostToDevice));
+    VSSR_HIP(h, hipMemcpy(h->d_cell.p, cell, sizeof(double) * 9 * n_cfg, hipMemcpyHostToDevice));
+    VSSR_HIP(h, hipMemcpy(h->d_invcell.p, inv.data(), sizeof(double) * 9 * n_cfg, hipMemcpyHostToDevice));
+    VSSR_HIP(h, hipMemcpy(h->d_nimg.p, nimg.data(), sizeof(int) * 3 * n_cfg, hipMemcpyHostToDevice));
+    VSSR_HIP(h, hipMemcpy(h->d_pbc.p, pbc, (size_t)3 * n_cfg, hipMemcpyHostToDevice));
+    h->n_cfg = n_cfg;
+    h->n_atoms = N;
+    h->h_n_atoms.assign(n_atoms, n_atoms + n_cfg);
+    h->h_cfg_start = start;
+    h->batch_valid = true;
+    return VSSR_OK;
+}
+
+int vssr_batch_set_positions(vssr_handle *h, const double *pos) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->batch_valid) return set_err(h, VSSR_E_STATE, "no resident batch");
+    if (!pos) return set_err(h, VSSR_E_BADARG, "null positions");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    VSSR_HIP(h, hipStreamSynchronize(h->stream));
+    VSSR_HIP(h, hipMemcpy(h->d_pos.p, pos, sizeof(double) * 3 * h->n_atoms, hipMemcpyHostToDevice));
+    return VSSR_OK;
+}
+
+int vssr_batch_run(vssr_handle *h, uint32_t want) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->batch_valid) return set_err(h, VSSR_E_STATE, "vssr_batch_run before vssr_batch_upload");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    int rc = run_any(h, want);
+    if (rc) return rc;
+    h->ran = true;
+    return VSSR_OK;
+}
+
+int vssr_synchronize(vssr_handle *h) {
+    if (!h) return VSSR_E_BADARG;
+    VSSR_HIP(h, hipSetDevice(h->device));
+    return sync_and_check(h, VSSR_WANT_ENERGY | VSSR_WANT_FORCES);
+}
+
+int vssr_batch_download(vssr_handle *h, uint32_t want, vssr_out *out) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->ran) return set_err(h, VSSR_E_STATE, "vssr_batch_download before vssr_batch_run");
+    if (!out) return set_err(h, VSSR_E_BADARG, "null output");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    int rc = sync_and_check(h, want);
+    if (rc) return rc;
+    const size_t B = h->n_cfg, N = h->n_atoms, M = h->n_models;
+    if (h->kind == 2) {
+        std::vector<double> e(B), ea(N), f(3 * N);
+        VSSR_HIP(h, hipMemcpy(e.data(), h->d_ters_e.p, sizeof(double) * B, hipMemcpyDeviceToHost));
+        if (out->energy) for (size_t b = 0; b < B; ++b) out->energy[b] = (float)e[b];
+        if (out->energy_atoms && (want & VSSR_WANT_PER_ATOM)) {
+            VSSR_HIP(h, hipMemcpy(ea.data(), h->d_ters_ea.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < N; ++i) out->energy_atoms[i] = (float)ea[i];
+        }
+        if (out->forces && (want & VSSR_WANT_FORCES)) {
+            VSSR_HIP(h, hipMemcpy(f.data(), h->d_ters_f.p, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < 3 * N; ++i) out->forces[i] = (float)f[i];
+        }
+        return VSSR_OK;
+    }
+    if (out->energy) VSSR_HIP(h, hipMemcpy(out->energy, h->d_energy.p, sizeof(float) * B, hipMemcpyDeviceToHost));
+    if (out->energy_std && (want & VSSR_WANT_STD))
+        VSSR_HIP(h, hipMemcpy(out->energy_std, h->d_energy_std.p, sizeof(float) * B, hipMemcpyDeviceToHost));
+    if (out->energy_models && (want & VSSR_WANT_PER_MODEL))
+        VSSR_HIP(h, hipMemcpy(out->energy_models, h->d_energy_models.p, sizeof(float) * B * M, hipMemcpyDeviceToHost));
+    if (out->energy_atoms && (want & VSSR_WANT_PER_ATOM))
+        VSSR_HIP(h, hipMemcpy(out->energy_atoms, h->d_e_atoms.p, sizeof(float) * N, hipMemcpyDeviceToHost));
+    if (want & VSSR_WANT_FORCES) {
+        if (out->forces) VSSR_HIP(h, hipMemcpy(out->forces, h->d_forces.p, sizeof(float) * 3 * N, hipMemcpyDeviceToHost));
+        if (out->forces_std && (want & VSSR_WANT_STD))
+            VSSR_HIP(h, hipMemcpy(out->forces_std, h->d_forces_std.p, sizeof(float) * 3 * N, hipMemcpyDeviceToHost));
+    }
+    return VSSR_OK;
+}
+
+int vssr_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, const int32_t *Z, const double *pos,
+                    const double *cell, const uint8_t *pbc, uint32_t want, vssr_out *out) {
+    int rc = vssr_batch_upload(h, n_cfg, n_atoms, Z, pos, cell, pbc);
+    if (rc) return rc;
+    rc = vssr_batch_run(h, want);
+    if (rc) return rc;
+    return vssr_batch_download(h, want, out);
+}
+
+int vssr_eval(vssr_handle *h, int32_t n_atoms, const int32_t *Z, const double *pos, const double cell[9],
+              const uint8_t pbc[3], uint32_t want, vssr_out *out) {
+    return vssr_eval_batch(h, 1, &n_atoms, Z, pos, cell, pbc, want, out);
+}
+
+int vssr_tersoff_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, const int32_t *type,
+                            const double *pos, const double *cell, const uint8_t *pbc, uint32_t want, vssr_out *out,
+                            double *energy_f64, double *energy_atoms_f64, double *forces_f64) {
+    if (!h) return VSSR_E_BADARG;
+    if (h->kind != 2) return set_err(h, VSSR_E_STATE, "not a Tersoff handle");
+    vssr_out dummy;
+    memset(&dummy, 0, sizeof dummy);
+    int rc = vssr_eval_batch(h, n_cfg, n_atoms, type, pos, cell, pbc, want, out ? out : &dummy);
+    if (rc) return rc;
+    if (energy_f64) VSSR_HIP(h, hipMemcpy(energy_f64, h->d_ters_e.p, sizeof(double) * h->n_cfg, hipMemcpyDeviceToHost));
+    if (energy_atoms_f64)
+        VSSR_HIP(h, hipMemcpy(energy_atoms_f64, h->d_ters_ea.p, sizeof(double) * h->n_atoms, hipMemcpyDeviceToHost));
+    if (forces_f64)
+        VSSR_HIP(h, hipMemcpy(forces_f64, h->d_ters_f.p, sizeof(double) * 3 * h->n_atoms, hipMemcpyDeviceToHost));
+    return VSSR_OK;
+}
+
+// ---- introspection ---------------------------------------------------------------------------------------
+int vssr_profile_enable(vssr_handle *h, int enable) {
+    if (!h) return VSSR_E_BADARG;
+    VSSR_HIP(h, hipStreamSynchronize(h->stream));
+    h->prof.collect();
+    h->prof.enabled = enable != 0;
+    return VSSR_OK;
+}
+int vssr_profile_reset(vssr_handle *h) {
+    if (!h) return VSSR_E_BADARG;
+    VSSR_HIP(h, hipStreamSynchronize(h->stream));
+    h->prof.reset();
+    return VSSR_OK;
+}
+int vssr_profile_read(vssr_handle *h, int32_t cap, const char **names, int64_t *launches, double *total_ms,
+                      int32_t *n_out) {
+    if (!h || !n_out) return VSSR_E_BADARG;
+    VSSR_HIP(h, hipStreamSynchronize(h->stream));
+    h->prof.collect();
+    int n = 0;
+    for (int k = 0; k < KC_COUNT && n < cap; ++k) {
+        if (names) names[n] = kKernelClassNames[k];
+        if (launches) launches[n] = h->prof.launches[k];
+        if (total_ms) total_ms[n] = h->prof.total_ms[k];
+        ++n;
+    }
+    *n_out = n;
+    return VSSR_OK;
+}
+
+int vssr_batch_stats(vssr_handle *h, int64_t *n_atoms, int64_t *n_edges, int64_t *n_slots) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->ran) return set_err(h, VSSR_E_STATE, "no completed run");
+    int rc = sync_and_check(h, VSSR_WANT_ENERGY | VSSR_WANT_FORCES);
+    if (rc) return rc;
+    if (n_atoms) *n_atoms = h->n_atoms;
+    if (n_edges) *n_edges = h->h_counters[1];
+    if (n_slots) *n_slots = h->h_counters[0];
+    return VSSR_OK;
+}
+
+int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, int32_t *eS, float *er,
+                         int64_t *n_edges) {
+    if (!h || !n_edges) return VSSR_E_BADARG;
+    if (!h->ran) return set_err(h, VSSR_E_STATE, "no completed run");
+    int rc = sync_and_check(h, VSSR_WANT_ENERGY | VSSR_WANT_FORCES);
+    if (rc) return rc;
+    const int N = h->n_atoms;
+    const int64_t slots = h->h_counters[0];
+    *n_edges = h->h_counters[1];
+    if (!ei && !ej && !eS && !er) return VSSR_OK;
+    std::vector<int> row(N + 1), S(slots), wrap((size_t)3 * N);
+    std::vector<float4> edge(slots);
+    VSSR_HIP(h, hipMemcpy(row.data(), h->d_row_start.p, sizeof(int) * (N + 1), hipMemcpyDeviceToHost));
+    VSSR_HIP(h, hipMemcpy(S.data(), h->d_edge_S.p, sizeof(int) * slots, hipMemcpyDeviceToHost));
+    VSSR_HIP(h, hipMemcpy(edge.data(), h->d_edge.p, sizeof(float4) * slots, hipMemcpyDeviceToHost));
+    VSSR_HIP(h, hipMemcpy(wrap.data(), h->d_wrap.p, sizeof(int) * 3 * N, hipMemcpyDeviceToHost));
+    int64_t n = 0;
+    for (int i = 0; i < N; ++i)
+        for (int e = row[i]; e < row[i + 1]; ++e) {
+            int j;
+            memcpy(&j, &edge[e].w, sizeof(int));
+            if (j < 0) continue;
+            if (n < cap) {
+                if (ei) ei[n] = i;
+                if (ej) ej[n] = j;
+                if (eS)  // true image shift: S = S' + wrap_i - wrap_j
+                    for (int k = 0; k < 3; ++k)
+                        eS[3 * n + k] = (((S[e] >> (8 * k)) & 255) - 128) + wrap[3 * i + k] - wrap[3 * j + k];
+                if (er) { er[3 * n] = edge[e].x; er[3 * n + 1] = edge[e].y; er[3 * n + 2] = edge[e].z; }
+            }
+            ++n;
+        }
+    return VSSR_OK;
+}
+
+int vssr_debug_read(vssr_handle *h, const char *name, int32_t model, float *dst, int64_t cap, int64_t *n_out) {
+    if (!h || !name || !n_out) return VSSR_E_BADARG;
+    if (!h->ran || h->kind != 1) return set_err(h, VSSR_E_STATE, "no completed PaiNN run");
+    if (model < 0 || model >= h->n_models) return set_err(h, VSSR_E_BADARG, "model index out of range");
+    int rc = sync_and_check(h, VSSR_WANT_ENERGY | VSSR_WANT_FORCES);
+    if (rc) return rc;
+    const size_t N = h->n_atoms;
+    const StateView &sv = h->sv;
+    const float *src = nullptr;
+    size_t per_atom = 0;
+    std::string nm(name);
+    auto layer_of = [&](const char *prefix) -> int {
+        size_t pl = strlen(prefix);
+        if (nm.compare(0, pl, prefix) != 0 || nm.size() != pl + 1) return -1;
+        int l = nm[pl] - '0';
+        return (l >= 0 && l < h->num_conv) ? l : -1;
+    };
+    int l;
+    if ((l = layer_of("phi")) >= 0) { src = sv.phi[l]; per_atom = F3; }
+    else if ((l = layer_of("s_msg")) >= 0) { src = sv.s_msg[l]; per_atom = F; }
+    else if ((l = layer_of("v_msg")) >= 0) { src = sv.v_msg[l]; per_atom = F3; }
+    else if ((l = layer_of("s_upd")) >= 0) { src = sv.s_in[l + 1]; per_atom = F; }
+    else if ((l = layer_of("v_upd")) >= 0) { src = sv.v_in[l + 1]; per_atom = F3; }
+    else if (nm == "e_atom") { src = sv.e_atom; per_atom = 1; }
+    else if (nm == "sbar_msg0") { src = sv.sbar_msg; per_atom = F; }   // reverse buffers hold the LAST layer processed
+    else if (nm == "vbar_msg0") { src = sv.vbar_msg; per_atom = F3; }
+    else return set_err(h, VSSR_E_BADARG, "unknown intermediate '%s'", name);
+    size_t n = N * per_atom;
+    *n_out = (int64_t)n;
+    if (!dst) return VSSR_OK;
+    if ((int64_t)n > cap) return set_err(h, VSSR_E_BADARG, "buffer too small for '%s'", name);
+    VSSR_HIP(h, hipMemcpy(dst, src + (size_t)model * n, n * sizeof(float), hipMemcpyDeviceToHost));
+    return VSSR_OK;
+}
+
+}  // extern "C"

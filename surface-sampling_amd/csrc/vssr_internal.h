@@ -1,0 +1,189 @@
+// vssr_internal.h — shared declarations of the gfx950 evaluation backend (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vssr_eval.h"
+
+namespace vssr {
+
+constexpr int F = 128;        // feat_dim (compiled value)
+constexpr int F3 = 3 * F;
+constexpr int MAX_LAYERS = 4;
+constexpr int MAX_MODELS = 8;
+constexpr int RB_MAX = 24;    // n_rbf + 1 (envelope/bias column) padded to a multiple of 4
+constexpr int NODE_TILE = 8;  // atoms per workgroup in the node kernels
+
+// ---- device-side views -------------------------------------------------------------------
+struct LayerW {
+    const float *W1, *W1t, *b1;  // [F][F], transposed [F][F]
+    const float *W2, *W2t, *b2;  // [3F][F], transposed [F][3F]
+    const float *Wd, *bd;        // [3F][R], [3F]
+    const float *U, *Ut, *V, *Vt;  // [F][F]
+    const float *W3, *W3t, *b3;  // [F][2F], transposed [2F][F]
+    const float *W4, *W4t, *b4;  // [3F][F], transposed [F][3F]
+};
+struct ModelW {
+    const float *embed;  // [n_embed][F]
+    LayerW layer[MAX_LAYERS];
+    const float *W5, *W5t, *b5, *w6, *b6;  // [H][F], [F][H], [H], [H], [1]
+};
+
+struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by centre)
+    int n_atoms;             // total atoms in the batch
+    int n_cfg;
+    const int *atom_cfg;     // [n_atoms] configuration (chain) of each atom
+    const int *cfg_start;    // [n_cfg+1]
+    const int *row_start;    // [n_atoms+1] first slot of each centre (slot counts are multiples of 4)
+    const int *deg;          // [n_atoms] real degree (unpadded)
+    const float4 *edge;      // [slots] {r_x, r_y, r_z, bitcast(j)} ; j < 0 marks a pad slot
+    const int *rev;          // [slots] slot of the reverse edge (j -> i, -S)
+};
+
+struct StateView {  // activations of all models: index [m][atom][...]
+    int n_atoms;
+    int n_models;
+    // forward
+    float *s_in[MAX_LAYERS + 1];  // [M][N][F]   state entering layer l (l = L: final)
+    float *v_in[MAX_LAYERS + 1];  // [M][N][3][F]
+    float *phi[MAX_LAYERS];       // [M][N][3F]
+    float *s_msg[MAX_LAYERS];     // after message block l
+    float *v_msg[MAX_LAYERS];
+    float *e_atom;                // [M][N]
+    float *e_excl;                // [M][N] excluded-volume part
+    // reverse
+    float *sbar;                  // [M][N][F]     adjoint of s_in[l+1] / s_in[l]
+    float *vbar;                  // [M][N][3][F]
+    float *sbar_msg;              // adjoint of s_msg[l]
+    float *vbar_msg;
+    float *phibar;                // [M][N][3F]
+    float4 *gbar;                 // [M][slots] dE/d r for the edge (j -> i) stored at slot (i, j)
+};
+
+// ---- host-side helpers ----------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {  // grow-only; contents are NOT preserved
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) return -1;
+        bytes = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+enum KernelClass {
+    KC_NBR = 0,
+    KC_EMBED,
+    KC_MSG_MLP,
+    KC_EDGE_FWD,
+    KC_UPDATE_FWD,
+    KC_READOUT,
+    KC_UPDATE_BWD,
+    KC_EDGE_BWD,
+    KC_MSG_MLP_BWD,
+    KC_FINALIZE,
+    KC_TERSOFF,
+    KC_COUNT
+};
+extern const char *const kKernelClassNames[KC_COUNT];
+
+struct Profiler {
+    bool enabled = false;
+    struct Rec { int kc; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    int64_t launches[KC_COUNT] = {0};
+    double total_ms[KC_COUNT] = {0};
+    hipEvent_t get_event();
+    void begin(int kc, hipStream_t s);
+    void end(hipStream_t s);
+    void collect();  // stream must be synchronised
+    void reset();
+    void destroy();
+};
+
+}  // namespace vssr
+
+struct vssr_handle {
+    int kind = 0;  // 1 = PaiNN ensemble, 2 = Tersoff
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    vssr::Profiler prof;
+
+    // configuration
+    int n_models = 0, n_rbf = 20, num_conv = 3, n_embed = 100, readout_hidden = 64;
+    float cutoff = 5.f;
+    int excl_vol = 1, excl_power = 12;
+    float excl_sigma = 1.5f;
+    double units_per_ev = 1.0;
+    bool has_offset = false;
+    double offset_const = 0.0;
+
+    // weights
+    vssr::DevBuf weights;        // all model blobs + transposed copies
+    vssr::DevBuf model_table;    // ModelW[n_models]
+    vssr::DevBuf offset_per_z;   // double[n_embed]
+
+    // tersoff
+    int n_types = 0;
+    double ters_cutmax = 0;
+    vssr::DevBuf ters_params;    // double[nt^3][14]
+
+    // resident batch
+    bool batch_valid = false, ran = false;
+    int n_cfg = 0, n_atoms = 0;
+    std::vector<int> h_n_atoms, h_cfg_start;
+    vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
+    vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
+    int64_t slot_cap = 0;
+    int *h_counters = nullptr;   // pinned: [0] total slots, [1] total real edges, [2] overflow flag
+
+    // state
+    vssr::DevBuf d_state;        // one arena for all activations
+    vssr::StateView sv;
+    vssr::DevBuf d_gbar;
+    // results (device)
+    vssr::DevBuf d_energy, d_energy_std, d_energy_models, d_forces, d_forces_std, d_e_atoms;
+    vssr::DevBuf d_ters_e, d_ters_ea, d_ters_f;  // fp64 Tersoff results
+};
+
+namespace vssr {
+
+int set_err(vssr_handle *h, int code, const char *fmt, ...);
+#define VSSR_HIP(h, expr)                                                                    \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return vssr::set_err(h, VSSR_E_DEVICE, "%s failed: %s (%s:%d)", #expr,          \
+                                 hipGetErrorString(_e), __FILE__, __LINE__);                 \
+    } while (0)
+
+// neighbor list (nbr.hip)
+int build_neighbors(vssr_handle *h, double cutoff);
+// PaiNN pipeline (painn.hip)
+int painn_alloc_state(vssr_handle *h);
+int painn_run(vssr_handle *h, uint32_t want);
+// Tersoff (tersoff.hip)
+int tersoff_run(vssr_handle *h, uint32_t want);
+
+}  // namespace vssr

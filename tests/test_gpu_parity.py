@@ -1,0 +1,278 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against the CPU oracle.
+
+Stated tolerances: GPU fp32 vs the fp64 oracle |dE| <= 1e-4 eV per structure
+(N <= ~270), max|dF| <= 2e-4 eV/A; vs the reference's printed known answers |dE| <= 2e-4 eV,
+|d fmax| <= 1e-5 eV/A; neighbor edge sets identical; Tersoff (fp64 on device) <= 1e-9 relative.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import top_layer
+
+pytestmark = pytest.mark.gpu
+
+E_TOL = 1e-4      # eV, GPU fp32 vs fp64 oracle
+F_TOL = 2e-4      # eV/A
+STD_TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def engine(golden):
+    from surface_sampling_amd import backend
+
+    table, const = golden.offset_table()
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    yield eng
+    eng.close()
+
+
+def _arrays(s):
+    return (s.numbers, s.positions, s.cell, s.pbc)
+
+
+def _oracle(golden, oracle_mod, s, bits=64):
+    table, const = golden.offset_table()
+    return oracle_mod.ensemble(golden.blobs, s.numbers, s.positions, s.cell, s.pbc, bits, table, const)
+
+
+def test_kat_structures_vs_reference_prints_and_oracle(golden, oracle_mod, engine):
+    tol = golden.kat["tolerance"]
+    for case in golden.kat["painn_ensemble"]:
+        s = golden.structure(case["structure"])
+        res = engine.evaluate([_arrays(s)])
+        ref = _oracle(golden, oracle_mod, s)
+        e = float(res["energy"][0])
+        assert abs(e - case["energy"]) <= tol["energy_abs"], (case["structure"], e)
+        assert abs(e - ref["energy"]) <= E_TOL
+        free = top_layer(s) if case["free_atoms"] == "top_layer" else np.array(case["free_atoms"])
+        fmax = np.linalg.norm(res["forces"][free].astype(np.float64), axis=1).max()
+        assert abs(fmax - case["fmax"]) <= 2e-5, (case["structure"], fmax)  # fp64-positions vs fp32 print
+        assert np.abs(res["forces"] - ref["forces"]).max() <= F_TOL
+        assert abs(float(res["energy_std"][0]) - ref["energy_std"]) <= STD_TOL
+        assert np.abs(res["forces_std"] - ref["forces_std"]).max() <= STD_TOL
+        assert np.abs(res["energy_models"][0] - ref["energy_models"]).max() <= 2e-4
+
+
+def test_neighbor_edge_sets_identical(golden, oracle_mod, engine):
+    from surface_sampling_amd import structures
+
+    base = golden.structure("SrTiO3_2x2_pristine")
+    big = base.repeat((2, 2, 1))
+    shifted = big.copy()
+    shifted.positions[::5] += 3 * big.cell[0] - 2 * big.cell[1]  # atoms far outside the cell
+    batch = [base, golden.structure("O44Sr12Ti16"), structures.synth_chain(big, 4), shifted,
+             golden.structure("SrTiO3_2x2x4_pristine")]
+    engine.evaluate([_arrays(s) for s in batch])
+    ei, ej, eS, er = engine.neighbors()
+    start = 0
+    got_all = sorted(zip(ei.tolist(), ej.tolist(), map(tuple, eS.tolist())))
+    want_all = []
+    for s in batch:
+        oi, oj, oS, orr = oracle_mod.neighbors(s.positions, s.cell, s.pbc, 5.0)
+        want_all += list(zip((oi + start).tolist(), (oj + start).tolist(), map(tuple, oS.tolist())))
+        start += len(s)
+    assert got_all == sorted(want_all)
+    st = engine.stats()
+    assert st["edges"] == len(want_all) and st["atoms"] == start and st["slots"] >= st["edges"]
+    # stored fp32 edge vectors agree with the fp64 ones
+    s = batch[0]
+    oi, oj, oS, orr = oracle_mod.neighbors(s.positions, s.cell, s.pbc, 5.0)
+    n0 = len(oi)
+    key_g = np.lexsort((eS[:n0, 2], eS[:n0, 1], eS[:n0, 0], ej[:n0], ei[:n0]))
+    key_o = np.lexsort((oS[:, 2], oS[:, 1], oS[:, 0], oj, oi))
+    assert np.abs(er[:n0][key_g] - orr[key_o]).max() < 2e-6
+
+
+def test_per_layer_intermediates_match_oracle(golden, oracle_mod, engine):
+    """Every stored activation of every layer vs the fp64 oracle (model 2 of the ensemble)."""
+    from surface_sampling_amd import structures
+
+    s = structures.synth_chain(golden.structure("SrTiO3_2x2_pristine"), 2, grid=(4, 4))
+    engine.evaluate([_arrays(s)])
+    m = 1
+    E, G, d = oracle_mod.painn(golden.blobs[m], s.numbers, s.positions, s.cell, s.pbc, 64, dump=True)
+    n = len(s)
+    report = []
+    for l in range(3):
+        for name, shape in (("phi", (n, 384)), ("s_msg", (n, 128)), ("v_msg", (n, 3, 128)),
+                            ("s_upd", (n, 128)), ("v_upd", (n, 3, 128))):
+            got = engine.debug_read(f"{name}{l}", m).reshape(shape).astype(np.float64)
+            want = d[name][l]
+            scale = max(1.0, np.abs(want).max())
+            report.append((f"{name}{l}", np.abs(got - want).max() / scale))
+    got = engine.debug_read("e_atom", m).astype(np.float64)
+    report.append(("e_atom", np.abs(got - d["e_atom"]).max() / max(1.0, np.abs(d["e_atom"]).max())))
+    for name, shape in (("sbar_msg", (n, 128)), ("vbar_msg", (n, 3, 128))):
+        got = engine.debug_read(f"{name}0", m).reshape(shape).astype(np.float64)
+        want = d[name][0]
+        report.append((f"{name}0", np.abs(got - want).max() / max(1.0, np.abs(want).max())))
+    bad = [(k, v) for k, v in report if not v < 2e-5]
+    assert not bad, f"intermediates off: {bad}; all: {report}"
+
+
+def test_batched_ragged_chains_vs_oracle_and_vs_single(golden, oracle_mod, engine):
+    from surface_sampling_amd import structures
+
+    big = golden.structure("SrTiO3_2x2_pristine").repeat((2, 2, 1))
+    chains = [structures.synth_chain(big, c) for c in (0, 7, 24)] + [golden.structure("O40Sr16Ti12")]
+    res = engine.evaluate([_arrays(s) for s in chains])
+    for b, s in enumerate(chains):
+        a0, a1 = res["cfg_start"][b], res["cfg_start"][b + 1]
+        assert a1 - a0 == len(s)
+        ref = _oracle(golden, oracle_mod, s)
+        assert abs(float(res["energy"][b]) - ref["energy"]) <= E_TOL, (b, float(res["energy"][b]), ref["energy"])
+        assert np.abs(res["forces"][a0:a1] - ref["forces"]).max() <= F_TOL
+        single = engine.evaluate([_arrays(s)])
+        assert float(single["energy"][0]) == float(res["energy"][b])  # batching changes nothing, bit for bit
+        assert np.array_equal(single["forces"], res["forces"][a0:a1])
+    # committed fp64 vectors (guards against oracle and GPU drifting together)
+    f = golden.fine
+    for name in ("S240", "chain17"):
+        r = engine.evaluate([(f[f"{name}.numbers"], f[f"{name}.positions"], f[f"{name}.cell"], f[f"{name}.pbc"])])
+        assert abs(float(r["energy"][0]) - float(f[f"{name}.energy"])) <= E_TOL
+        assert np.abs(r["forces"] - f[f"{name}.forces"]).max() <= F_TOL
+
+
+def test_run_to_run_determinism_and_energy_only(golden, engine):
+    from surface_sampling_amd import backend, structures
+
+    big = golden.structure("SrTiO3_2x2_pristine").repeat((2, 2, 1))
+    chains = [_arrays(structures.synth_chain(big, c)) for c in range(6)]
+    a = engine.evaluate(chains)
+    b = engine.evaluate(chains)
+    for k in ("energy", "forces", "energy_std", "forces_std"):
+        assert np.array_equal(a[k], b[k]), k
+    engine.upload(chains)
+    engine.run(backend.WANT_ENERGY)
+    e_only = engine.download(backend.WANT_ENERGY)
+    assert np.array_equal(e_only["energy"], a["energy"])
+
+
+def test_full_size_properties_256_chains(golden, engine):
+    """BASELINE config 4 size (256 chains x ~260 atoms): size-independent physical properties."""
+    from surface_sampling_amd import structures
+
+    big = golden.structure("SrTiO3_2x2_pristine").repeat((2, 2, 1))
+    chains = [structures.synth_chain(big, c) for c in range(256)]
+    res = engine.evaluate([_arrays(s) for s in chains])
+    assert np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()
+    cs = res["cfg_start"]
+    # (1) translation invariance: net force on every chain vanishes
+    net = np.array([res["forces"][cs[b]:cs[b + 1]].astype(np.float64).sum(0) for b in range(256)])
+    assert np.abs(net).max() < 5e-4
+    # (2) chains c and c+25k share the adsorbate count rule; identical inputs give identical outputs
+    dup = engine.evaluate([_arrays(chains[3]), _arrays(chains[3])])
+    assert dup["energy"][0] == dup["energy"][1] == res["energy"][3]
+    # (3) rigid translation + lattice-vector wrap + atom permutation leave E unchanged, permute F
+    s = chains[11]
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(s))
+    moved = structures.Structure(s.numbers[perm], s.positions[perm] + np.array([1.234, -0.77, 0.0]) + 2 * s.cell[1],
+                                 s.cell, s.pbc)
+    r2 = engine.evaluate([_arrays(moved)])
+    assert abs(float(r2["energy"][0]) - float(res["energy"][11])) < 2e-4
+    assert np.abs(r2["forces"] - res["forces"][cs[11]:cs[12]][perm]).max() < 3e-4
+    st = engine.stats()
+    assert st["atoms"] == len(moved)
+
+
+def test_forces_are_energy_gradient_on_gpu(golden, engine):
+    """Central finite differences of the GPU energy along random directions vs GPU forces."""
+    from surface_sampling_amd import backend, structures
+
+    s = structures.synth_chain(golden.structure("SrTiO3_2x2_pristine"), 1, grid=(4, 4))
+    res = engine.evaluate([_arrays(s)])
+    rng = np.random.default_rng(5)
+    h = 2e-3
+    for _ in range(3):
+        dirn = rng.normal(size=s.positions.shape)
+        dirn /= np.linalg.norm(dirn)
+        plus = engine.evaluate([(s.numbers, s.positions + h * dirn, s.cell, s.pbc)], backend.WANT_ENERGY | backend.WANT_PER_MODEL)
+        minus = engine.evaluate([(s.numbers, s.positions - h * dirn, s.cell, s.pbc)], backend.WANT_ENERGY | backend.WANT_PER_MODEL)
+        fd = -(float(plus["energy"][0]) - float(minus["energy"][0])) / (2 * h)
+        an = float((res["forces"].astype(np.float64) * dirn).sum())
+        assert abs(fd - an) < 5e-2 * max(1.0, abs(an)), (fd, an)  # fp32 energies: coarse FD only
+
+
+def test_tersoff_gpu_vs_oracle(golden, oracle_mod):
+    from surface_sampling_amd import backend
+
+    eng = backend.TersoffEngine(golden.tersoff_params, device=0)
+    s = golden.structure("GaN_3x3_pristine")
+    types = np.array([0 if z == 31 else 1 for z in s.numbers], np.int32)
+    f = golden.fine
+    batch = [(types, s.positions, s.cell, [1, 1, 1]), (f["GaN_rattled.types"], f["GaN_rattled.positions"], s.cell, [1, 1, 1])]
+    rng = np.random.default_rng(11)
+    ads = np.r_[s.positions, s.positions[18:30] + [0.3, 0.2, 1.9]] + rng.normal(0, 0.03, (48, 3))
+    batch.append((np.r_[types, np.zeros(12, np.int32)], ads, s.cell, [1, 1, 1]))  # 36 + 12 Ga (config 2)
+    e, ea, F = eng.evaluate_f64(batch)
+    assert abs(e[0] - golden.kat["tersoff"]["energy"]) <= golden.kat["tolerance"]["tersoff_energy_abs"]
+    o = 0
+    for b, (t, p, c, pbc) in enumerate(batch):
+        E0, ea0, F0 = oracle_mod.tersoff(golden.tersoff_params, t, p, c, pbc)
+        n = len(t)
+        assert abs(e[b] - E0) <= 1e-9 * abs(E0)
+        assert np.abs(ea[o:o + n] - ea0).max() <= 1e-9
+        assert np.abs(F[o:o + n] - F0).max() <= 1e-8
+        o += n
+    eng.close()
+
+
+def test_calculator_front_end_end_to_end(golden, oracle_mod):
+    """The reference-shaped calculator on plain Atoms-like objects (scripts/sample_surface.py:168-183)."""
+    import copy
+
+    from surface_sampling_amd.calculators import EnsembleNFFSurface, TersoffSurfCalc
+
+    calc = EnsembleNFFSurface(golden.blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV",
+                              offset_units="atomic")
+    calc.set(offset=True, offset_data=golden.offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0}, relax_steps=20)
+    s = golden.structure("O36Sr12Ti12")
+    s.calc = calc
+    e = s.get_potential_energy()
+    assert e.shape == (1,) and abs(float(e[0]) - (-467.525604)) <= 2e-4
+    f = s.get_forces()
+    assert f.shape == (len(s), 3)
+    se = calc.get_property("surface_energy", atoms=s)
+    ref = _oracle(golden, oracle_mod, s)
+    from surface_sampling_amd.calculators import surface_energy_from_energy
+
+    want = surface_energy_from_energy(ref["energy"], s.get_chemical_symbols(), calc.chem_pots, golden.offset_data)
+    assert abs(float(np.ravel(se)[0]) - want) < 2e-4
+    assert "energy" in s.results and "forces_std" in calc.results
+    twin = copy.deepcopy(calc)
+    assert abs(float(twin.get_potential_energy(s)[0]) - float(e[0])) == 0.0
+    outs = calc.calculate_batch([s, golden.structure("O44Sr12Ti16")], want_surface_energy=True)
+    assert abs(float(outs[0]["energy"][0]) - float(e[0])) == 0.0 and abs(float(np.ravel(outs[1]["surface_energy"])[0]) - 35.993) < 5e-3
+    # without the offset switch the stoichiometric offset is not applied
+    raw = EnsembleNFFSurface(golden.blobs, device="cuda:0")
+    e_raw = float(raw.get_potential_energy(s)[0])
+    table, const = golden.offset_table()
+    assert abs(e_raw + table[s.numbers].sum() + const - float(e[0])) < 5e-4
+
+    tcalc = TersoffSurfCalc(golden.tersoff_params, ["Ga", "N"], device="cuda:0")
+    g = golden.structure("GaN_3x3_pristine")
+    assert abs(tcalc.get_potential_energy(g) - (-144.059)) < 1e-3
+    assert tcalc.get_property("per_atom_energies", g).shape == (36,)
+    assert abs(tcalc.get_property("surface_energy", g) - tcalc.results["energy"]) == 0.0
+
+
+def test_error_paths(golden, engine):
+    from surface_sampling_amd import backend
+
+    s = golden.structure("SrTiO3_2x2_pristine")
+    with pytest.raises(backend.BackendError):
+        engine.evaluate([(np.full(len(s), 150, np.int32), s.positions, s.cell, s.pbc)])  # species out of range
+    bad = s.positions.copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(backend.BackendError):
+        engine.evaluate([(s.numbers, bad, s.cell, s.pbc)])
+    with pytest.raises(backend.BackendError):
+        engine.evaluate([(s.numbers, s.positions, np.zeros((3, 3)), s.pbc)])  # singular periodic cell
+    # the engine still works afterwards
+    ok = engine.evaluate([_arrays(s)])
+    assert abs(float(ok["energy"][0]) - (-467.5219)) < 1e-3
+    # a single isolated atom (no neighbors at all) is a valid configuration
+    lone = engine.evaluate([(np.array([8], np.int32), np.zeros((1, 3)), np.eye(3) * 30.0, [0, 0, 0])])
+    assert np.isfinite(lone["energy"][0]) and np.abs(lone["forces"]).max() == 0.0

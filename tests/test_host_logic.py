@@ -1,0 +1,139 @@
+"""CPU: host-side logic of the package — data formats, the calculator surface mirrored from the
+reference, the surface-energy wrapper KATs, and that the C-ABI library loads and exports every
+symbol include/vssr_eval.h declares (no compute calls without a GPU)."""
+
+import copy
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from surface_sampling_amd import backend, checkpoint, structures, tersoff
+from surface_sampling_amd import calculators as calcs
+
+
+def test_blob_layout_roundtrip(golden):
+    shapes = checkpoint.painn_blob_shapes()
+    total = sum(int(np.prod(s)) for s in shapes.values())
+    assert total == 589057 == golden.blobs[0].size
+    fields = checkpoint.blob_to_fields(golden.blobs[0])
+    assert fields["embed"].shape == (100, 128) and np.all(fields["embed"][0] == 0)  # padding row
+    assert fields["msg0.Wd"].shape == (384, 20) and fields["readout.w6"].shape == (1, 64)
+    with pytest.raises(ValueError):
+        checkpoint.blob_to_fields(golden.blobs[0][:-1])
+    assert len(checkpoint.painn_blob_order()) == 41
+
+
+def test_tersoff_parser(golden):
+    text = """# comment
+    Ga Ga Ga 1.0 0.007874 1.846 1.918000 0.75000 -0.301300 1.0 1.0
+             1.44970 410.132 2.87 0.15 1.60916 535.199
+    """
+    p = tersoff.parse_tersoff(text, ["Ga"])
+    assert p.shape == (1, 1, 1, 14) and p[0, 0, 0, 13] == 535.199 and p[0, 0, 0, 10] == 2.87
+    with pytest.raises(ValueError):
+        tersoff.parse_tersoff(text, ["Ga", "N"])  # missing triplets
+    P = golden.tersoff_params
+    assert P.shape == (2, 2, 2, 14) and abs(tersoff.max_cutoff(P) - 3.1) < 1e-12
+
+
+def test_structure_helpers(golden):
+    s = golden.structure("SrTiO3_2x2_pristine")
+    assert len(s) == 60 and s.formula_counts() == {"O": 36, "Sr": 12, "Ti": 12}
+    big = s.repeat((2, 2, 1))
+    assert len(big) == 240 and np.allclose(big.cell[0], 2 * s.cell[0])
+    c = structures.synth_chain(big, 5)
+    assert len(c) == 240 + 8 + 5
+    c2 = structures.synth_chain(big, 5)
+    assert np.array_equal(c.positions, c2.positions)  # deterministic in the chain index
+    Z, pos, cell, pbc = structures.as_arrays(s)
+    assert Z.dtype == np.int32 and pos.dtype == np.float64 and pbc.dtype == np.uint8
+
+
+def test_surface_energy_wrapper_kats(golden):
+    """tests/test_SrTiO3_terms.ipynb:257, tutorials/SrTiO3_001.ipynb:282 (reference calculators.py:379-446)."""
+    k = golden.kat["surface_energy"]
+    for case in k["cases"]:
+        symbols = [s for s, n in case["formula"].items() for _ in range(n)]
+        se = calcs.surface_energy_from_energy(case["relaxed_energy"], symbols, k["chem_pots"], golden.offset_data)
+        assert abs(se - case["surface_energy"]) <= golden.kat["tolerance"]["surface_energy_abs"], (case, se)
+
+
+def test_stoich_offset_table(golden):
+    table, const = golden.offset_table()
+    sd = golden.offset_data["stoidict"]
+    assert abs(table[38] - sd["Sr"] * 27.2114) < 1e-12 and abs(const - sd["offset"] * 27.2114) < 1e-12
+    assert table[1] == 0
+
+
+def test_calculator_surface_without_gpu(golden):
+    """Same constructor kwargs / attributes as the reference's EnsembleNFFSurface
+    (scripts/sample_surface.py:168-175, mcmc/system.py:104-105,463)."""
+    calc = calcs.EnsembleNFFSurface(golden.blobs, device="cuda:0", model_units="kcal/mol",
+                                    prediction_units="eV", offset_units="atomic")
+    assert {"energy", "forces", "energy_std", "forces_std", "surface_energy"} <= set(calc.implemented_properties)
+    assert len(calc.models) == 3
+    settings = {"relax_atoms": True, "optimizer": "BFGS", "relax_steps": 20, "offset": True,
+                "chem_pots": {"Sr": -2, "Ti": 0, "O": 0}, "offset_data": golden.offset_data, "some_unknown_key": 1}
+    changed = calc.set(**settings)
+    assert set(changed) == set(settings)
+    assert calc.parameters["relax_steps"] == 20 and calc.chem_pots["Sr"] == -2
+    assert calc.offset_data["ref_element"] == "Ti"
+    assert calc.set(relax_steps=20) == {}
+    twin = copy.deepcopy(calc)  # mcmc/system.py:583
+    assert twin.parameters == calc.parameters and twin.models[0] is calc.models[0]
+    empty = calcs.EnsembleNFFSurface(golden.blobs)
+    with pytest.raises(ValueError):
+        empty.get_surface_energy(golden.structure("SrTiO3_2x2_pristine"))
+    with pytest.raises(backend.BackendError):
+        calcs.EnsembleNFFSurface(golden.blobs, device="cpu")._get_engine()
+    with pytest.raises(ValueError):
+        calcs.EnsembleNFFSurface([golden.blobs[0][:100]])
+
+
+def test_mini_calculator_caching():
+    class Fake(calcs._MiniCalculator):
+        implemented_properties = ("energy", "forces")
+        n = 0
+
+        def calculate(self, atoms=None, properties=("energy",), system_changes=calcs.all_changes):
+            super().calculate(atoms, properties, system_changes)
+            Fake.n += 1
+            self.results = {"energy": 1.0, "forces": np.zeros((len(atoms), 3))}
+
+    s = structures.Structure([8, 8], [[0, 0, 0], [0, 0, 1.2]], np.eye(3) * 10)
+    c = Fake()
+    assert c.get_potential_energy(s) == 1.0 and c.get_forces(s).shape == (2, 3) and Fake.n == 1
+    s.positions[1, 2] = 1.3
+    c.get_potential_energy(s)
+    assert Fake.n == 2
+    with pytest.raises(NotImplementedError):
+        c.get_property("stress", s)
+
+
+def test_abi_library_exports_every_declared_symbol():
+    lib = backend.load_library()
+    header = open(os.path.join(ROOT, "include", "vssr_eval.h")).read()
+    declared = set(re.findall(r"\b(vssr_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(backend.EXPORTS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.vssr_abi_version() == 1
+    assert ctypes.sizeof(backend.PainnConfig) == 96
+
+
+def test_engine_fails_loudly_without_gpu(golden):
+    """No CPU fallback: on a box without a HIP device the create call must raise."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; from surface_sampling_amd import backend\n"
+            "blobs=[np.zeros(589057,np.float32)]\n"
+            "try:\n    backend.PainnEngine(blobs)\n    print('CREATED')\n"
+            "except backend.BackendError as e:\n    print('RAISED', e)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env={**os.environ, "HIP_VISIBLE_DEVICES": "-1", "ROCR_VISIBLE_DEVICES": "-1"}).stdout
+    assert "RAISED" in out and "no HIP device" in out, out

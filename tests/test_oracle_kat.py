@@ -1,0 +1,127 @@
+"""CPU: pin the oracle against the reference's own known answers and against
+the committed fp64 vectors; finite-difference checks of the hand-derived reverse passes."""
+
+import numpy as np
+import pytest
+
+from conftest import top_layer
+
+
+def test_painn_ensemble_kats(golden, oracle_mod):
+    """Energies / fmax printed by the reference (tutorials/SrTiO3_001.ipynb:241,
+    tests/test_SrTiO3_terms.ipynb:201,208,212).  fp32 mode mimics nff's float32 arithmetic."""
+    table, const = golden.offset_table()
+    tol = golden.kat["tolerance"]
+    for case in golden.kat["painn_ensemble"]:
+        s = golden.structure(case["structure"])
+        free = top_layer(s) if case["free_atoms"] == "top_layer" else np.array(case["free_atoms"])
+        for bits in (32, 64):
+            r = oracle_mod.ensemble(golden.blobs, s.numbers, s.positions, s.cell, s.pbc, bits, table, const)
+            assert abs(r["energy"] - case["energy"]) <= tol["energy_abs"], (case, bits, r["energy"])
+            fmax = np.linalg.norm(r["forces"][free], axis=1).max()
+            # fp64 differs from the reference's fp32 print by up to ~1.2e-5 on fmax
+            assert abs(fmax - case["fmax"]) <= (tol["fmax_abs"] if bits == 32 else 2e-5), (case, bits, fmax)
+
+
+def test_tersoff_kat(golden, oracle_mod):
+    """Energy -144.059 eV of the pristine GaN slab (tutorials/GaN_0001.ipynb:228)."""
+    k = golden.kat["tersoff"]
+    s = golden.structure(k["structure"])
+    types = np.array([0 if z == 31 else 1 for z in s.numbers], np.int32)
+    E, ea, F = oracle_mod.tersoff(golden.tersoff_params, types, s.positions, s.cell, k["pbc"])
+    assert abs(E - k["energy"]) <= golden.kat["tolerance"]["tersoff_energy_abs"]
+    assert abs(ea.sum() - E) < 1e-9
+    assert np.abs(F.sum(0)).max() < 1e-9
+
+
+def test_oracle_matches_committed_fp64_vectors(golden, oracle_mod):
+    table, const = golden.offset_table()
+    f = golden.fine
+    for name in ("S60", "S240", "chain3", "O44Sr12Ti16"):
+        Z, pos, cell, pbc = (f[f"{name}.{k}"] for k in ("numbers", "positions", "cell", "pbc"))
+        r = oracle_mod.ensemble(golden.blobs, Z, pos, cell, pbc, 64, table, const)
+        assert abs(r["energy"] - float(f[f"{name}.energy"])) < 1e-8
+        assert np.abs(r["forces"] - f[f"{name}.forces"]).max() < 1e-8
+        assert np.abs(r["energy_models"] - f[f"{name}.energy_models"]).max() < 1e-8
+        ei, ej, eS, er = oracle_mod.neighbors(pos, cell, pbc, 5.0)
+        assert len(ei) == int(f[f"{name}.n_edges"])
+    E, ea, F = oracle_mod.tersoff(golden.tersoff_params, f["GaN_rattled.types"], f["GaN_rattled.positions"],
+                                  golden.structure("GaN_3x3_pristine").cell, [1, 1, 1])
+    assert abs(E - float(f["GaN_rattled.energy"])) < 1e-10
+    assert np.abs(F - f["GaN_rattled.forces"]).max() < 1e-10
+
+
+def test_painn_gradient_finite_difference(golden, oracle_mod):
+    s = golden.structure("SrTiO3_2x2_pristine")
+    rng = np.random.default_rng(1)
+    pos = s.positions + rng.normal(0, 0.05, s.positions.shape)
+    _, G = oracle_mod.painn(golden.blobs[1], s.numbers, pos, s.cell, s.pbc, 64)
+    h = 1e-5
+    for i, x in [(0, 0), (7, 2), (37, 1), (59, 2)]:
+        p = pos.copy(); p[i, x] += h
+        Ep, _ = oracle_mod.painn(golden.blobs[1], s.numbers, p, s.cell, s.pbc, 64, want_grad=False)
+        p[i, x] -= 2 * h
+        Em, _ = oracle_mod.painn(golden.blobs[1], s.numbers, p, s.cell, s.pbc, 64, want_grad=False)
+        assert abs((Ep - Em) / (2 * h) - G[i, x]) < 1e-6
+    assert np.abs(G.sum(0)).max() < 1e-9  # translation invariance
+
+
+def test_tersoff_forces_finite_difference(golden, oracle_mod):
+    f = golden.fine
+    cell = golden.structure("GaN_3x3_pristine").cell
+    types, pos = f["GaN_rattled.types"], f["GaN_rattled.positions"]
+    _, _, F = oracle_mod.tersoff(golden.tersoff_params, types, pos, cell, [1, 1, 1])
+    h = 1e-5
+    for i, x in [(0, 0), (17, 2), (35, 1)]:
+        p = pos.copy(); p[i, x] += h
+        Ep, _, _ = oracle_mod.tersoff(golden.tersoff_params, types, p, cell, [1, 1, 1], False)
+        p[i, x] -= 2 * h
+        Em, _, _ = oracle_mod.tersoff(golden.tersoff_params, types, p, cell, [1, 1, 1], False)
+        assert abs(-(Ep - Em) / (2 * h) - F[i, x]) < 1e-7
+
+
+def test_neighbor_multigraph_properties(golden, oracle_mod):
+    """in the 60-atom slab (cell < 2*cutoff) pairs repeat through several images."""
+    s = golden.structure("SrTiO3_2x2_pristine")
+    ei, ej, eS, er = oracle_mod.neighbors(s.positions, s.cell, s.pbc, 5.0)
+    assert len(ei) == 2504
+    d = np.linalg.norm(er, axis=1)
+    assert d.max() <= 5.0 and d.min() > 0.5
+    # every edge has its reverse with the opposite shift
+    fwd = {(i, j, *S) for i, j, S in zip(ei, ej, map(tuple, eS))}
+    assert all((j, i, -a, -b, -c) in fwd for (i, j, a, b, c) in fwd)
+    pairs = {}
+    for i, j in zip(ei, ej):
+        pairs[(i, j)] = pairs.get((i, j), 0) + 1
+    assert sum(1 for v in pairs.values() if v > 1) > 0  # multigraph
+    # r = x_j + S.cell - x_i
+    r = s.positions[ej] + eS @ s.cell - s.positions[ei]
+    assert np.abs(r - er).max() < 1e-12
+    # atoms displaced by whole lattice vectors give the same edge vectors
+    shifted = s.positions.copy()
+    shifted[::3] += 2 * s.cell[0] - s.cell[1]
+    ei2, ej2, eS2, er2 = oracle_mod.neighbors(shifted, s.cell, s.pbc, 5.0)
+    assert len(ei2) == len(ei)
+    a = sorted(map(tuple, np.round(np.c_[ei, ej, er], 9)))
+    b = sorted(map(tuple, np.round(np.c_[ei2, ej2, er2], 9)))
+    assert a == b
+
+
+@pytest.mark.parametrize("pbc", [(1, 1, 1), (1, 1, 0), (0, 0, 0)])
+def test_neighbors_against_bruteforce(golden, oracle_mod, pbc):
+    s = golden.structure("GaN_3x3_pristine")  # non-orthogonal cell
+    rng = np.random.default_rng(3)
+    pos = s.positions + rng.normal(0, 0.1, s.positions.shape)
+    rc = 3.4
+    ei, ej, eS, er = oracle_mod.neighbors(pos, s.cell, pbc, rc)
+    ref = set()
+    rng_s = [range(-2, 3) if p else range(0, 1) for p in pbc]
+    for a in rng_s[0]:
+        for b in rng_s[1]:
+            for c in rng_s[2]:
+                shift = np.array([a, b, c]) @ s.cell
+                d = np.linalg.norm(pos[None, :, :] + shift - pos[:, None, :], axis=2)
+                for i, j in zip(*np.where((d <= rc) & (d > 0))):
+                    ref.add((int(i), int(j), a, b, c))
+    got = {(int(i), int(j), *map(int, S)) for i, j, S in zip(ei, ej, eS)}
+    assert got == ref

@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the read-only reference tree (run in the build container only).
+
+Everything written is DATA: model weights converted to flat fp32 blobs, structure arrays
+decoded from the reference's pickles/CIFs, the reference's offset/potential parameter files,
+the known answers printed in the reference's notebooks (with their file:line), and
+oracle-generated fine-grained vectors (fp64) that pin the oracle against drift.
+No reference source code is copied.  The GPU box never sees /root/reference.
+
+    python tools/make_golden.py [--reference /root/reference]
+"""
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from surface_sampling_amd import checkpoint, structures, tersoff  # noqa: E402
+
+import oracle  # noqa: E402  (test infrastructure)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    args = ap.parse_args()
+    R = args.reference
+    out = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(os.path.join(out, "weights"), exist_ok=True)
+
+    # --- PaiNN ensemble weights -> canonical blobs (include/vssr_eval.h layout) -------------
+    blobs = []
+    for m in (1, 2, 3):
+        src = os.path.join(R, f"tutorials/data/SrTiO3_001/nff/model0{m}/best_model")
+        blob = checkpoint.load_painn_blob(src)
+        blob.tofile(os.path.join(out, "weights", f"SrTiO3_painn_model0{m}.f32"))
+        blobs.append(blob)
+    attrs = checkpoint.read_model_attrs(os.path.join(R, "tutorials/data/SrTiO3_001/nff/model01/best_model"))
+    with open(os.path.join(out, "weights", "manifest.json"), "w") as fh:
+        json.dump({
+            "source": "tutorials/data/SrTiO3_001/nff/model0{1,2,3}/best_model (torch zip, 589057 fp32 params each)",
+            "layout": [[f, list(s)] for f, s in checkpoint.painn_blob_shapes().items()],
+            "hparams": checkpoint.DEFAULT_HPARAMS,
+            "module_attrs": attrs,
+        }, fh, indent=1)
+
+    # --- data files -------------------------------------------------------------------------
+    with open(os.path.join(R, "tutorials/data/SrTiO3_001/nff/offset_data.json")) as fh:
+        offset_data = json.load(fh)
+    with open(os.path.join(out, "offset_data.json"), "w") as fh:
+        json.dump(offset_data, fh, indent=1)
+    ters_text = open(os.path.join(R, "mcmc/potentials/GaN.tersoff")).read()
+    ters_params = tersoff.parse_tersoff(ters_text, ["Ga", "N"])
+    with open(os.path.join(out, "GaN_tersoff_params.json"), "w") as fh:
+        json.dump({"source": "mcmc/potentials/GaN.tersoff (Nord, Albe, Erhart, Nordlund, JPCM 15, 5649 (2003))",
+                   "species": ["Ga", "N"], "fields": list(tersoff.FIELD_NAMES),
+                   "params_ijk": ters_params.tolist()}, fh, indent=1)
+
+    # --- structures ---------------------------------------------------------------------------
+    S = {}
+    S["SrTiO3_2x2_pristine"] = structures.read_slab_pickle(
+        os.path.join(R, "tutorials/data/SrTiO3_001/SrTiO3_001_2x2_pristine_slab.pkl"))
+    S["SrTiO3_2x2x4_pristine"] = structures.read_slab_pickle(
+        os.path.join(R, "tutorials/data/SrTiO3_001/SrTiO3_001_2x2x4_pristine_slab.pkl"))
+    for name in ("O44Sr12Ti16", "O36Sr12Ti12", "O40Sr16Ti12"):
+        S[name] = structures.read_cif(os.path.join(R, f"tests/data/SrTiO3_001/{name}.cif"))
+    S["GaN_3x3_pristine"] = structures.read_slab_pickle(
+        os.path.join(R, "tutorials/data/GaN_0001/GaN_0001_3x3_pristine_slab.pkl"))
+    arrays = {}
+    for k, s in S.items():
+        arrays[f"{k}.numbers"] = s.numbers
+        arrays[f"{k}.positions"] = s.positions
+        arrays[f"{k}.cell"] = s.cell
+        arrays[f"{k}.pbc"] = s.pbc
+        if s.constraints_fixed is not None:
+            arrays[f"{k}.fixed"] = s.constraints_fixed
+    np.savez_compressed(os.path.join(out, "structures.npz"), **arrays)
+
+    # --- known answers printed by the reference itself ------------------------------------------
+    kat = {
+        "units": {"energy": "eV", "fmax": "eV/Angstrom"},
+        "tolerance": {"energy_abs": 2e-4, "fmax_abs": 1e-5, "tersoff_energy_abs": 1e-3,
+                      "surface_energy_abs": 1e-3},
+        "painn_ensemble": [
+            {"structure": "SrTiO3_2x2_pristine", "energy": -467.521881, "fmax": 0.204407,
+             "free_atoms": [7, 8, 22, 23, 37, 38, 52, 53],
+             "source": "tutorials/SrTiO3_001.ipynb:241 (BFGS step 0); free set from the log in cell 7"},
+            {"structure": "O44Sr12Ti16", "energy": -570.127991, "fmax": 0.737414, "free_atoms": "top_layer",
+             "source": "tests/test_SrTiO3_terms.ipynb:201"},
+            {"structure": "O36Sr12Ti12", "energy": -467.525604, "fmax": 0.141613, "free_atoms": "top_layer",
+             "source": "tests/test_SrTiO3_terms.ipynb:208"},
+            {"structure": "O40Sr16Ti12", "energy": -518.694092, "fmax": 0.779158, "free_atoms": "top_layer",
+             "source": "tests/test_SrTiO3_terms.ipynb:212"},
+        ],
+        "surface_energy": {
+            "chem_pots": {"Sr": -2, "Ti": 0, "O": 0},
+            "cases": [
+                {"formula": {"O": 44, "Sr": 12, "Ti": 16}, "relaxed_energy": -570.189758, "surface_energy": 35.931},
+                {"formula": {"O": 36, "Sr": 12, "Ti": 12}, "relaxed_energy": -467.534088, "surface_energy": 12.478},
+                {"formula": {"O": 40, "Sr": 16, "Ti": 12}, "relaxed_energy": -518.783630, "surface_energy": -4.876},
+                {"formula": {"O": 36, "Sr": 12, "Ti": 12}, "relaxed_energy": -467.541351, "surface_energy": 12.471},
+            ],
+            "source": "tests/test_SrTiO3_terms.ipynb:257 (cells 8-10), tutorials/SrTiO3_001.ipynb:282",
+        },
+        "tersoff": {"structure": "GaN_3x3_pristine", "species": ["Ga", "N"], "pbc": [1, 1, 1],
+                    "energy": -144.059, "source": "tutorials/GaN_0001.ipynb:228"},
+        "constants": {"EV_TO_KCAL_MOL": 23.0605, "HARTREE_TO_EV": 27.2114,
+                      "source": "nff/utils/constants.py values, confirmed by the KATs (SURVEY.md §8(c))"},
+    }
+    with open(os.path.join(out, "kat.json"), "w") as fh:
+        json.dump(kat, fh, indent=1)
+
+    # --- oracle-generated fine-grained vectors (fp64), to catch oracle drift --------------------
+    offz = np.zeros(100)
+    for k, v in offset_data["stoidict"].items():
+        if k != "offset":
+            offz[structures.ATOMIC_NUMBERS[k]] = v * oracle.HARTREE_TO_EV
+    offc = offset_data["stoidict"]["offset"] * oracle.HARTREE_TO_EV
+    fine = {}
+    base = S["SrTiO3_2x2_pristine"]
+    s240 = base.repeat((2, 2, 1))
+    cases = {"S60": base, "S240": s240, "chain3": structures.synth_chain(s240, 3),
+             "chain17": structures.synth_chain(s240, 17), "O44Sr12Ti16": S["O44Sr12Ti16"]}
+    for name, s in cases.items():
+        r = oracle.ensemble(blobs, s.numbers, s.positions, s.cell, s.pbc, 64, offz, offc)
+        ei, ej, eS, er = oracle.neighbors(s.positions, s.cell, s.pbc, 5.0)
+        fine[f"{name}.numbers"] = s.numbers
+        fine[f"{name}.positions"] = s.positions
+        fine[f"{name}.cell"] = s.cell
+        fine[f"{name}.pbc"] = s.pbc
+        fine[f"{name}.energy"] = np.array(r["energy"])
+        fine[f"{name}.energy_std"] = np.array(r["energy_std"])
+        fine[f"{name}.energy_models"] = r["energy_models"]
+        fine[f"{name}.forces"] = r["forces"]
+        fine[f"{name}.forces_std"] = r["forces_std"]
+        fine[f"{name}.n_edges"] = np.array(len(ei))
+        fine[f"{name}.edge_checksum"] = np.array(
+            [int(ei.sum()), int(ej.sum()), int(np.abs(eS).sum()), float(np.linalg.norm(er, axis=1).sum())])
+        print(name, len(s), len(ei), r["energy"])
+    g = S["GaN_3x3_pristine"]
+    types = np.array([0 if z == 31 else 1 for z in g.numbers], np.int32)
+    rng = np.random.default_rng(7)
+    gpos = g.positions + rng.normal(0, 0.05, g.positions.shape)
+    E, ea, F = oracle.tersoff(ters_params, types, gpos, g.cell, [1, 1, 1])
+    fine["GaN_rattled.positions"] = gpos
+    fine["GaN_rattled.types"] = types
+    fine["GaN_rattled.energy"] = np.array(E)
+    fine["GaN_rattled.e_atom"] = ea
+    fine["GaN_rattled.forces"] = F
+    np.savez_compressed(os.path.join(out, "oracle_fp64_vectors.npz"), **fine)
+    print("golden fixtures written to", out)
+
+
+if __name__ == "__main__":
+    main()
