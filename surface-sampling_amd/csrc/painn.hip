@@ -27,7 +27,7 @@ __device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ inline float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ inline float dswishf_(float x) {
     float sg = sigmoidf_(x);
-    return sg * (1.f + x * (1.f - sg));
+    return sg * fmaf(x, 1.f - sg, 1.f);
 }
 
 // ---- embedding: s0 = Emb[Z], v0 = 0 ------------------------------------------------------------
@@ -99,7 +99,7 @@ __device__ inline void stage_chunk(EdgeChunk &S, const float4 *__restrict__ edge
             float4 ed = edge[e0 + tid];
             j = __float_as_int(ed.w);
             if (j >= 0) {
-                d = sqrtf(ed.x * ed.x + ed.y * ed.y + ed.z * ed.z);
+                d = sqrtf(fmaf(ed.z, ed.z, fmaf(ed.y, ed.y, ed.x * ed.x)));
                 float inv = 1.f / d;
                 ux = ed.x * inv; uy = ed.y * inv; uz = ed.z * inv;
                 if (d < rc) {
@@ -124,7 +124,7 @@ __device__ inline void stage_chunk(EdgeChunk &S, const float4 *__restrict__ edge
             sincosf(a * d, &sn, &cs);
             float rb = sn / d;
             r = rb * S.fc[e];
-            if (DERIV) dr = (a * cs / d - sn / (d * d)) * S.fc[e] + rb * S.dfc[e];
+            if (DERIV) dr = fmaf(a * cs / d - sn / (d * d), S.fc[e], rb * S.dfc[e]);
         }
         S.rho[e][k] = r;
         if (DERIV) S.drho[e][k] = dr;
@@ -234,7 +234,7 @@ __device__ inline void update_forward_tile(const LayerW &W, int tid, float (*vs)
         float n2 = 0.f, in = 0.f;
         for (int x = 0; x < 3; ++x) {
             float vv = L.Vv[t * 3 + x];
-            n2 += vv * vv + 1e-15f;
+            n2 += fmaf(vv, vv, 1e-15f);
             in = fmaf(L.Uv[t * 3 + x], vv, in);
         }
         L.nrm[t] = sqrtf(n2);
@@ -297,7 +297,7 @@ k_update_fwd(int N, int l, const ModelW *__restrict__ MW, const float *__restric
         int atom = a0 + t;
         if (atom >= N) continue;
         size_t a = mN + atom;
-        s_out[a * F + tid] = L.s1[t] + L.asv[t] * L.inner[t] + L.ass[t];
+        s_out[a * F + tid] = fmaf(L.asv[t], L.inner[t], L.s1[t]) + L.ass[t];
         for (int x = 0; x < 3; ++x)
             v_out[(a * 3 + x) * F + tid] = fmaf(L.avv[t], L.Uv[t * 3 + x], vs[tid][t * 3 + x]);
     }
@@ -381,8 +381,9 @@ k_update_bwd(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW, cons
             int r = t * 3 + x;
             vbo[r] = (atom < N && !vbar_is_zero) ? vbar[(a * 3 + x) * F + tid] : 0.f;
             abar_vv = fmaf(vbo[r], L.Uv[r], abar_vv);
-            Ub[r] = vbo[r] * L.avv[t] + sb[t] * L.asv[t] * L.Vv[r];
-            Vb[r] = sb[t] * L.asv[t] * L.Uv[r];
+            float sa = sb[t] * L.asv[t];
+            Ub[r] = fmaf(vbo[r], L.avv[t], sa * L.Vv[r]);
+            Vb[r] = sa * L.Uv[r];
         }
         qb[tid][t] = abar_vv;
         qb[F + tid][t] = sb[t] * L.inner[t];
@@ -501,12 +502,12 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
             float vb2 = vbar_msg[(an * 3 + 2) * F + f];
             // unit vector of the edge (n -> c) = -(c -> n)
             float u0 = -S.u[e][0], u1 = -S.u[e][1], u2 = -S.u[e][2];
-            float p = vb0 * u0 + vb1 * u1 + vb2 * u2;
+            float p = fmaf(vb2, u2, fmaf(vb1, u1, vb0 * u0));
             accb = fmaf(wB, sbn, accb);
             accc = fmaf(wC, p, accc);
-            float dpart = pc_b * sbn * dB + pc_c * p * dC;
+            float dpart = fmaf(pc_b * sbn, dB, pc_c * p * dC);
             if (!L0) {
-                float q = vb0 * vc0 + vb1 * vc1 + vb2 * vc2;
+                float q = fmaf(vb2, vc2, fmaf(vb1, vc1, vb0 * vc0));
                 ax = fmaf(wA, vb0, ax);
                 ay = fmaf(wA, vb1, ay);
                 az = fmaf(wA, vb2, az);
@@ -532,10 +533,10 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
             float db = tots[f][0];
             if (L0 && excl_vol) db -= (float)excl_power * powf(excl_sigma / d, (float)excl_power) / d;
             float b0 = tots[f][1], b1 = tots[f][2], b2 = tots[f][3];
-            float dot = b0 * u0 + b1 * u1 + b2 * u2;
-            float g0 = db * u0 + (b0 - dot * u0) / d;
-            float g1 = db * u1 + (b1 - dot * u1) / d;
-            float g2 = db * u2 + (b2 - dot * u2) / d;
+            float dot = fmaf(b2, u2, fmaf(b1, u1, b0 * u0));
+            float g0 = fmaf(db, u0, (b0 - dot * u0) / d);
+            float g1 = fmaf(db, u1, (b1 - dot * u1) / d);
+            float g2 = fmaf(db, u2, (b2 - dot * u2) / d);
             if (accumulate) {
                 float4 old = gb[e0 + f];
                 g0 += old.x; g1 += old.y; g2 += old.z;
@@ -545,7 +546,7 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
         __syncthreads();
     }
     if (!L0) {
-        phibar[ac * F3 + f] = vc0 * ax + vc1 * ay + vc2 * az;
+        phibar[ac * F3 + f] = fmaf(vc2, az, fmaf(vc1, ay, vc0 * ax));
         phibar[ac * F3 + F + f] = accb;
         phibar[ac * F3 + 2 * F + f] = accc;
         vbar_in[(ac * 3 + 0) * F + f] = fmaf(pc_a, ax, vbar_msg[(ac * 3 + 0) * F + f]);
@@ -739,7 +740,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     P.end(st);
     for (int l = 0; l < L; ++l) {
         P.begin(KC_MSG_MLP, st);
-        hipLaunchKernelGGL(k_msg_mlp, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phi[l]);
+        if (h->node_impl) launch_msg_mlp_mfma(st, N, M, l, MW, sv.s_in[l], sv.phi[l]);
+        else hipLaunchKernelGGL(k_msg_mlp, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phi[l]);
         P.end(st);
         P.begin(KC_EDGE_FWD, st);
         if (l == 0)
@@ -752,8 +754,11 @@ int painn_run(vssr_handle *h, uint32_t want) {
                                sv.v_msg[l], sv.e_excl);
         P.end(st);
         P.begin(KC_UPDATE_FWD, st);
-        hipLaunchKernelGGL(k_update_fwd, g_tile, blk, 0, st, N, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1],
-                           sv.v_in[l + 1]);
+        if (h->node_impl)
+            launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
+        else
+            hipLaunchKernelGGL(k_update_fwd, g_tile, blk, 0, st, N, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1],
+                               sv.v_in[l + 1]);
         P.end(st);
     }
     P.begin(KC_READOUT, st);
@@ -764,8 +769,12 @@ int painn_run(vssr_handle *h, uint32_t want) {
     if (want & VSSR_WANT_FORCES) {
         for (int l = L - 1; l >= 0; --l) {
             P.begin(KC_UPDATE_BWD, st);
-            hipLaunchKernelGGL(k_update_bwd, g_tile, blk, 0, st, N, l, (int)(l == L - 1), MW, sv.s_msg[l],
-                               sv.v_msg[l], sv.sbar, sv.vbar, sv.sbar_msg, sv.vbar_msg);
+            if (h->node_impl)
+                launch_update_bwd_mfma(st, N, M, l, (int)(l == L - 1), MW, sv.s_msg[l], sv.v_msg[l], sv.sbar, sv.vbar,
+                                       sv.sbar_msg, sv.vbar_msg);
+            else
+                hipLaunchKernelGGL(k_update_bwd, g_tile, blk, 0, st, N, l, (int)(l == L - 1), MW, sv.s_msg[l],
+                                   sv.v_msg[l], sv.sbar, sv.vbar, sv.sbar_msg, sv.vbar_msg);
             P.end(st);
             P.begin(KC_EDGE_BWD, st);
             int accumulate = (l != L - 1);
@@ -780,8 +789,11 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.end(st);
             if (l > 0) {
                 P.begin(KC_MSG_MLP_BWD, st);
-                hipLaunchKernelGGL(k_msg_mlp_bwd, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phibar, sv.sbar_msg,
-                                   sv.sbar);
+                if (h->node_impl)
+                    launch_msg_mlp_bwd_mfma(st, N, M, l, MW, sv.s_in[l], sv.phibar, sv.sbar_msg, sv.sbar);
+                else
+                    hipLaunchKernelGGL(k_msg_mlp_bwd, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phibar,
+                                       sv.sbar_msg, sv.sbar);
                 P.end(st);
             }
         }

@@ -1,0 +1,425 @@
+// painn_node_mfma.hip — per-atom ("node") stages of PaiNN on the gfx950 matrix cores.
+//
+// The node stages are chains of small dense layers applied to every
+// atom of every chain and ensemble member: genuinely dense GEMMs with M = atoms (x3 Cartesian rows for
+// U/V), K, N in {128, 256, 384}.  They run on v_mfma_f32_32x32x2_f32 (exact fp32, the only fp32-input
+// MFMA rate on gfx950; no xf32 exists).
+//
+// Structure of every kernel: one workgroup = 4 waves = a tile of 32 atoms of one ensemble member.
+//   * activations (A operand) live in LDS, row-major with a +4 float pad (conflict-free ds_read_b128);
+//   * weights (B operand) were re-packed at vssr_create into MFMA fragment order
+//       packed[tile][q][lane][4] = W[tile*32 + (lane&31)][(lane>>5)*(K/2) + 4q .. 4q+3]
+//     so each wave streams its own column tiles with one fully coalesced 1 KiB dwordx4 load per 4 k-steps,
+//     L2-resident (all workgroups read the same 0.7 MB per layer);
+//   * the k index is permuted identically on A and B (lane half h covers k in [h*K/2, (h+1)*K/2)), which
+//     only reorders the fp32 summation;
+//   * wave w owns output features [32w, 32w+32) of every section, so gates, norms and residuals that
+//     combine several GEMM outputs for the same (atom, feature) stay in one lane's registers.
+#include "vssr_internal.h"
+
+namespace vssr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TA = 32;           // atoms per workgroup
+constexpr int LDV = F + 4;       // LDS row stride for K = 128 operands
+constexpr int LDH = 2 * F + 4;   // K = 256
+constexpr int LDQ = 3 * F + 4;   // K = 384
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float swish(float x) { return x * sigm(x); }
+__device__ __forceinline__ float dswish(float x) {
+    float sg = sigm(x);
+    return sg * fmaf(x, 1.f - sg, 1.f);
+}
+// row of accumulator register `reg` inside a 32x32 tile (MI355X guide: C/D layout of 32x32 MFMA)
+__device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// acc[t][c] += A(rows t*32.., K) * packed tile c.
+// One wave per SIMD leaves nobody else to hide L2 latency, so the weight fragments are fetched two
+// q-steps (8 k-steps) ahead of the MFMAs that consume them; A fragments one step ahead from LDS.
+template <int K, int NRT, int NCT>
+__device__ __forceinline__ void gemm_acc(const float *__restrict__ lds_a, int ld,
+                                         const float *const (&wp)[NCT], f32x16 (&acc)[NRT][NCT]) {
+    constexpr int NQ = K / 8;
+    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
+    const float *a_base = lds_a + r * ld + half * (K / 2);
+    float4 b0[NCT], b1[NCT], b2[NCT], a0[NRT], a1[NRT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        b0[c] = *reinterpret_cast<const float4 *>(wp[c] + ((size_t)0 * 64 + lane) * 4);
+        b1[c] = *reinterpret_cast<const float4 *>(wp[c] + ((size_t)1 * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) a0[t] = *reinterpret_cast<const float4 *>(a_base + t * 32 * ld);
+#pragma unroll 2
+    for (int q = 0; q < NQ; ++q) {
+        const int qb = (q + 2 < NQ) ? q + 2 : NQ - 1, qa = (q + 1 < NQ) ? q + 1 : NQ - 1;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) b2[c] = *reinterpret_cast<const float4 *>(wp[c] + ((size_t)qb * 64 + lane) * 4);
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) a1[t] = *reinterpret_cast<const float4 *>(a_base + t * 32 * ld + 4 * qa);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < NRT; ++t)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                    float av = s == 0 ? a0[t].x : s == 1 ? a0[t].y : s == 2 ? a0[t].z : a0[t].w;
+                    float bv = s == 0 ? b0[c].x : s == 1 ? b0[c].y : s == 2 ? b0[c].z : b0[c].w;
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t][c], 0, 0, 0);
+                }
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) { b0[c] = b1[c]; b1[c] = b2[c]; }
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) a0[t] = a1[t];
+    }
+}
+
+template <int NRT, int NCT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NRT][NCT]) {
+#pragma unroll
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][c][i] = 0.f;
+}
+
+// cooperative tile loads: rows of F floats, global row index given by a functor; rows >= valid are zero
+template <class RowPtr>
+__device__ __forceinline__ void load_rows(float *lds, int ld, int col0, int nrows, RowPtr rowptr) {
+    // F/4 = 32 float4 per row
+    for (int idx = threadIdx.x; idx < nrows * (F / 4); idx += blockDim.x) {
+        int row = idx >> 5, c4 = idx & 31;
+        const float *src = rowptr(row);
+        float4 v = src ? *reinterpret_cast<const float4 *>(src + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(lds + row * ld + col0 + 4 * c4) = v;
+    }
+}
+
+// ---- message MLP forward: phi = W2 swish(W1 s + b1) + b2 ---------------------------------------------------
+__global__ void __launch_bounds__(256, 1)
+k_msg_mlp_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
+               float *__restrict__ phi) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *xs = lds;                 // [TA][LDV]
+    float *hs = lds + TA * LDV;      // [TA][LDV]
+    const int m = blockIdx.y, a0 = blockIdx.x * TA, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = 32 * w + (lane & 31);
+    const LayerW &W = MW[m].layer[l];
+    const size_t mN = (size_t)m * N;
+    load_rows(xs, LDV, 0, TA, [&](int row) { int a = a0 + row; return a < N ? s_in + (mN + a) * F : nullptr; });
+    __syncthreads();
+    {
+        f32x16 acc[1][1];
+        zero_acc(acc);
+        const float *wp[1] = {W.pW1 + (size_t)w * 32 * F};
+        gemm_acc<F, 1, 1>(xs, LDV, wp, acc);
+        float b = W.b1[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hs[crow(i, half) * LDV + col] = swish(acc[0][0][i] + b);
+    }
+    __syncthreads();
+    f32x16 acc[1][3];
+    zero_acc(acc);
+    const float *wp[3] = {W.pW2 + (size_t)(w)*32 * F, W.pW2 + (size_t)(4 + w) * 32 * F, W.pW2 + (size_t)(8 + w) * 32 * F};
+    gemm_acc<F, 1, 3>(hs, LDV, wp, acc);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float b = W.b2[c * F + col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int a = a0 + crow(i, half);
+            if (a < N) phi[(mN + a) * F3 + c * F + col] = acc[0][c][i] + b;
+        }
+    }
+}
+
+// ---- message MLP reverse: sbar_in = sbar_msg + W1^T[(W2^T phibar) * swish'(W1 s + b1)] ------------------------------
+__global__ void __launch_bounds__(256, 1)
+k_msg_mlp_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
+                   const float *__restrict__ phibar, const float *__restrict__ sbar_msg, float *__restrict__ sbar_in) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *xs = lds;                 // [TA][LDV]  s tile, later h1bar
+    float *pb = lds + TA * LDV;      // [TA][LDQ]  phibar tile
+    const int m = blockIdx.y, a0 = blockIdx.x * TA, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = 32 * w + (lane & 31);
+    const LayerW &W = MW[m].layer[l];
+    const size_t mN = (size_t)m * N;
+    load_rows(xs, LDV, 0, TA, [&](int row) { int a = a0 + row; return a < N ? s_in + (mN + a) * F : nullptr; });
+    for (int c = 0; c < 3; ++c)
+        load_rows(pb, LDQ, c * F, TA,
+                  [&](int row) { int a = a0 + row; return a < N ? phibar + (mN + a) * F3 + c * F : nullptr; });
+    __syncthreads();
+    f32x16 h1[1][1], a1[1][1];
+    zero_acc(h1);
+    zero_acc(a1);
+    {
+        const float *wp[1] = {W.pW1 + (size_t)w * 32 * F};
+        gemm_acc<F, 1, 1>(xs, LDV, wp, h1);
+        const float *wq[1] = {W.pW2t + (size_t)w * 32 * F3};
+        gemm_acc<F3, 1, 1>(pb, LDQ, wq, a1);
+    }
+    __syncthreads();  // everyone is done reading xs
+    {
+        float b = W.b1[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xs[crow(i, half) * LDV + col] = a1[0][0][i] * dswish(h1[0][0][i] + b);
+    }
+    __syncthreads();
+    f32x16 acc[1][1];
+    zero_acc(acc);
+    const float *wp[1] = {W.pW1t + (size_t)w * 32 * F};
+    gemm_acc<F, 1, 1>(xs, LDV, wp, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int a = a0 + crow(i, half);
+        if (a < N) sbar_in[(mN + a) * F + col] = sbar_msg[(mN + a) * F + col] + acc[0][0][i];
+    }
+}
+
+// ---- update block -----------------------------------------------------------------------------------------------
+// LDS map (floats): vt [3*TA][LDV] | hs [TA][LDH] | as [TA][LDV]   (contiguous; the reverse pass overlays it)
+constexpr int OFF_VT = 0;
+constexpr int OFF_HS = 3 * TA * LDV;
+constexpr int OFF_AS = OFF_HS + TA * LDH;
+constexpr int UPD_LDS_FLOATS = OFF_AS + TA * LDV;   // 25 216 floats = 100 864 B
+
+struct UpdRegs {
+    f32x16 uv[3][2];   // [x][0] = U v, [x][1] = V v   for feature `col`, 16 atoms (rows) per lane
+    f32x16 h3;         // pre-activation of the gate MLP
+    f32x16 gate[3];    // a_vv, a_sv, a_ss
+    float nrm[16], inner[16];
+};
+
+// Shared forward part: needs vt (v_msg tile, rows x*TA+atom) and hs[:, :F] (s_msg tile) loaded + synced.
+__device__ __forceinline__ void update_forward(const LayerW &W, float *lds, int w, int half, int col, UpdRegs &R) {
+    float *vt = lds + OFF_VT, *hs = lds + OFF_HS, *as_ = lds + OFF_AS;
+    zero_acc(R.uv);
+    {
+        const float *wp[2] = {W.pU + (size_t)w * 32 * F, W.pV + (size_t)w * 32 * F};
+        gemm_acc<F, 3, 2>(vt, LDV, wp, R.uv);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float n2 = 0.f, in = 0.f;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            float vv = R.uv[x][1][i];
+            n2 += fmaf(vv, vv, 1e-15f);
+            in = fmaf(R.uv[x][0][i], vv, in);
+        }
+        R.nrm[i] = sqrtf(n2);
+        R.inner[i] = in;
+        hs[crow(i, half) * LDH + F + col] = R.nrm[i];
+    }
+    __syncthreads();
+    {
+        f32x16 acc[1][1];
+        zero_acc(acc);
+        const float *wp[1] = {W.pW3 + (size_t)w * 32 * 2 * F};
+        gemm_acc<2 * F, 1, 1>(hs, LDH, wp, acc);
+        float b = W.b3[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            R.h3[i] = acc[0][0][i] + b;
+            as_[crow(i, half) * LDV + col] = swish(R.h3[i]);
+        }
+    }
+    __syncthreads();
+    {
+        f32x16 acc[1][3];
+        zero_acc(acc);
+        const float *wp[3] = {W.pW4 + (size_t)(w)*32 * F, W.pW4 + (size_t)(4 + w) * 32 * F, W.pW4 + (size_t)(8 + w) * 32 * F};
+        gemm_acc<F, 1, 3>(as_, LDV, wp, acc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float b = W.b4[c * F + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) R.gate[c][i] = acc[0][c][i] + b;
+        }
+    }
+}
+
+__device__ __forceinline__ void load_update_tiles(float *lds, const float *__restrict__ s_msg,
+                                                  const float *__restrict__ v_msg, size_t mN, int a0, int N) {
+    load_rows(lds + OFF_VT, LDV, 0, 3 * TA, [&](int row) {
+        int x = row / TA, a = a0 + (row % TA);
+        return a < N ? v_msg + ((mN + a) * 3 + x) * F : nullptr;
+    });
+    load_rows(lds + OFF_HS, LDH, 0, TA, [&](int row) { int a = a0 + row; return a < N ? s_msg + (mN + a) * F : nullptr; });
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
+                  const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int m = blockIdx.y, a0 = blockIdx.x * TA, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = 32 * w + (lane & 31);
+    const LayerW &W = MW[m].layer[l];
+    const size_t mN = (size_t)m * N;
+    load_update_tiles(lds, s_msg, v_msg, mN, a0, N);
+    __syncthreads();
+    UpdRegs R;
+    update_forward(W, lds, w, half, col, R);
+    const float *vt = lds + OFF_VT, *hs = lds + OFF_HS;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int row = crow(i, half), a = a0 + row;
+        if (a >= N) continue;
+        size_t g = mN + a;
+        s_out[g * F + col] = fmaf(R.gate[1][i], R.inner[i], hs[row * LDH + col]) + R.gate[2][i];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+            v_out[(g * 3 + x) * F + col] = fmaf(R.gate[0][i], R.uv[x][0][i], vt[(x * TA + row) * LDV + col]);
+    }
+}
+
+// reverse: (sbar, vbar) of the block outputs -> (sbar_msg, vbar_msg) of its inputs.
+// Adjoint algebra as in the oracle (oracle/painn_impl.inc, "update block^T"):
+//   abar_vv = sum_x vbar_x Uv_x ; qbar = [abar_vv, sbar*inner, sbar]
+//   h3bar = (W4^T qbar) * swish'(h3) ; [sbar_extra ; nbar] = W3^T h3bar
+//   Ubar_x = vbar_x a_vv + sbar a_sv Vv_x ; Vbar_x = sbar a_sv Uv_x + nbar Vv_x / |Vv|
+//   vbar_msg = vbar + U^T Ubar + V^T Vbar ; sbar_msg = sbar + sbar_extra
+__global__ void __launch_bounds__(256, 1)
+k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
+                  const float *__restrict__ v_msg, const float *__restrict__ sbar, const float *__restrict__ vbar,
+                  float *__restrict__ sbar_msg, float *__restrict__ vbar_msg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int m = blockIdx.y, a0 = blockIdx.x * TA, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = 32 * w + (lane & 31);
+    const LayerW &W = MW[m].layer[l];
+    const size_t mN = (size_t)m * N;
+    load_update_tiles(lds, s_msg, v_msg, mN, a0, N);
+    __syncthreads();
+    UpdRegs R;
+    update_forward(W, lds, w, half, col, R);
+    // Every wave has passed the barrier in front of GEMM3, i.e. finished GEMM1/GEMM2: vt and hs are free.
+    float *qb = lds + OFF_VT;    // [TA][LDQ] overlays vt (12 416 <= 12 672 floats)
+    float sb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int row = crow(i, half), a = a0 + row;
+        size_t g = mN + a;
+        bool ok = a < N;
+        sb[i] = ok ? sbar[g * F + col] : 0.f;
+        float abar_vv = 0.f;
+        if (ok && !vbar_is_zero) {
+#pragma unroll
+            for (int x = 0; x < 3; ++x) abar_vv = fmaf(vbar[(g * 3 + x) * F + col], R.uv[x][0][i], abar_vv);
+        }
+        qb[row * LDQ + col] = abar_vv;
+        qb[row * LDQ + F + col] = sb[i] * R.inner[i];
+        qb[row * LDQ + 2 * F + col] = sb[i];
+    }
+    __syncthreads();   // qb complete; every wave is past GEMM3, so `as` may be overwritten
+    float *hb = lds + OFF_AS;    // [TA][LDV] h3bar
+    {
+        f32x16 acc[1][1];
+        zero_acc(acc);
+        const float *wp[1] = {W.pW4t + (size_t)w * 32 * F3};
+        gemm_acc<F3, 1, 1>(qb, LDQ, wp, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hb[crow(i, half) * LDV + col] = acc[0][0][i] * dswish(R.h3[i]);
+    }
+    __syncthreads();
+    f32x16 hbar[1][2];   // [0] = d/d s_msg part, [1] = d/d norm part, both for feature `col`
+    zero_acc(hbar);
+    {
+        const float *wp[2] = {W.pW3t + (size_t)w * 32 * F, W.pW3t + (size_t)(4 + w) * 32 * F};
+        gemm_acc<F, 1, 2>(hb, LDV, wp, hbar);
+    }
+    __syncthreads();   // all waves are done with qb / hb: the whole region becomes the [Ubar | Vbar] tile
+    float *ab = lds;     // [3*TA][LDH]: cols [0,F) = Ubar, [F,2F) = Vbar   (24 960 <= 25 216 floats)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int row = crow(i, half), a = a0 + row;
+        size_t g = mN + a;
+        bool ok = a < N;
+        if (ok) sbar_msg[g * F + col] = sb[i] + hbar[0][0][i];
+        float avv = R.gate[0][i], asv = R.gate[1][i];
+        float sc = hbar[0][1][i] / R.nrm[i];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            float vbo = (ok && !vbar_is_zero) ? vbar[(g * 3 + x) * F + col] : 0.f;
+            float u = R.uv[x][0][i], v = R.uv[x][1][i];
+            float sa = sb[i] * asv;
+            ab[(x * TA + row) * LDH + col] = fmaf(vbo, avv, sa * v);
+            ab[(x * TA + row) * LDH + F + col] = fmaf(sa, u, sc * v);
+        }
+    }
+    __syncthreads();
+    f32x16 out[3][1];
+    zero_acc(out);
+    {
+        const float *wp[1] = {W.pUVt + (size_t)w * 32 * 2 * F};
+        gemm_acc<2 * F, 3, 1>(ab, LDH, wp, out);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int row = crow(i, half), a = a0 + row;
+        if (a >= N) continue;
+        size_t g = mN + a;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            float vbo = vbar_is_zero ? 0.f : vbar[(g * 3 + x) * F + col];
+            vbar_msg[(g * 3 + x) * F + col] = vbo + out[x][0][i];
+        }
+    }
+}
+
+// ---- host: weight packing + launch helpers ------------------------------------------------------------------------
+// packed[tile][q][lane][t] = W[tile*32 + (lane&31)][(lane>>5)*(K/2) + 4q + t]   (W row-major [rows][K])
+void pack_mfma_tiles(const float *Wsrc, int rows, int K, float *dst) {
+    const int ntile = rows / 32, nq = K / 8;
+    for (int tile = 0; tile < ntile; ++tile)
+        for (int q = 0; q < nq; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 4; ++t)
+                    dst[(((size_t)tile * nq + q) * 64 + lane) * 4 + t] =
+                        Wsrc[(size_t)(tile * 32 + (lane & 31)) * K + (lane >> 5) * (K / 2) + 4 * q + t];
+}
+
+size_t node_mfma_lds_bytes(int which) {
+    switch (which) {
+        case 0: return sizeof(float) * 2 * TA * LDV;            // msg mlp fwd
+        case 1: return sizeof(float) * (TA * LDV + TA * LDQ);   // msg mlp bwd
+        default: return sizeof(float) * UPD_LDS_FLOATS;         // update fwd / bwd
+    }
+}
+
+int node_mfma_init(vssr_handle *h) {
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(0)));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(1)));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(2)));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(2)));
+    return VSSR_OK;
+}
+
+void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in, float *phi) {
+    hipLaunchKernelGGL(k_msg_mlp_mfma, dim3((N + TA - 1) / TA, M), dim3(256), node_mfma_lds_bytes(0), st, N, l, MW,
+                       s_in, phi);
+}
+void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in,
+                             const float *phibar, const float *sbar_msg, float *sbar_in) {
+    hipLaunchKernelGGL(k_msg_mlp_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(256), node_mfma_lds_bytes(1), st, N, l, MW,
+                       s_in, phibar, sbar_msg, sbar_in);
+}
+void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_msg,
+                            const float *v_msg, float *s_out, float *v_out) {
+    hipLaunchKernelGGL(k_update_fwd_mfma, dim3((N + TA - 1) / TA, M), dim3(256), node_mfma_lds_bytes(2), st, N, l, MW,
+                       s_msg, v_msg, s_out, v_out);
+}
+void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zero, const ModelW *MW,
+                            const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
+                            float *sbar_msg, float *vbar_msg) {
+    hipLaunchKernelGGL(k_update_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(256), node_mfma_lds_bytes(2), st, N, l,
+                       vbar_is_zero, MW, s_msg, v_msg, sbar, vbar, sbar_msg, vbar_msg);
+}
+
+}  // namespace vssr

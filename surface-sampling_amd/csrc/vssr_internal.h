@@ -29,6 +29,13 @@ struct LayerW {
     const float *U, *Ut, *V, *Vt;  // [F][F]
     const float *W3, *W3t, *b3;  // [F][2F], transposed [2F][F]
     const float *W4, *W4t, *b4;  // [3F][F], transposed [F][3F]
+    // MFMA fragment-order copies (painn_node_mfma.hip: packed[tile][q][lane][4])
+    const float *pW1, *pW2;      // forward:  W1 (4 tiles, K=F), W2 (12 tiles, K=F)
+    const float *pU, *pV;        //           U, V (4 tiles each, K=F)
+    const float *pW3, *pW4;      //           W3 (4 tiles, K=2F), W4 (12 tiles, K=F)
+    const float *pW1t, *pW2t;    // reverse:  W1^T (4 tiles, K=F), W2^T (4 tiles, K=3F)
+    const float *pW4t, *pW3t;    //           W4^T (4 tiles, K=3F), W3^T (8 tiles, K=F)
+    const float *pUVt;           //           [U;V]^T (4 tiles, K=2F)
 };
 struct ModelW {
     const float *embed;  // [n_embed][F]
@@ -130,6 +137,8 @@ struct vssr_handle {
     std::string err;
     vssr::Profiler prof;
 
+    int node_impl = 1;  // 1 = MFMA node kernels, 0 = v0 VALU kernels (VSSR_NODE_IMPL=v0, A/B validation only)
+
     // configuration
     int n_models = 0, n_rbf = 20, num_conv = 3, n_embed = 100, readout_hidden = 64;
     float cutoff = 5.f;
@@ -185,5 +194,16 @@ int painn_alloc_state(vssr_handle *h);
 int painn_run(vssr_handle *h, uint32_t want);
 // Tersoff (tersoff.hip)
 int tersoff_run(vssr_handle *h, uint32_t want);
+// MFMA node stages (painn_node_mfma.hip)
+void pack_mfma_tiles(const float *Wsrc, int rows, int K, float *dst);
+int node_mfma_init(vssr_handle *h);
+void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in, float *phi);
+void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in,
+                             const float *phibar, const float *sbar_msg, float *sbar_in);
+void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_msg,
+                            const float *v_msg, float *s_out, float *v_out);
+void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zero, const ModelW *MW,
+                            const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
+                            float *sbar_msg, float *vbar_msg);
 
 }  // namespace vssr
