@@ -131,7 +131,7 @@ __global__ void k_scan_rows(int n, const int *__restrict__ deg, int *__restrict_
         row_start[n] = (int)total;
         counters[0] = (int)total;
         counters[1] = (int)part_real[t];
-        counters[2] = (total > slot_cap || total > 2147483000LL) ? 1 : 0;
+        counters[2] = (total > slot_cap - 64 || total > 2147483000LL) ? 1 : 0;
     }
 }
 
@@ -158,6 +158,56 @@ __global__ void k_rev(int n, const int *__restrict__ row_start, const float4 *__
             }
         }
         rev[e] = found;
+    }
+}
+
+// Per-slot geometry tables for the PaiNN edge kernels: unit vector + chain-local neighbor index, edge length,
+// and the radial basis rho_k(d) = sin((k+1) pi d / rc)/d * fc(d) (k < 20), rho_20 = fc(d), with its derivative,
+// stored in the order the MFMA A operand wants them: table[slot][kq][ks] = rho_{kq + 4 ks}  (kq = lane >> 4).
+// One thread per (slot, kq).  sin/cos of the multiples come from one sincos + a rotation recurrence.
+__global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
+                            const int *__restrict__ cfg_start, const float4 *__restrict__ edge,
+                            const int *__restrict__ counters, float rc, float4 *__restrict__ erec,
+                            float *__restrict__ rho, float *__restrict__ drho, float *__restrict__ dist) {
+    if (counters[2]) return;
+    const int i = blockIdx.x;                 // centre atom
+    const int a0 = cfg_start[atom_cfg[i]];
+    const int e0 = row_start[i], e1 = row_start[i + 1];
+    const float alpha = 3.14159265358979323846f / rc;
+    for (int t = threadIdx.x; t < (e1 - e0) * 4; t += blockDim.x) {
+        const int slot = e0 + (t >> 2), kq = t & 3;
+        const float4 ed = edge[slot];
+        const int j = __float_as_int(ed.w);
+        const bool valid = j >= 0;
+        const float d2 = fmaf(ed.z, ed.z, fmaf(ed.y, ed.y, ed.x * ed.x));
+        const float d = valid ? sqrtf(d2) : 1.f;
+        const float inv = valid ? 1.f / d : 0.f;
+        float s1, c1;
+        sincosf(alpha * d, &s1, &c1);
+        const bool inside = valid && d < rc;
+        const float fc = inside ? 0.5f * (c1 + 1.f) : 0.f;
+        const float dfc = inside ? -0.5f * alpha * s1 : 0.f;
+        const float s2 = 2.f * s1 * c1, c2 = fmaf(c1, c1, -s1 * s1);
+        const float s3 = fmaf(s2, c1, c2 * s1), c3 = fmaf(c2, c1, -s2 * s1);
+        const float s4 = 2.f * s2 * c2, c4 = fmaf(c2, c2, -s2 * s2);
+        float sn = kq == 0 ? s1 : kq == 1 ? s2 : kq == 2 ? s3 : s4;
+        float cn = kq == 0 ? c1 : kq == 1 ? c2 : kq == 2 ? c3 : c4;
+        float nf = (float)(kq + 1);
+        float *r = rho + (size_t)slot * 24 + kq * 6, *dr = drho + (size_t)slot * 24 + kq * 6;
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const float rb = sn * inv;
+            r[ks] = rb * fc;
+            dr[ks] = fmaf(nf * alpha * cn * inv - rb * inv, fc, rb * dfc);
+            const float sn2 = fmaf(sn, c4, cn * s4), cn2 = fmaf(cn, c4, -sn * s4);
+            sn = sn2; cn = cn2; nf += 4.f;
+        }
+        r[5] = kq == 0 ? fc : 0.f;
+        dr[5] = kq == 0 ? dfc : 0.f;
+        if (kq == 0) {
+            erec[slot] = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, __int_as_float(valid ? j - a0 : 0));
+            dist[slot] = d;
+        }
     }
 }
 
@@ -192,6 +242,19 @@ int build_neighbors(vssr_handle *h, double cutoff) {
                        h->d_edge.as<float4>(), h->d_edge_S.as<int>(), (long long)h->slot_cap);
     hipLaunchKernelGGL(k_rev, grd, blk, 0, st, n, h->d_row_start.as<int>(), h->d_edge.as<float4>(),
                        h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>());
+    if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
+        if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
+            h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float) * h->slot_cap))
+            return set_err(h, VSSR_E_NOMEM, "edge geometry tables: out of device memory");
+        // the last slot of the capacity is never used by the CSR (counters[2] flags slots > cap - 64): it is the
+        // all-zero table entry that exhausted lanes of the edge kernels read
+        VSSR_HIP(h, hipMemsetAsync(h->d_rho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
+        VSSR_HIP(h, hipMemsetAsync(h->d_drho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
+        hipLaunchKernelGGL(k_edge_geom, dim3(n), dim3(64), 0, st, n, h->d_row_start.as<int>(), h->d_atom_cfg.as<int>(),
+                           h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,
+                           h->d_erec.as<float4>(), h->d_rho.as<float>(), h->d_drho.as<float>(),
+                           h->d_dist.as<float>());
+    }
     h->prof.end(st);
     VSSR_HIP(h, hipMemcpyAsync(h->h_counters, h->d_counters.as<int>(), sizeof(int) * 4,
                                hipMemcpyDeviceToHost, st));

@@ -728,6 +728,10 @@ int painn_run(vssr_handle *h, uint32_t want) {
     G.deg = h->d_deg.as<int>();
     G.edge = h->d_edge.as<float4>();
     G.rev = h->d_rev.as<int>();
+    G.erec = h->d_erec.as<float4>();
+    G.rho = h->d_rho.as<float>();
+    G.drho = h->d_drho.as<float>();
+    G.dist = h->d_dist.as<float>();
     const ModelW *MW = h->model_table.as<ModelW>();
     const int *counters = h->d_counters.as<int>();
     const int *Z = h->d_Z.as<int>();
@@ -744,7 +748,11 @@ int painn_run(vssr_handle *h, uint32_t want) {
         else hipLaunchKernelGGL(k_msg_mlp, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phi[l]);
         P.end(st);
         P.begin(KC_EDGE_FWD, st);
-        if (l == 0)
+        if (h->edge_impl && edge_fwd_mfma_fits(h->max_cfg_atoms))
+            launch_edge_fwd_mfma(st, N, h->n_cfg, M, l, h->max_cfg_atoms, MW, G, counters, (int)(h->slot_cap - 1), h->excl_vol,
+                                 h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
+                                 sv.v_msg[l], sv.e_excl);
+        else if (l == 0)
             hipLaunchKernelGGL(k_edge_fwd<true>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
                                h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
                                sv.v_msg[l], sv.e_excl);

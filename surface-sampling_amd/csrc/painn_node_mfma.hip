@@ -35,44 +35,32 @@ __device__ __forceinline__ float dswish(float x) {
 // row of accumulator register `reg` inside a 32x32 tile (MI355X guide: C/D layout of 32x32 MFMA)
 __device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
-// acc[t][c] += A(rows t*32.., K) * packed tile c.
-// One wave per SIMD leaves nobody else to hide L2 latency, so the weight fragments are fetched two
-// q-steps (8 k-steps) ahead of the MFMAs that consume them; A fragments one step ahead from LDS.
+// acc[t][c] += A(rows t*32.., K) * packed tile c
 template <int K, int NRT, int NCT>
 __device__ __forceinline__ void gemm_acc(const float *__restrict__ lds_a, int ld,
                                          const float *const (&wp)[NCT], f32x16 (&acc)[NRT][NCT]) {
-    constexpr int NQ = K / 8;
     const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
     const float *a_base = lds_a + r * ld + half * (K / 2);
-    float4 b0[NCT], b1[NCT], b2[NCT], a0[NRT], a1[NRT];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-        b0[c] = *reinterpret_cast<const float4 *>(wp[c] + ((size_t)0 * 64 + lane) * 4);
-        b1[c] = *reinterpret_cast<const float4 *>(wp[c] + ((size_t)1 * 64 + lane) * 4);
-    }
-#pragma unroll
-    for (int t = 0; t < NRT; ++t) a0[t] = *reinterpret_cast<const float4 *>(a_base + t * 32 * ld);
 #pragma unroll 2
-    for (int q = 0; q < NQ; ++q) {
-        const int qb = (q + 2 < NQ) ? q + 2 : NQ - 1, qa = (q + 1 < NQ) ? q + 1 : NQ - 1;
+    for (int q = 0; q < K / 8; ++q) {
+        float bv[NCT][4], av[NRT][4];
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) b2[c] = *reinterpret_cast<const float4 *>(wp[c] + ((size_t)qb * 64 + lane) * 4);
+        for (int c = 0; c < NCT; ++c) {
+            float4 b = *reinterpret_cast<const float4 *>(wp[c] + ((size_t)q * 64 + lane) * 4);
+            bv[c][0] = b.x; bv[c][1] = b.y; bv[c][2] = b.z; bv[c][3] = b.w;
+        }
 #pragma unroll
-        for (int t = 0; t < NRT; ++t) a1[t] = *reinterpret_cast<const float4 *>(a_base + t * 32 * ld + 4 * qa);
+        for (int t = 0; t < NRT; ++t) {
+            float4 a = *reinterpret_cast<const float4 *>(a_base + t * 32 * ld + 4 * q);
+            av[t][0] = a.x; av[t][1] = a.y; av[t][2] = a.z; av[t][3] = a.w;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int t = 0; t < NRT; ++t)
 #pragma unroll
-                for (int c = 0; c < NCT; ++c) {
-                    float av = s == 0 ? a0[t].x : s == 1 ? a0[t].y : s == 2 ? a0[t].z : a0[t].w;
-                    float bv = s == 0 ? b0[c].x : s == 1 ? b0[c].y : s == 2 ? b0[c].z : b0[c].w;
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t][c], 0, 0, 0);
-                }
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) { b0[c] = b1[c]; b1[c] = b2[c]; }
-#pragma unroll
-        for (int t = 0; t < NRT; ++t) a0[t] = a1[t];
+                for (int c = 0; c < NCT; ++c)
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][s], bv[c][s], acc[t][c], 0, 0, 0);
     }
 }
 
@@ -86,15 +74,22 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NRT][NCT]) {
             for (int i = 0; i < 16; ++i) acc[t][c][i] = 0.f;
 }
 
-// cooperative tile loads: rows of F floats, global row index given by a functor; rows >= valid are zero
-template <class RowPtr>
-__device__ __forceinline__ void load_rows(float *lds, int ld, int col0, int nrows, RowPtr rowptr) {
-    // F/4 = 32 float4 per row
-    for (int idx = threadIdx.x; idx < nrows * (F / 4); idx += blockDim.x) {
-        int row = idx >> 5, c4 = idx & 31;
-        const float *src = rowptr(row);
-        float4 v = src ? *reinterpret_cast<const float4 *>(src + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(lds + row * ld + col0 + 4 * c4) = v;
+// Cooperative tile load: NROWS rows of F floats.  rowptr(row) must always return a readable row
+// (tail rows are clamped to the last atom; their results are never stored), so that all loads are
+// unconditional and issued back-to-back before the first LDS store (no per-element branch / vmcnt(0)).
+template <int NROWS, class RowPtr>
+__device__ __forceinline__ void load_rows(float *lds, int ld, int col0, RowPtr rowptr) {
+    constexpr int NIT = NROWS * (F / 4) / 256;
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int idx = threadIdx.x + it * 256;
+        v[it] = *reinterpret_cast<const float4 *>(rowptr(idx >> 5) + 4 * (idx & 31));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int idx = threadIdx.x + it * 256;
+        *reinterpret_cast<float4 *>(lds + (idx >> 5) * ld + col0 + 4 * (idx & 31)) = v[it];
     }
 }
 
@@ -109,7 +104,7 @@ k_msg_mlp_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restr
     const int half = lane >> 5, col = 32 * w + (lane & 31);
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
-    load_rows(xs, LDV, 0, TA, [&](int row) { int a = a0 + row; return a < N ? s_in + (mN + a) * F : nullptr; });
+    load_rows<TA>(xs, LDV, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; });
     __syncthreads();
     {
         f32x16 acc[1][1];
@@ -147,10 +142,10 @@ k_msg_mlp_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__r
     const int half = lane >> 5, col = 32 * w + (lane & 31);
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
-    load_rows(xs, LDV, 0, TA, [&](int row) { int a = a0 + row; return a < N ? s_in + (mN + a) * F : nullptr; });
+    load_rows<TA>(xs, LDV, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; });
+#pragma unroll
     for (int c = 0; c < 3; ++c)
-        load_rows(pb, LDQ, c * F, TA,
-                  [&](int row) { int a = a0 + row; return a < N ? phibar + (mN + a) * F3 + c * F : nullptr; });
+        load_rows<TA>(pb, LDQ, c * F, [&](int row) { return phibar + (mN + min(a0 + row, N - 1)) * F3 + c * F; });
     __syncthreads();
     f32x16 h1[1][1], a1[1][1];
     zero_acc(h1);
@@ -244,11 +239,11 @@ __device__ __forceinline__ void update_forward(const LayerW &W, float *lds, int 
 
 __device__ __forceinline__ void load_update_tiles(float *lds, const float *__restrict__ s_msg,
                                                   const float *__restrict__ v_msg, size_t mN, int a0, int N) {
-    load_rows(lds + OFF_VT, LDV, 0, 3 * TA, [&](int row) {
-        int x = row / TA, a = a0 + (row % TA);
-        return a < N ? v_msg + ((mN + a) * 3 + x) * F : nullptr;
+    load_rows<3 * TA>(lds + OFF_VT, LDV, 0, [&](int row) {
+        int x = row / TA, a = min(a0 + (row % TA), N - 1);
+        return v_msg + ((mN + a) * 3 + x) * F;
     });
-    load_rows(lds + OFF_HS, LDH, 0, TA, [&](int row) { int a = a0 + row; return a < N ? s_msg + (mN + a) * F : nullptr; });
+    load_rows<TA>(lds + OFF_HS, LDH, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
 }
 
 __global__ void __launch_bounds__(256, 1)
@@ -300,12 +295,11 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     float sb[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        int row = crow(i, half), a = a0 + row;
-        size_t g = mN + a;
-        bool ok = a < N;
-        sb[i] = ok ? sbar[g * F + col] : 0.f;
+        int row = crow(i, half);
+        size_t g = mN + min(a0 + row, N - 1);
+        sb[i] = sbar[g * F + col];
         float abar_vv = 0.f;
-        if (ok && !vbar_is_zero) {
+        if (!vbar_is_zero) {   // wave-uniform
 #pragma unroll
             for (int x = 0; x < 3; ++x) abar_vv = fmaf(vbar[(g * 3 + x) * F + col], R.uv[x][0][i], abar_vv);
         }
@@ -335,14 +329,13 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         int row = crow(i, half), a = a0 + row;
-        size_t g = mN + a;
-        bool ok = a < N;
-        if (ok) sbar_msg[g * F + col] = sb[i] + hbar[0][0][i];
+        size_t g = mN + min(a, N - 1);
+        if (a < N) sbar_msg[g * F + col] = sb[i] + hbar[0][0][i];
         float avv = R.gate[0][i], asv = R.gate[1][i];
         float sc = hbar[0][1][i] / R.nrm[i];
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-            float vbo = (ok && !vbar_is_zero) ? vbar[(g * 3 + x) * F + col] : 0.f;
+            float vbo = vbar_is_zero ? 0.f : vbar[(g * 3 + x) * F + col];
             float u = R.uv[x][0][i], v = R.uv[x][1][i];
             float sa = sb[i] * asv;
             ab[(x * TA + row) * LDH + col] = fmaf(vbo, avv, sa * v);

@@ -245,7 +245,9 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     int rc = common_init(h, cfg->device);
     if (!rc) rc = upload_weights(h, cfg);
     if (!rc) rc = node_mfma_init(h);
+    if (!rc) rc = edge_mfma_init(h);
     if (const char *e = getenv("VSSR_NODE_IMPL")) h->node_impl = (strcmp(e, "v0") == 0) ? 0 : 1;
+    if (const char *e = getenv("VSSR_EDGE_IMPL")) h->edge_impl = (strcmp(e, "v0") == 0) ? 0 : 1;
     if (!rc && cfg->offset_per_z) {
         h->has_offset = true;
         h->offset_const = cfg->offset_const;
@@ -302,7 +304,7 @@ void vssr_destroy(vssr_handle *h) {
     h->prof.destroy();
     DevBuf *bufs[] = {&h->weights, &h->model_table, &h->offset_per_z, &h->ters_params, &h->d_pos, &h->d_wpos,
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
-                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters,
+                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
                       &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f};
     for (DevBuf *b : bufs) b->release();
@@ -359,6 +361,8 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
     VSSR_HIP(h, hipMemcpy(h->d_pbc.p, pbc, (size_t)3 * n_cfg, hipMemcpyHostToDevice));
     h->n_cfg = n_cfg;
     h->n_atoms = N;
+    h->max_cfg_atoms = 0;
+    for (int b = 0; b < n_cfg; ++b) h->max_cfg_atoms = n_atoms[b] > h->max_cfg_atoms ? n_atoms[b] : h->max_cfg_atoms;
     h->h_n_atoms.assign(n_atoms, n_atoms + n_cfg);
     h->h_cfg_start = start;
     h->batch_valid = true;

@@ -52,6 +52,11 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const int *deg;          // [n_atoms] real degree (unpadded)
     const float4 *edge;      // [slots] {r_x, r_y, r_z, bitcast(j)} ; j < 0 marks a pad slot
     const int *rev;          // [slots] slot of the reverse edge (j -> i, -S)
+    // per-slot geometry tables, computed once per evaluation and shared by every layer / model / feature slice
+    const float4 *erec;      // [slots] {u_x, u_y, u_z, bitcast(j local to its chain)} ; pads: u = 0, j = 0
+    const float *rho;        // [slots][4][6]  radial basis * envelope in MFMA A-fragment order: [kq][ks] = rho_{kq+4ks}
+    const float *drho;       // [slots][4][6]  d rho / d d, same order
+    const float *dist;       // [slots] edge length (pads: 1)
 };
 
 struct StateView {  // activations of all models: index [m][atom][...]
@@ -138,6 +143,8 @@ struct vssr_handle {
     vssr::Profiler prof;
 
     int node_impl = 1;  // 1 = MFMA node kernels, 0 = v0 VALU kernels (VSSR_NODE_IMPL=v0, A/B validation only)
+    int edge_impl = 1;  // 1 = LDS-slice + MFMA edge kernels (chains that fit LDS), 0 = gather kernels
+    int max_cfg_atoms = 0;
 
     // configuration
     int n_models = 0, n_rbf = 20, num_conv = 3, n_embed = 100, readout_hidden = 64;
@@ -164,6 +171,7 @@ struct vssr_handle {
     std::vector<int> h_n_atoms, h_cfg_start;
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
     vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
+    vssr::DevBuf d_erec, d_rho, d_drho, d_dist;
     int64_t slot_cap = 0;
     int *h_counters = nullptr;   // pinned: [0] total slots, [1] total real edges, [2] overflow flag
 
@@ -205,5 +213,12 @@ void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *M
 void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zero, const ModelW *MW,
                             const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
                             float *sbar_msg, float *vbar_msg);
+// LDS-slice + MFMA edge stages (painn_edge_mfma.hip)
+int edge_mfma_init(vssr_handle *h);
+bool edge_fwd_mfma_fits(int max_atoms);
+void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,
+                          const GraphView &G, const int *counters, int zero_slot, int excl_vol, float excl_sigma,
+                          int excl_power, const float *s_in, const float *v_in, const float *phi, float *s_msg,
+                          float *v_msg, float *e_excl);
 
 }  // namespace vssr
