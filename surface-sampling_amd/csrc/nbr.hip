@@ -167,8 +167,9 @@ __global__ void k_rev(int n, const int *__restrict__ row_start, const float4 *__
 // One thread per (slot, kq).  sin/cos of the multiples come from one sincos + a rotation recurrence.
 __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
                             const int *__restrict__ cfg_start, const float4 *__restrict__ edge,
-                            const int *__restrict__ counters, float rc, float4 *__restrict__ erec,
-                            float *__restrict__ rho, float *__restrict__ drho, float *__restrict__ dist) {
+                            const int *__restrict__ counters, float rc, float excl_sigma, int excl_power,
+                            float4 *__restrict__ erec, float *__restrict__ rho, float *__restrict__ drho,
+                            float2 *__restrict__ dist2) {
     if (counters[2]) return;
     const int i = blockIdx.x;                 // centre atom
     const int a0 = cfg_start[atom_cfg[i]];
@@ -206,7 +207,8 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
         dr[5] = kq == 0 ? dfc : 0.f;
         if (kq == 0) {
             erec[slot] = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, __int_as_float(valid ? j - a0 : 0));
-            dist[slot] = d;
+            dist2[slot] = valid ? make_float2(d, -(float)excl_power * powf(excl_sigma * inv, (float)excl_power) * inv)
+                                : make_float2(-1.f, 0.f);
         }
     }
 }
@@ -244,7 +246,7 @@ int build_neighbors(vssr_handle *h, double cutoff) {
                        h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>());
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
         if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
-            h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float) * h->slot_cap))
+            h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float2) * h->slot_cap))
             return set_err(h, VSSR_E_NOMEM, "edge geometry tables: out of device memory");
         // the last slot of the capacity is never used by the CSR (counters[2] flags slots > cap - 64): it is the
         // all-zero table entry that exhausted lanes of the edge kernels read
@@ -252,8 +254,8 @@ int build_neighbors(vssr_handle *h, double cutoff) {
         VSSR_HIP(h, hipMemsetAsync(h->d_drho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
         hipLaunchKernelGGL(k_edge_geom, dim3(n), dim3(64), 0, st, n, h->d_row_start.as<int>(), h->d_atom_cfg.as<int>(),
                            h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,
-                           h->d_erec.as<float4>(), h->d_rho.as<float>(), h->d_drho.as<float>(),
-                           h->d_dist.as<float>());
+                           h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),
+                           h->d_drho.as<float>(), h->d_dist.as<float2>());
     }
     h->prof.end(st);
     VSSR_HIP(h, hipMemcpyAsync(h->h_counters, h->d_counters.as<int>(), sizeof(int) * 4,

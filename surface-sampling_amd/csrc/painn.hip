@@ -601,20 +601,22 @@ k_msg_mlp_bwd(int N, int l, const ModelW *__restrict__ MW, const float *__restri
 
 // ---- ensemble reduction -----------------------------------------------------------------------------------------
 // forces: dE/dx_c = sum_{slots (c,n)} ( G[(n->c)] - G[(c->n)] ), G[(c->n)] lives at rev[slot].
-__global__ void k_finalize_forces(int N, int M, GraphView G, const int *__restrict__ counters,
+__global__ void k_finalize_forces(int N, int M, int n_groups, GraphView G, const int *__restrict__ counters,
                                   const float4 *__restrict__ gbar, long long gbar_stride, double units_per_ev,
                                   float *__restrict__ forces, float *__restrict__ forces_std) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N || counters[2]) return;
     double fm[3] = {0, 0, 0}, f2[3] = {0, 0, 0};
     for (int m = 0; m < M; ++m) {
-        const float4 *gb = gbar + (size_t)m * gbar_stride;
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        for (int e = G.row_start[c]; e < G.row_start[c + 1]; ++e) {
-            int r = G.rev[e];
-            if (r < 0) continue;
-            float4 a = gb[e], b = gb[r];
-            g0 += a.x - b.x; g1 += a.y - b.y; g2 += a.z - b.z;
+        for (int grp = 0; grp < n_groups; ++grp) {   // partial edge gradients of the feature-slice groups
+            const float4 *gb = gbar + (size_t)(m * n_groups + grp) * gbar_stride;
+            for (int e = G.row_start[c]; e < G.row_start[c + 1]; ++e) {
+                int r = G.rev[e];
+                if (r < 0) continue;
+                float4 a = gb[e], b = gb[r];
+                g0 += a.x - b.x; g1 += a.y - b.y; g2 += a.z - b.z;
+            }
         }
         double f[3] = {-(double)g0 / units_per_ev, -(double)g1 / units_per_ev, -(double)g2 / units_per_ev};
         for (int x = 0; x < 3; ++x) { fm[x] += f[x]; f2[x] += f[x] * f[x]; }
@@ -701,7 +703,7 @@ int painn_alloc_state(vssr_handle *h) {
     sv.sbar_msg = p; p += nS;
     sv.vbar_msg = p; p += nV;
     sv.phibar = p; p += nP;
-    if (h->d_gbar.ensure(sizeof(float4) * M * (size_t)h->slot_cap))
+    if (h->d_gbar.ensure(sizeof(float4) * M * (size_t)edge_bwd_groups() * (size_t)h->slot_cap))
         return set_err(h, VSSR_E_NOMEM, "edge-gradient buffer: out of device memory");
     sv.gbar = h->d_gbar.as<float4>();
     if (h->d_energy.ensure(sizeof(float) * h->n_cfg) || h->d_energy_std.ensure(sizeof(float) * h->n_cfg) ||
@@ -731,13 +733,14 @@ int painn_run(vssr_handle *h, uint32_t want) {
     G.erec = h->d_erec.as<float4>();
     G.rho = h->d_rho.as<float>();
     G.drho = h->d_drho.as<float>();
-    G.dist = h->d_dist.as<float>();
+    G.dist2 = h->d_dist.as<float2>();
     const ModelW *MW = h->model_table.as<ModelW>();
     const int *counters = h->d_counters.as<int>();
     const int *Z = h->d_Z.as<int>();
     dim3 blk(128);
     dim3 g_atom(N, M), g_tile((N + T - 1) / T, M);
     Profiler &P = h->prof;
+    const bool use_edge_mfma = h->edge_impl && edge_fwd_mfma_fits(h->max_cfg_atoms);   // chains fit the LDS slices
 
     P.begin(KC_EMBED, st);
     hipLaunchKernelGGL(k_embed, g_atom, blk, 0, st, N, Z, MW, sv.s_in[0], sv.v_in[0]);
@@ -748,7 +751,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
         else hipLaunchKernelGGL(k_msg_mlp, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phi[l]);
         P.end(st);
         P.begin(KC_EDGE_FWD, st);
-        if (h->edge_impl && edge_fwd_mfma_fits(h->max_cfg_atoms))
+        if (use_edge_mfma)
             launch_edge_fwd_mfma(st, N, h->n_cfg, M, l, h->max_cfg_atoms, MW, G, counters, (int)(h->slot_cap - 1), h->excl_vol,
                                  h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
                                  sv.v_msg[l], sv.e_excl);
@@ -786,7 +789,11 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.end(st);
             P.begin(KC_EDGE_BWD, st);
             int accumulate = (l != L - 1);
-            if (l == 0)
+            if (use_edge_mfma)
+                launch_edge_bwd_mfma(st, N, h->n_cfg, M, l, (int)(l == L - 1), h->max_cfg_atoms, MW, G, counters,
+                                     (int)(h->slot_cap - 1), h->excl_vol, sv.v_in[l], sv.phi[l], sv.sbar_msg,
+                                     sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap);
+            else if (l == 0)
                 hipLaunchKernelGGL(k_edge_bwd<true>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                    h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
                                    sv.sbar_msg, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap);
@@ -808,7 +815,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     }
     P.begin(KC_FINALIZE, st);
     if (want & VSSR_WANT_FORCES)
-        hipLaunchKernelGGL(k_finalize_forces, dim3((N + 127) / 128), dim3(128), 0, st, N, M, G, counters, sv.gbar,
+        hipLaunchKernelGGL(k_finalize_forces, dim3((N + 127) / 128), dim3(128), 0, st, N, M,
+                           use_edge_mfma ? edge_bwd_groups() : 1, G, counters, sv.gbar,
                            (long long)h->slot_cap, h->units_per_ev, h->d_forces.as<float>(),
                            h->d_forces_std.as<float>());
     hipLaunchKernelGGL(k_finalize_energy, dim3(h->n_cfg), dim3(256), 0, st, N, M, G.cfg_start, Z, sv.e_atom,

@@ -258,6 +258,281 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     }
 }
 
+// ======================================================================================================
+// Reverse pass of the message block (oracle: painn_impl.inc "message block^T").
+// Atom c in its role as SOURCE j: for every neighbor n the edge (n -> c) carried phi_c, v_c into n.
+//   phibar_c[b] += w[b] sbar_n ; phibar_c[c] += w[c] (vbar_n . u_nc) ; phibar_c[a] += w[a] (vbar_n . v_c)
+//   vbar_c     += phi_c[a] w[a] vbar_n
+//   dE/dd(n->c) = sum_f  dw[b] phi_c[b] sbar_n + dw[c] phi_c[c] (vbar_n.u_nc) + dw[a] phi_c[a] (vbar_n.v_c)
+//   dE/du(n->c) = sum_f  phi_c[c] w[c] vbar_n            (dw = Wd_ext . d rho/dd)
+// Same slot-major lane layout as the forward kernel: lane (p, fq) owns slot p and features 4fq..4fq+3, so
+// the sums over features are 4 in-lane terms + a reduction over the 4 feature quarters (lanes p, p+16,
+// p+32, p+48).  One workgroup = (chain, model, group of SLICES_PER_WG feature slices): it loops over its
+// slices, so the per-slot edge gradient G[m][group][slot] is accumulated by the SAME lane in a fixed order
+// (deterministic read-modify-write, L2 resident); finalize adds the groups.
+constexpr int BWD_THREADS = 512;
+constexpr int SLICES_PER_WG = 4;
+constexpr int NSG = NSLICE / SLICES_PER_WG;   // slice groups = partial edge-gradient buffers per model
+constexpr int ROWB = FS * 4 + 4;              // LDS row: [feature][sbar, vbar_x, vbar_y, vbar_z] + pad
+
+size_t edge_bwd_lds_bytes(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * ROWB + max_atoms + 4); }
+int edge_bwd_groups() { return NSG; }
+
+template <bool L0>
+__global__ void __launch_bounds__(BWD_THREADS)
+k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, GraphView G,
+                const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms, int excl_vol,
+                const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
+                const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
+                float4 *__restrict__ gbar, long long gbar_stride) {
+    constexpr int NSEC = L0 ? 2 : 3;
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    if (counters[2]) return;
+    const int wg = blockIdx.x, xcd = wg & 7, rest = wg >> 3;
+    const int per_chain = NSG * n_models;
+    const int t = rest % per_chain, b = (rest / per_chain) * 8 + xcd;
+    if (b >= G.n_cfg) return;
+    const int sg = t % NSG, m = t / NSG;
+    const int a0 = G.cfg_start[b], Nc = G.cfg_start[b + 1] - a0;
+    const size_t mN = (size_t)m * N;
+    const int tid = threadIdx.x;
+    int *rs = reinterpret_cast<int *>(tile + (size_t)max_atoms * ROWB);
+    for (int idx = tid; idx <= Nc; idx += BWD_THREADS) rs[idx] = G.row_start[a0 + idx];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, p = lane & 15, fq = lane >> 4, e = p & 3;
+    const int sid = wave * 4 + (p >> 2);
+    constexpr int nstreams = (BWD_THREADS / 64) * 4;
+    const int slot0 = rs[0], slots = rs[Nc] - slot0;
+    auto first_centre = [&](int sidx) {
+        const int target = slot0 + (int)(((long long)slots * sidx) / nstreams);
+        int lo = 0, hi = Nc;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (rs[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int c_first = sid == 0 ? 0 : first_centre(sid);
+    const int c_last = sid == nstreams - 1 ? Nc : first_centre(sid + 1);
+    const int stream_begin = rs[c_first], stream_end = rs[c_last];
+    const int last_slot = max(rs[Nc] - 1, 0);
+    const LayerW &W = MW[m].layer[l];
+    float4 *gb = gbar + (size_t)(m * NSG + sg) * gbar_stride;
+    const float *rho_lane = G.rho + fq * 6, *drho_lane = G.drho + fq * 6;
+
+    for (int si = 0; si < SLICES_PER_WG; ++si) {
+        const int fs = sg * SLICES_PER_WG + si;
+        const int fcol = fs * FS + 4 * fq;
+        __syncthreads();   // previous slice's gathers are done
+        // ---- stage [atom][f][sbar, vbar_x, vbar_y, vbar_z] of this slice ------------------------------------------
+        {
+            const int total = Nc * 16;   // 4 segments x 4 float4 per atom
+            for (int base = tid; base < total; base += 4 * BWD_THREADS) {
+                float4 v4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = min(base + u * BWD_THREADS, total - 1);
+                    const int atom = idx >> 4, seg = (idx >> 2) & 3, q4 = idx & 3;
+                    const size_t ga = mN + a0 + atom;
+                    const float *src = seg == 0 ? sbar_msg + ga * F + fs * FS + q4 * 4
+                                                : vbar_msg + (ga * 3 + (seg - 1)) * F + fs * FS + q4 * 4;
+                    v4[u] = *reinterpret_cast<const float4 *>(src);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + u * BWD_THREADS;
+                    if (idx < total) {
+                        const int atom = idx >> 4, seg = (idx >> 2) & 3, q4 = idx & 3;
+                        float *dst = tile + atom * ROWB + (q4 * 4) * 4 + seg;
+                        dst[0] = v4[u].x; dst[4] = v4[u].y; dst[8] = v4[u].z; dst[12] = v4[u].w;
+                    }
+                }
+            }
+        }
+        // ---- A operand: Wd_ext rows of this slice ------------------------------------------------------------------
+        float wA[NSEC][6];
+#pragma unroll
+        for (int s2 = 0; s2 < NSEC; ++s2) {
+            const int row = (L0 ? s2 + 1 : s2) * F + fs * FS + p;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                int k = 4 * ks + fq;
+                wA[s2][ks] = k < 20 ? W.Wd[(size_t)row * 20 + k] : (k == 20 ? W.bd[row] : 0.f);
+            }
+        }
+        __syncthreads();
+
+        // ---- per-centre data of this lane's 4 features: phi_c (a, b, c) and v_c; prefetched one centre ahead ------------
+        float4 pca = make_float4(0.f, 0.f, 0.f, 0.f), pcb, pcc, vcx = pca, vcy = pca, vcz = pca;
+        float4 npca = pca, npcb = pca, npcc = pca, nvcx = pca, nvcy = pca, nvcz = pca;
+        auto load_centre = [&](int cc, float4 &a, float4 &bq, float4 &cq, float4 &x, float4 &y, float4 &z) {
+            const size_t ga = mN + a0 + min(cc, Nc - 1);
+            const float *pr = phi + ga * F3 + fcol;
+            if (!L0) a = *reinterpret_cast<const float4 *>(pr);
+            bq = *reinterpret_cast<const float4 *>(pr + F);
+            cq = *reinterpret_cast<const float4 *>(pr + 2 * F);
+            if (!L0) {
+                x = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 0) * F + fcol);
+                y = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 1) * F + fcol);
+                z = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 2) * F + fcol);
+            }
+        };
+        int c = c_first, pos = stream_begin;
+        int cend = c < c_last ? rs[c + 1] : stream_end;
+        load_centre(c, pca, pcb, pcc, vcx, vcy, vcz);
+        load_centre(c + 1, npca, npcb, npcc, nvcx, nvcy, nvcz);
+        float accb[4] = {0.f, 0.f, 0.f, 0.f}, accc[4] = {0.f, 0.f, 0.f, 0.f};
+        float accx[4] = {0.f, 0.f, 0.f, 0.f}, accy[4] = {0.f, 0.f, 0.f, 0.f}, accz[4] = {0.f, 0.f, 0.f, 0.f};
+
+        auto flush_complete = [&]() {
+            while (c < c_last && pos >= cend) {
+                if (!L0) {
+                    float4 pa, pb, pc2, ox, oy, oz;
+                    float tb[4], tc[4], tx[4], ty[4], tz[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        tb[r] = quad_sum(accb[r]); tc[r] = quad_sum(accc[r]);
+                        tx[r] = quad_sum(accx[r]); ty[r] = quad_sum(accy[r]); tz[r] = quad_sum(accz[r]);
+                    }
+                    if (e == 0) {
+                        const size_t ga = mN + a0 + c;
+                        const float vx_[4] = {vcx.x, vcx.y, vcx.z, vcx.w}, vy_[4] = {vcy.x, vcy.y, vcy.z, vcy.w};
+                        const float vz_[4] = {vcz.x, vcz.y, vcz.z, vcz.w}, pa_[4] = {pca.x, pca.y, pca.z, pca.w};
+                        float a_[4], x_[4], y_[4], z_[4];
+                        const float *res = tile + c * ROWB + (4 * fq) * 4;   // [r][sbar, vbar_x, vbar_y, vbar_z]
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            a_[r] = fmaf(vz_[r], tz[r], fmaf(vy_[r], ty[r], vx_[r] * tx[r]));
+                            x_[r] = fmaf(pa_[r], tx[r], res[4 * r + 1]);
+                            y_[r] = fmaf(pa_[r], ty[r], res[4 * r + 2]);
+                            z_[r] = fmaf(pa_[r], tz[r], res[4 * r + 3]);
+                        }
+                        pa = make_float4(a_[0], a_[1], a_[2], a_[3]);
+                        pb = make_float4(tb[0], tb[1], tb[2], tb[3]);
+                        pc2 = make_float4(tc[0], tc[1], tc[2], tc[3]);
+                        ox = make_float4(x_[0], x_[1], x_[2], x_[3]);
+                        oy = make_float4(y_[0], y_[1], y_[2], y_[3]);
+                        oz = make_float4(z_[0], z_[1], z_[2], z_[3]);
+                        float *pbp = phibar + ga * F3 + fcol;
+                        *reinterpret_cast<float4 *>(pbp) = pa;
+                        *reinterpret_cast<float4 *>(pbp + F) = pb;
+                        *reinterpret_cast<float4 *>(pbp + 2 * F) = pc2;
+                        *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 0) * F + fcol) = ox;
+                        *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 1) * F + fcol) = oy;
+                        *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 2) * F + fcol) = oz;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
+                }
+                ++c;
+                cend = c < c_last ? rs[c + 1] : stream_end;
+                pca = npca; pcb = npcb; pcc = npcc; vcx = nvcx; vcy = nvcy; vcz = nvcz;
+                load_centre(c + 1, npca, npcb, npcc, nvcx, nvcy, nvcz);
+            }
+        };
+        flush_complete();
+
+        // table entries of this lane's slot; exhausted streams read the all-zero entry
+        float2 rh[2][3], dh[2][3];
+        float4 er[2];
+        float2 dd[2];
+        auto fetch = [&](int quad, int buf) {
+            const int sl = quad + e;
+            const size_t off = (size_t)(quad < stream_end ? sl : zero_slot) * 24;
+            const float2 *rp = reinterpret_cast<const float2 *>(rho_lane + off);
+            const float2 *dp = reinterpret_cast<const float2 *>(drho_lane + off);
+            rh[buf][0] = rp[0]; rh[buf][1] = rp[1]; rh[buf][2] = rp[2];
+            dh[buf][0] = dp[0]; dh[buf][1] = dp[1]; dh[buf][2] = dp[2];
+            er[buf] = G.erec[min(sl, last_slot)];
+            dd[buf] = G.dist2[min(sl, last_slot)];
+        };
+        fetch(pos, 0);
+        const float *trow = tile + (4 * fq) * 4;
+        const bool first_write = layer_first && si == 0;
+
+        while (__any(pos < stream_end)) {
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                fetch(pos + 4, ph ^ 1);
+                float tb[16];
+                {
+                    const float4 *row = reinterpret_cast<const float4 *>(trow + __float_as_int(er[ph].w) * ROWB);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 t4 = row[q];
+                        tb[4 * q] = t4.x; tb[4 * q + 1] = t4.y; tb[4 * q + 2] = t4.z; tb[4 * q + 3] = t4.w;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float rho[6] = {rh[ph][0].x, rh[ph][0].y, rh[ph][1].x, rh[ph][1].y, rh[ph][2].x, rh[ph][2].y};
+                const float drho[6] = {dh[ph][0].x, dh[ph][0].y, dh[ph][1].x, dh[ph][1].y, dh[ph][2].x, dh[ph][2].y};
+                f32x4 aw[NSEC], ad[NSEC];
+#pragma unroll
+                for (int s2 = 0; s2 < NSEC; ++s2) { aw[s2] = (f32x4){0.f, 0.f, 0.f, 0.f}; ad[s2] = aw[s2]; }
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+                    for (int s2 = 0; s2 < NSEC; ++s2) {
+                        aw[s2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[s2][ks], rho[ks], aw[s2], 0, 0, 0);
+                        ad[s2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[s2][ks], drho[ks], ad[s2], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                const float ux = er[ph].x, uy = er[ph].y, uz = er[ph].z;   // unit vector c -> n ; edge (n -> c) has -u
+                const float pcb_[4] = {pcb.x, pcb.y, pcb.z, pcb.w}, pcc_[4] = {pcc.x, pcc.y, pcc.z, pcc.w};
+                const float pca_[4] = {pca.x, pca.y, pca.z, pca.w};
+                const float vx_[4] = {vcx.x, vcx.y, vcx.z, vcx.w}, vy_[4] = {vcy.x, vcy.y, vcy.z, vcy.w};
+                const float vz_[4] = {vcz.x, vcz.y, vcz.z, vcz.w};
+                float dpart = 0.f, ub0 = 0.f, ub1 = 0.f, ub2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sbn = tb[4 * r], vb0 = tb[4 * r + 1], vb1 = tb[4 * r + 2], vb2 = tb[4 * r + 3];
+                    const float wB = aw[L0 ? 0 : 1][r], wC = aw[L0 ? 1 : 2][r];
+                    const float dB = ad[L0 ? 0 : 1][r], dC = ad[L0 ? 1 : 2][r];
+                    const float pn = -fmaf(vb2, uz, fmaf(vb1, uy, vb0 * ux));   // vbar_n . u_(n->c)
+                    accb[r] = fmaf(wB, sbn, accb[r]);
+                    accc[r] = fmaf(wC, pn, accc[r]);
+                    dpart = fmaf(pcb_[r] * sbn, dB, dpart);
+                    dpart = fmaf(pcc_[r] * pn, dC, dpart);
+                    if (!L0) {
+                        const float wAa = aw[0][r], dA = ad[0][r];
+                        const float q = fmaf(vb2, vz_[r], fmaf(vb1, vy_[r], vb0 * vx_[r]));
+                        accx[r] = fmaf(wAa, vb0, accx[r]);
+                        accy[r] = fmaf(wAa, vb1, accy[r]);
+                        accz[r] = fmaf(wAa, vb2, accz[r]);
+                        dpart = fmaf(pca_[r] * q, dA, dpart);
+                    }
+                    const float mc = pcc_[r] * wC;
+                    ub0 = fmaf(mc, vb0, ub0); ub1 = fmaf(mc, vb1, ub1); ub2 = fmaf(mc, vb2, ub2);
+                }
+                // sum over the 4 feature quarters (lanes p, p+16, p+32, p+48): fixed order, all lanes get the total
+                dpart += __shfl_xor(dpart, 16, 64); dpart += __shfl_xor(dpart, 32, 64);
+                ub0 += __shfl_xor(ub0, 16, 64); ub0 += __shfl_xor(ub0, 32, 64);
+                ub1 += __shfl_xor(ub1, 16, 64); ub1 += __shfl_xor(ub1, 32, 64);
+                ub2 += __shfl_xor(ub2, 16, 64); ub2 += __shfl_xor(ub2, 32, 64);
+                if (fq == 0 && pos < stream_end && dd[ph].x > 0.f) {   // one lane per real slot writes its gradient
+                    const float invd = 1.f / dd[ph].x;
+                    float db = dpart;
+                    if (L0 && excl_vol && fs == 0) db += dd[ph].y;     // excluded volume, once per slot and model
+                    // edge (n -> c): unit vector -u ; g = db (-u) + (ub - (ub.u) u) / d
+                    const float dotu = fmaf(ub2, uz, fmaf(ub1, uy, ub0 * ux));
+                    float g0 = fmaf(-db, ux, (ub0 - dotu * ux) * invd);
+                    float g1 = fmaf(-db, uy, (ub1 - dotu * uy) * invd);
+                    float g2 = fmaf(-db, uz, (ub2 - dotu * uz) * invd);
+                    const int slot = pos + e;
+                    if (!first_write) {
+                        const float4 old = gb[slot];
+                        g0 += old.x; g1 += old.y; g2 += old.z;
+                    }
+                    gb[slot] = make_float4(g0, g1, g2, 0.f);
+                }
+                if (pos < stream_end) pos += 4;
+                flush_complete();
+            }
+        }
+    }
+}
+
 // layer-0 excluded volume: e_excl[i] = sum_e (sigma/d_e)^p  (geometry only, identical for all ensemble
 // members that share sigma/p; written per member to keep the readout kernel's indexing)
 __global__ void __launch_bounds__(256)
@@ -280,10 +555,28 @@ int edge_mfma_init(vssr_handle *h) {
                                     160 * 1024));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_fwd_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
     return VSSR_OK;
 }
 
 bool edge_fwd_mfma_fits(int max_atoms) { return edge_fwd_lds_bytes(max_atoms, false) <= 160 * 1024; }
+
+void launch_edge_bwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int layer_first, int max_atoms,
+                          const ModelW *MW, const GraphView &G, const int *counters, int zero_slot, int excl_vol,
+                          const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
+                          float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride) {
+    dim3 grid(((n_cfg + 7) / 8) * 8 * NSG * M), blk(BWD_THREADS);
+    const size_t lds = edge_bwd_lds_bytes(max_atoms);
+    if (l == 0)
+        hipLaunchKernelGGL(k_edge_bwd_mfma<true>, grid, blk, lds, st, N, l, layer_first, MW, G, counters, zero_slot, M,
+                           max_atoms, excl_vol, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride);
+    else
+        hipLaunchKernelGGL(k_edge_bwd_mfma<false>, grid, blk, lds, st, N, l, layer_first, MW, G, counters, zero_slot, M,
+                           max_atoms, excl_vol, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride);
+}
 
 void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,
                           const GraphView &G, const int *counters, int zero_slot, int excl_vol, float excl_sigma,

@@ -56,7 +56,7 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const float4 *erec;      // [slots] {u_x, u_y, u_z, bitcast(j local to its chain)} ; pads: u = 0, j = 0
     const float *rho;        // [slots][4][6]  radial basis * envelope in MFMA A-fragment order: [kq][ks] = rho_{kq+4ks}
     const float *drho;       // [slots][4][6]  d rho / d d, same order
-    const float *dist;       // [slots] edge length (pads: 1)
+    const float2 *dist2;     // [slots] {edge length d (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
 };
 
 struct StateView {  // activations of all models: index [m][atom][...]
@@ -215,6 +215,11 @@ void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zer
                             float *sbar_msg, float *vbar_msg);
 // LDS-slice + MFMA edge stages (painn_edge_mfma.hip)
 int edge_mfma_init(vssr_handle *h);
+int edge_bwd_groups();
+void launch_edge_bwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int layer_first, int max_atoms,
+                          const ModelW *MW, const GraphView &G, const int *counters, int zero_slot, int excl_vol,
+                          const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
+                          float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride);
 bool edge_fwd_mfma_fits(int max_atoms);
 void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,
                           const GraphView &G, const int *counters, int zero_slot, int excl_vol, float excl_sigma,
