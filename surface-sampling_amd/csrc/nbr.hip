@@ -46,54 +46,87 @@ __global__ void k_wrap(int n, const double *__restrict__ pos, const int *__restr
     wpos[3 * i + 2] = q[2];
 }
 
-// FILL = false: count neighbors of each centre; FILL = true: write the slots.
+// One WAVE per centre atom: lane L tests candidate atom j = a0 + 64*chunk + L against all periodic images.
+// FILL = false counts, FILL = true writes the slots.  Slot order inside a centre is (j ascending, image shift
+// lexicographic), reproduced exactly by an exclusive wave scan of the per-lane hit counts, so the CSR is
+// identical however the work is spread over lanes.
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    total = __shfl(x, 63, 64);
+    return x - v;
+}
+
 template <bool FILL>
-__global__ void k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
-                      const int *__restrict__ cfg_start, const double *__restrict__ cell,
-                      const int *__restrict__ nimg, double rc2, int *__restrict__ deg,
-                      const int *__restrict__ row_start, float4 *__restrict__ edge,
-                      int *__restrict__ edge_S, long long slot_cap) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
+      const int *__restrict__ cfg_start, const double *__restrict__ cell, const int *__restrict__ nimg, double rc2,
+      int *__restrict__ deg, const int *__restrict__ row_start, float4 *__restrict__ edge,
+      int *__restrict__ edge_S, long long slot_cap) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
-    int c = atom_cfg[i];
-    int a0 = cfg_start[c], a1 = cfg_start[c + 1];
+    const int c = atom_cfg[i];
+    const int a0 = cfg_start[c], a1 = cfg_start[c + 1];
     const double *C = cell + 9 * c;
-    int n0 = nimg[3 * c], n1 = nimg[3 * c + 1], n2 = nimg[3 * c + 2];
-    double px = wpos[3 * i], py = wpos[3 * i + 1], pz = wpos[3 * i + 2];
+    const int n0 = nimg[3 * c], n1 = nimg[3 * c + 1], n2 = nimg[3 * c + 2];
+    const double C0 = C[0], C1 = C[1], C2 = C[2], C3 = C[3], C4 = C[4], C5 = C[5], C6 = C[6], C7 = C[7], C8 = C[8];
+    const double px = wpos[3 * i], py = wpos[3 * i + 1], pz = wpos[3 * i + 2];
     long long base = FILL ? (long long)row_start[i] : 0;
-    int cnt = 0;
-    for (int j = a0; j < a1; ++j) {
-        double bx = wpos[3 * j] - px, by = wpos[3 * j + 1] - py, bz = wpos[3 * j + 2] - pz;
-        for (int s0 = -n0; s0 <= n0; ++s0)
-            for (int s1 = -n1; s1 <= n1; ++s1)
-                for (int s2 = -n2; s2 <= n2; ++s2) {
-                    if (i == j && s0 == 0 && s1 == 0 && s2 == 0) continue;
-                    double rx = bx + s0 * C[0] + s1 * C[3] + s2 * C[6];
-                    double ry = by + s0 * C[1] + s1 * C[4] + s2 * C[7];
-                    double rz = bz + s0 * C[2] + s1 * C[5] + s2 * C[8];
-                    double d2 = rx * rx + ry * ry + rz * rz;
-                    if (d2 > rc2 || d2 <= 0.0) continue;
-                    if (FILL) {
-                        long long slot = base + cnt;
+    int run = 0;
+    for (int j0 = a0; j0 < a1; j0 += 64) {
+        const int j = j0 + lane;
+        const bool have = j < a1;
+        double bx = 0, by = 0, bz = 0;
+        if (have) { bx = wpos[3 * j] - px; by = wpos[3 * j + 1] - py; bz = wpos[3 * j + 2] - pz; }
+        int cnt = 0;
+        if (have) {
+            for (int s0 = -n0; s0 <= n0; ++s0)
+                for (int s1 = -n1; s1 <= n1; ++s1)
+                    for (int s2 = -n2; s2 <= n2; ++s2) {
+                        if (i == j && s0 == 0 && s1 == 0 && s2 == 0) continue;
+                        double rx = bx + s0 * C0 + s1 * C3 + s2 * C6;
+                        double ry = by + s0 * C1 + s1 * C4 + s2 * C7;
+                        double rz = bz + s0 * C2 + s1 * C5 + s2 * C8;
+                        double d2 = rx * rx + ry * ry + rz * rz;
+                        if (d2 <= rc2 && d2 > 0.0) ++cnt;
+                    }
+        }
+        int total;
+        const int off = wave_excl_scan(cnt, lane, total);
+        if (FILL && cnt > 0) {
+            long long slot = base + run + off;
+            for (int s0 = -n0; s0 <= n0; ++s0)
+                for (int s1 = -n1; s1 <= n1; ++s1)
+                    for (int s2 = -n2; s2 <= n2; ++s2) {
+                        if (i == j && s0 == 0 && s1 == 0 && s2 == 0) continue;
+                        double rx = bx + s0 * C0 + s1 * C3 + s2 * C6;
+                        double ry = by + s0 * C1 + s1 * C4 + s2 * C7;
+                        double rz = bz + s0 * C2 + s1 * C5 + s2 * C8;
+                        double d2 = rx * rx + ry * ry + rz * rz;
+                        if (d2 > rc2 || d2 <= 0.0) continue;
                         if (slot < slot_cap) {
                             edge[slot] = make_float4((float)rx, (float)ry, (float)rz, __int_as_float(j));
                             edge_S[slot] = pack_shift(s0, s1, s2);
                         }
+                        ++slot;
                     }
-                    ++cnt;
-                }
+        }
+        run += total;
     }
     if (FILL) {
-        int padded = (cnt + 3) & ~3;
-        for (int k = cnt; k < padded; ++k) {
-            long long slot = base + k;
-            if (slot < slot_cap) {
-                edge[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-                edge_S[slot] = pack_shift(0, 0, 0);
-            }
+        const int padded = (run + 3) & ~3;
+        const long long slot = base + run + lane;
+        if (lane < padded - run && slot < slot_cap) {
+            edge[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            edge_S[slot] = pack_shift(0, 0, 0);
         }
-    } else {
-        deg[i] = cnt;
+    } else if (lane == 0) {
+        deg[i] = run;
     }
 }
 
@@ -135,26 +168,25 @@ __global__ void k_scan_rows(int n, const int *__restrict__ deg, int *__restrict_
     }
 }
 
-// reverse-edge slot: for slot (i -> j, S') find (j -> i, -S') in j's row
-__global__ void k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
-                      const int *__restrict__ edge_S, int *__restrict__ rev,
-                      const int *__restrict__ counters) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// reverse-edge slot: for slot (i -> j, S') find (j -> i, -S') in j's row.  One wave per centre, lane per slot.
+__global__ void __launch_bounds__(256)
+k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
+      const int *__restrict__ edge_S, int *__restrict__ rev, const int *__restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n || counters[2]) return;
-    for (int e = row_start[i]; e < row_start[i + 1]; ++e) {
+    for (int e = row_start[i] + lane; e < row_start[i + 1]; e += 64) {
         int j = __float_as_int(edge[e].w);
-        if (j < 0) {
-            rev[e] = -1;
-            continue;
-        }
-        int s0, s1, s2;
-        unpack_shift(edge_S[e], s0, s1, s2);
-        int want = pack_shift(-s0, -s1, -s2);
         int found = -1;
-        for (int e2 = row_start[j]; e2 < row_start[j + 1]; ++e2) {
-            if (__float_as_int(edge[e2].w) == i && edge_S[e2] == want) {
-                found = e2;
-                break;
+        if (j >= 0) {
+            int s0, s1, s2;
+            unpack_shift(edge_S[e], s0, s1, s2);
+            const int want = pack_shift(-s0, -s1, -s2);
+            for (int e2 = row_start[j]; e2 < row_start[j + 1]; ++e2) {
+                if (__float_as_int(edge[e2].w) == i && edge_S[e2] == want) {
+                    found = e2;
+                    break;
+                }
             }
         }
         rev[e] = found;
@@ -229,20 +261,21 @@ int build_neighbors(vssr_handle *h, double cutoff) {
         return set_err(h, VSSR_E_NOMEM, "edge buffers: out of device memory");
     h->prof.begin(KC_NBR, st);
     dim3 blk(128), grd((n + 127) / 128);
+    dim3 wblk(256), wgrd((n + 3) / 4);   // one wave per centre
     hipLaunchKernelGGL(k_wrap, grd, blk, 0, st, n, h->d_pos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_pbc.as<uint8_t>(),
                        h->d_wpos.as<double>(), h->d_wrap.as<int>());
-    hipLaunchKernelGGL(k_nbr<false>, grd, blk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
+    hipLaunchKernelGGL(k_nbr<false>, wgrd, wblk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_nimg.as<int>(),
                        cutoff * cutoff, h->d_deg.as<int>(), (const int *)nullptr, (float4 *)nullptr,
                        (int *)nullptr, (long long)0);
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, n, h->d_deg.as<int>(),
                        h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap);
-    hipLaunchKernelGGL(k_nbr<true>, grd, blk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
+    hipLaunchKernelGGL(k_nbr<true>, wgrd, wblk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_nimg.as<int>(),
                        cutoff * cutoff, h->d_deg.as<int>(), h->d_row_start.as<int>(),
                        h->d_edge.as<float4>(), h->d_edge_S.as<int>(), (long long)h->slot_cap);
-    hipLaunchKernelGGL(k_rev, grd, blk, 0, st, n, h->d_row_start.as<int>(), h->d_edge.as<float4>(),
+    hipLaunchKernelGGL(k_rev, wgrd, wblk, 0, st, n, h->d_row_start.as<int>(), h->d_edge.as<float4>(),
                        h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>());
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
         if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
