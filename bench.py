@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 CHAINS_PER_GPU = 256
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (no xf32 on gfx950)
 F = 128
 
 
@@ -51,6 +52,29 @@ def neighbor_sum_bytes(n_atoms, n_edges, n_models, layer0):
     Layer 0 has v = 0 and no a-section: read phi b,c [N,2F] + s, write s', v'."""
     per_atom = (2 * F + F + F + 3 * F) * 4 if layer0 else (3 * F + 3 * F + F + F + 3 * F) * 4
     return n_models * (per_atom * n_atoms + 16 * n_edges)
+
+
+def neighbor_sum_flops(n_slots, n_models, layer0):
+    """fp32 FLOPs of the radial-filter GEMM inside ONE neighbor-sum launch as executed on the matrix cores:
+    per slot and model  sections * F * K * 2  with K = 24 (20 radial functions + envelope/bias column, padded to 4)."""
+    sections = 2 if layer0 else 3
+    return n_models * n_slots * sections * F * 24 * 2
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch from committed PMC passes (profiles/: FETCH_SIZE, WRITE_SIZE in KB, separate passes;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM for 16-B/lane streams).  None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_edge_kernels.json")
+    if not os.path.exists(path):
+        return None
+    raw = json.load(open(path))
+    tot, n = 0.0, 0
+    for name, d in raw.items():
+        if kernel in name and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            k = d["FETCH_SIZE"]["n"]
+            tot += k * (2.0 * d["FETCH_SIZE"]["mean_raw"] + d["WRITE_SIZE"]["mean_raw"]) * 1024.0
+            n += k
+    return tot / n if n else None
 
 
 def cpu_baseline(blobs, chains, table, const, budget_s=20.0):
@@ -161,8 +185,10 @@ def main():
         layers = 3
         bytes_per_step = sum(neighbor_sum_bytes(stats["atoms"], stats["edges"], M, l == 0) for l in range(layers))
         bytes_per_launch = bytes_per_step / layers
+        flops_per_launch = sum(neighbor_sum_flops(stats["slots"], M, l == 0) for l in range(layers)) / layers
         avg_ms = ns["total_ms"] / n_launch
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        hbm_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         step_ms = sum(v["total_ms"] for v in prof.values()) / args.steps
         line = {
             "metric": "MC energy-evaluations/sec (SrTiO3(001) ~250-atom slabs, 3-model PaiNN ensemble E+F incl. neighbor list)",
@@ -173,10 +199,16 @@ def main():
                                    f"(BASELINE configs[{3 if world == 1 else 4}]), 248-272 atoms/chain",
                        "chains_per_gpu": count, "atoms_per_gpu": stats["atoms"], "edges_per_gpu": stats["edges"],
                        "parallelism": f"chains sharded x{world}, RCCL all_gather of per-chain energies"},
-            "roofline": {"bound": "hbm", "kernel": "edge_message_fwd (neighbor-sum)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": avg_ms, "launches": ns["launches"]},
+            # The neighbor-sum kernel stages each phi / v element into LDS exactly once (HBM traffic ~ compulsory, see
+            # `traffic`), so what binds it is the fp32 radial-filter GEMM on the matrix cores:
+            # `achieved`/`peak` are TFLOP/s; the HBM view of the same launch is given beside it.
+            "roofline": {"bound": "mfma", "kernel": "edge_message_fwd (neighbor-sum)", "achieved": tflops,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": measured_traffic("k_edge_fwd_mfma"),
+                         "algorithmic_flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms,
+                         "launches": ns["launches"],
+                         "hbm_view": {"algorithmic_bytes_per_launch": bytes_per_launch, "achieved_GBps": hbm_gbs,
+                                      "peak_GBps": HBM_PEAK_GBS, "frac": hbm_gbs / HBM_PEAK_GBS}},
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]},
             "device_ms_per_step": step_ms,
         }
