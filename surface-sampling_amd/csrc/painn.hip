@@ -741,11 +741,31 @@ int painn_run(vssr_handle *h, uint32_t want) {
     dim3 g_atom(N, M), g_tile((N + T - 1) / T, M);
     Profiler &P = h->prof;
     const bool use_edge_mfma = h->edge_impl && edge_fwd_mfma_fits(h->max_cfg_atoms);   // chains fit the LDS slices
+    const bool l0_fact = use_edge_mfma && h->l0_enabled && h->l0_nz > 0;                // layer 0 by species factorisation
+    const int n_groups = use_edge_mfma ? ((L == 1 && l0_fact) ? 1 : edge_bwd_groups()) : 1;
+    h->l0_used = l0_fact;
 
-    P.begin(KC_EMBED, st);
-    hipLaunchKernelGGL(k_embed, g_atom, blk, 0, st, N, Z, MW, sv.s_in[0], sv.v_in[0]);
-    P.end(st);
+    if (!l0_fact) {   // s0 = Emb[Z], v0 = 0 (the factorised layer 0 reads the embedding directly)
+        P.begin(KC_EMBED, st);
+        hipLaunchKernelGGL(k_embed, g_atom, blk, 0, st, N, Z, MW, sv.s_in[0], sv.v_in[0]);
+        P.end(st);
+    }
     for (int l = 0; l < L; ++l) {
+        if (l == 0 && l0_fact) {   // phi0 is a per-species constant: no message MLP, no per-edge filter
+            P.begin(KC_EDGE_FWD, st);
+            rc = l0_run_forward(h, G, sv.s_msg[0], sv.v_msg[0]);
+            if (rc) return rc;
+            if (h->excl_vol) launch_excl_vol(st, N, M, G, counters, h->excl_sigma, h->excl_power, sv.e_excl);
+            P.end(st);
+            P.begin(KC_UPDATE_FWD, st);
+            if (h->node_impl)
+                launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
+            else
+                hipLaunchKernelGGL(k_update_fwd, g_tile, blk, 0, st, N, l, MW, sv.s_msg[l], sv.v_msg[l],
+                                   sv.s_in[l + 1], sv.v_in[l + 1]);
+            P.end(st);
+            continue;
+        }
         P.begin(KC_MSG_MLP, st);
         if (h->node_impl) launch_msg_mlp_mfma(st, N, M, l, MW, sv.s_in[l], sv.phi[l]);
         else hipLaunchKernelGGL(k_msg_mlp, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phi[l]);
@@ -789,10 +809,14 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.end(st);
             P.begin(KC_EDGE_BWD, st);
             int accumulate = (l != L - 1);
-            if (use_edge_mfma)
+            if (l == 0 && l0_fact) {
+                rc = l0_run_reverse(h, G, (int)(L == 1), sv.sbar_msg, sv.vbar_msg, sv.gbar, (long long)h->slot_cap,
+                                    n_groups);
+                if (rc) return rc;
+            } else if (use_edge_mfma)
                 launch_edge_bwd_mfma(st, N, h->n_cfg, M, l, (int)(l == L - 1), h->max_cfg_atoms, MW, G, counters,
                                      (int)(h->slot_cap - 1), h->excl_vol, sv.v_in[l], sv.phi[l], sv.sbar_msg,
-                                     sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap);
+                                     sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap, n_groups);
             else if (l == 0)
                 hipLaunchKernelGGL(k_edge_bwd<true>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                    h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
@@ -815,8 +839,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     }
     P.begin(KC_FINALIZE, st);
     if (want & VSSR_WANT_FORCES)
-        hipLaunchKernelGGL(k_finalize_forces, dim3((N + 127) / 128), dim3(128), 0, st, N, M,
-                           use_edge_mfma ? edge_bwd_groups() : 1, G, counters, sv.gbar,
+        hipLaunchKernelGGL(k_finalize_forces, dim3((N + 127) / 128), dim3(128), 0, st, N, M, n_groups, G, counters,
+                           sv.gbar,
                            (long long)h->slot_cap, h->units_per_ev, h->d_forces.as<float>(),
                            h->d_forces_std.as<float>());
     hipLaunchKernelGGL(k_finalize_energy, dim3(h->n_cfg), dim3(256), 0, st, N, M, G.cfg_start, Z, sv.e_atom,

@@ -284,7 +284,7 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                 const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms, int excl_vol,
                 const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
                 const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
-                float4 *__restrict__ gbar, long long gbar_stride) {
+                float4 *__restrict__ gbar, long long gbar_stride, int n_groups) {
     constexpr int NSEC = L0 ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) float tile[];
     if (counters[2]) return;
@@ -318,7 +318,7 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
     const int stream_begin = rs[c_first], stream_end = rs[c_last];
     const int last_slot = max(rs[Nc] - 1, 0);
     const LayerW &W = MW[m].layer[l];
-    float4 *gb = gbar + (size_t)(m * NSG + sg) * gbar_stride;
+    float4 *gb = gbar + (size_t)(m * n_groups + sg) * gbar_stride;
     const float *rho_lane = G.rho + fq * 6, *drho_lane = G.drho + fq * 6;
 
     for (int si = 0; si < SLICES_PER_WG; ++si) {
@@ -550,6 +550,11 @@ k_excl_vol(int N, int M, GraphView G, const int *__restrict__ counters, float si
     for (int m = 0; m < M; ++m) e_excl[(size_t)m * N + i] = tot;
 }
 
+void launch_excl_vol(hipStream_t st, int N, int M, const GraphView &G, const int *counters, float sigma, int power,
+                     float *e_excl) {
+    hipLaunchKernelGGL(k_excl_vol, dim3((N + 255) / 256), dim3(256), 0, st, N, M, G, counters, sigma, power, e_excl);
+}
+
 int edge_mfma_init(vssr_handle *h) {
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_fwd_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
@@ -567,15 +572,15 @@ bool edge_fwd_mfma_fits(int max_atoms) { return edge_fwd_lds_bytes(max_atoms, fa
 void launch_edge_bwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot, int excl_vol,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
-                          float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride) {
+                          float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups) {
     dim3 grid(((n_cfg + 7) / 8) * 8 * NSG * M), blk(BWD_THREADS);
     const size_t lds = edge_bwd_lds_bytes(max_atoms);
     if (l == 0)
         hipLaunchKernelGGL(k_edge_bwd_mfma<true>, grid, blk, lds, st, N, l, layer_first, MW, G, counters, zero_slot, M,
-                           max_atoms, excl_vol, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride);
+                           max_atoms, excl_vol, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
     else
         hipLaunchKernelGGL(k_edge_bwd_mfma<false>, grid, blk, lds, st, N, l, layer_first, MW, G, counters, zero_slot, M,
-                           max_atoms, excl_vol, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride);
+                           max_atoms, excl_vol, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
 }
 
 void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,

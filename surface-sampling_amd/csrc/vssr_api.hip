@@ -155,6 +155,25 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
         W.W5 = db + w5; W.W5t = db + w5t; W.b5 = db + b5; W.w6 = db + w6; W.b6 = db + b6;
     }
     VSSR_HIP(h, hipMemcpy(dbase, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    {   // layer-0 species factorisation tables (painn_l0.hip), from layer 0 of every model
+        const size_t per_model = (size_t)NE * 2 * 24 * F;
+        std::vector<float> A(per_model * M), At(per_model * M);
+        for (int m = 0; m < M; ++m) {
+            const float *hb = img.data() + (size_t)m * img_len;
+            size_t o = (size_t)NE * F;
+            const float *W1 = hb + o; o += (size_t)F * F;
+            const float *b1 = hb + o; o += F;
+            const float *W2 = hb + o; o += (size_t)F3 * F;
+            const float *b2 = hb + o; o += F3;
+            const float *Wd = hb + o; o += (size_t)F3 * R;
+            const float *bd = hb + o;
+            l0_build_tables(hb, W1, b1, W2, b2, Wd, bd, NE, A.data() + per_model * m, At.data() + per_model * m);
+        }
+        if (h->d_l0A.ensure(A.size() * sizeof(float)) || h->d_l0At.ensure(At.size() * sizeof(float)))
+            return set_err(h, VSSR_E_NOMEM, "layer-0 tables: out of device memory");
+        VSSR_HIP(h, hipMemcpy(h->d_l0A.p, A.data(), A.size() * sizeof(float), hipMemcpyHostToDevice));
+        VSSR_HIP(h, hipMemcpy(h->d_l0At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (h->model_table.ensure(sizeof(ModelW) * M)) return set_err(h, VSSR_E_NOMEM, "model table");
     VSSR_HIP(h, hipMemcpy(h->model_table.p, table.data(), sizeof(ModelW) * M, hipMemcpyHostToDevice));
     return VSSR_OK;
@@ -248,6 +267,7 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     if (!rc) rc = edge_mfma_init(h);
     if (const char *e = getenv("VSSR_NODE_IMPL")) h->node_impl = (strcmp(e, "v0") == 0) ? 0 : 1;
     if (const char *e = getenv("VSSR_EDGE_IMPL")) h->edge_impl = (strcmp(e, "v0") == 0) ? 0 : 1;
+    if (const char *e = getenv("VSSR_L0_FACTORISE")) h->l0_enabled = atoi(e);
     if (!rc && cfg->offset_per_z) {
         h->has_offset = true;
         h->offset_const = cfg->offset_const;
@@ -304,7 +324,7 @@ void vssr_destroy(vssr_handle *h) {
     h->prof.destroy();
     DevBuf *bufs[] = {&h->weights, &h->model_table, &h->offset_per_z, &h->ters_params, &h->d_pos, &h->d_wpos,
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
-                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist,
+                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
                       &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f};
     for (DevBuf *b : bufs) b->release();
@@ -361,6 +381,18 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
     VSSR_HIP(h, hipMemcpy(h->d_pbc.p, pbc, (size_t)3 * n_cfg, hipMemcpyHostToDevice));
     h->n_cfg = n_cfg;
     h->n_atoms = N;
+    if (h->kind == 1) {   // species present in this batch (layer-0 factorisation works per neighbor species)
+        std::vector<int> zmap(h->n_embed, -1), zlist;
+        for (int i = 0; i < N; ++i)
+            if (zmap[Z[i]] < 0) { zmap[Z[i]] = 1; }
+        for (int z = 0; z < h->n_embed; ++z)
+            if (zmap[z] > 0) { zmap[z] = (int)zlist.size(); zlist.push_back(z); }
+        h->l0_nz = (int)zlist.size() <= L0_MAX_SPECIES ? (int)zlist.size() : 0;
+        if (h->d_zmap.ensure(sizeof(int) * h->n_embed) || h->d_zlist.ensure(sizeof(int) * (zlist.size() + 1)))
+            return set_err(h, VSSR_E_NOMEM, "species tables");
+        VSSR_HIP(h, hipMemcpy(h->d_zmap.p, zmap.data(), sizeof(int) * h->n_embed, hipMemcpyHostToDevice));
+        VSSR_HIP(h, hipMemcpy(h->d_zlist.p, zlist.data(), sizeof(int) * zlist.size(), hipMemcpyHostToDevice));
+    }
     h->max_cfg_atoms = 0;
     for (int b = 0; b < n_cfg; ++b) h->max_cfg_atoms = n_atoms[b] > h->max_cfg_atoms ? n_atoms[b] : h->max_cfg_atoms;
     h->h_n_atoms.assign(n_atoms, n_atoms + n_cfg);
@@ -557,7 +589,11 @@ int vssr_debug_read(vssr_handle *h, const char *name, int32_t model, float *dst,
         return (l >= 0 && l < h->num_conv) ? l : -1;
     };
     int l;
-    if ((l = layer_of("phi")) >= 0) { src = sv.phi[l]; per_atom = F3; }
+    if ((l = layer_of("phi")) >= 0) {
+        if (l == 0 && h->l0_used)
+            return set_err(h, VSSR_E_STATE, "phi0 is not materialised (layer-0 species factorisation is active)");
+        src = sv.phi[l]; per_atom = F3;
+    }
     else if ((l = layer_of("s_msg")) >= 0) { src = sv.s_msg[l]; per_atom = F; }
     else if ((l = layer_of("v_msg")) >= 0) { src = sv.v_msg[l]; per_atom = F3; }
     else if ((l = layer_of("s_upd")) >= 0) { src = sv.s_in[l + 1]; per_atom = F; }

@@ -20,6 +20,7 @@ constexpr int MAX_LAYERS = 4;
 constexpr int MAX_MODELS = 8;
 constexpr int RB_MAX = 24;    // n_rbf + 1 (envelope/bias column) padded to a multiple of 4
 constexpr int NODE_TILE = 8;  // atoms per workgroup in the node kernels
+constexpr int L0_MAX_SPECIES = 8;  // layer-0 species factorisation is used when the batch has at most this many species
 
 // ---- device-side views -------------------------------------------------------------------
 struct LayerW {
@@ -172,6 +173,12 @@ struct vssr_handle {
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
     vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
     vssr::DevBuf d_erec, d_rho, d_drho, d_dist;
+    // layer-0 species factorisation (painn_l0.hip)
+    int l0_enabled = 1, l0_nz = 0;
+    bool l0_used = false;                // last run used the factorised layer 0
+    vssr::DevBuf d_l0A, d_l0At;          // [M][n_embed][2][24][F] and [M][n_embed][2][F][24], built at create
+    vssr::DevBuf d_zmap, d_zlist;        // species index of Z (or -1), distinct Z of the resident batch
+    vssr::DevBuf d_l0T, d_l0Q;
     int64_t slot_cap = 0;
     int *h_counters = nullptr;   // pinned: [0] total slots, [1] total real edges, [2] overflow flag
 
@@ -213,13 +220,21 @@ void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *M
 void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zero, const ModelW *MW,
                             const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
                             float *sbar_msg, float *vbar_msg);
+// layer-0 species factorisation (painn_l0.hip)
+void l0_build_tables(const float *blob_embed, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *Wd, const float *bd, int n_embed, float *A, float *At);
+int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_msg);
+int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const float *sbar_msg, const float *vbar_msg,
+                   float4 *gbar, long long gbar_stride, int n_groups);
+void launch_excl_vol(hipStream_t st, int N, int M, const GraphView &G, const int *counters, float sigma, int power,
+                     float *e_excl);
 // LDS-slice + MFMA edge stages (painn_edge_mfma.hip)
 int edge_mfma_init(vssr_handle *h);
 int edge_bwd_groups();
 void launch_edge_bwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot, int excl_vol,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
-                          float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride);
+                          float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups);
 bool edge_fwd_mfma_fits(int max_atoms);
 void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,
                           const GraphView &G, const int *counters, int zero_slot, int excl_vol, float excl_sigma,

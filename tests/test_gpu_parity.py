@@ -97,7 +97,11 @@ def test_per_layer_intermediates_match_oracle(golden, oracle_mod, engine):
     for l in range(3):
         for name, shape in (("phi", (n, 384)), ("s_msg", (n, 128)), ("v_msg", (n, 3, 128)),
                             ("s_upd", (n, 128)), ("v_upd", (n, 3, 128))):
-            got = engine.debug_read(f"{name}{l}", m).reshape(shape).astype(np.float64)
+            try:
+                got = engine.debug_read(f"{name}{l}", m).reshape(shape).astype(np.float64)
+            except Exception as exc:   # phi0 is not materialised when layer 0 is evaluated by species factorisation
+                assert name == "phi" and l == 0 and "not materialised" in str(exc)
+                continue
             want = d[name][l]
             scale = max(1.0, np.abs(want).max())
             report.append((f"{name}{l}", np.abs(got - want).max() / scale))
