@@ -66,10 +66,17 @@ def lib():
         L.orc_ensemble_eval.argtypes = [C.c_int, C.c_int32, C.POINTER(fp), C.c_int64, C.POINTER(HParams),
                                         C.c_double, dp, C.c_double, C.c_int32, ip, dp, dp, u8p,
                                         dp, dp, dp, dp, dp]
+        L.orc_set_threads.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
         L.orc_tersoff_eval.restype = C.c_int
         L.orc_tersoff_eval.argtypes = [C.c_int32, dp, C.c_int32, ip, dp, dp, u8p, dp, dp, dp]
         _lib = L
     return _lib
+
+
+def set_threads(n: int) -> int:
+    """OpenMP threads used by the oracle from now on."""
+    return int(lib().orc_set_threads(int(n)))
 
 
 def default_hparams(**over) -> HParams:

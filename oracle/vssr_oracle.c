@@ -5,8 +5,15 @@
 #include "vssr_oracle.h"
 
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
+
+int orc_set_threads(int n) {
+    if (n < 1) n = 1;
+    omp_set_num_threads(n);
+    return n;
+}
 
 /* ---- PaiNN in double and in float ------------------------------------------------------ */
 #define REAL double

@@ -88,6 +88,9 @@ int orc_tersoff_eval(int32_t n_types, const double *params, int32_t n, const int
                      const double *pos, const double cell[9], const uint8_t pbc[3],
                      double *energy, double *e_atom, double *forces);
 
+/* Number of OpenMP threads the oracle uses from now on (returns the value set). */
+int orc_set_threads(int n);
+
 #ifdef __cplusplus
 }
 #endif

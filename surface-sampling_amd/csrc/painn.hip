@@ -752,7 +752,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
     }
     for (int l = 0; l < L; ++l) {
         if (l == 0 && l0_fact) {   // phi0 is a per-species constant: no message MLP, no per-edge filter
-            P.begin(KC_EDGE_FWD, st);
+            P.begin(KC_L0_FWD, st);
             rc = l0_run_forward(h, G, sv.s_msg[0], sv.v_msg[0]);
             if (rc) return rc;
             if (h->excl_vol) launch_excl_vol(st, N, M, G, counters, h->excl_sigma, h->excl_power, sv.e_excl);
@@ -807,7 +807,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
                 hipLaunchKernelGGL(k_update_bwd, g_tile, blk, 0, st, N, l, (int)(l == L - 1), MW, sv.s_msg[l],
                                    sv.v_msg[l], sv.sbar, sv.vbar, sv.sbar_msg, sv.vbar_msg);
             P.end(st);
-            P.begin(KC_EDGE_BWD, st);
+            P.begin((l == 0 && l0_fact) ? KC_L0_BWD : KC_EDGE_BWD, st);
             int accumulate = (l != L - 1);
             if (l == 0 && l0_fact) {
                 rc = l0_run_reverse(h, G, (int)(L == 1), sv.sbar_msg, sv.vbar_msg, sv.gbar, (long long)h->slot_cap,

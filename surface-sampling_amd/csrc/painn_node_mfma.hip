@@ -35,6 +35,19 @@ __device__ __forceinline__ float dswish(float x) {
 // row of accumulator register `reg` inside a 32x32 tile (MI355X guide: C/D layout of 32x32 MFMA)
 __device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+// Weight pointers are read out of the ModelW table in memory, so the compiler would treat them as FLAT (flat loads
+// tick both vmcnt and lgkmcnt).  Loading through an explicit global address space pointer gives global_load.
+__device__ __forceinline__ float4 gload4(const float *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float gf32x4 __attribute__((ext_vector_type(4)));
+    typedef const gf32x4 __attribute__((address_space(1))) *gptr;
+    const gf32x4 v = *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+
 // acc[t][c] += A(rows t*32.., K) * packed tile c
 template <int K, int NRT, int NCT>
 __device__ __forceinline__ void gemm_acc(const float *__restrict__ lds_a, int ld,
@@ -46,7 +59,7 @@ __device__ __forceinline__ void gemm_acc(const float *__restrict__ lds_a, int ld
         float bv[NCT][4], av[NRT][4];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
-            float4 b = *reinterpret_cast<const float4 *>(wp[c] + ((size_t)q * 64 + lane) * 4);
+            float4 b = gload4(wp[c] + ((size_t)q * 64 + lane) * 4);
             bv[c][0] = b.x; bv[c][1] = b.y; bv[c][2] = b.z; bv[c][3] = b.w;
         }
 #pragma unroll

@@ -8,7 +8,8 @@ namespace vssr {
 
 const char *const kKernelClassNames[KC_COUNT] = {
     "neighbor_list", "embed", "message_mlp", "edge_message_fwd", "update_fwd", "readout",
-    "update_bwd", "edge_message_bwd", "message_mlp_bwd", "finalize", "tersoff"};
+    "update_bwd", "edge_message_bwd", "message_mlp_bwd", "finalize", "tersoff", "layer0_factorised_fwd",
+    "layer0_factorised_bwd"};
 
 static std::string g_create_error;
 

@@ -115,6 +115,8 @@ enum KernelClass {
     KC_MSG_MLP_BWD,
     KC_FINALIZE,
     KC_TERSOFF,
+    KC_L0_FWD,
+    KC_L0_BWD,
     KC_COUNT
 };
 extern const char *const kKernelClassNames[KC_COUNT];
