@@ -127,6 +127,21 @@ int vssr_batch_run(vssr_handle *h, uint32_t want); /* asynchronous on the handle
 int vssr_batch_download(vssr_handle *h, uint32_t want, vssr_out *out); /* synchronises */
 int vssr_synchronize(vssr_handle *h);
 
+/* ---- lock-step relaxation of the resident batch (reference optimize_slab, mcmc/dynamics.py:83-170) ---- */
+typedef struct {
+    int32_t max_steps; /* relax_steps (reference default 20) */
+    float fmax;        /* convergence: max_i |F_i| < fmax (reference: 0.01 eV/A) */
+    /* ASE FIRE parameters (ase/optimize/fire.py defaults: 0.1, 0.2, 1.0, 1.1, 0.5, 0.1, 0.99, 5) */
+    float dt, maxstep, dtmax, finc, fdec, astart, fa;
+    int32_t nmin;
+} vssr_fire_params;
+/* FIRE-relaxes every chain of the resident batch in lock step (forces and positions stay in HBM).
+ * fixed: [sum N] 1 = atom held by FixAtoms (force zeroed), NULL = all free.  Afterwards the batch holds the
+ * relaxed positions and the results of the last evaluation: fetch them with vssr_batch_download;
+ * pos_out [sum N][3], n_steps [B], converged [B] may each be NULL. */
+int vssr_batch_relax_fire(vssr_handle *h, const vssr_fire_params *params, const uint8_t *fixed, uint32_t want,
+                          double *pos_out, int32_t *n_steps, uint8_t *converged);
+
 /* ---- introspection used by tests and bench (no effect on results) ---------------------- */
 /* Per-kernel timing with HIP events on the handle's own stream.  enable=1 starts recording;
  * vssr_profile_read synchronises and returns, for each kernel class, the number of launches and

@@ -22,7 +22,7 @@ EXPORTS = (
     "vssr_batch_upload", "vssr_batch_set_positions", "vssr_batch_run", "vssr_batch_download",
     "vssr_synchronize", "vssr_profile_enable", "vssr_profile_reset", "vssr_profile_read",
     "vssr_batch_stats", "vssr_batch_neighbors", "vssr_debug_read", "vssr_tersoff_create",
-    "vssr_tersoff_eval_batch",
+    "vssr_tersoff_eval_batch", "vssr_batch_relax_fire",
 )
 
 
@@ -39,6 +39,17 @@ class PainnConfig(C.Structure):
         ("excl_power", C.c_int32), ("excl_sigma", C.c_float), ("model_units_per_ev", C.c_double),
         ("offset_per_z", C.POINTER(C.c_double)), ("offset_const", C.c_double),
     ]
+
+
+class FireParams(C.Structure):
+    """vssr_fire_params; defaults = ASE FIRE defaults and the reference's relax_steps / fmax."""
+    _fields_ = [("max_steps", C.c_int32), ("fmax", C.c_float), ("dt", C.c_float), ("maxstep", C.c_float),
+                ("dtmax", C.c_float), ("finc", C.c_float), ("fdec", C.c_float), ("astart", C.c_float),
+                ("fa", C.c_float), ("nmin", C.c_int32)]
+
+    @classmethod
+    def default(cls, max_steps=20, fmax=0.01):
+        return cls(int(max_steps), float(fmax), 0.1, 0.2, 1.0, 1.1, 0.5, 0.1, 0.99, 5)
 
 
 class Out(C.Structure):
@@ -99,6 +110,8 @@ def load_library():
     L.vssr_tersoff_create.argtypes = [C.c_int32, C.c_int32, dp, C.POINTER(vp)]
     L.vssr_tersoff_eval_batch.restype = C.c_int
     L.vssr_tersoff_eval_batch.argtypes = [vp, C.c_int32, ip, ip, dp, dp, u8p, C.c_uint32, C.POINTER(Out), dp, dp, dp]
+    L.vssr_batch_relax_fire.restype = C.c_int
+    L.vssr_batch_relax_fire.argtypes = [vp, C.POINTER(FireParams), u8p, C.c_uint32, dp, ip, u8p]
     if L.vssr_abi_version() != 1:
         raise BackendError("libvssr_eval.so ABI version mismatch")
     _lib = L
@@ -194,6 +207,26 @@ class _Handle:
         self.upload(structs)
         self.run(want)
         return self.download(want)
+
+    # -- lock-step relaxation ------------------------------------------------------------------------
+    def relax_fire(self, fixed=None, max_steps=20, fmax=0.01, want=WANT_ALL, params=None):
+        """FIRE-relax every chain of the resident batch on the device (reference optimize_slab with FIRE).
+        ``fixed``: bool/uint8 [sum N], True = held fixed.  Returns dict(positions [sum N,3] float64,
+        n_steps [B], converged [B]) — fetch energies/forces of the relaxed batch with download()."""
+        p = params or FireParams.default(max_steps, fmax)
+        N, B = self._n_atoms, self._n_cfg
+        fx = None
+        if fixed is not None:
+            fx = np.ascontiguousarray(fixed, dtype=np.uint8)
+            if fx.size != N:
+                raise ValueError("fixed mask does not match the resident batch")
+        pos = np.zeros((N, 3), np.float64)
+        steps = np.zeros(B, np.int32)
+        conv = np.zeros(B, np.uint8)
+        self._check(self._lib.vssr_batch_relax_fire(self._h, C.byref(p), _ptr(fx, C.c_uint8), int(want),
+                                                    _ptr(pos, C.c_double), _ptr(steps, C.c_int32),
+                                                    _ptr(conv, C.c_uint8)))
+        return {"positions": pos, "n_steps": steps, "converged": conv.astype(bool)}
 
     # -- introspection -----------------------------------------------------------------------------
     def profile_enable(self, on=True):

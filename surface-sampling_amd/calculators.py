@@ -348,6 +348,46 @@ class EnsembleNFFSurface(_Base):
         return out
 
 
+    # thresholds of the reference's out-of-bounds guard (mcmc/dynamics.py:17-18,159-168)
+    ENERGY_THRESHOLD = 1000.0
+    MAX_FORCE_THRESHOLD = 1000.0
+
+    def relax_batch(self, atoms_list, fixed_indices=None, relax_steps: int = 20, fmax: float = 0.01):
+        """Relax B independent slabs at once on the device with FIRE — the batched counterpart of
+        ``optimize_slab(slab, optimizer="FIRE", relax_steps=..., save_traj=False)`` (reference
+        ``mcmc/dynamics.py:83-170``).  ``fixed_indices``: per slab, the atom indices held by FixAtoms (or None).
+        Returns, per slab, the reference's tuple ``(relaxed_slab, traj=None, energy, energy_oob)`` where
+        ``energy_oob`` follows the same +-1000 guard, plus the results dict of the final evaluation."""
+        eng = self._get_engine()
+        packs = [structures.as_arrays(a) for a in atoms_list]
+        eng.upload(packs)
+        fixed = None
+        if fixed_indices is not None:
+            fixed = np.zeros(sum(len(p[0]) for p in packs), np.uint8)
+            o = 0
+            for p, idx in zip(packs, fixed_indices):
+                if idx is not None and len(idx):
+                    fixed[o + np.asarray(idx, dtype=np.int64)] = 1
+                o += len(p[0])
+        info = eng.relax_fire(fixed=fixed, max_steps=relax_steps, fmax=fmax)
+        res = eng.download()
+        out = []
+        for b, atoms in enumerate(atoms_list):
+            a0, a1 = int(res["cfg_start"][b]), int(res["cfg_start"][b + 1])
+            relaxed = atoms.copy()
+            relaxed.set_positions(info["positions"][a0:a1])
+            r = self._fill_results(res, b)
+            energy = float(r["energy"][0])
+            max_force = float(np.abs(r["forces"]).max()) if a1 > a0 else 0.0
+            oob = bool(abs(energy) > self.ENERGY_THRESHOLD or max_force > self.MAX_FORCE_THRESHOLD)
+            if oob:
+                energy = self.ENERGY_THRESHOLD
+            r["n_steps"] = int(info["n_steps"][b])
+            r["converged"] = bool(info["converged"][b])
+            out.append((relaxed, None, energy, oob, r))
+        return out
+
+
 class TersoffSurfCalc(_Base):
     """Tersoff energy / per-atom energies / forces on MI355X (drop-in for ``LAMMPSSurfCalc`` with
     ``pair_style tersoff``, reference ``calculators.py:492-752``): ``energy`` is the static energy,

@@ -325,7 +325,7 @@ void vssr_destroy(vssr_handle *h) {
     h->prof.destroy();
     DevBuf *bufs[] = {&h->weights, &h->model_table, &h->offset_per_z, &h->ters_params, &h->d_pos, &h->d_wpos,
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
-                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q,
+                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
                       &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f};
     for (DevBuf *b : bufs) b->release();
@@ -493,6 +493,24 @@ int vssr_tersoff_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atom
         VSSR_HIP(h, hipMemcpy(energy_atoms_f64, h->d_ters_ea.p, sizeof(double) * h->n_atoms, hipMemcpyDeviceToHost));
     if (forces_f64)
         VSSR_HIP(h, hipMemcpy(forces_f64, h->d_ters_f.p, sizeof(double) * 3 * h->n_atoms, hipMemcpyDeviceToHost));
+    return VSSR_OK;
+}
+
+int vssr_batch_relax_fire(vssr_handle *h, const vssr_fire_params *params, const uint8_t *fixed, uint32_t want,
+                          double *pos_out, int32_t *n_steps, uint8_t *converged) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->batch_valid) return set_err(h, VSSR_E_STATE, "vssr_batch_relax_fire before vssr_batch_upload");
+    if (!params || params->max_steps < 0 || !(params->fmax > 0) || !(params->dt > 0) || !(params->maxstep > 0))
+        return set_err(h, VSSR_E_BADARG, "bad FIRE parameters");
+    if (h->kind != 1) return set_err(h, VSSR_E_STATE, "FIRE relaxation is implemented for PaiNN handles");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    int rc = relax_fire(h, params, fixed, want);
+    if (rc) return rc;
+    VSSR_HIP(h, hipStreamSynchronize(h->stream));
+    h->prof.collect();
+    if (pos_out) VSSR_HIP(h, hipMemcpy(pos_out, h->d_pos.p, sizeof(double) * 3 * h->n_atoms, hipMemcpyDeviceToHost));
+    if (n_steps) VSSR_HIP(h, hipMemcpy(n_steps, h->d_relax_steps.p, sizeof(int) * h->n_cfg, hipMemcpyDeviceToHost));
+    if (converged) VSSR_HIP(h, hipMemcpy(converged, h->d_relax_conv.p, (size_t)h->n_cfg, hipMemcpyDeviceToHost));
     return VSSR_OK;
 }
 

@@ -181,6 +181,8 @@ struct vssr_handle {
     vssr::DevBuf d_l0A, d_l0At;          // [M][n_embed][2][24][F] and [M][n_embed][2][F][24], built at create
     vssr::DevBuf d_zmap, d_zlist;        // species index of Z (or -1), distinct Z of the resident batch
     vssr::DevBuf d_l0T, d_l0Q;
+    // lock-step relaxation (relax.hip)
+    vssr::DevBuf d_vel, d_fire, d_fixed, d_relax_steps, d_relax_conv;
     int64_t slot_cap = 0;
     int *h_counters = nullptr;   // pinned: [0] total slots, [1] total real edges, [2] overflow flag
 
@@ -211,6 +213,8 @@ int painn_alloc_state(vssr_handle *h);
 int painn_run(vssr_handle *h, uint32_t want);
 // Tersoff (tersoff.hip)
 int tersoff_run(vssr_handle *h, uint32_t want);
+// lock-step FIRE relaxation (relax.hip)
+int relax_fire(vssr_handle *h, const vssr_fire_params *fp, const uint8_t *fixed_host, uint32_t want);
 // MFMA node stages (painn_node_mfma.hip)
 void pack_mfma_tiles(const float *Wsrc, int rows, int K, float *dst);
 int node_mfma_init(vssr_handle *h);
