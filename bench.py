@@ -56,9 +56,10 @@ def neighbor_sum_bytes(n_atoms, n_edges, n_models, layer0):
 
 def neighbor_sum_flops(n_slots, n_models, layer0):
     """fp32 FLOPs of the radial-filter GEMM inside ONE neighbor-sum launch as executed on the matrix cores:
-    per slot and model  sections * F * K * 2  with K = 24 (20 radial functions + envelope/bias column, padded to 4)."""
+    per slot and model  sections * F * K * 2  with K = 20 radial functions (the envelope/bias column is folded into
+    the accumulator initialisation, one multiply per output, not counted)."""
     sections = 2 if layer0 else 3
-    return n_models * n_slots * sections * F * 24 * 2
+    return n_models * n_slots * sections * F * 20 * 2
 
 
 def measured_traffic(kernel):

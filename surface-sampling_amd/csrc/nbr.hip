@@ -195,7 +195,8 @@ k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
 
 // Per-slot geometry tables for the PaiNN edge kernels: unit vector + chain-local neighbor index, edge length,
 // and the radial basis rho_k(d) = sin((k+1) pi d / rc)/d * fc(d) (k < 20), rho_20 = fc(d), with its derivative,
-// stored in the order the MFMA A operand wants them: table[slot][kq][ks] = rho_{kq + 4 ks}  (kq = lane >> 4).
+// stored in the order the MFMA operand wants them: table[slot][kq][ks] = rho_{kq + 4 ks}  (kq = lane >> 4, ks < 5);
+// entry ks = 5 of every quarter holds the envelope fc (resp. its derivative).
 // One thread per (slot, kq).  sin/cos of the multiples come from one sincos + a rotation recurrence.
 __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
                             const int *__restrict__ cfg_start, const float4 *__restrict__ edge,
@@ -235,8 +236,8 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
             const float sn2 = fmaf(sn, c4, cn * s4), cn2 = fmaf(cn, c4, -sn * s4);
             sn = sn2; cn = cn2; nf += 4.f;
         }
-        r[5] = kq == 0 ? fc : 0.f;
-        dr[5] = kq == 0 ? dfc : 0.f;
+        r[5] = fc;      // envelope (bias column) replicated in every quarter: the edge kernels fold bd * fc into the
+        dr[5] = dfc;    // accumulator init instead of spending a sixth MFMA k-step on it
         if (kq == 0) {
             erec[slot] = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, __int_as_float(valid ? j - a0 : 0));
             dist2[slot] = valid ? make_float2(d, -(float)excl_power * powf(excl_sigma * inv, (float)excl_power) * inv)

@@ -120,15 +120,15 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int nstreams = (EDGE_THREADS / 64) * 4;
     // ---- A operand: Wd_ext[section row = feature (lane & 15)][k = 4 ks + (lane >> 4)] ---------------------------
     const LayerW &W = MW[m].layer[l];
-    float wA[LY::NSEC][6];
+    // 20 radial functions = 5 k-steps; the bias column (bd * envelope) is folded into the accumulator init
+    float wA[LY::NSEC][5], bias[LY::NSEC][4];
 #pragma unroll
     for (int s = 0; s < LY::NSEC; ++s) {
         const int row = (L0 ? s + 1 : s) * F + fs * FS + p;
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {
-            int k = 4 * ks + fq;
-            wA[s][ks] = k < 20 ? W.Wd[(size_t)row * 20 + k] : (k == 20 ? W.bd[row] : 0.f);
-        }
+        for (int ks = 0; ks < 5; ++ks) wA[s][ks] = W.Wd[(size_t)row * 20 + 4 * ks + fq];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[s][r] = W.bd[(L0 ? s + 1 : s) * F + fs * FS + 4 * fq + r];
     }
 
     // ---- every stream walks a contiguous run of CSR slots, cut at centre boundaries, ~equal slot counts ---------
@@ -222,12 +222,14 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- filter GEMM  D[feature][slot] = Wd_ext[feature][k] rho[k][slot] ------------------------------------
-            const float rho[6] = {rh[ph][0].x, rh[ph][0].y, rh[ph][1].x, rh[ph][1].y, rh[ph][2].x, rh[ph][2].y};
+            const float rho[5] = {rh[ph][0].x, rh[ph][0].y, rh[ph][1].x, rh[ph][1].y, rh[ph][2].x};
+            const float fc = rh[ph][2].y;   // envelope of this lane's slot
             f32x4 acc[LY::NSEC];
 #pragma unroll
-            for (int s2 = 0; s2 < LY::NSEC; ++s2) acc[s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int s2 = 0; s2 < LY::NSEC; ++s2)
+                acc[s2] = (f32x4){bias[s2][0] * fc, bias[s2][1] * fc, bias[s2][2] * fc, bias[s2][3] * fc};
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks)
+            for (int ks = 0; ks < 5; ++ks)
 #pragma unroll
                 for (int s2 = 0; s2 < LY::NSEC; ++s2)
                     acc[s2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[s2][ks], rho[ks], acc[s2], 0, 0, 0);
@@ -351,15 +353,14 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
             }
         }
         // ---- A operand: Wd_ext rows of this slice ------------------------------------------------------------------
-        float wA[NSEC][6];
+        float wA[NSEC][5], bias[NSEC][4];   // bias column folded into the accumulator init (5 k-steps instead of 6)
 #pragma unroll
         for (int s2 = 0; s2 < NSEC; ++s2) {
             const int row = (L0 ? s2 + 1 : s2) * F + fs * FS + p;
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                int k = 4 * ks + fq;
-                wA[s2][ks] = k < 20 ? W.Wd[(size_t)row * 20 + k] : (k == 20 ? W.bd[row] : 0.f);
-            }
+            for (int ks = 0; ks < 5; ++ks) wA[s2][ks] = W.Wd[(size_t)row * 20 + 4 * ks + fq];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias[s2][r] = W.bd[(L0 ? s2 + 1 : s2) * F + fs * FS + 4 * fq + r];
         }
         __syncthreads();
 
@@ -465,13 +466,17 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const float rho[6] = {rh[ph][0].x, rh[ph][0].y, rh[ph][1].x, rh[ph][1].y, rh[ph][2].x, rh[ph][2].y};
-                const float drho[6] = {dh[ph][0].x, dh[ph][0].y, dh[ph][1].x, dh[ph][1].y, dh[ph][2].x, dh[ph][2].y};
+                const float rho[5] = {rh[ph][0].x, rh[ph][0].y, rh[ph][1].x, rh[ph][1].y, rh[ph][2].x};
+                const float drho[5] = {dh[ph][0].x, dh[ph][0].y, dh[ph][1].x, dh[ph][1].y, dh[ph][2].x};
+                const float fc = rh[ph][2].y, dfc = dh[ph][2].y;
                 f32x4 aw[NSEC], ad[NSEC];
 #pragma unroll
-                for (int s2 = 0; s2 < NSEC; ++s2) { aw[s2] = (f32x4){0.f, 0.f, 0.f, 0.f}; ad[s2] = aw[s2]; }
+                for (int s2 = 0; s2 < NSEC; ++s2) {
+                    aw[s2] = (f32x4){bias[s2][0] * fc, bias[s2][1] * fc, bias[s2][2] * fc, bias[s2][3] * fc};
+                    ad[s2] = (f32x4){bias[s2][0] * dfc, bias[s2][1] * dfc, bias[s2][2] * dfc, bias[s2][3] * dfc};
+                }
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks)
+                for (int ks = 0; ks < 5; ++ks)
 #pragma unroll
                     for (int s2 = 0; s2 < NSEC; ++s2) {
                         aw[s2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[s2][ks], rho[ks], aw[s2], 0, 0, 0);

@@ -198,7 +198,10 @@ void l0_build_tables(const float *blob_embed, const float *W1, const float *b1, 
         }
         for (int sec = 0; sec < 2; ++sec)           // 0: b-section (scalar message), 1: c-section (vector message)
             for (int kap = 0; kap < KP; ++kap) {
-                const int k = (kap / 6) + 4 * (kap % 6);
+                // table order: kappa = kq * 6 + ks ; ks < 5 -> radial index k = kq + 4 ks ; ks = 5 -> envelope (bias
+                // column), which the table replicates in every quarter: only quarter 0 carries the bias weight
+                const int kq = kap / 6, ks = kap % 6;
+                const int k = ks < 5 ? kq + 4 * ks : (kq == 0 ? 20 : 99);
                 for (int f = 0; f < F; ++f) {
                     const int row = (sec + 1) * F + f;
                     const float w = k < 20 ? Wd[(size_t)row * 20 + k] : (k == 20 ? bd[row] : 0.f);
