@@ -18,7 +18,7 @@
 
 namespace vssr {
 
-constexpr int T = NODE_TILE;
+constexpr int T = NODE_TILE;   // atoms per workgroup of the readout kernel
 constexpr int RB = 21;       // n_rbf (20) radial functions * envelope, + the envelope itself (bias column)
 constexpr int ECHUNK = 16;   // edges staged per step in the edge kernels
 constexpr float PI_F = 3.14159265358979323846f;
@@ -40,44 +40,6 @@ __global__ void __launch_bounds__(128) k_embed(int N, const int *__restrict__ Z,
     v0[(a * 3 + 0) * F + f] = 0.f;
     v0[(a * 3 + 1) * F + f] = 0.f;
     v0[(a * 3 + 2) * F + f] = 0.f;
-}
-
-// ---- message MLP: phi = W2 swish(W1 s + b1) + b2 -------------------------------------------------
-__global__ void __launch_bounds__(128) k_msg_mlp(int N, int l, const ModelW *__restrict__ MW,
-                                                 const float *__restrict__ s_in, float *__restrict__ phi) {
-    __shared__ float xs[F][T];
-    __shared__ float hs[F][T];
-    const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
-    const LayerW &W = MW[m].layer[l];
-    for (int t = 0; t < T; ++t) {
-        int atom = a0 + t;
-        xs[tid][t] = atom < N ? s_in[((size_t)m * N + atom) * F + tid] : 0.f;
-    }
-    __syncthreads();
-    float acc[T];
-    {
-        float b = W.b1[tid];
-        for (int t = 0; t < T; ++t) acc[t] = b;
-        for (int k = 0; k < F; ++k) {
-            float w = W.W1t[k * F + tid];
-            for (int t = 0; t < T; ++t) acc[t] = fmaf(w, xs[k][t], acc[t]);
-        }
-        for (int t = 0; t < T; ++t) hs[tid][t] = swishf_(acc[t]);
-    }
-    __syncthreads();
-    for (int c = 0; c < 3; ++c) {
-        int o = tid + c * F;
-        float b = W.b2[o];
-        for (int t = 0; t < T; ++t) acc[t] = b;
-        for (int k = 0; k < F; ++k) {
-            float w = W.W2t[k * F3 + o];
-            for (int t = 0; t < T; ++t) acc[t] = fmaf(w, hs[k][t], acc[t]);
-        }
-        for (int t = 0; t < T; ++t) {
-            int atom = a0 + t;
-            if (atom < N) phi[((size_t)m * N + atom) * F3 + o] = acc[t];
-        }
-    }
 }
 
 // ---- per-chunk edge geometry shared by the two edge kernels ----------------------------------------
@@ -209,100 +171,6 @@ k_edge_fwd(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *
     }
 }
 
-// ---- update block pieces shared by forward and reverse -----------------------------------------------
-struct UpdateLocals {
-    float Uv[3 * T], Vv[3 * T];  // [t*3+x]
-    float nrm[T], inner[T], s1[T], h3[T], avv[T], asv[T], ass[T];
-};
-
-// Computes the update block for feature `tid` of the T atoms of the tile.  vs: v_msg tile
-// [k][t*3+x]; hs/as: scratch.  Leaves hs = [s1; nrm], as_ = swish(h3).
-__device__ inline void update_forward_tile(const LayerW &W, int tid, float (*vs)[3 * T], float (*hs)[T],
-                                           float (*as_)[T], const float *__restrict__ s_msg, size_t mN,
-                                           int a0, int N, UpdateLocals &L) {
-    for (int r = 0; r < 3 * T; ++r) { L.Uv[r] = 0.f; L.Vv[r] = 0.f; }
-    for (int k = 0; k < F; ++k) {
-        float wu = W.Ut[k * F + tid], wv = W.Vt[k * F + tid];
-#pragma unroll
-        for (int r = 0; r < 3 * T; ++r) {
-            float x = vs[k][r];
-            L.Uv[r] = fmaf(wu, x, L.Uv[r]);
-            L.Vv[r] = fmaf(wv, x, L.Vv[r]);
-        }
-    }
-    for (int t = 0; t < T; ++t) {
-        float n2 = 0.f, in = 0.f;
-        for (int x = 0; x < 3; ++x) {
-            float vv = L.Vv[t * 3 + x];
-            n2 += fmaf(vv, vv, 1e-15f);
-            in = fmaf(L.Uv[t * 3 + x], vv, in);
-        }
-        L.nrm[t] = sqrtf(n2);
-        L.inner[t] = in;
-        int atom = a0 + t;
-        L.s1[t] = atom < N ? s_msg[(mN + atom) * F + tid] : 0.f;
-        hs[tid][t] = L.s1[t];
-        hs[F + tid][t] = L.nrm[t];
-    }
-    __syncthreads();
-    {
-        float b = W.b3[tid];
-        for (int t = 0; t < T; ++t) L.h3[t] = b;
-        for (int k = 0; k < 2 * F; ++k) {
-            float w = W.W3t[k * F + tid];
-            for (int t = 0; t < T; ++t) L.h3[t] = fmaf(w, hs[k][t], L.h3[t]);
-        }
-        for (int t = 0; t < T; ++t) as_[tid][t] = swishf_(L.h3[t]);
-    }
-    __syncthreads();
-    {
-        float b0 = W.b4[tid], b1 = W.b4[F + tid], b2 = W.b4[2 * F + tid];
-        for (int t = 0; t < T; ++t) { L.avv[t] = b0; L.asv[t] = b1; L.ass[t] = b2; }
-        for (int k = 0; k < F; ++k) {
-            float w0 = W.W4t[k * F3 + tid], w1 = W.W4t[k * F3 + F + tid], w2 = W.W4t[k * F3 + 2 * F + tid];
-            for (int t = 0; t < T; ++t) {
-                float a = as_[k][t];
-                L.avv[t] = fmaf(w0, a, L.avv[t]);
-                L.asv[t] = fmaf(w1, a, L.asv[t]);
-                L.ass[t] = fmaf(w2, a, L.ass[t]);
-            }
-        }
-    }
-}
-
-__device__ inline void load_v_tile(float (*vs)[3 * T], const float *__restrict__ v, size_t mN, int a0, int N,
-                                   int tid) {
-    for (int t = 0; t < T; ++t) {
-        int atom = a0 + t;
-        for (int x = 0; x < 3; ++x)
-            vs[tid][t * 3 + x] = atom < N ? v[((mN + atom) * 3 + x) * F + tid] : 0.f;
-    }
-}
-
-// ---- update block, forward ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(128)
-k_update_fwd(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
-             const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out) {
-    __shared__ float vs[F][3 * T];
-    __shared__ float hs[2 * F][T];
-    __shared__ float as_[F][T];
-    const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
-    const LayerW &W = MW[m].layer[l];
-    const size_t mN = (size_t)m * N;
-    load_v_tile(vs, v_msg, mN, a0, N, tid);
-    __syncthreads();
-    UpdateLocals L;
-    update_forward_tile(W, tid, vs, hs, as_, s_msg, mN, a0, N, L);
-    for (int t = 0; t < T; ++t) {
-        int atom = a0 + t;
-        if (atom >= N) continue;
-        size_t a = mN + atom;
-        s_out[a * F + tid] = fmaf(L.asv[t], L.inner[t], L.s1[t]) + L.ass[t];
-        for (int x = 0; x < 3; ++x)
-            v_out[(a * 3 + x) * F + tid] = fmaf(L.avv[t], L.Uv[t * 3 + x], vs[tid][t * 3 + x]);
-    }
-}
-
 // ---- readout (+ its own reverse): e_i = w6.swish(W5 s + b5) + b6 ; sbar = W5^T (w6 * swish'(h5)) ---------
 __global__ void __launch_bounds__(128)
 k_readout(int N, int H, const ModelW *__restrict__ MW, const float *__restrict__ s, const float *__restrict__ e_excl,
@@ -349,91 +217,6 @@ k_readout(int N, int H, const ModelW *__restrict__ MW, const float *__restrict__
     for (int t = 0; t < T; ++t) {
         int atom = a0 + t;
         if (atom < N) sbar[(mN + atom) * F + tid] = acc[t];
-    }
-}
-
-// ---- update block, reverse: (sbar, vbar) of the block outputs -> (sbar_msg, vbar_msg) of its inputs --------
-__global__ void __launch_bounds__(128)
-k_update_bwd(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
-             const float *__restrict__ v_msg, const float *__restrict__ sbar, const float *__restrict__ vbar,
-             float *__restrict__ sbar_msg, float *__restrict__ vbar_msg) {
-    __shared__ float vs[F][3 * T];
-    __shared__ float hs[2 * F][T];
-    __shared__ float as_[F][T];
-    __shared__ float qb[F3][T];
-    __shared__ float ub[F][3 * T];
-    __shared__ float vb[F][3 * T];
-    const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
-    const LayerW &W = MW[m].layer[l];
-    const size_t mN = (size_t)m * N;
-    load_v_tile(vs, v_msg, mN, a0, N, tid);
-    __syncthreads();
-    UpdateLocals L;
-    update_forward_tile(W, tid, vs, hs, as_, s_msg, mN, a0, N, L);
-
-    float Ub[3 * T], Vb[3 * T], vbo[3 * T], sb[T];
-    for (int t = 0; t < T; ++t) {
-        int atom = a0 + t;
-        size_t a = mN + atom;
-        sb[t] = atom < N ? sbar[a * F + tid] : 0.f;
-        float abar_vv = 0.f;
-        for (int x = 0; x < 3; ++x) {
-            int r = t * 3 + x;
-            vbo[r] = (atom < N && !vbar_is_zero) ? vbar[(a * 3 + x) * F + tid] : 0.f;
-            abar_vv = fmaf(vbo[r], L.Uv[r], abar_vv);
-            float sa = sb[t] * L.asv[t];
-            Ub[r] = fmaf(vbo[r], L.avv[t], sa * L.Vv[r]);
-            Vb[r] = sa * L.Uv[r];
-        }
-        qb[tid][t] = abar_vv;
-        qb[F + tid][t] = sb[t] * L.inner[t];
-        qb[2 * F + tid][t] = sb[t];
-    }
-    __syncthreads();  // qb complete; as_ (swish(h3)) no longer needed
-    float acc[T];
-    for (int t = 0; t < T; ++t) acc[t] = 0.f;
-    for (int c = 0; c < F3; ++c) {
-        float w = W.W4[c * F + tid];
-        for (int t = 0; t < T; ++t) acc[t] = fmaf(w, qb[c][t], acc[t]);
-    }
-    for (int t = 0; t < T; ++t) as_[tid][t] = acc[t] * dswishf_(L.h3[t]);  // h3bar
-    __syncthreads();
-    float hs_s[T], hs_n[T];
-    for (int t = 0; t < T; ++t) { hs_s[t] = 0.f; hs_n[t] = 0.f; }
-    for (int o = 0; o < F; ++o) {
-        float w0 = W.W3[o * 2 * F + tid], w1 = W.W3[o * 2 * F + F + tid];
-        for (int t = 0; t < T; ++t) {
-            float g = as_[o][t];
-            hs_s[t] = fmaf(w0, g, hs_s[t]);
-            hs_n[t] = fmaf(w1, g, hs_n[t]);
-        }
-    }
-    for (int t = 0; t < T; ++t) {
-        int atom = a0 + t;
-        if (atom < N) sbar_msg[(mN + atom) * F + tid] = sb[t] + hs_s[t];
-        float sc = hs_n[t] / L.nrm[t];
-        for (int x = 0; x < 3; ++x) {
-            int r = t * 3 + x;
-            Vb[r] = fmaf(sc, L.Vv[r], Vb[r]);
-            ub[tid][r] = Ub[r];
-            vb[tid][r] = Vb[r];
-        }
-    }
-    __syncthreads();
-    float out[3 * T];
-    for (int r = 0; r < 3 * T; ++r) out[r] = vbo[r];
-    for (int fo = 0; fo < F; ++fo) {
-        float wu = W.U[fo * F + tid], wv = W.V[fo * F + tid];
-#pragma unroll
-        for (int r = 0; r < 3 * T; ++r) {
-            out[r] = fmaf(wu, ub[fo][r], out[r]);
-            out[r] = fmaf(wv, vb[fo][r], out[r]);
-        }
-    }
-    for (int t = 0; t < T; ++t) {
-        int atom = a0 + t;
-        if (atom >= N) continue;
-        for (int x = 0; x < 3; ++x) vbar_msg[((mN + atom) * 3 + x) * F + tid] = out[t * 3 + x];
     }
 }
 
@@ -552,50 +335,6 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
         vbar_in[(ac * 3 + 0) * F + f] = fmaf(pc_a, ax, vbar_msg[(ac * 3 + 0) * F + f]);
         vbar_in[(ac * 3 + 1) * F + f] = fmaf(pc_a, ay, vbar_msg[(ac * 3 + 1) * F + f]);
         vbar_in[(ac * 3 + 2) * F + f] = fmaf(pc_a, az, vbar_msg[(ac * 3 + 2) * F + f]);
-    }
-}
-
-// ---- message MLP, reverse: sbar_in = sbar_msg + W1^T [ (W2^T phibar) * swish'(W1 s + b1) ] -------------------
-__global__ void __launch_bounds__(128)
-k_msg_mlp_bwd(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
-              const float *__restrict__ phibar, const float *__restrict__ sbar_msg, float *__restrict__ sbar_in) {
-    __shared__ float xs[F][T];
-    __shared__ float pb[F3][T];
-    __shared__ float hb[F][T];
-    const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
-    const LayerW &W = MW[m].layer[l];
-    const size_t mN = (size_t)m * N;
-    for (int t = 0; t < T; ++t) {
-        int atom = a0 + t;
-        bool ok = atom < N;
-        xs[tid][t] = ok ? s_in[(mN + atom) * F + tid] : 0.f;
-        for (int c = 0; c < 3; ++c) pb[c * F + tid][t] = ok ? phibar[(mN + atom) * F3 + c * F + tid] : 0.f;
-    }
-    __syncthreads();
-    float h1[T], acc[T];
-    {
-        float b = W.b1[tid];
-        for (int t = 0; t < T; ++t) h1[t] = b;
-        for (int k = 0; k < F; ++k) {
-            float w = W.W1t[k * F + tid];
-            for (int t = 0; t < T; ++t) h1[t] = fmaf(w, xs[k][t], h1[t]);
-        }
-    }
-    for (int t = 0; t < T; ++t) acc[t] = 0.f;
-    for (int c = 0; c < F3; ++c) {
-        float w = W.W2[c * F + tid];
-        for (int t = 0; t < T; ++t) acc[t] = fmaf(w, pb[c][t], acc[t]);
-    }
-    for (int t = 0; t < T; ++t) hb[tid][t] = acc[t] * dswishf_(h1[t]);
-    __syncthreads();
-    for (int t = 0; t < T; ++t) acc[t] = 0.f;
-    for (int o = 0; o < F; ++o) {
-        float w = W.W1[o * F + tid];
-        for (int t = 0; t < T; ++t) acc[t] = fmaf(w, hb[o][t], acc[t]);
-    }
-    for (int t = 0; t < T; ++t) {
-        int atom = a0 + t;
-        if (atom < N) sbar_in[(mN + atom) * F + tid] = sbar_msg[(mN + atom) * F + tid] + acc[t];
     }
 }
 
@@ -741,8 +480,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     dim3 g_atom(N, M), g_tile((N + T - 1) / T, M);
     Profiler &P = h->prof;
     const bool use_edge_mfma = h->edge_impl && edge_fwd_mfma_fits(h->max_cfg_atoms);   // chains fit the LDS slices
-    const bool l0_fact = use_edge_mfma && h->l0_enabled && h->l0_nz > 0;                // layer 0 by species factorisation
-    const int n_groups = use_edge_mfma ? ((L == 1 && l0_fact) ? 1 : edge_bwd_groups()) : 1;
+    const bool l0_fact = h->l0_enabled && h->l0_nz > 0;   // layer 0 by species factorisation (any chain size)
+    const int n_groups = (use_edge_mfma && !(L == 1 && l0_fact)) ? edge_bwd_groups() : 1;   // partial gbar buffers
     h->l0_used = l0_fact;
 
     if (!l0_fact) {   // s0 = Emb[Z], v0 = 0 (the factorised layer 0 reads the embedding directly)
@@ -758,17 +497,12 @@ int painn_run(vssr_handle *h, uint32_t want) {
             if (h->excl_vol) launch_excl_vol(st, N, M, G, counters, h->excl_sigma, h->excl_power, sv.e_excl);
             P.end(st);
             P.begin(KC_UPDATE_FWD, st);
-            if (h->node_impl)
-                launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
-            else
-                hipLaunchKernelGGL(k_update_fwd, g_tile, blk, 0, st, N, l, MW, sv.s_msg[l], sv.v_msg[l],
-                                   sv.s_in[l + 1], sv.v_in[l + 1]);
+            launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
             P.end(st);
             continue;
         }
         P.begin(KC_MSG_MLP, st);
-        if (h->node_impl) launch_msg_mlp_mfma(st, N, M, l, MW, sv.s_in[l], sv.phi[l]);
-        else hipLaunchKernelGGL(k_msg_mlp, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phi[l]);
+        launch_msg_mlp_mfma(st, N, M, l, MW, sv.s_in[l], sv.phi[l]);
         P.end(st);
         P.begin(KC_EDGE_FWD, st);
         if (use_edge_mfma)
@@ -785,11 +519,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
                                sv.v_msg[l], sv.e_excl);
         P.end(st);
         P.begin(KC_UPDATE_FWD, st);
-        if (h->node_impl)
-            launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
-        else
-            hipLaunchKernelGGL(k_update_fwd, g_tile, blk, 0, st, N, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1],
-                               sv.v_in[l + 1]);
+        launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
         P.end(st);
     }
     P.begin(KC_READOUT, st);
@@ -800,12 +530,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     if (want & VSSR_WANT_FORCES) {
         for (int l = L - 1; l >= 0; --l) {
             P.begin(KC_UPDATE_BWD, st);
-            if (h->node_impl)
-                launch_update_bwd_mfma(st, N, M, l, (int)(l == L - 1), MW, sv.s_msg[l], sv.v_msg[l], sv.sbar, sv.vbar,
-                                       sv.sbar_msg, sv.vbar_msg);
-            else
-                hipLaunchKernelGGL(k_update_bwd, g_tile, blk, 0, st, N, l, (int)(l == L - 1), MW, sv.s_msg[l],
-                                   sv.v_msg[l], sv.sbar, sv.vbar, sv.sbar_msg, sv.vbar_msg);
+            launch_update_bwd_mfma(st, N, M, l, (int)(l == L - 1), MW, sv.s_msg[l], sv.v_msg[l], sv.sbar, sv.vbar,
+                                   sv.sbar_msg, sv.vbar_msg);
             P.end(st);
             P.begin((l == 0 && l0_fact) ? KC_L0_BWD : KC_EDGE_BWD, st);
             int accumulate = (l != L - 1);
@@ -828,11 +554,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.end(st);
             if (l > 0) {
                 P.begin(KC_MSG_MLP_BWD, st);
-                if (h->node_impl)
-                    launch_msg_mlp_bwd_mfma(st, N, M, l, MW, sv.s_in[l], sv.phibar, sv.sbar_msg, sv.sbar);
-                else
-                    hipLaunchKernelGGL(k_msg_mlp_bwd, g_tile, blk, 0, st, N, l, MW, sv.s_in[l], sv.phibar,
-                                       sv.sbar_msg, sv.sbar);
+                launch_msg_mlp_bwd_mfma(st, N, M, l, MW, sv.s_in[l], sv.phibar, sv.sbar_msg, sv.sbar);
                 P.end(st);
             }
         }

@@ -266,8 +266,7 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     if (!rc) rc = upload_weights(h, cfg);
     if (!rc) rc = node_mfma_init(h);
     if (!rc) rc = edge_mfma_init(h);
-    if (const char *e = getenv("VSSR_NODE_IMPL")) h->node_impl = (strcmp(e, "v0") == 0) ? 0 : 1;
-    if (const char *e = getenv("VSSR_EDGE_IMPL")) h->edge_impl = (strcmp(e, "v0") == 0) ? 0 : 1;
+    if (const char *e = getenv("VSSR_EDGE_IMPL")) h->edge_impl = (strcmp(e, "gather") == 0) ? 0 : 1;
     if (const char *e = getenv("VSSR_L0_FACTORISE")) h->l0_enabled = atoi(e);
     if (!rc && cfg->offset_per_z) {
         h->has_offset = true;

@@ -145,8 +145,8 @@ struct vssr_handle {
     std::string err;
     vssr::Profiler prof;
 
-    int node_impl = 1;  // 1 = MFMA node kernels, 0 = v0 VALU kernels (VSSR_NODE_IMPL=v0, A/B validation only)
-    int edge_impl = 1;  // 1 = LDS-slice + MFMA edge kernels (chains that fit LDS), 0 = gather kernels
+    int edge_impl = 1;  // 1 = LDS-slice + MFMA edge kernels for chains that fit LDS; 0 forces the gather kernels
+                        // (VSSR_EDGE_IMPL=gather: debug knob, also the automatic path for very large chains)
     int max_cfg_atoms = 0;
 
     // configuration

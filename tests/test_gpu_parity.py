@@ -280,3 +280,45 @@ def test_error_paths(golden, engine):
     # a single isolated atom (no neighbors at all) is a valid configuration
     lone = engine.evaluate([(np.array([8], np.int32), np.zeros((1, 3)), np.eye(3) * 30.0, [0, 0, 0])])
     assert np.isfinite(lone["energy"][0]) and np.abs(lone["forces"]).max() == 0.0
+
+
+def test_fallback_paths_large_chain_many_species_and_forced_gather(golden, oracle_mod):
+    """Paths that the BASELINE workload does not touch: (1) a chain too large for the LDS slices (960 atoms) runs
+    the gather kernels, (2) more than 8 species disables the layer-0 factorisation, (3) forcing the gather kernels
+    (VSSR_EDGE_IMPL=gather) or the per-edge layer 0 (VSSR_L0_FACTORISE=0) gives the same physics."""
+    import os
+
+    from surface_sampling_amd import backend, structures
+
+    table, const = golden.offset_table()
+    base = golden.structure("SrTiO3_2x2_pristine")
+    big = base.repeat((4, 4, 1))                       # 960 atoms > LDS-slice capacity
+    rng = np.random.default_rng(3)
+    big.positions += rng.normal(0, 0.03, big.positions.shape)
+    small = structures.synth_chain(base, 5, grid=(4, 4))
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    res = eng.evaluate([_arrays(big), _arrays(small)])
+    for b, s in enumerate((big, small)):
+        ref = _oracle(golden, oracle_mod, s)
+        a0, a1 = res["cfg_start"][b], res["cfg_start"][b + 1]
+        assert abs(float(res["energy"][b]) - ref["energy"]) <= (4e-4 if len(s) > 500 else E_TOL), (b, res["energy"][b], ref["energy"])
+        assert np.abs(res["forces"][a0:a1] - ref["forces"]).max() <= F_TOL
+    # (2) nine species: the embedding rows of the extra species are untrained but perfectly valid inputs
+    many = small.copy()
+    many.numbers[:9] = np.array([1, 6, 7, 9, 13, 14, 20, 26, 29], np.int32)
+    r9 = eng.evaluate([_arrays(many)])
+    ref9 = _oracle(golden, oracle_mod, many)
+    assert abs(float(r9["energy"][0]) - ref9["energy"]) <= 3e-4 and np.abs(r9["forces"] - ref9["forces"]).max() <= 5e-4
+    ref_small = eng.evaluate([_arrays(small)])
+    eng.close()
+    # (3) debug knobs select the other code paths; results agree to fp32 re-association noise
+    for var, val in (("VSSR_EDGE_IMPL", "gather"), ("VSSR_L0_FACTORISE", "0")):
+        os.environ[var] = val
+        try:
+            alt = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+            r = alt.evaluate([_arrays(small)])
+            alt.close()
+        finally:
+            del os.environ[var]
+        assert abs(float(r["energy"][0]) - float(ref_small["energy"][0])) <= 1e-4, var
+        assert np.abs(r["forces"] - ref_small["forces"]).max() <= 1e-4, var
