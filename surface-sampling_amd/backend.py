@@ -316,6 +316,21 @@ class TersoffEngine(_Handle):
             msg = self._lib.vssr_last_error(None)
             raise BackendError(f"vssr_tersoff_create failed ({rc}): {msg.decode() if msg else '?'}")
 
+    def relax_f64(self, structs, fixed=None, max_steps=100, fmax=0.01):
+        """FIRE-relax (types, positions, cell, pbc) structures; returns (energy [B], e_atom [N], forces [N,3],
+        positions [N,3], n_steps [B], converged [B]) with fp64 energies/forces of the relaxed structures."""
+        self.upload(structs)
+        info = self.relax_fire(fixed=fixed, max_steps=max_steps, fmax=fmax,
+                               want=WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM)
+        packs = []
+        o = 0
+        for t, p, c, b in structs:
+            n = len(t)
+            packs.append((t, info["positions"][o:o + n], c, b))
+            o += n
+        e, ea, f = self.evaluate_f64(packs)
+        return e, ea, f, info["positions"], info["n_steps"], info["converged"]
+
     def evaluate_f64(self, structs, want=WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM):
         """structs: list of (types, positions, cell, pbc). Returns fp64 energy [B], e_atom [N], forces [N,3]."""
         n_atoms, T, pos, cell, pbc = pack_batch(structs)

@@ -394,7 +394,7 @@ class TersoffSurfCalc(_Base):
     ``per_atom_energies`` is LAMMPS' ``pe/atom``; periodic in all directions like the reference's
     ``boundary p p p`` template."""
 
-    implemented_properties = ("energy", "forces", "per_atom_energies", "surface_energy")
+    implemented_properties = ("energy", "relaxed_energy", "forces", "per_atom_energies", "surface_energy")
     name = "tersoff_mi355x"
 
     def __init__(self, potential, species, device="cuda", all_periodic=True, logger=None, **kwargs):
@@ -462,8 +462,28 @@ class TersoffSurfCalc(_Base):
         self.results["energy"] = float(e[0])
         self.results["per_atom_energies"] = ea
         self.results["forces"] = f
+        if "relaxed_energy" in properties:   # reference calculators.py:688-691
+            _, e_rel, ea_rel = self.run_lammps_opt(atoms)
+            self.results["relaxed_energy"] = e_rel
+            self.results["per_atom_energies"] = ea_rel
         if "surface_energy" in properties:
             self.results["surface_energy"] = self.results["energy"]
+
+    def run_lammps_opt(self, slab, run_dir=None, fixed_indices=None, **kwargs):
+        """Relaxation counterpart of ``LAMMMPSCalc.run_lammps_opt`` (reference ``calculators.py:600-619``; the
+        reference minimises with LAMMPS CG for ``relax_steps`` iterations): here FIRE on the device.  Returns the
+        reference's tuple ``(relaxed_slab, energy, per_atom_energies)``."""
+        types, pos, cell, pbc = self._pack(slab)
+        fixed = None
+        if fixed_indices is not None and len(fixed_indices):
+            fixed = np.zeros(len(types), np.uint8)
+            fixed[np.asarray(fixed_indices, dtype=np.int64)] = 1
+        e, ea, f, new_pos, steps, conv = self._get_engine().relax_f64(
+            [(types, pos, cell, pbc)], fixed=fixed, max_steps=int(self.relax_steps), fmax=kwargs.get("fmax", 0.01))
+        relaxed = slab.copy()
+        relaxed.set_positions(new_pos)
+        relaxed.calc = getattr(slab, "calc", None)
+        return relaxed, float(e[0]), ea
 
     def calculate_batch(self, atoms_list) -> list[dict]:
         packs = [self._pack(a) for a in atoms_list]

@@ -123,6 +123,11 @@ k_fire_step(const int *__restrict__ cfg_start, const float *__restrict__ forces,
     }
 }
 
+__global__ void k_narrow_forces(int n3, const double *__restrict__ f64, float *__restrict__ f32) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) f32[i] = (float)f64[i];
+}
+
 __global__ void k_fire_report(int B, const FireState *__restrict__ st, int *__restrict__ steps, uint8_t *__restrict__ conv) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -150,8 +155,12 @@ int relax_fire(vssr_handle *h, const vssr_fire_params *fp, const uint8_t *fixed_
         if (rc) return rc;
         if (it == fp->max_steps) break;
         VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
+        if (h->kind == 2) {   // Tersoff forces are fp64 on the device: the optimizer state works on an fp32 copy
+            if (h->d_forces.ensure(sizeof(float) * 3 * N)) return set_err(h, VSSR_E_NOMEM, "force buffer");
+            hipLaunchKernelGGL(k_narrow_forces, dim3((3 * N + 255) / 256), dim3(256), 0, st, 3 * N,
+                               h->d_ters_f.as<double>(), h->d_forces.as<float>());
+        }
         const float *forces = h->d_forces.as<float>();
-        if (h->kind == 2) return set_err(h, VSSR_E_STATE, "FIRE relaxation is implemented for PaiNN handles");
         hipLaunchKernelGGL(k_fire_step, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), forces, fixed,
                            (double)fp->fmax, (double)fp->maxstep, (double)fp->dtmax, (double)fp->finc, (double)fp->fdec,
                            (double)fp->astart, (double)fp->fa, fp->nmin, h->d_pos.as<double>(), h->d_vel.as<double>(),

@@ -501,7 +501,6 @@ int vssr_batch_relax_fire(vssr_handle *h, const vssr_fire_params *params, const 
     if (!h->batch_valid) return set_err(h, VSSR_E_STATE, "vssr_batch_relax_fire before vssr_batch_upload");
     if (!params || params->max_steps < 0 || !(params->fmax > 0) || !(params->dt > 0) || !(params->maxstep > 0))
         return set_err(h, VSSR_E_BADARG, "bad FIRE parameters");
-    if (h->kind != 1) return set_err(h, VSSR_E_STATE, "FIRE relaxation is implemented for PaiNN handles");
     VSSR_HIP(h, hipSetDevice(h->device));
     int rc = relax_fire(h, params, fixed, want);
     if (rc) return rc;

@@ -93,3 +93,27 @@ def test_relax_batch_front_end(golden):
     assert energy > -467.56                      # reference BFGS reaches -467.534088 (tests/test_SrTiO3_terms.ipynb:208-210)
     assert np.abs(slab.positions[fixed] - s.positions[fixed]).max() == 0.0
     assert r["n_steps"] <= 20
+
+
+@pytest.mark.gpu
+def test_tersoff_relaxation(golden, oracle_mod):
+    """GaN (config 2): FIRE on Tersoff forces lowers the energy of a rattled slab back towards the pristine minimum."""
+    from surface_sampling_amd.calculators import TersoffSurfCalc
+    from surface_sampling_amd.structures import Structure
+
+    g = golden.structure("GaN_3x3_pristine")
+    rng = np.random.default_rng(2)
+    rattled = Structure(g.numbers, g.positions + rng.normal(0, 0.04, g.positions.shape), g.cell, g.pbc)
+    calc = TersoffSurfCalc(golden.tersoff_params, ["Ga", "N"], device="cuda:0")
+    calc.set(relax_steps=60)
+    e0 = calc.get_potential_energy(rattled)
+    relaxed, e1, ea = calc.run_lammps_opt(rattled, fixed_indices=np.arange(0, 12))
+    assert e1 < e0 - 0.05 and e1 >= -144.059 - 0.6      # towards (a relaxed variant of) the pristine slab
+    assert abs(ea.sum() - e1) < 1e-9
+    assert np.abs(relaxed.positions[:12] - rattled.positions[:12]).max() == 0.0
+    types = np.array([0 if z == 31 else 1 for z in g.numbers], np.int32)
+    E, _, F = oracle_mod.tersoff(golden.tersoff_params, types, relaxed.positions, g.cell, [1, 1, 1])
+    assert abs(E - e1) <= 1e-9 * abs(E)
+    _, e_free, _ = calc.run_lammps_opt(rattled)              # no FixAtoms mask, like the calculator property
+    assert calc.get_property("relaxed_energy", rattled) == pytest.approx(e_free, abs=1e-9)
+    assert e_free <= e1 + 1e-9
