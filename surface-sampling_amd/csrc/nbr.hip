@@ -198,11 +198,34 @@ k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
 // stored in the order the MFMA operand wants them: table[slot][kq][ks] = rho_{kq + 4 ks}  (kq = lane >> 4, ks < 5);
 // entry ks = 5 of every quarter holds the envelope fc (resp. its derivative).
 // One thread per (slot, kq).  sin/cos of the multiples come from one sincos + a rotation recurrence.
+// Exact 3-way bf16 split by truncation: x = h + m + l with h, m, l representable in bf16 (the residuals x - h and
+// x - h - m are exact in fp32).  Returns the three 16-bit patterns.
+__device__ __forceinline__ void split3_bf16(float x, unsigned &h, unsigned &m, unsigned &l) {
+    const unsigned xb = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(xb);
+    const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    h = xb >> 16; m = mb >> 16; l = __float_as_uint(r2) >> 16;
+}
+// Operand-ready record of one (slot, quarter) for v_mfma_f32_16x16x32_bf16: the quarter's 5 radial values
+// (k = kq + 4 kk) in the 30 K-slots [h x5 | m x5 | h x5 | m x5 | l x5 | h x5] that pair with the weight pieces
+// [Wh | Wh | Wm | Wm | Wh | Wl] (6 partial products, everything >= 2^-16 relative: fp32-level accuracy).  The 16 operand
+// dwords contain only 10 distinct ones: stored as A B C D | E F G H | I J 0 0 (48 bytes), see painn_edge_mfma.hip.
+__device__ __forceinline__ void write_b16_record(const float (&v)[5], uint4 *__restrict__ rec) {
+    unsigned h[5], m[5], l[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) split3_bf16(v[k], h[k], m[k], l[k]);
+    auto pk = [](unsigned lo, unsigned hi) { return lo | (hi << 16); };
+    rec[0] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], m[0]), pk(m[1], m[2]));   // A B C D
+    rec[1] = make_uint4(pk(m[3], m[4]), pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], h[0]));   // E F G H
+    rec[2] = make_uint4(pk(h[1], h[2]), pk(h[3], h[4]), 0u, 0u);                           // I J 0 0
+}
+
 __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
                             const int *__restrict__ cfg_start, const float4 *__restrict__ edge,
                             const int *__restrict__ counters, float rc, float excl_sigma, int excl_power,
                             float4 *__restrict__ erec, float *__restrict__ rho, float *__restrict__ drho,
-                            float2 *__restrict__ dist2) {
+                            float2 *__restrict__ dist2, uint4 *__restrict__ rho16, uint4 *__restrict__ drho16) {
     if (counters[2]) return;
     const int i = blockIdx.x;                 // centre atom
     const int a0 = cfg_start[atom_cfg[i]];
@@ -235,6 +258,11 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
             dr[ks] = fmaf(nf * alpha * cn * inv - rb * inv, fc, rb * dfc);
             const float sn2 = fmaf(sn, c4, cn * s4), cn2 = fmaf(cn, c4, -sn * s4);
             sn = sn2; cn = cn2; nf += 4.f;
+        }
+        {
+            const float rv[5] = {r[0], r[1], r[2], r[3], r[4]}, dv[5] = {dr[0], dr[1], dr[2], dr[3], dr[4]};
+            write_b16_record(rv, rho16 + ((size_t)slot * 4 + kq) * 3);
+            write_b16_record(dv, drho16 + ((size_t)slot * 4 + kq) * 3);
         }
         r[5] = fc;      // envelope (bias column) replicated in every quarter: the edge kernels fold bd * fc into the
         dr[5] = dfc;    // accumulator init instead of spending a sixth MFMA k-step on it
@@ -280,16 +308,20 @@ int build_neighbors(vssr_handle *h, double cutoff) {
                        h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>());
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
         if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
-            h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float2) * h->slot_cap))
+            h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float2) * h->slot_cap) ||
+            h->d_rho16.ensure(sizeof(uint4) * 12 * h->slot_cap) || h->d_drho16.ensure(sizeof(uint4) * 12 * h->slot_cap))
             return set_err(h, VSSR_E_NOMEM, "edge geometry tables: out of device memory");
         // the last slot of the capacity is never used by the CSR (counters[2] flags slots > cap - 64): it is the
         // all-zero table entry that exhausted lanes of the edge kernels read
         VSSR_HIP(h, hipMemsetAsync(h->d_rho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
         VSSR_HIP(h, hipMemsetAsync(h->d_drho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
+        VSSR_HIP(h, hipMemsetAsync(h->d_rho16.as<uint4>() + 12 * (size_t)(h->slot_cap - 1), 0, 12 * sizeof(uint4), st));
+        VSSR_HIP(h, hipMemsetAsync(h->d_drho16.as<uint4>() + 12 * (size_t)(h->slot_cap - 1), 0, 12 * sizeof(uint4), st));
         hipLaunchKernelGGL(k_edge_geom, dim3(n), dim3(64), 0, st, n, h->d_row_start.as<int>(), h->d_atom_cfg.as<int>(),
                            h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,
                            h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),
-                           h->d_drho.as<float>(), h->d_dist.as<float2>());
+                           h->d_drho.as<float>(), h->d_dist.as<float2>(), h->d_rho16.as<uint4>(),
+                           h->d_drho16.as<uint4>());
     }
     h->prof.end(st);
     VSSR_HIP(h, hipMemcpyAsync(h->h_counters, h->d_counters.as<int>(), sizeof(int) * 4,

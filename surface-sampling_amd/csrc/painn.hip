@@ -473,6 +473,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     G.rho = h->d_rho.as<float>();
     G.drho = h->d_drho.as<float>();
     G.dist2 = h->d_dist.as<float2>();
+    G.rho16 = h->d_rho16.as<uint4>();
+    G.drho16 = h->d_drho16.as<uint4>();
     const ModelW *MW = h->model_table.as<ModelW>();
     const int *counters = h->d_counters.as<int>();
     const int *Z = h->d_Z.as<int>();

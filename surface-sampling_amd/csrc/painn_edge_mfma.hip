@@ -22,10 +22,64 @@
 namespace vssr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- radial filter on the bf16 matrix pipe with fp32-level accuracy --------------------------------------------------
+// fp32 MFMA shares the FP32 datapath with the VALU (measured: MFMA cycles and instruction-issue cycles add up), the
+// bf16 MFMA does not.  Both operands are split exactly into three bf16 pieces x = h + m + l (truncation; residuals are
+// exact in fp32) and the six products with weight >= 2^-16 are kept:  Wh rh + Wh rm + Wm rh + Wm rm + Wh rl + Wl rh ;
+// the dropped ones are <= 2^-24 relative, i.e. fp32 rounding level.  Per lane quarter kq the 5 radial indices
+// k = kq + 4 kk occupy 30 of the 32 K-slots of four v_mfma_f32_16x16x32_bf16 (slot order in nbr.hip / build_wd16):
+// 4 matrix-pipe instructions replace 5 fp32 MFMAs.  Pieces of rho are pre-split once per evaluation (k_edge_geom),
+// pieces of the weights once per handle (build_wd16): no split arithmetic in the hot loop.
+union Op16 { uint4 u; bf16x8 v; };
+__device__ __forceinline__ void rho_operands(const uint4 q0, const uint4 q1, const uint4 q2, Op16 (&b)[4]) {
+    b[0].u = q0;                                          // A B C D
+    b[1].u = make_uint4(q1.x, q0.x, q0.y, q0.z);          // E A B C
+    b[2].u = make_uint4(q0.w, q1.x, q1.y, q1.z);          // D E F G
+    b[3].u = make_uint4(q1.w, q2.x, q2.y, 0u);            // H I J 0
+}
+
+// host: weight pieces in A-operand order.  dst[row][kq][16 dwords]; K-slot t = 0..29 of quarter kq pairs weight piece
+// wp[t / 5] of W[row][kq + 4 (t % 5)] with the rho pieces [h m h m l h] written by write_b16_record (nbr.hip).
+void build_wd16(const float *Wd, unsigned *dst) {
+    auto split3 = [](float x, unsigned (&p)[3]) {
+        unsigned xb;
+        memcpy(&xb, &x, 4);
+        xb &= 0xFFFF0000u;
+        float hf;
+        memcpy(&hf, &xb, 4);
+        float r1 = x - hf;
+        unsigned mb;
+        memcpy(&mb, &r1, 4);
+        mb &= 0xFFFF0000u;
+        float mf;
+        memcpy(&mf, &mb, 4);
+        float r2 = r1 - mf;
+        unsigned lb;
+        memcpy(&lb, &r2, 4);
+        p[0] = xb >> 16; p[1] = mb >> 16; p[2] = lb >> 16;
+    };
+    static const int wpiece[6] = {0, 0, 1, 1, 0, 2};   // Wh Wh Wm Wm Wh Wl
+    for (int row = 0; row < F3; ++row)
+        for (int kq = 0; kq < 4; ++kq) {
+            unsigned half[32];
+            for (int t = 0; t < 32; ++t) {
+                half[t] = 0;
+                if (t < 30) {
+                    unsigned p3[3];
+                    split3(Wd[(size_t)row * 20 + kq + 4 * (t % 5)], p3);
+                    half[t] = p3[wpiece[t / 5]];
+                }
+            }
+            unsigned *o = dst + ((size_t)row * 4 + kq) * 16;
+            for (int q = 0; q < 16; ++q) o[q] = half[2 * q] | (half[2 * q + 1] << 16);
+        }
+}
 
 constexpr int FS = 16;           // features per slice
 constexpr int NSLICE = F / FS;   // 8
-constexpr int EDGE_THREADS = 1024;  // 16 waves: 4 per SIMD at one workgroup per CU
+constexpr int EDGE_THREADS = 768;   // 12 waves = 48 CSR streams per workgroup, 3 waves per SIMD (<= 168 VGPRs per lane)
 
 // LDS slice layout: tile[atom][feature f][NSEG] with NSEG = {a, b, c, v_x, v_y, v_z} (layer 0: {b, c}): the values
 // a lane needs for its 4 features of one neighbor are 96 contiguous bytes = 6 ds_read_b128 (layer 0: 2).
@@ -120,13 +174,16 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int nstreams = (EDGE_THREADS / 64) * 4;
     // ---- A operand: Wd_ext[section row = feature (lane & 15)][k = 4 ks + (lane >> 4)] ---------------------------
     const LayerW &W = MW[m].layer[l];
-    // 20 radial functions = 5 k-steps; the bias column (bd * envelope) is folded into the accumulator init
-    float wA[LY::NSEC][5], bias[LY::NSEC][4];
+    // A operand: bf16-split filter weights of feature row p, quarter fq (4 x 16 B per section); bias column folded into
+    // the accumulator init (bd * envelope)
+    Op16 wA[LY::NSEC][4];
+    float bias[LY::NSEC][4];
 #pragma unroll
     for (int s = 0; s < LY::NSEC; ++s) {
         const int row = (L0 ? s + 1 : s) * F + fs * FS + p;
+        const uint4 *wsrc = W.wd16 + ((size_t)row * 4 + fq) * 4;
 #pragma unroll
-        for (int ks = 0; ks < 5; ++ks) wA[s][ks] = W.Wd[(size_t)row * 20 + 4 * ks + fq];
+        for (int i4 = 0; i4 < 4; ++i4) wA[s][i4].u = wsrc[i4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[s][r] = W.bd[(L0 ? s + 1 : s) * F + fs * FS + 4 * fq + r];
     }
@@ -153,16 +210,20 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int fcol = fs * FS + 4 * fq;            // first of this lane's 4 global feature columns
 
     // table entry of this lane's slot; exhausted streams read the reserved all-zero entry (filter = 0)
-    const float *rho_lane = G.rho + fq * 6;
+    const uint4 *rho_lane = G.rho16 + fq * 3;
+    const float *fc_tab = G.rho + 5;              // envelope of a slot: fp32 table entry [slot][0][5]
     const float4 *erec = G.erec;
     const int last_slot = max(rs[Nc] - 1, 0);     // records are always read from inside the chain (finite values)
 
-    float2 rh[2][3];
+    uint4 rq[2][3];
+    float fcv[2];
     float4 er[2];
     {
         const int sl = pos + e;
-        const float2 *rp = reinterpret_cast<const float2 *>(rho_lane + (size_t)(pos < stream_end ? sl : zero_slot) * 24);
-        rh[0][0] = rp[0]; rh[0][1] = rp[1]; rh[0][2] = rp[2];
+        const size_t tsl = pos < stream_end ? sl : zero_slot;
+        const uint4 *rp = rho_lane + tsl * 12;
+        rq[0][0] = rp[0]; rq[0][1] = rp[1]; rq[0][2] = rp[2];
+        fcv[0] = fc_tab[tsl * 24];
         er[0] = erec[min(sl, last_slot)];
     }
 
@@ -205,9 +266,10 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             // prefetch the next step's table entries (in flight during this step's math)
             {
                 const int sl = pos + 4 + e;
-                const float2 *rp =
-                    reinterpret_cast<const float2 *>(rho_lane + (size_t)(pos + 4 < stream_end ? sl : zero_slot) * 24);
-                rh[ph ^ 1][0] = rp[0]; rh[ph ^ 1][1] = rp[1]; rh[ph ^ 1][2] = rp[2];
+                const size_t tsl = pos + 4 < stream_end ? sl : zero_slot;
+                const uint4 *rp = rho_lane + tsl * 12;
+                rq[ph ^ 1][0] = rp[0]; rq[ph ^ 1][1] = rp[1]; rq[ph ^ 1][2] = rp[2];
+                fcv[ph ^ 1] = fc_tab[tsl * 24];
                 er[ph ^ 1] = erec[min(sl, last_slot)];
             }
             // gather this slot's neighbor row: 4 features x NSEG values, contiguous in LDS
@@ -222,17 +284,18 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- filter GEMM  D[feature][slot] = Wd_ext[feature][k] rho[k][slot] ------------------------------------
-            const float rho[5] = {rh[ph][0].x, rh[ph][0].y, rh[ph][1].x, rh[ph][1].y, rh[ph][2].x};
-            const float fc = rh[ph][2].y;   // envelope of this lane's slot
+            Op16 rb[4];
+            rho_operands(rq[ph][0], rq[ph][1], rq[ph][2], rb);
+            const float fc = fcv[ph];   // envelope of this lane's slot
             f32x4 acc[LY::NSEC];
 #pragma unroll
             for (int s2 = 0; s2 < LY::NSEC; ++s2)
                 acc[s2] = (f32x4){bias[s2][0] * fc, bias[s2][1] * fc, bias[s2][2] * fc, bias[s2][3] * fc};
 #pragma unroll
-            for (int ks = 0; ks < 5; ++ks)
+            for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
                 for (int s2 = 0; s2 < LY::NSEC; ++s2)
-                    acc[s2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[s2][ks], rho[ks], acc[s2], 0, 0, 0);
+                    acc[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[s2][i4].v, rb[i4].v, acc[s2], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             // ---- messages of this lane's slot for its 4 features (filter = 0 exactly for pads / foreign slots) -----------
             const float ux = er[ph].x, uy = er[ph].y, uz = er[ph].z;

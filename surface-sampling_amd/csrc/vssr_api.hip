@@ -156,6 +156,24 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
         W.W5 = db + w5; W.W5t = db + w5t; W.b5 = db + b5; W.w6 = db + w6; W.b6 = db + b6;
     }
     VSSR_HIP(h, hipMemcpy(dbase, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    {   // radial-filter weights split into bf16 pieces in MFMA operand order (painn_edge_mfma.hip), per model / layer
+        const size_t per_layer16 = (size_t)F3 * 4 * 16;   // dwords
+        std::vector<unsigned> w16(per_layer16 * L * M);
+        for (int m = 0; m < M; ++m) {
+            const float *hb = img.data() + (size_t)m * img_len;
+            size_t o = (size_t)NE * F;
+            for (int l = 0; l < L; ++l) {
+                const float *Wd = hb + o + (size_t)F * F + F + (size_t)F3 * F + F3;
+                build_wd16(Wd, w16.data() + ((size_t)m * L + l) * per_layer16);
+                o += per_layer;
+            }
+        }
+        if (h->wd16.ensure(w16.size() * sizeof(unsigned))) return set_err(h, VSSR_E_NOMEM, "split filter weights");
+        VSSR_HIP(h, hipMemcpy(h->wd16.p, w16.data(), w16.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        for (int m = 0; m < M; ++m)
+            for (int l = 0; l < L; ++l)
+                table[m].layer[l].wd16 = h->wd16.as<uint4>() + ((size_t)m * L + l) * per_layer16 / 4;
+    }
     {   // layer-0 species factorisation tables (painn_l0.hip), from layer 0 of every model
         const size_t per_model = (size_t)NE * 2 * 24 * F;
         std::vector<float> A(per_model * M), At(per_model * M);
@@ -324,7 +342,7 @@ void vssr_destroy(vssr_handle *h) {
     h->prof.destroy();
     DevBuf *bufs[] = {&h->weights, &h->model_table, &h->offset_per_z, &h->ters_params, &h->d_pos, &h->d_wpos,
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
-                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv,
+                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->wd16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
                       &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f};
     for (DevBuf *b : bufs) b->release();

@@ -37,6 +37,7 @@ struct LayerW {
     const float *pW1t, *pW2t;    // reverse:  W1^T (4 tiles, K=F), W2^T (4 tiles, K=3F)
     const float *pW4t, *pW3t;    //           W4^T (4 tiles, K=3F), W3^T (8 tiles, K=F)
     const float *pUVt;           //           [U;V]^T (4 tiles, K=2F)
+    const uint4 *wd16;           // radial-filter weights, 3-way bf16 split in MFMA A-operand order: [3F rows][4 quarters][4]
 };
 struct ModelW {
     const float *embed;  // [n_embed][F]
@@ -57,6 +58,8 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const float4 *erec;      // [slots] {u_x, u_y, u_z, bitcast(j local to its chain)} ; pads: u = 0, j = 0
     const float *rho;        // [slots][4][6]  radial basis * envelope in MFMA A-fragment order: [kq][ks] = rho_{kq+4ks}
     const float *drho;       // [slots][4][6]  d rho / d d, same order
+    const uint4 *rho16;      // [slots][4][3] operand-ready 3-way bf16 split of rho (48 B per (slot, quarter)), see nbr.hip
+    const uint4 *drho16;     // same for d rho / d d
     const float2 *dist2;     // [slots] {edge length d (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
 };
 
@@ -160,6 +163,7 @@ struct vssr_handle {
 
     // weights
     vssr::DevBuf weights;        // all model blobs + transposed copies
+    vssr::DevBuf wd16;           // bf16-split radial-filter weights in MFMA operand order
     vssr::DevBuf model_table;    // ModelW[n_models]
     vssr::DevBuf offset_per_z;   // double[n_embed]
 
@@ -174,7 +178,7 @@ struct vssr_handle {
     std::vector<int> h_n_atoms, h_cfg_start;
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
     vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
-    vssr::DevBuf d_erec, d_rho, d_drho, d_dist;
+    vssr::DevBuf d_erec, d_rho, d_drho, d_dist, d_rho16, d_drho16;
     // layer-0 species factorisation (painn_l0.hip)
     int l0_enabled = 1, l0_nz = 0;
     bool l0_used = false;                // last run used the factorised layer 0
@@ -227,6 +231,7 @@ void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zer
                             const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
                             float *sbar_msg, float *vbar_msg);
 // layer-0 species factorisation (painn_l0.hip)
+void build_wd16(const float *Wd, unsigned *dst /*[3F][4][16]*/);
 void l0_build_tables(const float *blob_embed, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *Wd, const float *bd, int n_embed, float *A, float *At);
 int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_msg);
