@@ -207,18 +207,21 @@ __device__ __forceinline__ void split3_bf16(float x, unsigned &h, unsigned &m, u
     const float r2 = r1 - __uint_as_float(mb);
     h = xb >> 16; m = mb >> 16; l = __float_as_uint(r2) >> 16;
 }
-// Operand-ready record of one (slot, quarter) for v_mfma_f32_16x16x32_bf16: the quarter's 5 radial values
-// (k = kq + 4 kk) in the 30 K-slots [h x5 | m x5 | h x5 | m x5 | l x5 | h x5] that pair with the weight pieces
-// [Wh | Wh | Wm | Wm | Wh | Wl] (6 partial products, everything >= 2^-16 relative: fp32-level accuracy).  The 16 operand
-// dwords contain only 10 distinct ones: stored as A B C D | E F G H | I J 0 0 (48 bytes), see painn_edge_mfma.hip.
-__device__ __forceinline__ void write_b16_record(const float (&v)[5], uint4 *__restrict__ rec) {
-    unsigned h[5], m[5], l[5];
+// Operand-ready record of one (slot, quarter) for v_mfma_f32_16x16x32_bf16.  The quarter contributes 8 of the 32 K
+// entries of the filter contraction: its 5 radial values (k = kq + 4 kk), the envelope fc (partner of the bias column,
+// which the weight side carries in quarter 0 only) and two zeros.  Each bf16 piece of those 8 entries is one complete
+// MFMA operand (8 x bf16 = 16 B), stored as H | M | L (48 bytes): the edge kernels issue the six partial products
+// Wh.H + Wh.M + Wm.H + Wm.M + Wh.L + Wl.H (everything >= 2^-16 relative: fp32-level accuracy) straight from the loaded
+// registers -- no operand assembly, no separate bias multiply.
+__device__ __forceinline__ void write_b16_record(const float (&v)[5], float env, uint4 *__restrict__ rec) {
+    unsigned h[6], m[6], l[6];
 #pragma unroll
     for (int k = 0; k < 5; ++k) split3_bf16(v[k], h[k], m[k], l[k]);
+    split3_bf16(env, h[5], m[5], l[5]);
     auto pk = [](unsigned lo, unsigned hi) { return lo | (hi << 16); };
-    rec[0] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], m[0]), pk(m[1], m[2]));   // A B C D
-    rec[1] = make_uint4(pk(m[3], m[4]), pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], h[0]));   // E F G H
-    rec[2] = make_uint4(pk(h[1], h[2]), pk(h[3], h[4]), 0u, 0u);                           // I J 0 0
+    rec[0] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), 0u);
+    rec[1] = make_uint4(pk(m[0], m[1]), pk(m[2], m[3]), pk(m[4], m[5]), 0u);
+    rec[2] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), 0u);
 }
 
 __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
@@ -261,8 +264,8 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
         }
         {
             const float rv[5] = {r[0], r[1], r[2], r[3], r[4]}, dv[5] = {dr[0], dr[1], dr[2], dr[3], dr[4]};
-            write_b16_record(rv, rho16 + ((size_t)slot * 4 + kq) * 3);
-            write_b16_record(dv, drho16 + ((size_t)slot * 4 + kq) * 3);
+            write_b16_record(rv, fc, rho16 + ((size_t)slot * 4 + kq) * 3);
+            write_b16_record(dv, dfc, drho16 + ((size_t)slot * 4 + kq) * 3);
         }
         r[5] = fc;      // envelope (bias column) replicated in every quarter: the edge kernels fold bd * fc into the
         dr[5] = dfc;    // accumulator init instead of spending a sixth MFMA k-step on it

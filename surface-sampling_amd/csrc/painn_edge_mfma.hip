@@ -28,21 +28,28 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // fp32 MFMA shares the FP32 datapath with the VALU (measured: MFMA cycles and instruction-issue cycles add up), the
 // bf16 MFMA does not.  Both operands are split exactly into three bf16 pieces x = h + m + l (truncation; residuals are
 // exact in fp32) and the six products with weight >= 2^-16 are kept:  Wh rh + Wh rm + Wm rh + Wm rm + Wh rl + Wl rh ;
-// the dropped ones are <= 2^-24 relative, i.e. fp32 rounding level.  Per lane quarter kq the 5 radial indices
-// k = kq + 4 kk occupy 30 of the 32 K-slots of four v_mfma_f32_16x16x32_bf16 (slot order in nbr.hip / build_wd16):
-// 4 matrix-pipe instructions replace 5 fp32 MFMAs.  Pieces of rho are pre-split once per evaluation (k_edge_geom),
-// pieces of the weights once per handle (build_wd16): no split arithmetic in the hot loop.
+// the dropped ones are <= 2^-24 relative, i.e. fp32 rounding level.  The K = 32 entries of one
+// v_mfma_f32_16x16x32_bf16 are, per lane quarter kq: the 5 radial indices k = kq + 4 kk, the bias column (weights: bd in
+// quarter 0, zero elsewhere; rho side: the envelope fc) and two zeros.  Every piece is a complete 16-byte operand, so a
+// tile costs six matrix-pipe instructions fed directly from loaded registers.  Pieces of rho are pre-split once per
+// evaluation (k_edge_geom, nbr.hip), pieces of the weights once per handle (build_wd16): nothing is split, shuffled or
+// bias-multiplied in the hot loop.
 union Op16 { uint4 u; bf16x8 v; };
-__device__ __forceinline__ void rho_operands(const uint4 q0, const uint4 q1, const uint4 q2, Op16 (&b)[4]) {
-    b[0].u = q0;                                          // A B C D
-    b[1].u = make_uint4(q1.x, q0.x, q0.y, q0.z);          // E A B C
-    b[2].u = make_uint4(q0.w, q1.x, q1.y, q1.z);          // D E F G
-    b[3].u = make_uint4(q1.w, q2.x, q2.y, 0u);            // H I J 0
+
+// D += W . rho for one 16 x 16 tile: six partial products, smallest first
+__device__ __forceinline__ f32x4 filter_tile(const Op16 (&w)[3], const Op16 (&r)[3], f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0].v, r[2].v, acc, 0, 0, 0);   // Wh rl
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2].v, r[0].v, acc, 0, 0, 0);   // Wl rh
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1].v, r[1].v, acc, 0, 0, 0);   // Wm rm
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0].v, r[1].v, acc, 0, 0, 0);   // Wh rm
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1].v, r[0].v, acc, 0, 0, 0);   // Wm rh
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0].v, r[0].v, acc, 0, 0, 0);   // Wh rh
+    return acc;
 }
 
-// host: weight pieces in A-operand order.  dst[row][kq][16 dwords]; K-slot t = 0..29 of quarter kq pairs weight piece
-// wp[t / 5] of W[row][kq + 4 (t % 5)] with the rho pieces [h m h m l h] written by write_b16_record (nbr.hip).
-void build_wd16(const float *Wd, unsigned *dst) {
+// host: weight pieces in A-operand order.  dst[row][kq][piece h, m, l][4 dwords]: entries 0..4 = W[row][kq + 4 kk],
+// entry 5 = bd[row] in quarter 0 (pairs with the envelope entry written by write_b16_record, nbr.hip), rest zero.
+void build_wd16(const float *Wd, const float *bd, unsigned *dst) {
     auto split3 = [](float x, unsigned (&p)[3]) {
         unsigned xb;
         memcpy(&xb, &x, 4);
@@ -60,20 +67,18 @@ void build_wd16(const float *Wd, unsigned *dst) {
         memcpy(&lb, &r2, 4);
         p[0] = xb >> 16; p[1] = mb >> 16; p[2] = lb >> 16;
     };
-    static const int wpiece[6] = {0, 0, 1, 1, 0, 2};   // Wh Wh Wm Wm Wh Wl
     for (int row = 0; row < F3; ++row)
         for (int kq = 0; kq < 4; ++kq) {
-            unsigned half[32];
-            for (int t = 0; t < 32; ++t) {
-                half[t] = 0;
-                if (t < 30) {
-                    unsigned p3[3];
-                    split3(Wd[(size_t)row * 20 + kq + 4 * (t % 5)], p3);
-                    half[t] = p3[wpiece[t / 5]];
-                }
+            unsigned half[3][8] = {};
+            for (int t = 0; t < 6; ++t) {
+                if (t == 5 && kq != 0) continue;
+                unsigned p3[3];
+                split3(t < 5 ? Wd[(size_t)row * 20 + kq + 4 * t] : bd[row], p3);
+                for (int pc = 0; pc < 3; ++pc) half[pc][t] = p3[pc];
             }
-            unsigned *o = dst + ((size_t)row * 4 + kq) * 16;
-            for (int q = 0; q < 16; ++q) o[q] = half[2 * q] | (half[2 * q + 1] << 16);
+            unsigned *o = dst + ((size_t)row * 4 + kq) * 12;
+            for (int pc = 0; pc < 3; ++pc)
+                for (int q = 0; q < 4; ++q) o[pc * 4 + q] = half[pc][2 * q] | (half[pc][2 * q + 1] << 16);
         }
 }
 
@@ -100,6 +105,12 @@ __device__ __forceinline__ float quad_sum(float x) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
     return x;
+}
+// (a hand-written v_add_f32_dpp variant was tried and dropped: the compiler's wait-count / hazard bookkeeping does not
+// look inside inline asm, and the kernel produced run-to-run differences while table loads were in flight)
+__device__ __forceinline__ void quad_sum4(float (&x)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = quad_sum(x[r]);
 }
 
 // Lane roles ("slot-major"): p = lane & 15 is the slot position inside the step's 16-slot tile, stream = p >> 2
@@ -174,18 +185,15 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int nstreams = (EDGE_THREADS / 64) * 4;
     // ---- A operand: Wd_ext[section row = feature (lane & 15)][k = 4 ks + (lane >> 4)] ---------------------------
     const LayerW &W = MW[m].layer[l];
-    // A operand: bf16-split filter weights of feature row p, quarter fq (4 x 16 B per section); bias column folded into
-    // the accumulator init (bd * envelope)
-    Op16 wA[LY::NSEC][4];
-    float bias[LY::NSEC][4];
+    // A operand: bf16 pieces (h, m, l) of the filter weights of feature row p, quarter fq: 3 x 16 B per section, bias
+    // column included (build_wd16)
+    Op16 wA[LY::NSEC][3];
 #pragma unroll
     for (int s = 0; s < LY::NSEC; ++s) {
         const int row = (L0 ? s + 1 : s) * F + fs * FS + p;
-        const uint4 *wsrc = W.wd16 + ((size_t)row * 4 + fq) * 4;
+        const uint4 *wsrc = W.wd16 + ((size_t)row * 4 + fq) * 3;
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) wA[s][i4].u = wsrc[i4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[s][r] = W.bd[(L0 ? s + 1 : s) * F + fs * FS + 4 * fq + r];
+        for (int i3 = 0; i3 < 3; ++i3) wA[s][i3].u = wsrc[i3];
     }
 
     // ---- every stream walks a contiguous run of CSR slots, cut at centre boundaries, ~equal slot counts ---------
@@ -211,19 +219,18 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 
     // table entry of this lane's slot; exhausted streams read the reserved all-zero entry (filter = 0)
     const uint4 *rho_lane = G.rho16 + fq * 3;
-    const float *fc_tab = G.rho + 5;              // envelope of a slot: fp32 table entry [slot][0][5]
     const float4 *erec = G.erec;
     const int last_slot = max(rs[Nc] - 1, 0);     // records are always read from inside the chain (finite values)
 
-    uint4 rq[2][3];
-    float fcv[2];
+    // rho pieces of the current step (single buffer: the next step's loads are issued right after the MFMAs that read
+    // them and complete during the message arithmetic); unit vector / neighbor id double-buffered
+    Op16 rq[3];
     float4 er[2];
     {
         const int sl = pos + e;
         const size_t tsl = pos < stream_end ? sl : zero_slot;
         const uint4 *rp = rho_lane + tsl * 12;
-        rq[0][0] = rp[0]; rq[0][1] = rp[1]; rq[0][2] = rp[2];
-        fcv[0] = fc_tab[tsl * 24];
+        rq[0].u = rp[0]; rq[1].u = rp[1]; rq[2].u = rp[2];
         er[0] = erec[min(sl, last_slot)];
     }
 
@@ -232,10 +239,11 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     auto flush_complete = [&]() {
         while (c < c_last && pos >= cend) {
             float4 so, vxo, vyo, vzo;
-            so.x = quad_sum(ds[0]); so.y = quad_sum(ds[1]); so.z = quad_sum(ds[2]); so.w = quad_sum(ds[3]);
-            vxo.x = quad_sum(dvx[0]); vxo.y = quad_sum(dvx[1]); vxo.z = quad_sum(dvx[2]); vxo.w = quad_sum(dvx[3]);
-            vyo.x = quad_sum(dvy[0]); vyo.y = quad_sum(dvy[1]); vyo.z = quad_sum(dvy[2]); vyo.w = quad_sum(dvy[3]);
-            vzo.x = quad_sum(dvz[0]); vzo.y = quad_sum(dvz[1]); vzo.z = quad_sum(dvz[2]); vzo.w = quad_sum(dvz[3]);
+            quad_sum4(ds); quad_sum4(dvx); quad_sum4(dvy); quad_sum4(dvz);
+            so = make_float4(ds[0], ds[1], ds[2], ds[3]);
+            vxo = make_float4(dvx[0], dvx[1], dvx[2], dvx[3]);
+            vyo = make_float4(dvy[0], dvy[1], dvy[2], dvy[3]);
+            vzo = make_float4(dvz[0], dvz[1], dvz[2], dvz[3]);
             if (e == 0) {
                 const size_t ga = mN + a0 + c;
                 const float4 sr = *reinterpret_cast<const float4 *>(s_tile + c * FS + 4 * fq);
@@ -262,16 +270,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const float *trow = tile + (4 * fq) * LY::NSEG;
     while (__any(pos < stream_end)) {
 #pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: ping-pong the prefetch registers
-            // prefetch the next step's table entries (in flight during this step's math)
-            {
-                const int sl = pos + 4 + e;
-                const size_t tsl = pos + 4 < stream_end ? sl : zero_slot;
-                const uint4 *rp = rho_lane + tsl * 12;
-                rq[ph ^ 1][0] = rp[0]; rq[ph ^ 1][1] = rp[1]; rq[ph ^ 1][2] = rp[2];
-                fcv[ph ^ 1] = fc_tab[tsl * 24];
-                er[ph ^ 1] = erec[min(sl, last_slot)];
-            }
+        for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: ping-pong the unit-vector registers
             // gather this slot's neighbor row: 4 features x NSEG values, contiguous in LDS
             float tv[4 * LY::NSEG];
             {
@@ -282,20 +281,19 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                     tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- filter GEMM  D[feature][slot] = Wd_ext[feature][k] rho[k][slot] ------------------------------------
-            Op16 rb[4];
-            rho_operands(rq[ph][0], rq[ph][1], rq[ph][2], rb);
-            const float fc = fcv[ph];   // envelope of this lane's slot
+            // ---- filter GEMM  D[feature][slot] = Wd_ext[feature][k] rho[k][slot]  (bias . fc included) ---------------
             f32x4 acc[LY::NSEC];
 #pragma unroll
-            for (int s2 = 0; s2 < LY::NSEC; ++s2)
-                acc[s2] = (f32x4){bias[s2][0] * fc, bias[s2][1] * fc, bias[s2][2] * fc, bias[s2][3] * fc};
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4)
-#pragma unroll
-                for (int s2 = 0; s2 < LY::NSEC; ++s2)
-                    acc[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[s2][i4].v, rb[i4].v, acc[s2], 0, 0, 0);
+            for (int s2 = 0; s2 < LY::NSEC; ++s2) acc[s2] = filter_tile(wA[s2], rq, (f32x4){0.f, 0.f, 0.f, 0.f});
+            __builtin_amdgcn_sched_barrier(0);
+            // next step's table entries (in flight during this step's message arithmetic)
+            {
+                const int sl = pos + 4 + e;
+                const size_t tsl = pos + 4 < stream_end ? sl : zero_slot;
+                const uint4 *rp = rho_lane + tsl * 12;
+                rq[0].u = rp[0]; rq[1].u = rp[1]; rq[2].u = rp[2];
+                er[ph ^ 1] = erec[min(sl, last_slot)];
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- messages of this lane's slot for its 4 features (filter = 0 exactly for pads / foreign slots) -----------
             const float ux = er[ph].x, uy = er[ph].y, uz = er[ph].z;
@@ -384,7 +382,7 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
     const int last_slot = max(rs[Nc] - 1, 0);
     const LayerW &W = MW[m].layer[l];
     float4 *gb = gbar + (size_t)(m * n_groups + sg) * gbar_stride;
-    const float *rho_lane = G.rho + fq * 6, *drho_lane = G.drho + fq * 6;
+    const uint4 *rho_lane = G.rho16 + fq * 3, *drho_lane = G.drho16 + fq * 3;
 
     for (int si = 0; si < SLICES_PER_WG; ++si) {
         const int fs = sg * SLICES_PER_WG + si;
@@ -416,14 +414,13 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
             }
         }
         // ---- A operand: Wd_ext rows of this slice ------------------------------------------------------------------
-        float wA[NSEC][5], bias[NSEC][4];   // bias column folded into the accumulator init (5 k-steps instead of 6)
+        Op16 wA[NSEC][3];   // bf16 pieces (h, m, l) of the slice's filter rows, bias column included (build_wd16)
 #pragma unroll
         for (int s2 = 0; s2 < NSEC; ++s2) {
             const int row = (L0 ? s2 + 1 : s2) * F + fs * FS + p;
+            const uint4 *wsrc = W.wd16 + ((size_t)row * 4 + fq) * 3;
 #pragma unroll
-            for (int ks = 0; ks < 5; ++ks) wA[s2][ks] = W.Wd[(size_t)row * 20 + 4 * ks + fq];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bias[s2][r] = W.bd[(L0 ? s2 + 1 : s2) * F + fs * FS + 4 * fq + r];
+            for (int i3 = 0; i3 < 3; ++i3) wA[s2][i3].u = wsrc[i3];
         }
         __syncthreads();
 
@@ -453,12 +450,8 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
             while (c < c_last && pos >= cend) {
                 if (!L0) {
                     float4 pa, pb, pc2, ox, oy, oz;
-                    float tb[4], tc[4], tx[4], ty[4], tz[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        tb[r] = quad_sum(accb[r]); tc[r] = quad_sum(accc[r]);
-                        tx[r] = quad_sum(accx[r]); ty[r] = quad_sum(accy[r]); tz[r] = quad_sum(accz[r]);
-                    }
+                    quad_sum4(accb); quad_sum4(accc); quad_sum4(accx); quad_sum4(accy); quad_sum4(accz);
+                    const float (&tb)[4] = accb, (&tc)[4] = accc, (&tx)[4] = accx, (&ty)[4] = accy, (&tz)[4] = accz;
                     if (e == 0) {
                         const size_t ga = mN + a0 + c;
                         const float vx_[4] = {vcx.x, vcx.y, vcx.z, vcx.w}, vy_[4] = {vcy.x, vcy.y, vcy.z, vcy.w};
@@ -497,28 +490,31 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
         };
         flush_complete();
 
-        // table entries of this lane's slot; exhausted streams read the all-zero entry
-        float2 rh[2][3], dh[2][3];
+        // table entries of this lane's slot; exhausted streams read the all-zero entry.  rho / drho pieces are single
+        // buffered (the next step's loads are issued right after the MFMAs that consume them), the small records
+        // (unit vector + neighbor id, distance) are double buffered.
+        Op16 rq[3], dq[3];
         float4 er[2];
         float2 dd[2];
-        auto fetch = [&](int quad, int buf) {
-            const int sl = quad + e;
-            const size_t off = (size_t)(quad < stream_end ? sl : zero_slot) * 24;
-            const float2 *rp = reinterpret_cast<const float2 *>(rho_lane + off);
-            const float2 *dp = reinterpret_cast<const float2 *>(drho_lane + off);
-            rh[buf][0] = rp[0]; rh[buf][1] = rp[1]; rh[buf][2] = rp[2];
-            dh[buf][0] = dp[0]; dh[buf][1] = dp[1]; dh[buf][2] = dp[2];
-            er[buf] = G.erec[min(sl, last_slot)];
-            dd[buf] = G.dist2[min(sl, last_slot)];
+        auto fetch_tables = [&](int quad) {
+            const size_t off = (size_t)(quad < stream_end ? quad + e : zero_slot) * 12;
+            const uint4 *rp = rho_lane + off, *dp = drho_lane + off;
+            rq[0].u = rp[0]; rq[1].u = rp[1]; rq[2].u = rp[2];
+            dq[0].u = dp[0]; dq[1].u = dp[1]; dq[2].u = dp[2];
         };
-        fetch(pos, 0);
+        auto fetch_rec = [&](int quad, int buf) {
+            const int sl = min(quad + e, last_slot);
+            er[buf] = G.erec[sl];
+            dd[buf] = G.dist2[sl];
+        };
+        fetch_tables(pos);
+        fetch_rec(pos, 0);
         const float *trow = tile + (4 * fq) * 4;
         const bool first_write = layer_first && si == 0;
 
         while (__any(pos < stream_end)) {
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
-                fetch(pos + 4, ph ^ 1);
                 float tb[16];
                 {
                     const float4 *row = reinterpret_cast<const float4 *>(trow + __float_as_int(er[ph].w) * ROWB);
@@ -528,23 +524,16 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                         tb[4 * q] = t4.x; tb[4 * q + 1] = t4.y; tb[4 * q + 2] = t4.z; tb[4 * q + 3] = t4.w;
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                const float rho[5] = {rh[ph][0].x, rh[ph][0].y, rh[ph][1].x, rh[ph][1].y, rh[ph][2].x};
-                const float drho[5] = {dh[ph][0].x, dh[ph][0].y, dh[ph][1].x, dh[ph][1].y, dh[ph][2].x};
-                const float fc = rh[ph][2].y, dfc = dh[ph][2].y;
+                // filter and its radial derivative for this lane's slot and 4 features (bias . fc / bias . fc' included)
                 f32x4 aw[NSEC], ad[NSEC];
 #pragma unroll
                 for (int s2 = 0; s2 < NSEC; ++s2) {
-                    aw[s2] = (f32x4){bias[s2][0] * fc, bias[s2][1] * fc, bias[s2][2] * fc, bias[s2][3] * fc};
-                    ad[s2] = (f32x4){bias[s2][0] * dfc, bias[s2][1] * dfc, bias[s2][2] * dfc, bias[s2][3] * dfc};
+                    aw[s2] = filter_tile(wA[s2], rq, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    ad[s2] = filter_tile(wA[s2], dq, (f32x4){0.f, 0.f, 0.f, 0.f});
                 }
-#pragma unroll
-                for (int ks = 0; ks < 5; ++ks)
-#pragma unroll
-                    for (int s2 = 0; s2 < NSEC; ++s2) {
-                        aw[s2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[s2][ks], rho[ks], aw[s2], 0, 0, 0);
-                        ad[s2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[s2][ks], drho[ks], ad[s2], 0, 0, 0);
-                    }
+                __builtin_amdgcn_sched_barrier(0);
+                fetch_tables(pos + 4);
+                fetch_rec(pos + 4, ph ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const float ux = er[ph].x, uy = er[ph].y, uz = er[ph].z;   // unit vector c -> n ; edge (n -> c) has -u
                 const float pcb_[4] = {pcb.x, pcb.y, pcb.z, pcb.w}, pcc_[4] = {pcc.x, pcc.y, pcc.z, pcc.w};

@@ -157,14 +157,14 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
     }
     VSSR_HIP(h, hipMemcpy(dbase, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
     {   // radial-filter weights split into bf16 pieces in MFMA operand order (painn_edge_mfma.hip), per model / layer
-        const size_t per_layer16 = (size_t)F3 * 4 * 16;   // dwords
+        const size_t per_layer16 = (size_t)F3 * 4 * 12;   // dwords
         std::vector<unsigned> w16(per_layer16 * L * M);
         for (int m = 0; m < M; ++m) {
             const float *hb = img.data() + (size_t)m * img_len;
             size_t o = (size_t)NE * F;
             for (int l = 0; l < L; ++l) {
                 const float *Wd = hb + o + (size_t)F * F + F + (size_t)F3 * F + F3;
-                build_wd16(Wd, w16.data() + ((size_t)m * L + l) * per_layer16);
+                build_wd16(Wd, Wd + (size_t)F3 * 20, w16.data() + ((size_t)m * L + l) * per_layer16);
                 o += per_layer;
             }
         }

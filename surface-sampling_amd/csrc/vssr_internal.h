@@ -37,7 +37,7 @@ struct LayerW {
     const float *pW1t, *pW2t;    // reverse:  W1^T (4 tiles, K=F), W2^T (4 tiles, K=3F)
     const float *pW4t, *pW3t;    //           W4^T (4 tiles, K=3F), W3^T (8 tiles, K=F)
     const float *pUVt;           //           [U;V]^T (4 tiles, K=2F)
-    const uint4 *wd16;           // radial-filter weights, 3-way bf16 split in MFMA A-operand order: [3F rows][4 quarters][4]
+    const uint4 *wd16;           // radial-filter weights, 3-way bf16 split in MFMA A-operand order: [3F rows][4 quarters][h, m, l]
 };
 struct ModelW {
     const float *embed;  // [n_embed][F]
@@ -231,7 +231,7 @@ void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zer
                             const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
                             float *sbar_msg, float *vbar_msg);
 // layer-0 species factorisation (painn_l0.hip)
-void build_wd16(const float *Wd, unsigned *dst /*[3F][4][16]*/);
+void build_wd16(const float *Wd, const float *bd, unsigned *dst /*[3F][4][3][4]*/);
 void l0_build_tables(const float *blob_embed, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *Wd, const float *bd, int n_embed, float *A, float *At);
 int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_msg);
