@@ -271,7 +271,7 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
         dr[5] = dfc;    // accumulator init instead of spending a sixth MFMA k-step on it
         if (kq == 0) {
             erec[slot] = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, __int_as_float(valid ? j - a0 : 0));
-            dist2[slot] = valid ? make_float2(d, -(float)excl_power * powf(excl_sigma * inv, (float)excl_power) * inv)
+            dist2[slot] = valid ? make_float2(inv, -(float)excl_power * powf(excl_sigma * inv, (float)excl_power) * inv)
                                 : make_float2(-1.f, 0.f);
         }
     }

@@ -483,7 +483,9 @@ int painn_run(vssr_handle *h, uint32_t want) {
     Profiler &P = h->prof;
     const bool use_edge_mfma = h->edge_impl && edge_fwd_mfma_fits(h->max_cfg_atoms);   // chains fit the LDS slices
     const bool l0_fact = h->l0_enabled && h->l0_nz > 0;   // layer 0 by species factorisation (any chain size)
-    const int n_groups = (use_edge_mfma && !(L == 1 && l0_fact)) ? edge_bwd_groups() : 1;   // partial gbar buffers
+    // The MFMA edge kernels serve layers >= 1.  Layer 0 is factorised by species (painn_l0.hip) or, with more than 8
+    // species / VSSR_L0_FACTORISE=0, runs the gather kernels (its v input is zero and only two filter sections matter).
+    const int n_groups = (use_edge_mfma && L > 1) ? edge_bwd_groups() : 1;   // partial gbar buffers per model
     h->l0_used = l0_fact;
 
     if (!l0_fact) {   // s0 = Emb[Z], v0 = 0 (the factorised layer 0 reads the embedding directly)
@@ -507,10 +509,9 @@ int painn_run(vssr_handle *h, uint32_t want) {
         launch_msg_mlp_mfma(st, N, M, l, MW, sv.s_in[l], sv.phi[l]);
         P.end(st);
         P.begin(KC_EDGE_FWD, st);
-        if (use_edge_mfma)
-            launch_edge_fwd_mfma(st, N, h->n_cfg, M, l, h->max_cfg_atoms, MW, G, counters, (int)(h->slot_cap - 1), h->excl_vol,
-                                 h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
-                                 sv.v_msg[l], sv.e_excl);
+        if (use_edge_mfma && l > 0)
+            launch_edge_fwd_mfma(st, N, h->n_cfg, M, l, h->max_cfg_atoms, MW, G, counters, (int)(h->slot_cap - 1),
+                                 sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l], sv.v_msg[l]);
         else if (l == 0)
             hipLaunchKernelGGL(k_edge_fwd<true>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
                                h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
@@ -541,14 +542,15 @@ int painn_run(vssr_handle *h, uint32_t want) {
                 rc = l0_run_reverse(h, G, (int)(L == 1), sv.sbar_msg, sv.vbar_msg, sv.gbar, (long long)h->slot_cap,
                                     n_groups);
                 if (rc) return rc;
-            } else if (use_edge_mfma)
+            } else if (use_edge_mfma && l > 0)
                 launch_edge_bwd_mfma(st, N, h->n_cfg, M, l, (int)(l == L - 1), h->max_cfg_atoms, MW, G, counters,
-                                     (int)(h->slot_cap - 1), h->excl_vol, sv.v_in[l], sv.phi[l], sv.sbar_msg,
+                                     (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l], sv.sbar_msg,
                                      sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap, n_groups);
-            else if (l == 0)
+            else if (l == 0)   // adds into partial buffer 0 of every model (model stride = n_groups buffers)
                 hipLaunchKernelGGL(k_edge_bwd<true>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                    h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
-                                   sv.sbar_msg, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap);
+                                   sv.sbar_msg, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
+                                   (long long)h->slot_cap * n_groups);
             else
                 hipLaunchKernelGGL(k_edge_bwd<false>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                    h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],

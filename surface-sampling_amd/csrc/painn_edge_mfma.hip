@@ -34,17 +34,54 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // tile costs six matrix-pipe instructions fed directly from loaded registers.  Pieces of rho are pre-split once per
 // evaluation (k_edge_geom, nbr.hip), pieces of the weights once per handle (build_wd16): nothing is split, shuffled or
 // bias-multiplied in the hot loop.
-union Op16 { uint4 u; bf16x8 v; };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one MFMA operand: 8 x bf16
+
+// Ordering rule for these kernels (found the hard way, tools/gpu_stress.py): between the first MFMA of a step and the
+// first VALU consumer of the final accumulators NO load -- global or LDS -- may be issued.  Dependent MFMAs wait queued
+// for their accumulator and read their A / B / C registers late; the compiler reuses dead operand / accumulator registers
+// as load destinations guarded only by a fixed s_nop count, and a fast return (LDS ~50 cycles, TCP hit) lands first:
+// isolated wrong filter values, run-to-run differences.  mfma_load_fence() makes the order a data dependency: the slot
+// index every following address is computed from passes through the same (empty) asm as results of every accumulator
+// chain, so those loads cannot be issued before the consumers, which cannot issue before the MFMAs have retired.
+// tools/check_mfma_loads.py verifies the emitted ISA.
+// Loads written before the MFMAs must also be ISSUED before them: a memory-clobbering asm that the MFMA operands pass
+// through -- loads cannot sink below it, MFMAs cannot rise above it.
+__device__ __forceinline__ void mfma_pre_fence(u32x4 &a, u32x4 &b, u32x4 &c) {
+    asm volatile("; mfma_pre_fence" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
+}
+__device__ __forceinline__ void mfma_load_fence(int &index, float &a, float &b, float &c) {
+    asm volatile("; mfma_load_fence" : "+v"(index), "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void mfma_load_fence(int &index, float &a, float &b, float &c, float &d) {
+    asm volatile("; mfma_load_fence" : "+v"(index), "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 
 // D += W . rho for one 16 x 16 tile: six partial products, smallest first
-__device__ __forceinline__ f32x4 filter_tile(const Op16 (&w)[3], const Op16 (&r)[3], f32x4 acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0].v, r[2].v, acc, 0, 0, 0);   // Wh rl
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2].v, r[0].v, acc, 0, 0, 0);   // Wl rh
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1].v, r[1].v, acc, 0, 0, 0);   // Wm rm
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0].v, r[1].v, acc, 0, 0, 0);   // Wh rm
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1].v, r[0].v, acc, 0, 0, 0);   // Wm rh
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0].v, r[0].v, acc, 0, 0, 0);   // Wh rh
-    return acc;
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+// Filter tiles of one step.  The six partial products of a tile form a dependent accumulator chain, and dependent MFMAs
+// issued back to back stall INSIDE the matrix pipe: everything queued behind them reads its source registers much later
+// than the compiler's wait-state model assumes, while the compiler already reuses those registers (observed: VALU and
+// LDS writes into MFMA sources a few wait states after issue -> wrong forces).  So the products are issued in rounds
+// across all NT tiles, smallest product first: an MFMA's predecessor in its chain is NT instructions back and has
+// retired when it reaches the pipe, nothing queues up, and the compiler's model holds.  The scheduling barriers pin
+// the issue order (without them the scheduler re-serialises the chains to save registers, or ends one round and starts
+// the next on the same tile).
+template <int NT>
+__device__ __forceinline__ void filter_tiles(const u32x4 (*const (&w)[NT])[3], const u32x4 (*const (&r)[NT])[3], f32x4 (&acc)[NT]) {
+    constexpr int wi[6] = {0, 2, 1, 0, 1, 0}, ri[6] = {2, 0, 1, 1, 0, 0};   // Wh rl, Wl rh, Wm rm, Wh rm, Wm rh, Wh rh
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = mfma_bf16((*w[t])[wi[k]], (*r[t])[ri[k]], acc[t]);
+            if (NT < 3) asm volatile("s_nop 7");   // two tiles (layer-0 fallback path): keep the chain producer 2 MFMAs + 16 wait states back
+            __builtin_amdgcn_sched_barrier(0);       // fixed tile order inside the round as well
+        }
+    }
 }
 
 // host: weight pieces in A-operand order.  dst[row][kq][piece h, m, l][4 dwords]: entries 0..4 = W[row][kq + 4 kk],
@@ -86,18 +123,18 @@ constexpr int FS = 16;           // features per slice
 constexpr int NSLICE = F / FS;   // 8
 constexpr int EDGE_THREADS = 768;   // 12 waves = 48 CSR streams per workgroup, 3 waves per SIMD (<= 168 VGPRs per lane)
 
-// LDS slice layout: tile[atom][feature f][NSEG] with NSEG = {a, b, c, v_x, v_y, v_z} (layer 0: {b, c}): the values
-// a lane needs for its 4 features of one neighbor are 96 contiguous bytes = 6 ds_read_b128 (layer 0: 2).
-template <bool L0> struct EdgeLayout {
-    static constexpr int NSEC = L0 ? 2 : 3;          // filter sections used (layer 0: b, c; v = 0)
-    static constexpr int NSEG = L0 ? 2 : 6;          // values staged per (atom, feature)
+// LDS slice layout: tile[atom][feature f][NSEG] with NSEG = {a, b, c, v_x, v_y, v_z}: the values a lane needs for its 4
+// features of one neighbor are 96 contiguous bytes = 6 ds_read_b128.  (Layer 0 never comes here: it is either
+// factorised by species, painn_l0.hip, or -- more than 8 species / VSSR_L0_FACTORISE=0 -- runs the gather kernels.)
+struct EdgeLayout {
+    static constexpr int NSEC = 3;                   // filter sections a, b, c
+    static constexpr int NSEG = 6;                   // values staged per (atom, feature): phi a, b, c and v x, y, z
     static constexpr int ROW = NSEG * FS + 4;        // LDS row stride (floats); rows stay 16-B aligned
 };
 
 // LDS carve-up: tile [max_atoms][ROW] | s slice [max_atoms][FS] | row_start [max_atoms + 1] (ints)
-size_t edge_fwd_lds_bytes(int max_atoms, bool l0) {
-    const int row = l0 ? EdgeLayout<true>::ROW : EdgeLayout<false>::ROW;
-    return sizeof(float) * ((size_t)max_atoms * (row + FS) + max_atoms + 4);
+size_t edge_fwd_lds_bytes(int max_atoms) {
+    return sizeof(float) * ((size_t)max_atoms * (EdgeLayout::ROW + FS) + max_atoms + 4);
 }
 
 // sum over the 4 lanes of a quad (lanes 4q..4q+3), result in every lane: two DPP quad_perm adds
@@ -119,13 +156,12 @@ __device__ __forceinline__ void quad_sum4(float (&x)[4]) {
 // (A[i = feature][k]) and rho as B (B[k][j = slot]) the filter tile D[feature][slot] puts the 4 feature values of
 // slot p into the 4 accumulator registers of lane (p, fq): the lane that loaded rho for slot p (its k-quarter is
 // fq) also owns that slot's messages, so one table address serves both and no cross-lane traffic is needed.
-template <bool L0>
 __global__ void __launch_bounds__(EDGE_THREADS)
 k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *__restrict__ counters,
                 int zero_slot, int n_models, int max_atoms, const float *__restrict__ s_in,
                 const float *__restrict__ v_in, const float *__restrict__ phi, float *__restrict__ s_msg,
                 float *__restrict__ v_msg) {
-    using LY = EdgeLayout<L0>;
+    using LY = EdgeLayout;
     extern __shared__ __attribute__((aligned(16))) float tile[];
     if (counters[2]) return;
     // XCD-aware 1-D grid: workgroup id -> XCD id % 8 (observed dispatch rule).  All (slice, model) workgroups of
@@ -152,7 +188,6 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             int atom = idx / PER_ATOM, rem = idx - atom * PER_ATOM, seg = rem >> 2, q4 = rem & 3;
             const size_t ga = mN + a0 + atom;
             if (seg == LY::NSEG) return s_in + ga * F + fs * FS + q4 * 4;                  // s slice
-            if (L0) return phi + ga * F3 + (seg + 1) * F + fs * FS + q4 * 4;               // sections b, c
             if (seg < 3) return phi + ga * F3 + seg * F + fs * FS + q4 * 4;                // sections a, b, c
             return v_in + (ga * 3 + (seg - 3)) * F + fs * FS + q4 * 4;                     // v_x, v_y, v_z
         };
@@ -187,13 +222,13 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const LayerW &W = MW[m].layer[l];
     // A operand: bf16 pieces (h, m, l) of the filter weights of feature row p, quarter fq: 3 x 16 B per section, bias
     // column included (build_wd16)
-    Op16 wA[LY::NSEC][3];
+    u32x4 wA[LY::NSEC][3];
 #pragma unroll
     for (int s = 0; s < LY::NSEC; ++s) {
-        const int row = (L0 ? s + 1 : s) * F + fs * FS + p;
-        const uint4 *wsrc = W.wd16 + ((size_t)row * 4 + fq) * 3;
+        const int row = s * F + fs * FS + p;
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 3;
 #pragma unroll
-        for (int i3 = 0; i3 < 3; ++i3) wA[s][i3].u = wsrc[i3];
+        for (int i3 = 0; i3 < 3; ++i3) wA[s][i3] = wsrc[i3];
     }
 
     // ---- every stream walks a contiguous run of CSR slots, cut at centre boundaries, ~equal slot counts ---------
@@ -218,19 +253,19 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int fcol = fs * FS + 4 * fq;            // first of this lane's 4 global feature columns
 
     // table entry of this lane's slot; exhausted streams read the reserved all-zero entry (filter = 0)
-    const uint4 *rho_lane = G.rho16 + fq * 3;
+    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 3;
     const float4 *erec = G.erec;
     const int last_slot = max(rs[Nc] - 1, 0);     // records are always read from inside the chain (finite values)
 
     // rho pieces of the current step (single buffer: the next step's loads are issued right after the MFMAs that read
     // them and complete during the message arithmetic); unit vector / neighbor id double-buffered
-    Op16 rq[3];
+    u32x4 rq[3];
     float4 er[2];
     {
         const int sl = pos + e;
         const size_t tsl = pos < stream_end ? sl : zero_slot;
-        const uint4 *rp = rho_lane + tsl * 12;
-        rq[0].u = rp[0]; rq[1].u = rp[1]; rq[2].u = rp[2];
+        const u32x4 *rp = rho_lane + tsl * 12;
+        rq[0] = rp[0]; rq[1] = rp[1]; rq[2] = rp[2];
         er[0] = erec[min(sl, last_slot)];
     }
 
@@ -248,12 +283,10 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                 const size_t ga = mN + a0 + c;
                 const float4 sr = *reinterpret_cast<const float4 *>(s_tile + c * FS + 4 * fq);
                 so.x += sr.x; so.y += sr.y; so.z += sr.z; so.w += sr.w;
-                if (!L0) {
-                    const float *vc = tile + c * LY::ROW + (4 * fq) * LY::NSEG;
-                    vxo.x += vc[3]; vxo.y += vc[9]; vxo.z += vc[15]; vxo.w += vc[21];
-                    vyo.x += vc[4]; vyo.y += vc[10]; vyo.z += vc[16]; vyo.w += vc[22];
-                    vzo.x += vc[5]; vzo.y += vc[11]; vzo.z += vc[17]; vzo.w += vc[23];
-                }
+                const float *vc = tile + c * LY::ROW + (4 * fq) * LY::NSEG;
+                vxo.x += vc[3]; vxo.y += vc[9]; vxo.z += vc[15]; vxo.w += vc[21];
+                vyo.x += vc[4]; vyo.y += vc[10]; vyo.z += vc[16]; vyo.w += vc[22];
+                vzo.x += vc[5]; vzo.y += vc[11]; vzo.z += vc[17]; vzo.w += vc[23];
                 *reinterpret_cast<float4 *>(s_msg + ga * F + fcol) = so;
                 *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 0) * F + fcol) = vxo;
                 *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 1) * F + fcol) = vyo;
@@ -281,40 +314,41 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                     tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
                 }
             }
+            mfma_pre_fence(rq[0], rq[1], rq[2]);   // gathers are issued before the first MFMA
             // ---- filter GEMM  D[feature][slot] = Wd_ext[feature][k] rho[k][slot]  (bias . fc included) ---------------
             f32x4 acc[LY::NSEC];
-#pragma unroll
-            for (int s2 = 0; s2 < LY::NSEC; ++s2) acc[s2] = filter_tile(wA[s2], rq, (f32x4){0.f, 0.f, 0.f, 0.f});
-            __builtin_amdgcn_sched_barrier(0);
-            // next step's table entries (in flight during this step's message arithmetic)
             {
-                const int sl = pos + 4 + e;
-                const size_t tsl = pos + 4 < stream_end ? sl : zero_slot;
-                const uint4 *rp = rho_lane + tsl * 12;
-                rq[0].u = rp[0]; rq[1].u = rp[1]; rq[2].u = rp[2];
-                er[ph ^ 1] = erec[min(sl, last_slot)];
+                const u32x4 (*wp[LY::NSEC])[3], (*rp3[LY::NSEC])[3];
+#pragma unroll
+                for (int s2 = 0; s2 < LY::NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq; }
+                filter_tiles<LY::NSEC>(wp, rp3, acc);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- messages of this lane's slot for its 4 features (filter = 0 exactly for pads / foreign slots) -----------
             const float ux = er[ph].x, uy = er[ph].y, uz = er[ph].z;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            auto message = [&](int r) {
                 const float *tr = tv + r * LY::NSEG;
-                if (L0) {
-                    const float wb = acc[0][r], wc = acc[1][r];
-                    ds[r] = fmaf(tr[0], wb, ds[r]);
-                    const float mc = tr[1] * wc;
-                    dvx[r] = fmaf(mc, ux, dvx[r]); dvy[r] = fmaf(mc, uy, dvy[r]); dvz[r] = fmaf(mc, uz, dvz[r]);
-                } else {
-                    const float wa = acc[0][r], wb = acc[1][r], wc = acc[2][r];
-                    ds[r] = fmaf(tr[1], wb, ds[r]);
-                    const float mc = tr[2] * wc, ma = tr[0] * wa;
-                    dvx[r] = fmaf(mc, ux, dvx[r]); dvy[r] = fmaf(mc, uy, dvy[r]); dvz[r] = fmaf(mc, uz, dvz[r]);
-                    dvx[r] = fmaf(ma, tr[3], dvx[r]);
-                    dvy[r] = fmaf(ma, tr[4], dvy[r]);
-                    dvz[r] = fmaf(ma, tr[5], dvz[r]);
-                }
+                const float wa = acc[0][r], wb = acc[1][r], wc = acc[2][r];
+                ds[r] = fmaf(tr[1], wb, ds[r]);
+                const float mc = tr[2] * wc, ma = tr[0] * wa;
+                dvx[r] = fmaf(mc, ux, dvx[r]); dvy[r] = fmaf(mc, uy, dvy[r]); dvz[r] = fmaf(mc, uz, dvz[r]);
+                dvx[r] = fmaf(ma, tr[3], dvx[r]);
+                dvy[r] = fmaf(ma, tr[4], dvy[r]);
+                dvz[r] = fmaf(ma, tr[5], dvz[r]);
+            };
+            message(0);   // consumes every accumulator tile
+            // next step's table entries (in flight during the rest of the message arithmetic); see mfma_load_fence
+            int nsl = pos + 4 + e;
+            mfma_load_fence(nsl, ds[0], dvx[0], dvy[0]);
+            {
+                const size_t tsl = pos + 4 < stream_end ? nsl : zero_slot;
+                const u32x4 *rp = rho_lane + tsl * 12;
+                rq[0] = rp[0]; rq[1] = rp[1]; rq[2] = rp[2];
+                er[ph ^ 1] = erec[min(nsl, last_slot)];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) message(r);
             if (pos < stream_end) pos += 4;
             flush_complete();
         }
@@ -341,14 +375,13 @@ constexpr int ROWB = FS * 4 + 4;              // LDS row: [feature][sbar, vbar_x
 size_t edge_bwd_lds_bytes(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * ROWB + max_atoms + 4); }
 int edge_bwd_groups() { return NSG; }
 
-template <bool L0>
 __global__ void __launch_bounds__(BWD_THREADS)
 k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, GraphView G,
-                const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms, int excl_vol,
+                const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms,
                 const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
                 const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
                 float4 *__restrict__ gbar, long long gbar_stride, int n_groups) {
-    constexpr int NSEC = L0 ? 2 : 3;
+    constexpr int NSEC = 3;
     extern __shared__ __attribute__((aligned(16))) float tile[];
     if (counters[2]) return;
     const int wg = blockIdx.x, xcd = wg & 7, rest = wg >> 3;
@@ -382,7 +415,8 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
     const int last_slot = max(rs[Nc] - 1, 0);
     const LayerW &W = MW[m].layer[l];
     float4 *gb = gbar + (size_t)(m * n_groups + sg) * gbar_stride;
-    const uint4 *rho_lane = G.rho16 + fq * 3, *drho_lane = G.drho16 + fq * 3;
+    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 3;
+    const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 3;
 
     for (int si = 0; si < SLICES_PER_WG; ++si) {
         const int fs = sg * SLICES_PER_WG + si;
@@ -414,13 +448,13 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
             }
         }
         // ---- A operand: Wd_ext rows of this slice ------------------------------------------------------------------
-        Op16 wA[NSEC][3];   // bf16 pieces (h, m, l) of the slice's filter rows, bias column included (build_wd16)
+        u32x4 wA[NSEC][3];   // bf16 pieces (h, m, l) of the slice's filter rows, bias column included (build_wd16)
 #pragma unroll
         for (int s2 = 0; s2 < NSEC; ++s2) {
-            const int row = (L0 ? s2 + 1 : s2) * F + fs * FS + p;
-            const uint4 *wsrc = W.wd16 + ((size_t)row * 4 + fq) * 3;
+            const int row = s2 * F + fs * FS + p;
+            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 3;
 #pragma unroll
-            for (int i3 = 0; i3 < 3; ++i3) wA[s2][i3].u = wsrc[i3];
+            for (int i3 = 0; i3 < 3; ++i3) wA[s2][i3] = wsrc[i3];
         }
         __syncthreads();
 
@@ -430,14 +464,12 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
         auto load_centre = [&](int cc, float4 &a, float4 &bq, float4 &cq, float4 &x, float4 &y, float4 &z) {
             const size_t ga = mN + a0 + min(cc, Nc - 1);
             const float *pr = phi + ga * F3 + fcol;
-            if (!L0) a = *reinterpret_cast<const float4 *>(pr);
+            a = *reinterpret_cast<const float4 *>(pr);
             bq = *reinterpret_cast<const float4 *>(pr + F);
             cq = *reinterpret_cast<const float4 *>(pr + 2 * F);
-            if (!L0) {
-                x = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 0) * F + fcol);
-                y = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 1) * F + fcol);
-                z = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 2) * F + fcol);
-            }
+            x = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 0) * F + fcol);
+            y = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 1) * F + fcol);
+            z = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 2) * F + fcol);
         };
         int c = c_first, pos = stream_begin;
         int cend = c < c_last ? rs[c + 1] : stream_end;
@@ -448,40 +480,38 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
 
         auto flush_complete = [&]() {
             while (c < c_last && pos >= cend) {
-                if (!L0) {
-                    float4 pa, pb, pc2, ox, oy, oz;
-                    quad_sum4(accb); quad_sum4(accc); quad_sum4(accx); quad_sum4(accy); quad_sum4(accz);
-                    const float (&tb)[4] = accb, (&tc)[4] = accc, (&tx)[4] = accx, (&ty)[4] = accy, (&tz)[4] = accz;
-                    if (e == 0) {
-                        const size_t ga = mN + a0 + c;
-                        const float vx_[4] = {vcx.x, vcx.y, vcx.z, vcx.w}, vy_[4] = {vcy.x, vcy.y, vcy.z, vcy.w};
-                        const float vz_[4] = {vcz.x, vcz.y, vcz.z, vcz.w}, pa_[4] = {pca.x, pca.y, pca.z, pca.w};
-                        float a_[4], x_[4], y_[4], z_[4];
-                        const float *res = tile + c * ROWB + (4 * fq) * 4;   // [r][sbar, vbar_x, vbar_y, vbar_z]
+                float4 pa, pb, pc2, ox, oy, oz;
+                quad_sum4(accb); quad_sum4(accc); quad_sum4(accx); quad_sum4(accy); quad_sum4(accz);
+                const float (&tb)[4] = accb, (&tc)[4] = accc, (&tx)[4] = accx, (&ty)[4] = accy, (&tz)[4] = accz;
+                if (e == 0) {
+                    const size_t ga = mN + a0 + c;
+                    const float vx_[4] = {vcx.x, vcx.y, vcx.z, vcx.w}, vy_[4] = {vcy.x, vcy.y, vcy.z, vcy.w};
+                    const float vz_[4] = {vcz.x, vcz.y, vcz.z, vcz.w}, pa_[4] = {pca.x, pca.y, pca.z, pca.w};
+                    float a_[4], x_[4], y_[4], z_[4];
+                    const float *res = tile + c * ROWB + (4 * fq) * 4;   // [r][sbar, vbar_x, vbar_y, vbar_z]
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            a_[r] = fmaf(vz_[r], tz[r], fmaf(vy_[r], ty[r], vx_[r] * tx[r]));
-                            x_[r] = fmaf(pa_[r], tx[r], res[4 * r + 1]);
-                            y_[r] = fmaf(pa_[r], ty[r], res[4 * r + 2]);
-                            z_[r] = fmaf(pa_[r], tz[r], res[4 * r + 3]);
-                        }
-                        pa = make_float4(a_[0], a_[1], a_[2], a_[3]);
-                        pb = make_float4(tb[0], tb[1], tb[2], tb[3]);
-                        pc2 = make_float4(tc[0], tc[1], tc[2], tc[3]);
-                        ox = make_float4(x_[0], x_[1], x_[2], x_[3]);
-                        oy = make_float4(y_[0], y_[1], y_[2], y_[3]);
-                        oz = make_float4(z_[0], z_[1], z_[2], z_[3]);
-                        float *pbp = phibar + ga * F3 + fcol;
-                        *reinterpret_cast<float4 *>(pbp) = pa;
-                        *reinterpret_cast<float4 *>(pbp + F) = pb;
-                        *reinterpret_cast<float4 *>(pbp + 2 * F) = pc2;
-                        *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 0) * F + fcol) = ox;
-                        *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 1) * F + fcol) = oy;
-                        *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 2) * F + fcol) = oz;
+                    for (int r = 0; r < 4; ++r) {
+                        a_[r] = fmaf(vz_[r], tz[r], fmaf(vy_[r], ty[r], vx_[r] * tx[r]));
+                        x_[r] = fmaf(pa_[r], tx[r], res[4 * r + 1]);
+                        y_[r] = fmaf(pa_[r], ty[r], res[4 * r + 2]);
+                        z_[r] = fmaf(pa_[r], tz[r], res[4 * r + 3]);
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
+                    pa = make_float4(a_[0], a_[1], a_[2], a_[3]);
+                    pb = make_float4(tb[0], tb[1], tb[2], tb[3]);
+                    pc2 = make_float4(tc[0], tc[1], tc[2], tc[3]);
+                    ox = make_float4(x_[0], x_[1], x_[2], x_[3]);
+                    oy = make_float4(y_[0], y_[1], y_[2], y_[3]);
+                    oz = make_float4(z_[0], z_[1], z_[2], z_[3]);
+                    float *pbp = phibar + ga * F3 + fcol;
+                    *reinterpret_cast<float4 *>(pbp) = pa;
+                    *reinterpret_cast<float4 *>(pbp + F) = pb;
+                    *reinterpret_cast<float4 *>(pbp + 2 * F) = pc2;
+                    *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 0) * F + fcol) = ox;
+                    *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 1) * F + fcol) = oy;
+                    *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 2) * F + fcol) = oz;
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
                 ++c;
                 cend = c < c_last ? rs[c + 1] : stream_end;
                 pca = npca; pcb = npcb; pcc = npcc; vcx = nvcx; vcy = nvcy; vcz = nvcz;
@@ -493,14 +523,14 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
         // table entries of this lane's slot; exhausted streams read the all-zero entry.  rho / drho pieces are single
         // buffered (the next step's loads are issued right after the MFMAs that consume them), the small records
         // (unit vector + neighbor id, distance) are double buffered.
-        Op16 rq[3], dq[3];
+        u32x4 rq[3], dq[3];
         float4 er[2];
         float2 dd[2];
         auto fetch_tables = [&](int quad) {
             const size_t off = (size_t)(quad < stream_end ? quad + e : zero_slot) * 12;
-            const uint4 *rp = rho_lane + off, *dp = drho_lane + off;
-            rq[0].u = rp[0]; rq[1].u = rp[1]; rq[2].u = rp[2];
-            dq[0].u = dp[0]; dq[1].u = dp[1]; dq[2].u = dp[2];
+            const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
+            rq[0] = rp[0]; rq[1] = rp[1]; rq[2] = rp[2];
+            dq[0] = dp[0]; dq[1] = dp[1]; dq[2] = dp[2];
         };
         auto fetch_rec = [&](int quad, int buf) {
             const int sl = min(quad + e, last_slot);
@@ -509,8 +539,12 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
         };
         fetch_tables(pos);
         fetch_rec(pos, 0);
-        const float *trow = tile + (4 * fq) * 4;
+        // partial edge gradient written by the previous slice for this lane's slot: fetched one step ahead so that the
+        // read-modify-write never stalls the step (a slot is visited once per slice, so the early read is safe)
         const bool first_write = layer_first && si == 0;
+        float4 gold = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!first_write) gold = gb[min(pos + e, last_slot)];
+        const float *trow = tile + (4 * fq) * 4;
 
         while (__any(pos < stream_end)) {
 #pragma unroll
@@ -524,16 +558,17 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                         tb[4 * q] = t4.x; tb[4 * q + 1] = t4.y; tb[4 * q + 2] = t4.z; tb[4 * q + 3] = t4.w;
                     }
                 }
+                mfma_pre_fence(rq[0], rq[1], rq[2]);   // gathers are issued before the first MFMA
+                mfma_pre_fence(dq[0], dq[1], dq[2]);
                 // filter and its radial derivative for this lane's slot and 4 features (bias . fc / bias . fc' included)
-                f32x4 aw[NSEC], ad[NSEC];
+                f32x4 awd[2 * NSEC];   // tiles [0, NSEC): filter w, [NSEC, 2 NSEC): radial derivative dw
+                {
+                    const u32x4 (*wp[2 * NSEC])[3], (*rp3[2 * NSEC])[3];
 #pragma unroll
-                for (int s2 = 0; s2 < NSEC; ++s2) {
-                    aw[s2] = filter_tile(wA[s2], rq, (f32x4){0.f, 0.f, 0.f, 0.f});
-                    ad[s2] = filter_tile(wA[s2], dq, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    for (int s2 = 0; s2 < NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq; wp[NSEC + s2] = &wA[s2]; rp3[NSEC + s2] = &dq; }
+                    filter_tiles<2 * NSEC>(wp, rp3, awd);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                fetch_tables(pos + 4);
-                fetch_rec(pos + 4, ph ^ 1);
+                const f32x4 *aw = awd, *ad = awd + NSEC;
                 __builtin_amdgcn_sched_barrier(0);
                 const float ux = er[ph].x, uy = er[ph].y, uz = er[ph].z;   // unit vector c -> n ; edge (n -> c) has -u
                 const float pcb_[4] = {pcb.x, pcb.y, pcb.z, pcb.w}, pcc_[4] = {pcc.x, pcc.y, pcc.z, pcc.w};
@@ -541,48 +576,48 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                 const float vx_[4] = {vcx.x, vcx.y, vcx.z, vcx.w}, vy_[4] = {vcy.x, vcy.y, vcy.z, vcy.w};
                 const float vz_[4] = {vcz.x, vcz.y, vcz.z, vcz.w};
                 float dpart = 0.f, ub0 = 0.f, ub1 = 0.f, ub2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                auto feature = [&](int r) {
                     const float sbn = tb[4 * r], vb0 = tb[4 * r + 1], vb1 = tb[4 * r + 2], vb2 = tb[4 * r + 3];
-                    const float wB = aw[L0 ? 0 : 1][r], wC = aw[L0 ? 1 : 2][r];
-                    const float dB = ad[L0 ? 0 : 1][r], dC = ad[L0 ? 1 : 2][r];
+                    const float wB = aw[1][r], wC = aw[2][r];
+                    const float dB = ad[1][r], dC = ad[2][r];
                     const float pn = -fmaf(vb2, uz, fmaf(vb1, uy, vb0 * ux));   // vbar_n . u_(n->c)
                     accb[r] = fmaf(wB, sbn, accb[r]);
                     accc[r] = fmaf(wC, pn, accc[r]);
                     dpart = fmaf(pcb_[r] * sbn, dB, dpart);
                     dpart = fmaf(pcc_[r] * pn, dC, dpart);
-                    if (!L0) {
-                        const float wAa = aw[0][r], dA = ad[0][r];
-                        const float q = fmaf(vb2, vz_[r], fmaf(vb1, vy_[r], vb0 * vx_[r]));
-                        accx[r] = fmaf(wAa, vb0, accx[r]);
-                        accy[r] = fmaf(wAa, vb1, accy[r]);
-                        accz[r] = fmaf(wAa, vb2, accz[r]);
-                        dpart = fmaf(pca_[r] * q, dA, dpart);
-                    }
+                    const float wAa = aw[0][r], dA = ad[0][r];
+                    const float q = fmaf(vb2, vz_[r], fmaf(vb1, vy_[r], vb0 * vx_[r]));
+                    accx[r] = fmaf(wAa, vb0, accx[r]);
+                    accy[r] = fmaf(wAa, vb1, accy[r]);
+                    accz[r] = fmaf(wAa, vb2, accz[r]);
+                    dpart = fmaf(pca_[r] * q, dA, dpart);
                     const float mc = pcc_[r] * wC;
                     ub0 = fmaf(mc, vb0, ub0); ub1 = fmaf(mc, vb1, ub1); ub2 = fmaf(mc, vb2, ub2);
-                }
+                };
+                feature(0);   // consumes every accumulator tile
+                int nquad = pos + 4;
+                mfma_load_fence(nquad, accb[0], accc[0], dpart, ub0);
+                fetch_tables(nquad);
+                fetch_rec(nquad, ph ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 1; r < 4; ++r) feature(r);
                 // sum over the 4 feature quarters (lanes p, p+16, p+32, p+48): fixed order, all lanes get the total
                 dpart += __shfl_xor(dpart, 16, 64); dpart += __shfl_xor(dpart, 32, 64);
                 ub0 += __shfl_xor(ub0, 16, 64); ub0 += __shfl_xor(ub0, 32, 64);
                 ub1 += __shfl_xor(ub1, 16, 64); ub1 += __shfl_xor(ub1, 32, 64);
                 ub2 += __shfl_xor(ub2, 16, 64); ub2 += __shfl_xor(ub2, 32, 64);
                 if (fq == 0 && pos < stream_end && dd[ph].x > 0.f) {   // one lane per real slot writes its gradient
-                    const float invd = 1.f / dd[ph].x;
-                    float db = dpart;
-                    if (L0 && excl_vol && fs == 0) db += dd[ph].y;     // excluded volume, once per slot and model
+                    const float invd = dd[ph].x;
+                    const float db = dpart;
                     // edge (n -> c): unit vector -u ; g = db (-u) + (ub - (ub.u) u) / d
                     const float dotu = fmaf(ub2, uz, fmaf(ub1, uy, ub0 * ux));
-                    float g0 = fmaf(-db, ux, (ub0 - dotu * ux) * invd);
-                    float g1 = fmaf(-db, uy, (ub1 - dotu * uy) * invd);
-                    float g2 = fmaf(-db, uz, (ub2 - dotu * uz) * invd);
-                    const int slot = pos + e;
-                    if (!first_write) {
-                        const float4 old = gb[slot];
-                        g0 += old.x; g1 += old.y; g2 += old.z;
-                    }
-                    gb[slot] = make_float4(g0, g1, g2, 0.f);
+                    const float g0 = fmaf(-db, ux, (ub0 - dotu * ux) * invd) + gold.x;
+                    const float g1 = fmaf(-db, uy, (ub1 - dotu * uy) * invd) + gold.y;
+                    const float g2 = fmaf(-db, uz, (ub2 - dotu * uz) * invd) + gold.z;
+                    gb[pos + e] = make_float4(g0, g1, g2, 0.f);
                 }
+                if (!first_write) gold = gb[min(nquad + e, last_slot)];   // index from the fence: never hoisted into the MFMAs
                 if (pos < stream_end) pos += 4;
                 flush_complete();
             }
@@ -613,48 +648,29 @@ void launch_excl_vol(hipStream_t st, int N, int M, const GraphView &G, const int
 }
 
 int edge_mfma_init(vssr_handle *h) {
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_fwd_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_fwd_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return VSSR_OK;
 }
 
-bool edge_fwd_mfma_fits(int max_atoms) { return edge_fwd_lds_bytes(max_atoms, false) <= 160 * 1024; }
+bool edge_fwd_mfma_fits(int max_atoms) { return edge_fwd_lds_bytes(max_atoms) <= 160 * 1024; }
 
+// layers >= 1 only (layer 0: painn_l0.hip or the gather kernels, see painn_run)
 void launch_edge_bwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int layer_first, int max_atoms,
-                          const ModelW *MW, const GraphView &G, const int *counters, int zero_slot, int excl_vol,
+                          const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
                           float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups) {
     dim3 grid(((n_cfg + 7) / 8) * 8 * NSG * M), blk(BWD_THREADS);
-    const size_t lds = edge_bwd_lds_bytes(max_atoms);
-    if (l == 0)
-        hipLaunchKernelGGL(k_edge_bwd_mfma<true>, grid, blk, lds, st, N, l, layer_first, MW, G, counters, zero_slot, M,
-                           max_atoms, excl_vol, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
-    else
-        hipLaunchKernelGGL(k_edge_bwd_mfma<false>, grid, blk, lds, st, N, l, layer_first, MW, G, counters, zero_slot, M,
-                           max_atoms, excl_vol, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
+    hipLaunchKernelGGL(k_edge_bwd_mfma, grid, blk, edge_bwd_lds_bytes(max_atoms), st, N, l, layer_first, MW, G, counters,
+                       zero_slot, M, max_atoms, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
 }
 
 void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,
-                          const GraphView &G, const int *counters, int zero_slot, int excl_vol, float excl_sigma,
-                          int excl_power, const float *s_in, const float *v_in, const float *phi, float *s_msg,
-                          float *v_msg, float *e_excl) {
+                          const GraphView &G, const int *counters, int zero_slot, const float *s_in, const float *v_in,
+                          const float *phi, float *s_msg, float *v_msg) {
     dim3 grid(((n_cfg + 7) / 8) * 8 * NSLICE * M), blk(EDGE_THREADS);
-    if (l == 0) {
-        hipLaunchKernelGGL(k_edge_fwd_mfma<true>, grid, blk, edge_fwd_lds_bytes(max_atoms, true), st, N, l, MW, G,
-                           counters, zero_slot, M, max_atoms, s_in, v_in, phi, s_msg, v_msg);
-        if (excl_vol)
-            hipLaunchKernelGGL(k_excl_vol, dim3((N + 255) / 256), dim3(256), 0, st, N, M, G, counters, excl_sigma,
-                               excl_power, e_excl);
-    } else {
-        hipLaunchKernelGGL(k_edge_fwd_mfma<false>, grid, blk, edge_fwd_lds_bytes(max_atoms, false), st, N, l, MW, G,
-                           counters, zero_slot, M, max_atoms, s_in, v_in, phi, s_msg, v_msg);
-    }
+    hipLaunchKernelGGL(k_edge_fwd_mfma, grid, blk, edge_fwd_lds_bytes(max_atoms), st, N, l, MW, G, counters, zero_slot, M,
+                       max_atoms, s_in, v_in, phi, s_msg, v_msg);
 }
 
 }  // namespace vssr

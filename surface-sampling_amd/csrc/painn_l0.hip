@@ -162,7 +162,7 @@ k_l0_bwd(int N, int M, int nz, int first_write, int excl_vol, GraphView G, const
                 const float ux = er.x, uy = er.y, uz = er.z;   // unit vector c -> n; the edge (n -> c) has -u
                 float db = d0 - (dx * ux + dy * uy + dz * uz);
                 if (excl_vol) db += dd.y;
-                const float invd = 1.f / dd.x;
+                const float invd = dd.x;
                 const float dotu = fmaf(bz, uz, fmaf(by, uy, bx * ux));
                 float g0 = fmaf(-db, ux, (bx - dotu * ux) * invd);
                 float g1 = fmaf(-db, uy, (by - dotu * uy) * invd);

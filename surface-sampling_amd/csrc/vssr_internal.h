@@ -60,7 +60,7 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const float *drho;       // [slots][4][6]  d rho / d d, same order
     const uint4 *rho16;      // [slots][4][3] operand-ready 3-way bf16 split of rho (48 B per (slot, quarter)), see nbr.hip
     const uint4 *drho16;     // same for d rho / d d
-    const float2 *dist2;     // [slots] {edge length d (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
+    const float2 *dist2;     // [slots] {1 / edge length (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
 };
 
 struct StateView {  // activations of all models: index [m][atom][...]
@@ -243,13 +243,12 @@ void launch_excl_vol(hipStream_t st, int N, int M, const GraphView &G, const int
 int edge_mfma_init(vssr_handle *h);
 int edge_bwd_groups();
 void launch_edge_bwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int layer_first, int max_atoms,
-                          const ModelW *MW, const GraphView &G, const int *counters, int zero_slot, int excl_vol,
+                          const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
                           float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups);
 bool edge_fwd_mfma_fits(int max_atoms);
 void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,
-                          const GraphView &G, const int *counters, int zero_slot, int excl_vol, float excl_sigma,
-                          int excl_power, const float *s_in, const float *v_in, const float *phi, float *s_msg,
-                          float *v_msg, float *e_excl);
+                          const GraphView &G, const int *counters, int zero_slot, const float *s_in, const float *v_in,
+                          const float *phi, float *s_msg, float *v_msg);
 
 }  // namespace vssr

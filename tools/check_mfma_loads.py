@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Build-time check of the MFMA / load ordering rule of the edge kernels (see mfma_load_fence in painn_edge_mfma.hip):
+in the emitted gfx950 ISA no load (LDS, global, scratch, flat) may sit between the first MFMA of a step and the
+'; mfma_load_fence' marker that follows it.  Usage: check_mfma_loads.py [file.hip ...]  (exit code 1 on violation)."""
+import os, re, subprocess, sys, tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "surface-sampling_amd", "csrc")
+LOAD = re.compile(r"^\s*(ds_read|ds_load|global_load|buffer_load|scratch_load|flat_load)")
+
+
+def check(hip):
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                        "-save-temps", "-c", hip, "-o", os.path.join(tmp, "x.o")], cwd=tmp, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]
+        lines = open(os.path.join(tmp, asm)).read().splitlines()
+    bad = 0
+    kernel = None
+    open_group = None          # line index of the first MFMA since the last fence
+    loads = []
+    groups = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\w+):", l)
+        if m:
+            kernel, open_group, loads = m.group(1), None, []
+        t = l.strip()
+        if t.startswith("v_mfma"):
+            if open_group is None:
+                open_group, loads = i, []
+        elif "mfma_load_fence" in t:
+            if open_group is not None:
+                groups += 1
+                if loads:
+                    bad += 1
+                    print(f"VIOLATION in {kernel}: {len(loads)} load(s) between MFMA at line {open_group} and fence at {i}:")
+                    for j in loads[:6]:
+                        print("    ", lines[j].strip())
+            open_group = None
+        elif open_group is not None and LOAD.match(l):
+            loads.append(i)
+        elif t.startswith("s_endpgm"):
+            if open_group is not None and kernel and "edge" in kernel and "mfma" in kernel:
+                print(f"note: {kernel}: MFMA group at line {open_group} without a following fence")
+            open_group = None
+    print(f"{os.path.basename(hip)}: {groups} MFMA groups checked, {bad} violations")
+    return bad
+
+
+if __name__ == "__main__":
+    files = sys.argv[1:] or [os.path.join(CSRC, "painn_edge_mfma.hip")]
+    sys.exit(1 if sum(check(f) for f in files) else 0)
