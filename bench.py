@@ -46,26 +46,36 @@ def build_chains(S, first, count):
     return [structures.synth_chain(big, c) for c in range(first, first + count)]
 
 
-def neighbor_sum_bytes(n_atoms, n_edges, n_models, layer0):
-    """Algorithmic bytes of ONE neighbor-sum (edge_message_fwd) launch, SURVEY.md §8(d):
-    read phi [N,3F], v [N,3,F], s [N,F] + 16 B per edge; write s' [N,F], v' [N,3,F].
-    Layer 0 has v = 0 and no a-section: read phi b,c [N,2F] + s, write s', v'."""
-    per_atom = (2 * F + F + F + 3 * F) * 4 if layer0 else (3 * F + 3 * F + F + F + 3 * F) * 4
+def neighbor_sum_bytes(n_atoms, n_edges, n_models):
+    """Algorithmic HBM bytes of ONE forward neighbor-sum launch (layer >= 1), SURVEY.md §8(d):
+    read phi [N,3F], v [N,3,F], s [N,F] + 16 B per edge; write s' [N,F], v' [N,3,F]."""
+    per_atom = (3 * F + 3 * F + F + F + 3 * F) * 4
     return n_models * (per_atom * n_atoms + 16 * n_edges)
 
 
-def neighbor_sum_flops(n_slots, n_models, layer0):
-    """fp32 FLOPs of the radial-filter GEMM inside ONE neighbor-sum launch as executed on the matrix cores:
-    per slot and model  sections * F * K * 2  with K = 20 radial functions (the envelope/bias column is folded into
-    the accumulator initialisation, one multiply per output, not counted)."""
-    sections = 2 if layer0 else 3
-    return n_models * n_slots * sections * F * 20 * 2
+def neighbor_sum_flops(n_slots, n_models):
+    """fp32 FLOPs of ONE forward neighbor-sum launch: per slot and model the radial filter (3F x 21 GEMV, bias column
+    included) plus the message arithmetic of painn_edge_mfma.hip (18 flops per feature: 3 products, 7 fma)."""
+    return n_models * n_slots * (3 * F * 21 * 2 + F * 18)
+
+
+def reverse_pass_bytes(n_atoms, n_edges, n_models):
+    """Algorithmic HBM bytes of ONE reverse neighbor-pass launch: read sbar, vbar [N,4F], phi [N,3F], v [N,3,F];
+    write phibar [N,3F], vbar_in [N,3,F]; per edge 16 B geometry in, 16 B edge gradient out."""
+    return n_models * ((4 * F + 3 * F + 3 * F + 3 * F + 3 * F) * 4 * n_atoms + 32 * n_edges)
+
+
+def reverse_pass_flops(n_slots, n_models):
+    """fp32 FLOPs of ONE reverse neighbor-pass launch: the filter AND its radial derivative (2 x 3F x 21 GEMV) plus
+    the per-feature adjoint arithmetic (36 flops per feature, `feature()` in k_edge_bwd_mfma).  These are the
+    fp32-precision flops the algorithm needs; the kernel executes each GEMV as six bf16 partial products."""
+    return n_models * n_slots * (2 * 3 * F * 21 * 2 + F * 36)
 
 
 def measured_traffic(kernel):
     """HBM bytes per launch from committed PMC passes (profiles/: FETCH_SIZE, WRITE_SIZE in KB, separate passes;
     FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM for 16-B/lane streams).  None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_edge_kernels.json")
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_edge_kernels_v3.json")
     if not os.path.exists(path):
         return None
     raw = json.load(open(path))
@@ -182,18 +192,20 @@ def main():
         total_evals = world * count * args.steps
         value = total_evals / elapsed
         M = len(blobs)
-        ns = prof.get("edge_message_fwd", {"launches": 0, "total_ms": 0.0})
-        n_launch = max(1, ns["launches"])
-        # layer 0 runs through the exact species factorisation (own profiler class): the neighbor-sum launches
-        # are layers 1..2 unless the factorisation was not applicable (then layer 0 is a 2-section launch)
-        l0_fact = prof.get("layer0_factorised_fwd", {"launches": 0})["launches"] > 0
-        layer_list = [1, 2] if l0_fact else [0, 1, 2]
-        bytes_per_launch = sum(neighbor_sum_bytes(stats["atoms"], stats["edges"], M, l == 0)
-                               for l in layer_list) / len(layer_list)
-        flops_per_launch = sum(neighbor_sum_flops(stats["slots"], M, l == 0) for l in layer_list) / len(layer_list)
-        avg_ms = ns["total_ms"] / n_launch
-        hbm_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        # Dominant kernel: the reverse neighbor pass (k_edge_bwd_mfma, layers 2 and 1; layer 0 runs through the species
+        # factorisation and has its own profiler class).  Launch durations are HIP-event times on the handle's stream.
+        def kernel_view(cls, flops, nbytes):
+            k = prof.get(cls, {"launches": 0, "total_ms": 0.0})
+            ms = k["total_ms"] / max(1, k["launches"])
+            return {"avg_launch_ms": ms, "launches": k["launches"], "algorithmic_flops_per_launch": flops,
+                    "achieved_TFLOPs": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                    "algorithmic_bytes_per_launch": nbytes,
+                    "achieved_GBps": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+
+        bwd = kernel_view("edge_message_bwd", reverse_pass_flops(stats["slots"], M),
+                          reverse_pass_bytes(stats["atoms"], stats["edges"], M))
+        fwd = kernel_view("edge_message_fwd", neighbor_sum_flops(stats["slots"], M),
+                          neighbor_sum_bytes(stats["atoms"], stats["edges"], M))
         step_ms = sum(v["total_ms"] for v in prof.values()) / args.steps
         line = {
             "metric": "MC energy-evaluations/sec (SrTiO3(001) ~250-atom slabs, 3-model PaiNN ensemble E+F incl. neighbor list)",
@@ -204,16 +216,25 @@ def main():
                                    f"(BASELINE configs[{3 if world == 1 else 4}]), 248-272 atoms/chain",
                        "chains_per_gpu": count, "atoms_per_gpu": stats["atoms"], "edges_per_gpu": stats["edges"],
                        "parallelism": f"chains sharded x{world}, RCCL all_gather of per-chain energies"},
-            # The neighbor-sum kernel stages each phi / v element into LDS exactly once (HBM traffic ~ compulsory, see
-            # `traffic`), so what binds it is the fp32 radial-filter GEMM on the matrix cores:
-            # `achieved`/`peak` are TFLOP/s; the HBM view of the same launch is given beside it.
-            "roofline": {"bound": "mfma", "kernel": "edge_message_fwd (neighbor-sum)", "achieved": tflops,
-                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": measured_traffic("k_edge_fwd_mfma"),
-                         "algorithmic_flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms,
-                         "launches": ns["launches"],
-                         "hbm_view": {"algorithmic_bytes_per_launch": bytes_per_launch, "achieved_GBps": hbm_gbs,
-                                      "peak_GBps": HBM_PEAK_GBS, "frac": hbm_gbs / HBM_PEAK_GBS}},
+            # The reverse neighbor pass is instruction / matrix-pipe bound, not HBM bound (its HBM view is given beside
+            # it): `achieved` = fp32-precision algorithmic TFLOP/s (filter GEMVs + adjoint arithmetic, formulas above)
+            # against the fp32 peak of MI355X_MICROARCH.md; the filter runs as 6 bf16 partial products per GEMV on
+            # the bf16 MFMA pipe (3-way exact split, fp32-level accuracy), the rest on the fp32 VALU.
+            "roofline": {"bound": "mfma", "kernel": "edge_message_bwd (reverse neighbor pass, k_edge_bwd_mfma)",
+                         "achieved": bwd["achieved_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": bwd["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": measured_traffic("k_edge_bwd_mfma"),
+                         "algorithmic_flops_per_launch": bwd["algorithmic_flops_per_launch"],
+                         "avg_launch_ms": bwd["avg_launch_ms"], "launches": bwd["launches"],
+                         "hbm_view": {"algorithmic_bytes_per_launch": bwd["algorithmic_bytes_per_launch"],
+                                      "achieved_GBps": bwd["achieved_GBps"], "peak_GBps": HBM_PEAK_GBS,
+                                      "frac": bwd["achieved_GBps"] / HBM_PEAK_GBS},
+                         "second_kernel": {"kernel": "edge_message_fwd (neighbor-sum, k_edge_fwd_mfma)",
+                                           "achieved": fwd["achieved_TFLOPs"],
+                                           "frac": fwd["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS,
+                                           "avg_launch_ms": fwd["avg_launch_ms"],
+                                           "traffic": measured_traffic("k_edge_fwd_mfma"),
+                                           "algorithmic_bytes_per_launch": fwd["algorithmic_bytes_per_launch"]}},
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]},
             "device_ms_per_step": step_ms,
         }

@@ -322,3 +322,34 @@ def test_fallback_paths_large_chain_many_species_and_forced_gather(golden, oracl
             del os.environ[var]
         assert abs(float(r["energy"][0]) - float(ref_small["energy"][0])) <= 1e-4, var
         assert np.abs(r["forces"] - ref_small["forces"]).max() <= 1e-4, var
+
+
+@pytest.mark.gpu
+def test_repeatability_stress_many_chains(golden):
+    """64 independent chains evaluated repeatedly on fresh engines give bit-identical energies and forces, on the default
+    path and on the per-edge layer-0 path.  This is the test that exposed the MFMA source-register hazard (isolated wrong
+    messages once in a few hundred chain evaluations; the small parity cases never hit it): a repeat that differs in one
+    bit fails."""
+    import os
+
+    from surface_sampling_amd import backend, structures
+
+    table, const = golden.offset_table()
+    base = golden.structure("SrTiO3_2x2_pristine")
+    chains = [_arrays(structures.synth_chain(base, c, grid=(4, 4))) for c in range(64)]
+    for env in ({}, {"VSSR_L0_FACTORISE": "0"}):
+        os.environ.update(env)
+        try:
+            ref = None
+            for _ in range(2):
+                eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+                for _ in range(12):
+                    r = eng.evaluate(chains)
+                    if ref is None:
+                        ref = (r["energy"].copy(), r["forces"].copy())
+                    assert np.array_equal(r["energy"], ref[0]), env
+                    assert np.array_equal(r["forces"], ref[1]), env
+                eng.close()
+        finally:
+            for k in env:
+                del os.environ[k]

@@ -137,3 +137,17 @@ def test_engine_fails_loudly_without_gpu(golden):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                          env={**os.environ, "HIP_VISIBLE_DEVICES": "-1", "ROCR_VISIBLE_DEVICES": "-1"}).stdout
     assert "RAISED" in out and "no HIP device" in out, out
+
+
+def test_edge_kernel_isa_keeps_loads_out_of_mfma_windows():
+    """The MFMA edge kernels must not issue any load between the first MFMA of a step and the fence that follows its
+    consumers (mfma_load_fence, painn_edge_mfma.hip): gfx950 does not interlock MFMA source registers against loads.
+    Cross-compiles the kernel file and inspects the emitted ISA (no GPU needed)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_mfma_loads.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "4 MFMA groups checked, 0 violations" in r.stdout, r.stdout
