@@ -1,0 +1,245 @@
+"""Batched MC proposal / change / acceptance — host logic, no GPU.
+
+Mirrors the reference's tests for this path (``tests/test_slab.py:41-87`` change_site, ``tests/events/test_criterion.py:
+14-46`` Metropolis) and adds the properties the batched design must keep: the vectorised state is equivalent to the
+reference's per-chain index bookkeeping, trajectories do not depend on batching / sharding (counter-based RNG), and the
+chain samples the Boltzmann distribution of a toy lattice gas (detailed balance)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from surface_sampling_amd import mc, structures
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_philox4x32_known_answers():
+    """Random123 known-answer vectors for Philox4x32-10."""
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+        ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+         (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+    ]
+    for ctr, key, out in kat:
+        got = mc.philox4x32(np.array(ctr, np.uint64), np.array(key, np.uint64))
+        assert tuple(int(x) for x in got) == out
+    # vectorised call = element-wise calls
+    ctrs = np.array([k[0] for k in kat], np.uint64)
+    keys = np.array([k[1] for k in kat], np.uint64)
+    assert np.array_equal(mc.philox4x32(ctrs, keys), np.array([k[2] for k in kat], np.uint32))
+
+
+def test_chain_uniforms_depend_only_on_seed_chain_step():
+    u_all = mc.chain_uniforms(7, np.arange(16), step=5)
+    u_part = mc.chain_uniforms(7, np.arange(8, 16), step=5)
+    assert np.array_equal(u_all[8:], u_part)
+    assert (u_all >= 0).all() and (u_all < 1).all()
+    assert not np.array_equal(u_all, mc.chain_uniforms(7, np.arange(16), step=6))
+    assert not np.array_equal(u_all, mc.chain_uniforms(8, np.arange(16), step=5))
+    big = mc.chain_uniforms(1, np.arange(20000), step=1)
+    assert abs(big.mean() - 0.5) < 0.01 and abs(big.var() - 1 / 12) < 0.005
+
+
+# ---- change_site: the reference's fixture (tests/test_slab.py:21-33) ------------------------------------------------
+@pytest.fixture()
+def system():
+    Z = structures.ATOMIC_NUMBERS
+    return mc.SiteState(numbers=np.array([Z["Ga"], Z["As"], Z["Ga"], Z["As"]], np.int32),
+                        positions=np.array([[0, 0, 0], [0, 0, 3], [1, 1, 1], [1, 1, 4]], float),
+                        ads_group=np.array([0, 1, 2, 0]), occ=np.array([1, 2, 0]),
+                        ads_coords=np.array([(0, 0, 3), (1, 1, 1), (2, 2, 5)], float))
+
+
+def test_change_site_with_existing_adsorbate(system):
+    new = mc.change_site(system, 0, "O")
+    assert len(new) == 4
+    assert np.allclose(new.occ, [3, 1, 0])
+    assert new.symbols[3] == "O"
+    assert np.allclose(new.ads_group, [0, 1, 0, 3])
+    assert np.allclose(new.positions[3], [0, 0, 3])
+
+
+def test_change_site_with_empty_site(system):
+    new = mc.change_site(system, 2, "Ir")
+    assert len(new) == 5
+    assert np.allclose(new.occ, [1, 2, 4])
+    assert new.symbols[4] == "Ir"
+    assert np.allclose(new.ads_group, [0, 1, 2, 0, 4])
+
+
+def test_change_site_with_desorption(system):
+    new = mc.change_site(system, 0, "None")
+    assert len(new) == 3
+    assert np.allclose(new.occ, [0, 1, 0])
+    assert new.symbols[2] == "As"
+    assert np.allclose(new.ads_group, [0, 1, 0])
+    assert len(system) == 4 and np.allclose(system.occ, [1, 2, 0])   # the "before" state is untouched
+
+
+def test_change_site_with_invalid_site_index(system):
+    with pytest.raises(IndexError):
+        mc.change_site(system, 5, "As")
+
+
+# ---- Metropolis (tests/events/test_criterion.py:14-46) --------------------------------------------------------------
+def test_metropolis_criterion_accept_reject_equal():
+    kT = 0.0257
+    assert mc.metropolis_accept(10.0, 5.0, kT, 0.999999)            # downhill: always
+    assert not mc.metropolis_accept(10.0, 15.0, kT, 1e-12)          # +5 eV at 300 K: exp(-194) never
+    assert mc.metropolis_accept(5.0, 5.0, kT, 0.999999)             # no energy change: exp(0) = 1
+    # vectorised, overflow (huge downhill) and +inf (out-of-bounds clamp) handled
+    acc = mc.metropolis_accept(np.array([0.0, 0.0, 0.0]), np.array([-1e6, 1e6, 0.01]), kT, np.array([0.9, 0.0, 0.5]))
+    assert acc.tolist() == [True, False, True]
+    p = np.exp(-0.01 / kT)
+    u = np.linspace(0, 1, 10001)[:-1]
+    assert abs(mc.metropolis_accept(0.0, 0.01, kT, u).mean() - p) < 2e-4
+
+
+def test_anneal_schedule_matches_reference_recurrence():
+    t = mc.create_anneal_schedule(start_temp=1.0, total_sweeps=5, alpha=0.9)
+    assert np.allclose(t, [1.0, 0.9, 0.81, 0.729, 0.6561])
+    t = mc.create_anneal_schedule(start_temp=0.2, total_sweeps=520, multiple_anneal=True)
+    assert len(t) == 520 and t[0] == 0.2 and abs(t[100] - 0.10) < 1e-12 and abs(t[300] - 0.08) < 1e-12
+    assert abs(t[501] - 0.08) < 1e-12 and t[510] == pytest.approx(0.2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class LatticeGasCalc:
+    """Toy energy backend with the calculators' batch interface: E = sum_ads eps[Z] + J * (# adsorbate pairs closer than
+    r0).  Counts calls so that tests can check the lock-step batching."""
+
+    def __init__(self, n_base, eps, J=0.0, r0=1.5):
+        self.n_base, self.eps, self.J, self.r0 = n_base, eps, J, r0
+        self.calls = 0
+
+    def _energy(self, s):
+        z, x = s.numbers[self.n_base:], s.positions[self.n_base:]
+        e = sum(self.eps[int(k)] for k in z)
+        for i, j in itertools.combinations(range(len(z)), 2):
+            if np.linalg.norm(x[i] - x[j]) < self.r0:
+                e += self.J
+        return e
+
+    def calculate_batch(self, slabs):
+        self.calls += 1
+        return [{"energy": np.array([self._energy(s)])} for s in slabs]
+
+    def relax_batch(self, slabs, fixed_indices=None, relax_steps=20, fmax=0.01):
+        self.calls += 1
+        return [(s.copy(), None, self._energy(s), False, {}) for s in slabs]
+
+
+def _toy(n_chains, n_sites=6, first_chain=0, seed=3, relax=False, **kw):
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[1.0 * s, 0.0, 2.0] for s in range(n_sites)], float)
+    calc = LatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.03)
+    ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), n_chains, calc, seed=seed, first_chain=first_chain, relax=relax,
+                           temperature=0.05, **kw)
+    return ens, calc
+
+
+def test_proposals_follow_the_reference_rule():
+    ens, _ = _toy(4000)
+    rng = np.random.default_rng(0)
+    ens.state.species[:] = rng.integers(0, 3, ens.state.species.shape)   # 0 = Sr, 1 = O, 2 = empty
+    site, end, start, u = ens.propose(step=1)
+    assert ((site >= 0) & (site < 6)).all() and ((end >= 0) & (end <= 2)).all()
+    assert (end != start).all()                           # never the adsorbate already on the site / "None" for empty
+    assert (start == ens.state.species[np.arange(4000), site]).all()
+    # uniform over sites and over the two remaining choices
+    assert np.abs(np.bincount(site, minlength=6) / 4000 - 1 / 6).max() < 0.03
+    for s0 in range(3):
+        sel = start == s0
+        others = [c for c in range(3) if c != s0]
+        frac = (end[sel] == others[0]).mean()
+        assert abs(frac - 0.5) < 0.06
+    assert ((u >= 0) & (u < 1)).all()
+
+
+def test_batched_state_equals_reference_bookkeeping():
+    """Random change sequences: the [B, S] arrays and the reference's per-chain occ / atom-order bookkeeping agree."""
+    ens, _ = _toy(5)
+    B, S = ens.state.species.shape
+    singles = [mc.SiteState(ens.base.numbers.copy(), ens.base.positions.copy(), np.zeros(len(ens.base), np.int64),
+                            np.zeros(S, np.int64), ens.ads_coords) for _ in range(B)]
+    state = ens.state
+    names = ens.adsorbates + ["None"]
+    for step in range(1, 60):
+        site, end, _, _ = ens.propose(step, state)
+        state = ens.apply(state, site, end)
+        singles = [mc.change_site(s, int(site[b]), names[int(end[b])]) for b, s in enumerate(singles)]
+        occ = ens.occ(state)
+        for b in range(B):
+            st = ens.structure(b, state)
+            assert np.array_equal(st.numbers, singles[b].numbers)
+            assert np.allclose(st.positions, singles[b].positions)
+            assert np.array_equal(occ[b], singles[b].occ)
+    assert (ens.num_adsorbates(state) == [np.count_nonzero(s.occ) for s in singles]).all()
+
+
+def test_trajectories_do_not_depend_on_batching_or_sharding():
+    whole, calc_w = _toy(8)
+    lo, _ = _toy(4, first_chain=0)
+    hi, _ = _toy(4, first_chain=4)
+    for ens in (whole, lo, hi):
+        ens.initialize()
+    acc_w = [whole.step_semigrand() for _ in range(40)]
+    acc_l = [lo.step_semigrand() for _ in range(40)]
+    acc_h = [hi.step_semigrand() for _ in range(40)]
+    assert np.array_equal(np.array(acc_w), np.hstack([np.array(acc_l), np.array(acc_h)]))
+    assert np.array_equal(whole.state.species, np.vstack([lo.state.species, hi.state.species]))
+    assert np.allclose(whole.state.energy, np.hstack([lo.state.energy, hi.state.energy]))
+    assert 0 < np.mean(acc_w) < 1
+    assert calc_w.calls == 41                              # one lock-step batched evaluation per MC step (+ the start)
+    # rejected chains keep the energy of the restored "before" state
+    e_check, _ = whole.evaluate(whole.state)
+    assert np.allclose(e_check, whole.state.energy)
+
+
+def test_relaxation_path_uses_relax_batch_and_fixed_atoms():
+    ens, calc = _toy(3, relax=True, fixed_indices=[0, 1], relax_steps=7, fmax=0.02)
+    seen = {}
+    orig = calc.relax_batch
+
+    def spy(slabs, fixed_indices=None, relax_steps=20, fmax=0.01):
+        seen.update(n=len(slabs), fixed=fixed_indices, steps=relax_steps, fmax=fmax)
+        return orig(slabs, fixed_indices, relax_steps, fmax)
+
+    calc.relax_batch = spy
+    ens.initialize()
+    ens.step_semigrand()
+    assert seen["n"] == 3 and seen["steps"] == 7 and seen["fmax"] == 0.02
+    assert all(np.array_equal(f, [0, 1]) for f in seen["fixed"])
+    assert all(r is not None for r in ens.relaxed)
+
+
+def test_detailed_balance_on_a_two_site_lattice_gas():
+    """2 sites, adsorbates {Sr, O}: 9 states with known energies -> visit frequencies follow exp(-E/kT)."""
+    ens, calc = _toy(512, n_sites=2, seed=11)
+    ens.temp = 0.05
+    ens.initialize()
+    for _ in range(150):                                   # burn-in
+        ens.step_semigrand()
+    counts = np.zeros((3, 3))
+    for _ in range(400):
+        ens.step_semigrand()
+        np.add.at(counts, (ens.state.species[:, 0], ens.state.species[:, 1]), 1)
+    freq = counts / counts.sum()
+    Z = structures.ATOMIC_NUMBERS
+    eps = [calc.eps[Z["Sr"]], calc.eps[Z["O"]], 0.0]
+    E = np.array([[eps[a] + eps[b] + (calc.J if a < 2 and b < 2 else 0.0) for b in range(3)] for a in range(3)])
+    boltz = np.exp(-E / ens.temp)
+    boltz /= boltz.sum()
+    assert np.abs(freq - boltz).max() < 0.02, (freq, boltz)
+
+
+def test_run_with_annealing_returns_per_chain_history():
+    ens, _ = _toy(6)
+    hist = ens.run(total_sweeps=3, sweep_size=5, start_temp=0.1, alpha=0.5)
+    assert np.allclose(hist["temperature"], [0.1, 0.05, 0.025])
+    assert len(hist["energy"]) == 3 and hist["energy"][0].shape == (6,)
+    assert ((hist["acceptance_rate"][0] >= 0) & (hist["acceptance_rate"][0] <= 1)).all()
+    assert ens.step_count == 15

@@ -1,0 +1,52 @@
+"""Batched MC step through the real PaiNN calculator on the GPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _site_grid(base, n=4, dz=1.5):
+    ztop = base.positions[:, 2].max()
+    a, b = base.cell[0], base.cell[1]
+    return np.array([(i + 0.5) / n * a + (j + 0.5) / n * b + np.array([0.0, 0.0, ztop + dz - ((i + 0.5) / n * a + (j + 0.5) / n * b)[2]])
+                     for i in range(n) for j in range(n)], float)
+
+
+def test_semigrand_steps_with_device_relaxation(golden):
+    """8 chains, 4 MC steps, every proposed slab relaxed on the device in lock-step: the stored energies are the
+    surface energies of the stored states, rejected chains are restored, two runs give identical trajectories."""
+    from surface_sampling_amd import mc
+    from surface_sampling_amd.calculators import EnsembleNFFSurface
+
+    base = golden.structure("SrTiO3_2x2_pristine")
+    coords = _site_grid(base)
+    fixed = np.flatnonzero(base.positions[:, 2] < base.positions[:, 2].max() - 4.0)   # bulk_idx-like FixAtoms mask
+    runs = []
+    for _ in range(2):
+        calc = EnsembleNFFSurface(golden.blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV",
+                                  offset_units="atomic")
+        calc.set(offset=True, offset_data=golden.offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0})
+        ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 8, calc, seed=5, relax=True, relax_steps=5, fmax=0.05,
+                               fixed_indices=fixed, temperature=0.5)
+        e0 = ens.initialize()
+        assert np.allclose(e0, e0[0]) and np.isfinite(e0).all()          # every chain starts from the pristine slab
+        accepts, states = [], []
+        for _ in range(4):
+            before = ens.state.copy()
+            acc = ens.step_semigrand()
+            accepts.append(acc)
+            states.append(ens.state.species.copy())
+            rej = ~acc
+            assert np.array_equal(ens.state.species[rej], before.species[rej])
+            assert np.array_equal(ens.state.energy[rej], before.energy[rej])
+        e_check, _ = ens.evaluate(ens.state)
+        assert np.allclose(e_check, ens.state.energy, atol=2e-4)          # energy of the kept state, re-relaxed
+        assert ens.n_evaluations == 8 * 6
+        for b in range(8):
+            assert len(ens.relaxed[b]) == len(base) + ens.num_adsorbates()[b]
+            moved = np.abs(ens.relaxed[b].positions[: len(base)][fixed] - base.positions[fixed]).max()
+            assert moved == 0.0                                            # FixAtoms mask honoured
+        runs.append((np.array(accepts), np.array(states), ens.state.energy.copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    assert np.array_equal(runs[0][2], runs[1][2])
+    assert runs[0][0].any()                                                # T = 0.5 eV: something is accepted

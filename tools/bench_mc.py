@@ -1,0 +1,57 @@
+"""Secondary measurement (not the BASELINE metric): batched semigrand MC steps per second, B chains on one GPU, every
+step = propose + change + lock-step device FIRE relaxation (<= relax_steps evaluations) + Metropolis.  Prints one JSON
+line.  Usage: python tools/bench_mc.py [--chains 256] [--steps 5] [--relax-steps 20]"""
+import argparse, json, os, sys, time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (golden loaders)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chains", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--relax-steps", type=int, default=20)
+    args = ap.parse_args()
+    from surface_sampling_amd import mc, structures
+    from surface_sampling_amd.calculators import EnsembleNFFSurface
+
+    blobs, S, offset_data = bench.load_golden()
+    k = "SrTiO3_2x2_pristine"
+    base = structures.Structure(S[f"{k}.numbers"], S[f"{k}.positions"], S[f"{k}.cell"], S[f"{k}.pbc"]).repeat((2, 2, 1))
+    n = 8
+    ztop = base.positions[:, 2].max()
+    coords = []
+    for i in range(n):
+        for j in range(n):
+            p = (i + 0.5) / n * base.cell[0] + (j + 0.5) / n * base.cell[1]
+            coords.append([p[0], p[1], ztop + 1.5])
+    fixed = np.flatnonzero(base.positions[:, 2] < ztop - 4.0)
+    calc = EnsembleNFFSurface(blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV", offset_units="atomic")
+    calc.set(offset=True, offset_data=offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0})
+    ens = mc.ChainEnsemble(base, np.array(coords), ("Sr", "O"), args.chains, calc, seed=1, relax=True,
+                           relax_steps=args.relax_steps, fmax=0.01, fixed_indices=fixed, temperature=0.1)
+    # pre-populate so that chains look like mid-run states (8..32 adsorbates)
+    state = ens.state
+    for s in range(1, 21):
+        site, end, _, _ = ens.propose(10_000 + s, state)
+        state = ens.apply(state, site, end)
+    ens.state = state
+    ens.initialize()
+    t_host = 0.0
+    t0 = time.perf_counter()
+    acc = []
+    for _ in range(args.steps):
+        acc.append(ens.step_semigrand().mean())
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "batched semigrand MC steps/s (all chains advance one Change event incl. FIRE relaxation)",
+                      "chains": args.chains, "atoms_per_chain": int(len(base) + ens.num_adsorbates().mean()),
+                      "relax_steps": args.relax_steps, "mc_steps": args.steps, "s_per_lockstep": dt / args.steps,
+                      "chain_steps_per_s": args.chains * args.steps / dt, "acceptance": float(np.mean(acc))}))
+
+
+if __name__ == "__main__":
+    main()
