@@ -2,8 +2,12 @@
 //
 // The node stages are chains of small dense layers applied to every
 // atom of every chain and ensemble member: genuinely dense GEMMs with M = atoms (x3 Cartesian rows for
-// U/V), K, N in {128, 256, 384}.  They run on v_mfma_f32_32x32x2_f32 (exact fp32, the only fp32-input
-// MFMA rate on gfx950; no xf32 exists).
+// U/V), K, N in {128, 256, 384}.  gfx950 has no fp32-rate-above-vector matrix path (v_mfma_f32_32x32x2_f32 runs at the
+// fp32 vector rate, and measurably conflicts with the VALU; no xf32 exists), so the GEMMs run on the bf16 pipe with
+// fp32-level accuracy: both operands are split exactly into three bf16 pieces (x = h + m + l) and the six partial
+// products >= 2^-16 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (gemm_acc16) -- 6 MFMAs of 32 cycles replace
+// 8 fp32 MFMAs of 64 cycles per K = 16.  Weights are pre-split at vssr_create (pack_mfma_tiles16), activations are split
+// in registers when a fragment is read from its fp32 LDS tile.  -DVSSR_NODE_FP32 selects the fp32 MFMA path (gemm_acc).
 //
 // Structure of every kernel: one workgroup = 4 waves = a tile of 32 atoms of one ensemble member.
 //   * activations (A operand) live in LDS, row-major with a +4 float pad (conflict-free ds_read_b128);
@@ -77,6 +81,113 @@ __device__ __forceinline__ void gemm_acc(const float *__restrict__ lds_a, int ld
     }
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ u32x4 gload4u(const uint4 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const u32x4 __attribute__((address_space(1))) *gptr;
+    return *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
+#else
+    return *reinterpret_cast<const u32x4 *>(p);
+#endif
+}
+
+// Exact 3-way bf16 split of 8 consecutive fp32 values into three MFMA operands (h, m, l pieces, 8 x bf16 each).
+// v_perm_b32 packs the upper halves of two dwords; the residuals x - h and x - h - m are exact in fp32.
+__device__ __forceinline__ void split8(const float4 lo, const float4 hi, u32x4 (&o)[3]) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    float r1[8], r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);
+        r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[0][j] = __builtin_amdgcn_perm(__float_as_uint(x[2 * j + 1]), __float_as_uint(x[2 * j]), 0x07060302u);
+        o[1][j] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * j + 1]), __float_as_uint(r1[2 * j]), 0x07060302u);
+        o[2][j] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * j + 1]), __float_as_uint(r2[2 * j]), 0x07060302u);
+    }
+}
+
+// acc[t][c] += A(rows t*32.., K) * W tile c, bf16-split.  wq[c]: the tile's pieces, [K/16][3][64 lanes] uint4
+// (pack_mfma_tiles16).  Lane (r = lane & 31, half = lane >> 5) supplies row r / column r and k = 16 q + 8 half .. + 7.
+// Issue order (see painn_edge_mfma.hip, MFMA hazard rules): the six partial products of a tile form a dependent
+// accumulator chain, so products are issued in rounds over all independent accumulators; a GEMM with fewer than three
+// tiles gets NACC K-interleaved partial accumulators (summed at the end) so that a chain's producer is always >= 3
+// MFMAs back.  No load is issued inside the MFMA block of a chunk group.
+template <int K, int NRT, int NCT>
+__device__ __forceinline__ void gemm_acc16(const float *__restrict__ lds_a, int ld, const uint4 *const (&wq)[NCT],
+                                           f32x16 (&acc)[NRT][NCT]) {
+    constexpr int NT = NRT * NCT, NACC = NT >= 3 ? 1 : (NT == 2 ? 2 : 4);
+    constexpr int wi[6] = {0, 2, 1, 0, 1, 0}, ri[6] = {2, 0, 1, 1, 0, 0};   // A-piece, W-piece: smallest products first
+    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
+    const float *a_base = lds_a + r * ld + 8 * half;
+    f32x16 part[NACC][NRT][NCT];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int t = 0; t < NRT; ++t)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                if (j == 0) part[0][t][c] = acc[t][c];
+                else
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) part[j][t][c][i] = 0.f;
+            }
+#pragma unroll 1
+    for (int q0 = 0; q0 < K / 16; q0 += NACC) {
+        u32x4 a[NACC][NRT][3], b[NACC][NCT][3];
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+            const int q = q0 + j;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) b[j][c][pc] = gload4u(wq[c] + ((size_t)(q * 3 + pc) * 64 + lane));
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                const float *ap = a_base + t * 32 * ld + 16 * q;
+                split8(*reinterpret_cast<const float4 *>(ap), *reinterpret_cast<const float4 *>(ap + 4), a[j][t]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int j = 0; j < NACC; ++j)
+#pragma unroll
+                for (int t = 0; t < NRT; ++t)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) {
+                        part[j][t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[j][t][wi[k]]), __builtin_bit_cast(bf16x8, b[j][c][ri[k]]),
+                            part[j][t][c], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+    }
+#pragma unroll
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            acc[t][c] = part[0][t][c];
+#pragma unroll
+            for (int j = 1; j < NACC; ++j) acc[t][c] += part[j][t][c];
+        }
+}
+
+// weight-tile pointers of the two paths: tile index and K select the 32-column tile of a packed matrix
+#ifdef VSSR_NODE_FP32
+#define WTILE(name, tile, K) (W.p##name + (size_t)(tile) * 32 * (K))
+#define WPTR const float *
+#define GEMM gemm_acc
+#else
+#define WTILE(name, tile, K) (W.q##name + (size_t)(tile) * 12 * (K))
+#define WPTR const uint4 *
+#define GEMM gemm_acc16
+#endif
+
 template <int NRT, int NCT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NRT][NCT]) {
 #pragma unroll
@@ -122,8 +233,8 @@ k_msg_mlp_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restr
     {
         f32x16 acc[1][1];
         zero_acc(acc);
-        const float *wp[1] = {W.pW1 + (size_t)w * 32 * F};
-        gemm_acc<F, 1, 1>(xs, LDV, wp, acc);
+        WPTR wp[1] = {WTILE(W1, w, F)};
+        GEMM<F, 1, 1>(xs, LDV, wp, acc);
         float b = W.b1[col];
 #pragma unroll
         for (int i = 0; i < 16; ++i) hs[crow(i, half) * LDV + col] = swish(acc[0][0][i] + b);
@@ -131,8 +242,8 @@ k_msg_mlp_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restr
     __syncthreads();
     f32x16 acc[1][3];
     zero_acc(acc);
-    const float *wp[3] = {W.pW2 + (size_t)(w)*32 * F, W.pW2 + (size_t)(4 + w) * 32 * F, W.pW2 + (size_t)(8 + w) * 32 * F};
-    gemm_acc<F, 1, 3>(hs, LDV, wp, acc);
+    WPTR wp[3] = {WTILE(W2, w, F), WTILE(W2, 4 + w, F), WTILE(W2, 8 + w, F)};
+    GEMM<F, 1, 3>(hs, LDV, wp, acc);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float b = W.b2[c * F + col];
@@ -164,10 +275,10 @@ k_msg_mlp_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__r
     zero_acc(h1);
     zero_acc(a1);
     {
-        const float *wp[1] = {W.pW1 + (size_t)w * 32 * F};
-        gemm_acc<F, 1, 1>(xs, LDV, wp, h1);
-        const float *wq[1] = {W.pW2t + (size_t)w * 32 * F3};
-        gemm_acc<F3, 1, 1>(pb, LDQ, wq, a1);
+        WPTR wp[1] = {WTILE(W1, w, F)};
+        GEMM<F, 1, 1>(xs, LDV, wp, h1);
+        WPTR wq[1] = {WTILE(W2t, w, F3)};
+        GEMM<F3, 1, 1>(pb, LDQ, wq, a1);
     }
     __syncthreads();  // everyone is done reading xs
     {
@@ -178,8 +289,8 @@ k_msg_mlp_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__r
     __syncthreads();
     f32x16 acc[1][1];
     zero_acc(acc);
-    const float *wp[1] = {W.pW1t + (size_t)w * 32 * F};
-    gemm_acc<F, 1, 1>(xs, LDV, wp, acc);
+    WPTR wp[1] = {WTILE(W1t, w, F)};
+    GEMM<F, 1, 1>(xs, LDV, wp, acc);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         int a = a0 + crow(i, half);
@@ -206,8 +317,8 @@ __device__ __forceinline__ void update_forward(const LayerW &W, float *lds, int 
     float *vt = lds + OFF_VT, *hs = lds + OFF_HS, *as_ = lds + OFF_AS;
     zero_acc(R.uv);
     {
-        const float *wp[2] = {W.pU + (size_t)w * 32 * F, W.pV + (size_t)w * 32 * F};
-        gemm_acc<F, 3, 2>(vt, LDV, wp, R.uv);
+        WPTR wp[2] = {WTILE(U, w, F), WTILE(V, w, F)};
+        GEMM<F, 3, 2>(vt, LDV, wp, R.uv);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -226,8 +337,8 @@ __device__ __forceinline__ void update_forward(const LayerW &W, float *lds, int 
     {
         f32x16 acc[1][1];
         zero_acc(acc);
-        const float *wp[1] = {W.pW3 + (size_t)w * 32 * 2 * F};
-        gemm_acc<2 * F, 1, 1>(hs, LDH, wp, acc);
+        WPTR wp[1] = {WTILE(W3, w, 2 * F)};
+        GEMM<2 * F, 1, 1>(hs, LDH, wp, acc);
         float b = W.b3[col];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -239,8 +350,8 @@ __device__ __forceinline__ void update_forward(const LayerW &W, float *lds, int 
     {
         f32x16 acc[1][3];
         zero_acc(acc);
-        const float *wp[3] = {W.pW4 + (size_t)(w)*32 * F, W.pW4 + (size_t)(4 + w) * 32 * F, W.pW4 + (size_t)(8 + w) * 32 * F};
-        gemm_acc<F, 1, 3>(as_, LDV, wp, acc);
+        WPTR wp[3] = {WTILE(W4, w, F), WTILE(W4, 4 + w, F), WTILE(W4, 8 + w, F)};
+        GEMM<F, 1, 3>(as_, LDV, wp, acc);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float b = W.b4[c * F + col];
@@ -325,8 +436,8 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     {
         f32x16 acc[1][1];
         zero_acc(acc);
-        const float *wp[1] = {W.pW4t + (size_t)w * 32 * F3};
-        gemm_acc<F3, 1, 1>(qb, LDQ, wp, acc);
+        WPTR wp[1] = {WTILE(W4t, w, F3)};
+        GEMM<F3, 1, 1>(qb, LDQ, wp, acc);
 #pragma unroll
         for (int i = 0; i < 16; ++i) hb[crow(i, half) * LDV + col] = acc[0][0][i] * dswish(R.h3[i]);
     }
@@ -334,8 +445,8 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     f32x16 hbar[1][2];   // [0] = d/d s_msg part, [1] = d/d norm part, both for feature `col`
     zero_acc(hbar);
     {
-        const float *wp[2] = {W.pW3t + (size_t)w * 32 * F, W.pW3t + (size_t)(4 + w) * 32 * F};
-        gemm_acc<F, 1, 2>(hb, LDV, wp, hbar);
+        WPTR wp[2] = {WTILE(W3t, w, F), WTILE(W3t, 4 + w, F)};
+        GEMM<F, 1, 2>(hb, LDV, wp, hbar);
     }
     __syncthreads();   // all waves are done with qb / hb: the whole region becomes the [Ubar | Vbar] tile
     float *ab = lds;     // [3*TA][LDH]: cols [0,F) = Ubar, [F,2F) = Vbar   (24 960 <= 25 216 floats)
@@ -359,8 +470,8 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     f32x16 out[3][1];
     zero_acc(out);
     {
-        const float *wp[1] = {W.pUVt + (size_t)w * 32 * 2 * F};
-        gemm_acc<2 * F, 3, 1>(ab, LDH, wp, out);
+        WPTR wp[1] = {WTILE(UVt, w, 2 * F)};
+        GEMM<2 * F, 3, 1>(ab, LDH, wp, out);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -385,6 +496,38 @@ void pack_mfma_tiles(const float *Wsrc, int rows, int K, float *dst) {
                 for (int t = 0; t < 4; ++t)
                     dst[(((size_t)tile * nq + q) * 64 + lane) * 4 + t] =
                         Wsrc[(size_t)(tile * 32 + (lane & 31)) * K + (lane >> 5) * (K / 2) + 4 * q + t];
+}
+
+// bf16-split fragment order for v_mfma_f32_32x32x16_bf16:
+//   dst[tile][q][piece][lane][j] = piece(W[tile*32 + (lane&31)][16 q + 8 (lane>>5) + 2 j]) | piece(W[..][.. + 1]) << 16
+void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst) {
+    auto split3 = [](float x, unsigned (&p)[3]) {
+        unsigned xb, mb, lb;
+        memcpy(&xb, &x, 4);
+        unsigned hb = xb & 0xFFFF0000u;
+        float hf, mf;
+        memcpy(&hf, &hb, 4);
+        float r1 = x - hf;
+        memcpy(&mb, &r1, 4);
+        mb &= 0xFFFF0000u;
+        memcpy(&mf, &mb, 4);
+        float r2 = r1 - mf;
+        memcpy(&lb, &r2, 4);
+        p[0] = hb >> 16; p[1] = mb >> 16; p[2] = lb >> 16;
+    };
+    const int ntile = rows / 32, nq = K / 16;
+    for (int tile = 0; tile < ntile; ++tile)
+        for (int q = 0; q < nq; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const size_t row = (size_t)tile * 32 + (lane & 31);
+                    const int k = 16 * q + 8 * (lane >> 5) + 2 * j;
+                    unsigned p0[3], p1[3];
+                    split3(Wsrc[row * K + k], p0);
+                    split3(Wsrc[row * K + k + 1], p1);
+                    for (int pc = 0; pc < 3; ++pc)
+                        dst[((((size_t)tile * nq + q) * 3 + pc) * 64 + lane) * 4 + j] = p0[pc] | (p1[pc] << 16);
+                }
 }
 
 size_t node_mfma_lds_bytes(int which) {

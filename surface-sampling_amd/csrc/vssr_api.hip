@@ -92,6 +92,9 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
     if (h->weights.ensure(img.size() * sizeof(float)))
         return set_err(h, VSSR_E_NOMEM, "weights: out of device memory");
     float *dbase = h->weights.as<float>();
+    // bf16-split fragment-order copies of the node-GEMM weights: 22 F^2 elements x 6 B per (model, layer)
+    const size_t node16_per_layer = (size_t)22 * F * F * 3 / 2;   // dwords
+    std::vector<unsigned> node16(node16_per_layer * L * M);
     for (int m = 0; m < M; ++m) {
         float *hb = img.data() + (size_t)m * img_len;
         float *db = dbase + (size_t)m * img_len;
@@ -145,6 +148,15 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
                         uvt[(size_t)g * 2 * F + F + k] = hb[v + (size_t)k * F + g];
                     }
                 pack_mfma_tiles(uvt.data(), F, 2 * F, hb + puvt);
+                // bf16-split copies, same order as the q* pointers are assigned below
+                unsigned *q = node16.data() + ((size_t)m * L + l) * node16_per_layer;
+                auto put16 = [&](const float *src, int rows, int K) {
+                    pack_mfma_tiles16(src, rows, K, q);
+                    q += (size_t)rows * K * 3 / 2;
+                };
+                put16(hb + w1, F, F); put16(hb + w2, F3, F); put16(hb + u, F, F); put16(hb + v, F, F);
+                put16(hb + w3, F, 2 * F); put16(hb + w4, F3, F); put16(hb + w1t, F, F); put16(hb + w2t, F, F3);
+                put16(hb + w4t, F, F3); put16(hb + w3t, 2 * F, F); put16(uvt.data(), F, 2 * F);
             }
             Lw.pW1 = db + pw1; Lw.pW2 = db + pw2; Lw.pU = db + pu; Lw.pV = db + pv; Lw.pW3 = db + pw3;
             Lw.pW4 = db + pw4; Lw.pW1t = db + pw1t; Lw.pW2t = db + pw2t; Lw.pW4t = db + pw4t;
@@ -156,6 +168,19 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
         W.W5 = db + w5; W.W5t = db + w5t; W.b5 = db + b5; W.w6 = db + w6; W.b6 = db + b6;
     }
     VSSR_HIP(h, hipMemcpy(dbase, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    {   // node-GEMM weights as bf16 pieces (painn_node_mfma.hip)
+        if (h->node16.ensure(node16.size() * sizeof(unsigned))) return set_err(h, VSSR_E_NOMEM, "split node weights");
+        VSSR_HIP(h, hipMemcpy(h->node16.p, node16.data(), node16.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        for (int m = 0; m < M; ++m)
+            for (int l = 0; l < L; ++l) {
+                LayerW &Lw = table[m].layer[l];
+                const uint4 *q = h->node16.as<uint4>() + ((size_t)m * L + l) * node16_per_layer / 4;
+                auto next = [&](int rows, int K) { const uint4 *r = q; q += (size_t)rows * K * 3 / 8; return r; };
+                Lw.qW1 = next(F, F); Lw.qW2 = next(F3, F); Lw.qU = next(F, F); Lw.qV = next(F, F);
+                Lw.qW3 = next(F, 2 * F); Lw.qW4 = next(F3, F); Lw.qW1t = next(F, F); Lw.qW2t = next(F, F3);
+                Lw.qW4t = next(F, F3); Lw.qW3t = next(2 * F, F); Lw.qUVt = next(F, 2 * F);
+            }
+    }
     {   // radial-filter weights split into bf16 pieces in MFMA operand order (painn_edge_mfma.hip), per model / layer
         const size_t per_layer16 = (size_t)F3 * 4 * 12;   // dwords
         std::vector<unsigned> w16(per_layer16 * L * M);
@@ -342,7 +367,7 @@ void vssr_destroy(vssr_handle *h) {
     h->prof.destroy();
     DevBuf *bufs[] = {&h->weights, &h->model_table, &h->offset_per_z, &h->ters_params, &h->d_pos, &h->d_wpos,
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
-                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->wd16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv,
+                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->wd16, &h->node16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
                       &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f};
     for (DevBuf *b : bufs) b->release();
