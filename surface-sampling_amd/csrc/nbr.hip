@@ -198,30 +198,27 @@ k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
 // stored in the order the MFMA operand wants them: table[slot][kq][ks] = rho_{kq + 4 ks}  (kq = lane >> 4, ks < 5);
 // entry ks = 5 of every quarter holds the envelope fc (resp. its derivative).
 // One thread per (slot, kq).  sin/cos of the multiples come from one sincos + a rotation recurrence.
-// Exact 3-way bf16 split by truncation: x = h + m + l with h, m, l representable in bf16 (the residuals x - h and
-// x - h - m are exact in fp32).  Returns the three 16-bit patterns.
-__device__ __forceinline__ void split3_bf16(float x, unsigned &h, unsigned &m, unsigned &l) {
-    const unsigned xb = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(xb);
-    const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(mb);
-    h = xb >> 16; m = mb >> 16; l = __float_as_uint(r2) >> 16;
-}
-// Operand-ready record of one (slot, quarter) for v_mfma_f32_16x16x32_bf16.  The quarter contributes 8 of the 32 K
+// Operand-ready record of one (slot, quarter) for v_mfma_f32_16x16x32_f16.  The quarter contributes 8 of the 32 K
 // entries of the filter contraction: its 5 radial values (k = kq + 4 kk), the envelope fc (partner of the bias column,
-// which the weight side carries in quarter 0 only) and two zeros.  Each bf16 piece of those 8 entries is one complete
-// MFMA operand (8 x bf16 = 16 B), stored as H | M | L (48 bytes): the edge kernels issue the six partial products
-// Wh.H + Wh.M + Wm.H + Wm.M + Wh.L + Wl.H (everything >= 2^-16 relative: fp32-level accuracy) straight from the loaded
-// registers -- no operand assembly, no separate bias multiply.
-__device__ __forceinline__ void write_b16_record(const float (&v)[5], float env, uint4 *__restrict__ rec) {
-    unsigned h[6], m[6], l[6];
+// which the weight side carries in quarter 0 only) and two zeros.  Every value is split into two fp16 pieces
+// x = h + l (h = fp16(x), l = fp16(x - h); 22 mantissa bits, fp16 subnormals are honoured by the matrix core --
+// tools/micro/mfma_f16_denorm.hip); each piece of the 8 entries is one complete 16-byte MFMA operand, stored H | L
+// (32 bytes).  The edge kernels issue Wh.L + Wl.H + Wh.H: the dropped product is 2^-22 relative, and measured against
+// fp64 the 3-product result is as accurate as a plain fp32 dot product (max 2.0e-7 vs 1.9e-7 on the real weights).
+__device__ __forceinline__ void split2_f16(float x, unsigned &h, unsigned &l) {
+    const _Float16 hh = (_Float16)x;
+    const _Float16 ll = (_Float16)(x - (float)hh);
+    h = __builtin_bit_cast(unsigned short, hh);
+    l = __builtin_bit_cast(unsigned short, ll);
+}
+__device__ __forceinline__ void write_f16_record(const float (&v)[5], float env, uint4 *__restrict__ rec) {
+    unsigned h[6], l[6];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) split3_bf16(v[k], h[k], m[k], l[k]);
-    split3_bf16(env, h[5], m[5], l[5]);
+    for (int k = 0; k < 5; ++k) split2_f16(v[k], h[k], l[k]);
+    split2_f16(env, h[5], l[5]);
     auto pk = [](unsigned lo, unsigned hi) { return lo | (hi << 16); };
     rec[0] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), 0u);
-    rec[1] = make_uint4(pk(m[0], m[1]), pk(m[2], m[3]), pk(m[4], m[5]), 0u);
-    rec[2] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), 0u);
+    rec[1] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), 0u);
 }
 
 __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
@@ -264,8 +261,8 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
         }
         {
             const float rv[5] = {r[0], r[1], r[2], r[3], r[4]}, dv[5] = {dr[0], dr[1], dr[2], dr[3], dr[4]};
-            write_b16_record(rv, fc, rho16 + ((size_t)slot * 4 + kq) * 3);
-            write_b16_record(dv, dfc, drho16 + ((size_t)slot * 4 + kq) * 3);
+            write_f16_record(rv, fc, rho16 + ((size_t)slot * 4 + kq) * 2);
+            write_f16_record(dv, dfc, drho16 + ((size_t)slot * 4 + kq) * 2);
         }
         r[5] = fc;      // envelope (bias column) replicated in every quarter: the edge kernels fold bd * fc into the
         dr[5] = dfc;    // accumulator init instead of spending a sixth MFMA k-step on it
@@ -312,14 +309,14 @@ int build_neighbors(vssr_handle *h, double cutoff) {
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
         if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
             h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float2) * h->slot_cap) ||
-            h->d_rho16.ensure(sizeof(uint4) * 12 * h->slot_cap) || h->d_drho16.ensure(sizeof(uint4) * 12 * h->slot_cap))
+            h->d_rho16.ensure(sizeof(uint4) * 8 * h->slot_cap) || h->d_drho16.ensure(sizeof(uint4) * 8 * h->slot_cap))
             return set_err(h, VSSR_E_NOMEM, "edge geometry tables: out of device memory");
         // the last slot of the capacity is never used by the CSR (counters[2] flags slots > cap - 64): it is the
         // all-zero table entry that exhausted lanes of the edge kernels read
         VSSR_HIP(h, hipMemsetAsync(h->d_rho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
         VSSR_HIP(h, hipMemsetAsync(h->d_drho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
-        VSSR_HIP(h, hipMemsetAsync(h->d_rho16.as<uint4>() + 12 * (size_t)(h->slot_cap - 1), 0, 12 * sizeof(uint4), st));
-        VSSR_HIP(h, hipMemsetAsync(h->d_drho16.as<uint4>() + 12 * (size_t)(h->slot_cap - 1), 0, 12 * sizeof(uint4), st));
+        VSSR_HIP(h, hipMemsetAsync(h->d_rho16.as<uint4>() + 8 * (size_t)(h->slot_cap - 1), 0, 8 * sizeof(uint4), st));
+        VSSR_HIP(h, hipMemsetAsync(h->d_drho16.as<uint4>() + 8 * (size_t)(h->slot_cap - 1), 0, 8 * sizeof(uint4), st));
         hipLaunchKernelGGL(k_edge_geom, dim3(n), dim3(64), 0, st, n, h->d_row_start.as<int>(), h->d_atom_cfg.as<int>(),
                            h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,
                            h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),

@@ -22,19 +22,19 @@
 namespace vssr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// ---- radial filter on the bf16 matrix pipe with fp32-level accuracy --------------------------------------------------
-// fp32 MFMA shares the FP32 datapath with the VALU (measured: MFMA cycles and instruction-issue cycles add up), the
-// bf16 MFMA does not.  Both operands are split exactly into three bf16 pieces x = h + m + l (truncation; residuals are
-// exact in fp32) and the six products with weight >= 2^-16 are kept:  Wh rh + Wh rm + Wm rh + Wm rm + Wh rl + Wl rh ;
-// the dropped ones are <= 2^-24 relative, i.e. fp32 rounding level.  The K = 32 entries of one
-// v_mfma_f32_16x16x32_bf16 are, per lane quarter kq: the 5 radial indices k = kq + 4 kk, the bias column (weights: bd in
-// quarter 0, zero elsewhere; rho side: the envelope fc) and two zeros.  Every piece is a complete 16-byte operand, so a
-// tile costs six matrix-pipe instructions fed directly from loaded registers.  Pieces of rho are pre-split once per
-// evaluation (k_edge_geom, nbr.hip), pieces of the weights once per handle (build_wd16): nothing is split, shuffled or
-// bias-multiplied in the hot loop.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one MFMA operand: 8 x bf16
+// ---- radial filter on the matrix pipe with fp32-level accuracy -----------------------------------------------------------
+// fp32 MFMA shares the FP32 datapath with the VALU (measured: worse than additive), the 16-bit MFMAs do not.  Both
+// operands are split into two fp16 pieces x = h + l (22 mantissa bits) and three products are kept, Wh rl + Wl rh + Wh rh;
+// the dropped Wl rl is 2^-22 relative.  Measured on the real weights against fp64 this is as accurate as a plain fp32 dot
+// product (nbr.hip).  The K = 32 entries of one v_mfma_f32_16x16x32_f16 are, per lane quarter kq: the 5 radial indices
+// k = kq + 4 kk, the bias column (weights: bd in quarter 0, zero elsewhere; rho side: the envelope fc) and two zeros.
+// Every piece is a complete 16-byte operand, so a tile costs three matrix-pipe instructions fed directly from loaded
+// registers.  Pieces of rho are pre-split once per evaluation (k_edge_geom, nbr.hip), pieces of the weights once per
+// handle (build_wd16): nothing is split, shuffled or bias-multiplied in the hot loop.  (An exact 3-way bf16 split with
+// six products was used first: same accuracy, twice the matrix work and 1.5x the table bytes.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one MFMA operand: 8 x fp16
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Ordering rule for these kernels (found the hard way, tools/gpu_stress.py): between the first MFMA of a step and the
 // first VALU consumer of the final accumulators NO load -- global or LDS -- may be issued.  Dependent MFMAs wait queued
@@ -46,8 +46,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one MFMA operan
 // tools/check_mfma_loads.py verifies the emitted ISA.
 // Loads written before the MFMAs must also be ISSUED before them: a memory-clobbering asm that the MFMA operands pass
 // through -- loads cannot sink below it, MFMAs cannot rise above it.
-__device__ __forceinline__ void mfma_pre_fence(u32x4 &a, u32x4 &b, u32x4 &c) {
-    asm volatile("; mfma_pre_fence" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
+__device__ __forceinline__ void mfma_pre_fence(u32x4 &a, u32x4 &b) {
+    asm volatile("; mfma_pre_fence" : "+v"(a), "+v"(b) : : "memory");
 }
 __device__ __forceinline__ void mfma_load_fence(int &index, float &a, float &b, float &c) {
     asm volatile("; mfma_load_fence" : "+v"(index), "+v"(a), "+v"(b), "+v"(c));
@@ -57,10 +57,10 @@ __device__ __forceinline__ void mfma_load_fence(int &index, float &a, float &b, 
 }
 
 // D += W . rho for one 16 x 16 tile: six partial products, smallest first
-__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 acc) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
-// Filter tiles of one step.  The six partial products of a tile form a dependent accumulator chain, and dependent MFMAs
+// Filter tiles of one step.  The three partial products of a tile form a dependent accumulator chain, and dependent MFMAs
 // issued back to back stall INSIDE the matrix pipe: everything queued behind them reads its source registers much later
 // than the compiler's wait-state model assumes, while the compiler already reuses those registers (observed: VALU and
 // LDS writes into MFMA sources a few wait states after issue -> wrong forces).  So the products are issued in rounds
@@ -69,52 +69,43 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 acc) {
 // the issue order (without them the scheduler re-serialises the chains to save registers, or ends one round and starts
 // the next on the same tile).
 template <int NT>
-__device__ __forceinline__ void filter_tiles(const u32x4 (*const (&w)[NT])[3], const u32x4 (*const (&r)[NT])[3], f32x4 (&acc)[NT]) {
-    constexpr int wi[6] = {0, 2, 1, 0, 1, 0}, ri[6] = {2, 0, 1, 1, 0, 0};   // Wh rl, Wl rh, Wm rm, Wh rm, Wm rh, Wh rh
+__device__ __forceinline__ void filter_tiles(const u32x4 (*const (&w)[NT])[2], const u32x4 (*const (&r)[NT])[2], f32x4 (&acc)[NT]) {
+    constexpr int wi[3] = {0, 1, 0}, ri[3] = {1, 0, 0};   // Wh rl, Wl rh, Wh rh
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 3; ++k) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            acc[t] = mfma_bf16((*w[t])[wi[k]], (*r[t])[ri[k]], acc[t]);
+            acc[t] = mfma_f16((*w[t])[wi[k]], (*r[t])[ri[k]], acc[t]);
             if (NT < 3) asm volatile("s_nop 7");   // two tiles (layer-0 fallback path): keep the chain producer 2 MFMAs + 16 wait states back
             __builtin_amdgcn_sched_barrier(0);       // fixed tile order inside the round as well
         }
     }
 }
 
-// host: weight pieces in A-operand order.  dst[row][kq][piece h, m, l][4 dwords]: entries 0..4 = W[row][kq + 4 kk],
-// entry 5 = bd[row] in quarter 0 (pairs with the envelope entry written by write_b16_record, nbr.hip), rest zero.
+// host: weight pieces in A-operand order.  dst[row][kq][piece h, l][4 dwords]: entries 0..4 = W[row][kq + 4 kk],
+// entry 5 = bd[row] in quarter 0 (pairs with the envelope entry written by write_f16_record, nbr.hip), rest zero.
 void build_wd16(const float *Wd, const float *bd, unsigned *dst) {
-    auto split3 = [](float x, unsigned (&p)[3]) {
-        unsigned xb;
-        memcpy(&xb, &x, 4);
-        xb &= 0xFFFF0000u;
-        float hf;
-        memcpy(&hf, &xb, 4);
-        float r1 = x - hf;
-        unsigned mb;
-        memcpy(&mb, &r1, 4);
-        mb &= 0xFFFF0000u;
-        float mf;
-        memcpy(&mf, &mb, 4);
-        float r2 = r1 - mf;
-        unsigned lb;
-        memcpy(&lb, &r2, 4);
-        p[0] = xb >> 16; p[1] = mb >> 16; p[2] = lb >> 16;
+    auto split2 = [](float x, unsigned (&p)[2]) {
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        unsigned short hb, lb;
+        memcpy(&hb, &h, 2);
+        memcpy(&lb, &l, 2);
+        p[0] = hb; p[1] = lb;
     };
     for (int row = 0; row < F3; ++row)
         for (int kq = 0; kq < 4; ++kq) {
-            unsigned half[3][8] = {};
+            unsigned half[2][8] = {};
             for (int t = 0; t < 6; ++t) {
                 if (t == 5 && kq != 0) continue;
-                unsigned p3[3];
-                split3(t < 5 ? Wd[(size_t)row * 20 + kq + 4 * t] : bd[row], p3);
-                for (int pc = 0; pc < 3; ++pc) half[pc][t] = p3[pc];
+                unsigned p2[2];
+                split2(t < 5 ? Wd[(size_t)row * 20 + kq + 4 * t] : bd[row], p2);
+                for (int pc = 0; pc < 2; ++pc) half[pc][t] = p2[pc];
             }
-            unsigned *o = dst + ((size_t)row * 4 + kq) * 12;
-            for (int pc = 0; pc < 3; ++pc)
+            unsigned *o = dst + ((size_t)row * 4 + kq) * 8;
+            for (int pc = 0; pc < 2; ++pc)
                 for (int q = 0; q < 4; ++q) o[pc * 4 + q] = half[pc][2 * q] | (half[pc][2 * q + 1] << 16);
         }
 }
@@ -220,15 +211,15 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int nstreams = (EDGE_THREADS / 64) * 4;
     // ---- A operand: Wd_ext[section row = feature (lane & 15)][k = 4 ks + (lane >> 4)] ---------------------------
     const LayerW &W = MW[m].layer[l];
-    // A operand: bf16 pieces (h, m, l) of the filter weights of feature row p, quarter fq: 3 x 16 B per section, bias
+    // A operand: fp16 pieces (h, l) of the filter weights of feature row p, quarter fq: 2 x 16 B per section, bias
     // column included (build_wd16)
-    u32x4 wA[LY::NSEC][3];
+    u32x4 wA[LY::NSEC][2];
 #pragma unroll
     for (int s = 0; s < LY::NSEC; ++s) {
         const int row = s * F + fs * FS + p;
-        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 3;
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 2;
 #pragma unroll
-        for (int i3 = 0; i3 < 3; ++i3) wA[s][i3] = wsrc[i3];
+        for (int i3 = 0; i3 < 2; ++i3) wA[s][i3] = wsrc[i3];
     }
 
     // ---- every stream walks a contiguous run of CSR slots, cut at centre boundaries, ~equal slot counts ---------
@@ -253,19 +244,19 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int fcol = fs * FS + 4 * fq;            // first of this lane's 4 global feature columns
 
     // table entry of this lane's slot; exhausted streams read the reserved all-zero entry (filter = 0)
-    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 3;
+    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 2;
     const float4 *erec = G.erec;
     const int last_slot = max(rs[Nc] - 1, 0);     // records are always read from inside the chain (finite values)
 
     // rho pieces of the current step (single buffer: the next step's loads are issued right after the MFMAs that read
     // them and complete during the message arithmetic); unit vector / neighbor id double-buffered
-    u32x4 rq[3];
+    u32x4 rq[2];
     float4 er[2];
     {
         const int sl = pos + e;
         const size_t tsl = pos < stream_end ? sl : zero_slot;
-        const u32x4 *rp = rho_lane + tsl * 12;
-        rq[0] = rp[0]; rq[1] = rp[1]; rq[2] = rp[2];
+        const u32x4 *rp = rho_lane + tsl * 8;
+        rq[0] = rp[0]; rq[1] = rp[1];
         er[0] = erec[min(sl, last_slot)];
     }
 
@@ -314,11 +305,11 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                     tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
                 }
             }
-            mfma_pre_fence(rq[0], rq[1], rq[2]);   // gathers are issued before the first MFMA
+            mfma_pre_fence(rq[0], rq[1]);   // gathers are issued before the first MFMA
             // ---- filter GEMM  D[feature][slot] = Wd_ext[feature][k] rho[k][slot]  (bias . fc included) ---------------
             f32x4 acc[LY::NSEC];
             {
-                const u32x4 (*wp[LY::NSEC])[3], (*rp3[LY::NSEC])[3];
+                const u32x4 (*wp[LY::NSEC])[2], (*rp3[LY::NSEC])[2];
 #pragma unroll
                 for (int s2 = 0; s2 < LY::NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq; }
                 filter_tiles<LY::NSEC>(wp, rp3, acc);
@@ -342,8 +333,8 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             mfma_load_fence(nsl, ds[0], dvx[0], dvy[0]);
             {
                 const size_t tsl = pos + 4 < stream_end ? nsl : zero_slot;
-                const u32x4 *rp = rho_lane + tsl * 12;
-                rq[0] = rp[0]; rq[1] = rp[1]; rq[2] = rp[2];
+                const u32x4 *rp = rho_lane + tsl * 8;
+                rq[0] = rp[0]; rq[1] = rp[1];
                 er[ph ^ 1] = erec[min(nsl, last_slot)];
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -415,8 +406,8 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
     const int last_slot = max(rs[Nc] - 1, 0);
     const LayerW &W = MW[m].layer[l];
     float4 *gb = gbar + (size_t)(m * n_groups + sg) * gbar_stride;
-    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 3;
-    const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 3;
+    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 2;
+    const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 2;
 
     for (int si = 0; si < SLICES_PER_WG; ++si) {
         const int fs = sg * SLICES_PER_WG + si;
@@ -448,13 +439,13 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
             }
         }
         // ---- A operand: Wd_ext rows of this slice ------------------------------------------------------------------
-        u32x4 wA[NSEC][3];   // bf16 pieces (h, m, l) of the slice's filter rows, bias column included (build_wd16)
+        u32x4 wA[NSEC][2];   // fp16 pieces (h, l) of the slice's filter rows, bias column included (build_wd16)
 #pragma unroll
         for (int s2 = 0; s2 < NSEC; ++s2) {
             const int row = s2 * F + fs * FS + p;
-            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 3;
+            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 2;
 #pragma unroll
-            for (int i3 = 0; i3 < 3; ++i3) wA[s2][i3] = wsrc[i3];
+            for (int i3 = 0; i3 < 2; ++i3) wA[s2][i3] = wsrc[i3];
         }
         __syncthreads();
 
@@ -523,14 +514,14 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
         // table entries of this lane's slot; exhausted streams read the all-zero entry.  rho / drho pieces are single
         // buffered (the next step's loads are issued right after the MFMAs that consume them), the small records
         // (unit vector + neighbor id, distance) are double buffered.
-        u32x4 rq[3], dq[3];
+        u32x4 rq[2], dq[2];
         float4 er[2];
         float2 dd[2];
         auto fetch_tables = [&](int quad) {
-            const size_t off = (size_t)(quad < stream_end ? quad + e : zero_slot) * 12;
+            const size_t off = (size_t)(quad < stream_end ? quad + e : zero_slot) * 8;
             const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
-            rq[0] = rp[0]; rq[1] = rp[1]; rq[2] = rp[2];
-            dq[0] = dp[0]; dq[1] = dp[1]; dq[2] = dp[2];
+            rq[0] = rp[0]; rq[1] = rp[1];
+            dq[0] = dp[0]; dq[1] = dp[1];
         };
         auto fetch_rec = [&](int quad, int buf) {
             const int sl = min(quad + e, last_slot);
@@ -558,12 +549,12 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                         tb[4 * q] = t4.x; tb[4 * q + 1] = t4.y; tb[4 * q + 2] = t4.z; tb[4 * q + 3] = t4.w;
                     }
                 }
-                mfma_pre_fence(rq[0], rq[1], rq[2]);   // gathers are issued before the first MFMA
-                mfma_pre_fence(dq[0], dq[1], dq[2]);
+                mfma_pre_fence(rq[0], rq[1]);   // gathers are issued before the first MFMA
+                mfma_pre_fence(dq[0], dq[1]);
                 // filter and its radial derivative for this lane's slot and 4 features (bias . fc / bias . fc' included)
                 f32x4 awd[2 * NSEC];   // tiles [0, NSEC): filter w, [NSEC, 2 NSEC): radial derivative dw
                 {
-                    const u32x4 (*wp[2 * NSEC])[3], (*rp3[2 * NSEC])[3];
+                    const u32x4 (*wp[2 * NSEC])[2], (*rp3[2 * NSEC])[2];
 #pragma unroll
                     for (int s2 = 0; s2 < NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq; wp[NSEC + s2] = &wA[s2]; rp3[NSEC + s2] = &dq; }
                     filter_tiles<2 * NSEC>(wp, rp3, awd);

@@ -182,7 +182,7 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
             }
     }
     {   // radial-filter weights split into bf16 pieces in MFMA operand order (painn_edge_mfma.hip), per model / layer
-        const size_t per_layer16 = (size_t)F3 * 4 * 12;   // dwords
+        const size_t per_layer16 = (size_t)F3 * 4 * 8;   // dwords
         std::vector<unsigned> w16(per_layer16 * L * M);
         for (int m = 0; m < M; ++m) {
             const float *hb = img.data() + (size_t)m * img_len;

@@ -39,7 +39,7 @@ struct LayerW {
     const float *pUVt;           //           [U;V]^T (4 tiles, K=2F)
     // the same eleven matrices as 3-way bf16 pieces in v_mfma_f32_32x32x16_bf16 B-fragment order (pack_mfma_tiles16)
     const uint4 *qW1, *qW2, *qU, *qV, *qW3, *qW4, *qW1t, *qW2t, *qW4t, *qW3t, *qUVt;
-    const uint4 *wd16;           // radial-filter weights, 3-way bf16 split in MFMA A-operand order: [3F rows][4 quarters][h, m, l]
+    const uint4 *wd16;           // radial-filter weights, 2-way fp16 split in MFMA A-operand order: [3F rows][4 quarters][h, l]
 };
 struct ModelW {
     const float *embed;  // [n_embed][F]
@@ -60,7 +60,7 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const float4 *erec;      // [slots] {u_x, u_y, u_z, bitcast(j local to its chain)} ; pads: u = 0, j = 0
     const float *rho;        // [slots][4][6]  radial basis * envelope in MFMA A-fragment order: [kq][ks] = rho_{kq+4ks}
     const float *drho;       // [slots][4][6]  d rho / d d, same order
-    const uint4 *rho16;      // [slots][4][3] operand-ready 3-way bf16 split of rho (48 B per (slot, quarter)), see nbr.hip
+    const uint4 *rho16;      // [slots][4][2] operand-ready 2-way fp16 split of rho (32 B per (slot, quarter)), see nbr.hip
     const uint4 *drho16;     // same for d rho / d d
     const float2 *dist2;     // [slots] {1 / edge length (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
 };
@@ -235,7 +235,7 @@ void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zer
                             float *sbar_msg, float *vbar_msg);
 // layer-0 species factorisation (painn_l0.hip)
 void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst /*[rows/32][K/16][3][64][4]*/);
-void build_wd16(const float *Wd, const float *bd, unsigned *dst /*[3F][4][3][4]*/);
+void build_wd16(const float *Wd, const float *bd, unsigned *dst /*[3F][4][2][4]*/);
 void l0_build_tables(const float *blob_embed, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *Wd, const float *bd, int n_embed, float *A, float *At);
 int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_msg);
