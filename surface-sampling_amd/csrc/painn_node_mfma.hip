@@ -3,11 +3,13 @@
 // The node stages are chains of small dense layers applied to every
 // atom of every chain and ensemble member: genuinely dense GEMMs with M = atoms (x3 Cartesian rows for
 // U/V), K, N in {128, 256, 384}.  gfx950 has no fp32-rate-above-vector matrix path (v_mfma_f32_32x32x2_f32 runs at the
-// fp32 vector rate, and measurably conflicts with the VALU; no xf32 exists), so the GEMMs run on the bf16 pipe with
-// fp32-level accuracy: both operands are split exactly into three bf16 pieces (x = h + m + l) and the six partial
-// products >= 2^-16 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (gemm_acc16) -- 6 MFMAs of 32 cycles replace
-// 8 fp32 MFMAs of 64 cycles per K = 16.  Weights are pre-split at vssr_create (pack_mfma_tiles16), activations are split
-// in registers when a fragment is read from its fp32 LDS tile.  -DVSSR_NODE_FP32 selects the fp32 MFMA path (gemm_acc).
+// fp32 vector rate, and measurably conflicts with the VALU; no xf32 exists), so the GEMMs run on the 16-bit matrix pipe
+// with fp32-level accuracy: both operands are split into two fp16 pieces x = h + l (h = fp16(x), l = fp16(x - h): 22
+// mantissa bits; fp16 subnormals are honoured by the matrix core) and the three products a_h w_l + a_l w_h + a_h w_h are
+// accumulated in fp32 on v_mfma_f32_32x32x16_f16 (gemm_acc16) -- 3 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles
+// per K = 16.  Weights are pre-split at vssr_create (pack_mfma_tiles16), activations are split in registers when a
+// fragment is read from its fp32 LDS tile (clamped to the fp16 range first: measured activations / adjoints of the
+// SrTiO3 models peak at ~160, tools/gpu_ranges.py).  -DVSSR_NODE_FP32 selects the fp32 MFMA path (gemm_acc).
 //
 // Structure of every kernel: one workgroup = 4 waves = a tile of 32 atoms of one ensemble member.
 //   * activations (A operand) live in LDS, row-major with a +4 float pad (conflict-free ds_read_b128);
@@ -82,7 +84,9 @@ __device__ __forceinline__ void gemm_acc(const float *__restrict__ lds_a, int ld
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u32x4 gload4u(const uint4 *p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -93,27 +97,23 @@ __device__ __forceinline__ u32x4 gload4u(const uint4 *p) {
 #endif
 }
 
-// Exact 3-way bf16 split of 8 consecutive fp32 values into three MFMA operands (h, m, l pieces, 8 x bf16 each).
-// v_perm_b32 packs the upper halves of two dwords; the residuals x - h and x - h - m are exact in fp32.
-__device__ __forceinline__ void split8(const float4 lo, const float4 hi, u32x4 (&o)[3]) {
+// 2-way fp16 split of 8 consecutive fp32 values into two MFMA operands (h and l pieces, 8 x fp16 each)
+__device__ __forceinline__ void split8(const float4 lo, const float4 hi, u32x4 (&o)[2]) {
     const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    float r1[8], r2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);
-        r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        o[0][j] = __builtin_amdgcn_perm(__float_as_uint(x[2 * j + 1]), __float_as_uint(x[2 * j]), 0x07060302u);
-        o[1][j] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * j + 1]), __float_as_uint(r1[2 * j]), 0x07060302u);
-        o[2][j] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * j + 1]), __float_as_uint(r2[2 * j]), 0x07060302u);
+        const f32x2 xc = {__builtin_amdgcn_fmed3f(x[2 * j], -65504.f, 65504.f),
+                          __builtin_amdgcn_fmed3f(x[2 * j + 1], -65504.f, 65504.f)};
+        const f16x2 h = __builtin_convertvector(xc, f16x2);
+        const f16x2 l = __builtin_convertvector(xc - __builtin_convertvector(h, f32x2), f16x2);
+        o[0][j] = __builtin_bit_cast(unsigned, h);
+        o[1][j] = __builtin_bit_cast(unsigned, l);
     }
 }
 
-// acc[t][c] += A(rows t*32.., K) * W tile c, bf16-split.  wq[c]: the tile's pieces, [K/16][3][64 lanes] uint4
+// acc[t][c] += A(rows t*32.., K) * W tile c, fp16-split.  wq[c]: the tile's pieces, [K/16][2][64 lanes] uint4
 // (pack_mfma_tiles16).  Lane (r = lane & 31, half = lane >> 5) supplies row r / column r and k = 16 q + 8 half .. + 7.
-// Issue order (see painn_edge_mfma.hip, MFMA hazard rules): the six partial products of a tile form a dependent
+// Issue order (see painn_edge_mfma.hip, MFMA hazard rules): the three partial products of a tile form a dependent
 // accumulator chain, so products are issued in rounds over all independent accumulators; a GEMM with fewer than three
 // tiles gets NACC K-interleaved partial accumulators (summed at the end) so that a chain's producer is always >= 3
 // MFMAs back.  No load is issued inside the MFMA block of a chunk group.
@@ -121,7 +121,7 @@ template <int K, int NRT, int NCT>
 __device__ __forceinline__ void gemm_acc16(const float *__restrict__ lds_a, int ld, const uint4 *const (&wq)[NCT],
                                            f32x16 (&acc)[NRT][NCT]) {
     constexpr int NT = NRT * NCT, NACC = NT >= 3 ? 1 : (NT == 2 ? 2 : 4);
-    constexpr int wi[6] = {0, 2, 1, 0, 1, 0}, ri[6] = {2, 0, 1, 1, 0, 0};   // A-piece, W-piece: smallest products first
+    constexpr int wi[3] = {0, 1, 0}, ri[3] = {1, 0, 0};   // A-piece, W-piece: a_h w_l, a_l w_h, a_h w_h
     const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
     const float *a_base = lds_a + r * ld + 8 * half;
     f32x16 part[NACC][NRT][NCT];
@@ -138,14 +138,14 @@ __device__ __forceinline__ void gemm_acc16(const float *__restrict__ lds_a, int 
             }
 #pragma unroll 1
     for (int q0 = 0; q0 < K / 16; q0 += NACC) {
-        u32x4 a[NACC][NRT][3], b[NACC][NCT][3];
+        u32x4 a[NACC][NRT][2], b[NACC][NCT][2];
 #pragma unroll
         for (int j = 0; j < NACC; ++j) {
             const int q = q0 + j;
 #pragma unroll
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) b[j][c][pc] = gload4u(wq[c] + ((size_t)(q * 3 + pc) * 64 + lane));
+                for (int pc = 0; pc < 2; ++pc) b[j][c][pc] = gload4u(wq[c] + ((size_t)(q * 2 + pc) * 64 + lane));
 #pragma unroll
             for (int t = 0; t < NRT; ++t) {
                 const float *ap = a_base + t * 32 * ld + 16 * q;
@@ -154,15 +154,15 @@ __device__ __forceinline__ void gemm_acc16(const float *__restrict__ lds_a, int 
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int j = 0; j < NACC; ++j)
 #pragma unroll
                 for (int t = 0; t < NRT; ++t)
 #pragma unroll
                     for (int c = 0; c < NCT; ++c) {
-                        part[j][t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, a[j][t][wi[k]]), __builtin_bit_cast(bf16x8, b[j][c][ri[k]]),
+                        part[j][t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, a[j][t][wi[k]]), __builtin_bit_cast(f16x8, b[j][c][ri[k]]),
                             part[j][t][c], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -183,7 +183,7 @@ __device__ __forceinline__ void gemm_acc16(const float *__restrict__ lds_a, int 
 #define WPTR const float *
 #define GEMM gemm_acc
 #else
-#define WTILE(name, tile, K) (W.q##name + (size_t)(tile) * 12 * (K))
+#define WTILE(name, tile, K) (W.q##name + (size_t)(tile) * 8 * (K))
 #define WPTR const uint4 *
 #define GEMM gemm_acc16
 #endif
@@ -498,22 +498,16 @@ void pack_mfma_tiles(const float *Wsrc, int rows, int K, float *dst) {
                         Wsrc[(size_t)(tile * 32 + (lane & 31)) * K + (lane >> 5) * (K / 2) + 4 * q + t];
 }
 
-// bf16-split fragment order for v_mfma_f32_32x32x16_bf16:
+// fp16-split fragment order for v_mfma_f32_32x32x16_f16:
 //   dst[tile][q][piece][lane][j] = piece(W[tile*32 + (lane&31)][16 q + 8 (lane>>5) + 2 j]) | piece(W[..][.. + 1]) << 16
 void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst) {
-    auto split3 = [](float x, unsigned (&p)[3]) {
-        unsigned xb, mb, lb;
-        memcpy(&xb, &x, 4);
-        unsigned hb = xb & 0xFFFF0000u;
-        float hf, mf;
-        memcpy(&hf, &hb, 4);
-        float r1 = x - hf;
-        memcpy(&mb, &r1, 4);
-        mb &= 0xFFFF0000u;
-        memcpy(&mf, &mb, 4);
-        float r2 = r1 - mf;
-        memcpy(&lb, &r2, 4);
-        p[0] = hb >> 16; p[1] = mb >> 16; p[2] = lb >> 16;
+    auto split2 = [](float x, unsigned (&p)[2]) {
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        unsigned short hb, lb;
+        memcpy(&hb, &h, 2);
+        memcpy(&lb, &l, 2);
+        p[0] = hb; p[1] = lb;
     };
     const int ntile = rows / 32, nq = K / 16;
     for (int tile = 0; tile < ntile; ++tile)
@@ -522,11 +516,11 @@ void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst) {
                 for (int j = 0; j < 4; ++j) {
                     const size_t row = (size_t)tile * 32 + (lane & 31);
                     const int k = 16 * q + 8 * (lane >> 5) + 2 * j;
-                    unsigned p0[3], p1[3];
-                    split3(Wsrc[row * K + k], p0);
-                    split3(Wsrc[row * K + k + 1], p1);
-                    for (int pc = 0; pc < 3; ++pc)
-                        dst[((((size_t)tile * nq + q) * 3 + pc) * 64 + lane) * 4 + j] = p0[pc] | (p1[pc] << 16);
+                    unsigned p0[2], p1[2];
+                    split2(Wsrc[row * K + k], p0);
+                    split2(Wsrc[row * K + k + 1], p1);
+                    for (int pc = 0; pc < 2; ++pc)
+                        dst[((((size_t)tile * nq + q) * 2 + pc) * 64 + lane) * 4 + j] = p0[pc] | (p1[pc] << 16);
                 }
 }
 

@@ -92,8 +92,8 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
     if (h->weights.ensure(img.size() * sizeof(float)))
         return set_err(h, VSSR_E_NOMEM, "weights: out of device memory");
     float *dbase = h->weights.as<float>();
-    // bf16-split fragment-order copies of the node-GEMM weights: 22 F^2 elements x 6 B per (model, layer)
-    const size_t node16_per_layer = (size_t)22 * F * F * 3 / 2;   // dwords
+    // fp16-split fragment-order copies of the node-GEMM weights: 22 F^2 elements x 4 B per (model, layer)
+    const size_t node16_per_layer = (size_t)22 * F * F;   // dwords
     std::vector<unsigned> node16(node16_per_layer * L * M);
     for (int m = 0; m < M; ++m) {
         float *hb = img.data() + (size_t)m * img_len;
@@ -148,11 +148,11 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
                         uvt[(size_t)g * 2 * F + F + k] = hb[v + (size_t)k * F + g];
                     }
                 pack_mfma_tiles(uvt.data(), F, 2 * F, hb + puvt);
-                // bf16-split copies, same order as the q* pointers are assigned below
+                // fp16-split copies, same order as the q* pointers are assigned below
                 unsigned *q = node16.data() + ((size_t)m * L + l) * node16_per_layer;
                 auto put16 = [&](const float *src, int rows, int K) {
                     pack_mfma_tiles16(src, rows, K, q);
-                    q += (size_t)rows * K * 3 / 2;
+                    q += (size_t)rows * K;
                 };
                 put16(hb + w1, F, F); put16(hb + w2, F3, F); put16(hb + u, F, F); put16(hb + v, F, F);
                 put16(hb + w3, F, 2 * F); put16(hb + w4, F3, F); put16(hb + w1t, F, F); put16(hb + w2t, F, F3);
@@ -168,14 +168,14 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
         W.W5 = db + w5; W.W5t = db + w5t; W.b5 = db + b5; W.w6 = db + w6; W.b6 = db + b6;
     }
     VSSR_HIP(h, hipMemcpy(dbase, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
-    {   // node-GEMM weights as bf16 pieces (painn_node_mfma.hip)
+    {   // node-GEMM weights as fp16 pieces (painn_node_mfma.hip)
         if (h->node16.ensure(node16.size() * sizeof(unsigned))) return set_err(h, VSSR_E_NOMEM, "split node weights");
         VSSR_HIP(h, hipMemcpy(h->node16.p, node16.data(), node16.size() * sizeof(unsigned), hipMemcpyHostToDevice));
         for (int m = 0; m < M; ++m)
             for (int l = 0; l < L; ++l) {
                 LayerW &Lw = table[m].layer[l];
                 const uint4 *q = h->node16.as<uint4>() + ((size_t)m * L + l) * node16_per_layer / 4;
-                auto next = [&](int rows, int K) { const uint4 *r = q; q += (size_t)rows * K * 3 / 8; return r; };
+                auto next = [&](int rows, int K) { const uint4 *r = q; q += (size_t)rows * K / 4; return r; };
                 Lw.qW1 = next(F, F); Lw.qW2 = next(F3, F); Lw.qU = next(F, F); Lw.qV = next(F, F);
                 Lw.qW3 = next(F, 2 * F); Lw.qW4 = next(F3, F); Lw.qW1t = next(F, F); Lw.qW2t = next(F, F3);
                 Lw.qW4t = next(F, F3); Lw.qW3t = next(2 * F, F); Lw.qUVt = next(F, 2 * F);

@@ -37,7 +37,7 @@ struct LayerW {
     const float *pW1t, *pW2t;    // reverse:  W1^T (4 tiles, K=F), W2^T (4 tiles, K=3F)
     const float *pW4t, *pW3t;    //           W4^T (4 tiles, K=3F), W3^T (8 tiles, K=F)
     const float *pUVt;           //           [U;V]^T (4 tiles, K=2F)
-    // the same eleven matrices as 3-way bf16 pieces in v_mfma_f32_32x32x16_bf16 B-fragment order (pack_mfma_tiles16)
+    // the same eleven matrices as 2-way fp16 pieces in v_mfma_f32_32x32x16_f16 B-fragment order (pack_mfma_tiles16)
     const uint4 *qW1, *qW2, *qU, *qV, *qW3, *qW4, *qW1t, *qW2t, *qW4t, *qW3t, *qUVt;
     const uint4 *wd16;           // radial-filter weights, 2-way fp16 split in MFMA A-operand order: [3F rows][4 quarters][h, l]
 };
@@ -166,7 +166,7 @@ struct vssr_handle {
     // weights
     vssr::DevBuf weights;        // all model blobs + transposed copies
     vssr::DevBuf wd16;           // bf16-split radial-filter weights in MFMA operand order
-    vssr::DevBuf node16;         // bf16-split node-GEMM weights in MFMA fragment order
+    vssr::DevBuf node16;         // fp16-split node-GEMM weights in MFMA fragment order
     vssr::DevBuf model_table;    // ModelW[n_models]
     vssr::DevBuf offset_per_z;   // double[n_embed]
 
@@ -234,7 +234,7 @@ void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zer
                             const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
                             float *sbar_msg, float *vbar_msg);
 // layer-0 species factorisation (painn_l0.hip)
-void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst /*[rows/32][K/16][3][64][4]*/);
+void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst /*[rows/32][K/16][2][64][4]*/);
 void build_wd16(const float *Wd, const float *bd, unsigned *dst /*[3F][4][2][4]*/);
 void l0_build_tables(const float *blob_embed, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *Wd, const float *bd, int n_embed, float *A, float *At);
