@@ -181,7 +181,7 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
                 Lw.qW4t = next(F, F3); Lw.qW3t = next(2 * F, F); Lw.qUVt = next(F, 2 * F);
             }
     }
-    {   // radial-filter weights split into bf16 pieces in MFMA operand order (painn_edge_mfma.hip), per model / layer
+    {   // radial-filter weights split into fp16 pieces in MFMA operand order (painn_edge_mfma.hip), per model / layer
         const size_t per_layer16 = (size_t)F3 * 4 * 8;   // dwords
         std::vector<unsigned> w16(per_layer16 * L * M);
         for (int m = 0; m < M; ++m) {
