@@ -83,38 +83,62 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
         const bool have = j < a1;
         double bx = 0, by = 0, bz = 0;
         if (have) { bx = wpos[3 * j] - px; by = wpos[3 * j + 1] - py; bz = wpos[3 * j + 2] - pz; }
+        // count the images of j inside the cutoff; remember which ones (bit = running image index) so that the fill
+        // pass revisits only the hits instead of all (2 n0 + 1)(2 n1 + 1)(2 n2 + 1) images again
         int cnt = 0;
+        unsigned long long hits = 0ull;
         if (have) {
+            int img = 0;
             for (int s0 = -n0; s0 <= n0; ++s0)
                 for (int s1 = -n1; s1 <= n1; ++s1)
-                    for (int s2 = -n2; s2 <= n2; ++s2) {
+                    for (int s2 = -n2; s2 <= n2; ++s2, ++img) {
                         if (i == j && s0 == 0 && s1 == 0 && s2 == 0) continue;
                         double rx = bx + s0 * C0 + s1 * C3 + s2 * C6;
                         double ry = by + s0 * C1 + s1 * C4 + s2 * C7;
                         double rz = bz + s0 * C2 + s1 * C5 + s2 * C8;
                         double d2 = rx * rx + ry * ry + rz * rz;
-                        if (d2 <= rc2 && d2 > 0.0) ++cnt;
+                        if (d2 <= rc2 && d2 > 0.0) {
+                            ++cnt;
+                            if (img < 64) hits |= 1ull << img;
+                        }
                     }
         }
         int total;
         const int off = wave_excl_scan(cnt, lane, total);
         if (FILL && cnt > 0) {
             long long slot = base + run + off;
-            for (int s0 = -n0; s0 <= n0; ++s0)
-                for (int s1 = -n1; s1 <= n1; ++s1)
-                    for (int s2 = -n2; s2 <= n2; ++s2) {
-                        if (i == j && s0 == 0 && s1 == 0 && s2 == 0) continue;
-                        double rx = bx + s0 * C0 + s1 * C3 + s2 * C6;
-                        double ry = by + s0 * C1 + s1 * C4 + s2 * C7;
-                        double rz = bz + s0 * C2 + s1 * C5 + s2 * C8;
-                        double d2 = rx * rx + ry * ry + rz * rz;
-                        if (d2 > rc2 || d2 <= 0.0) continue;
-                        if (slot < slot_cap) {
-                            edge[slot] = make_float4((float)rx, (float)ry, (float)rz, __int_as_float(j));
-                            edge_S[slot] = pack_shift(s0, s1, s2);
-                        }
-                        ++slot;
+            const int w1 = 2 * n1 + 1, w2 = 2 * n2 + 1;
+            if ((2 * n0 + 1) * w1 * w2 <= 64) {   // the usual case: replay the set bits in ascending (= lexicographic) order
+                while (hits) {
+                    const int img = __builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    const int s0 = img / (w1 * w2) - n0, s1 = (img / w2) % w1 - n1, s2 = img % w2 - n2;
+                    const double rx = bx + s0 * C0 + s1 * C3 + s2 * C6;
+                    const double ry = by + s0 * C1 + s1 * C4 + s2 * C7;
+                    const double rz = bz + s0 * C2 + s1 * C5 + s2 * C8;
+                    if (slot < slot_cap) {
+                        edge[slot] = make_float4((float)rx, (float)ry, (float)rz, __int_as_float(j));
+                        edge_S[slot] = pack_shift(s0, s1, s2);
                     }
+                    ++slot;
+                }
+            } else {
+                for (int s0 = -n0; s0 <= n0; ++s0)
+                    for (int s1 = -n1; s1 <= n1; ++s1)
+                        for (int s2 = -n2; s2 <= n2; ++s2) {
+                            if (i == j && s0 == 0 && s1 == 0 && s2 == 0) continue;
+                            double rx = bx + s0 * C0 + s1 * C3 + s2 * C6;
+                            double ry = by + s0 * C1 + s1 * C4 + s2 * C7;
+                            double rz = bz + s0 * C2 + s1 * C5 + s2 * C8;
+                            double d2 = rx * rx + ry * ry + rz * rz;
+                            if (d2 > rc2 || d2 <= 0.0) continue;
+                            if (slot < slot_cap) {
+                                edge[slot] = make_float4((float)rx, (float)ry, (float)rz, __int_as_float(j));
+                                edge_S[slot] = pack_shift(s0, s1, s2);
+                            }
+                            ++slot;
+                        }
+            }
         }
         run += total;
     }
