@@ -141,6 +141,17 @@ __device__ __forceinline__ void quad_sum4(float (&x)[4]) {
     for (int r = 0; r < 4; ++r) x[r] = quad_sum(x[r]);
 }
 
+// sum over the four 16-lane rows (lanes l, l^16, l^32, l^48), result in every lane: the gfx950 row-swap instructions
+// (VALU) instead of two dependent ds_bpermute round trips through the LDS
+__device__ __forceinline__ float xrow_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float y = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+    const unsigned v = __float_as_uint(y);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+}
+
 // Lane roles ("slot-major"): p = lane & 15 is the slot position inside the step's 16-slot tile, stream = p >> 2
 // (4 independent CSR streams per wave, 4 slots each per step), e = p & 3 the slot inside the quad, and
 // fq = lane >> 4 selects features 4 fq .. 4 fq + 3 of the slice.  With the WEIGHTS as MFMA A operand
@@ -593,11 +604,8 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 1; r < 4; ++r) feature(r);
-                // sum over the 4 feature quarters (lanes p, p+16, p+32, p+48): fixed order, all lanes get the total
-                dpart += __shfl_xor(dpart, 16, 64); dpart += __shfl_xor(dpart, 32, 64);
-                ub0 += __shfl_xor(ub0, 16, 64); ub0 += __shfl_xor(ub0, 32, 64);
-                ub1 += __shfl_xor(ub1, 16, 64); ub1 += __shfl_xor(ub1, 32, 64);
-                ub2 += __shfl_xor(ub2, 16, 64); ub2 += __shfl_xor(ub2, 32, 64);
+                // sum over the 4 feature quarters (lanes p, p+16, p+32, p+48): fixed order, all lanes get the total (xrow_sum)
+                dpart = xrow_sum(dpart); ub0 = xrow_sum(ub0); ub1 = xrow_sum(ub1); ub2 = xrow_sum(ub2);
                 if (fq == 0 && pos < stream_end && dd[ph].x > 0.f) {   // one lane per real slot writes its gradient
                     const float invd = dd[ph].x;
                     const float db = dpart;
