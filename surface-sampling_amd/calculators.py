@@ -20,7 +20,9 @@ All numerical work happens in ``libvssr_eval.so``; there is no CPU fallback.
 from __future__ import annotations
 
 import copy
+import dataclasses
 import logging
+import re
 from collections import Counter
 
 import numpy as np
@@ -303,6 +305,13 @@ class EnsembleNFFSurface(_Base):
         return surface_energy_from_energy(energy, atoms.get_chemical_symbols(), chem_pots, offset_data,
                                           self.offset_units)
 
+    def surface_energy_of(self, energy, atoms):
+        """Surface energy of a configuration whose potential energy is already known (used by the batched paths and by
+        ``mc.ChainEnsemble``); subclasses override the arithmetic (``NFFPourbaix``)."""
+        return surface_energy_from_energy(energy, atoms.get_chemical_symbols(),
+                                          self._require(self.chem_pots, "chemical potentials"),
+                                          self._require(self.offset_data, "offset data"), self.offset_units)
+
     def _fill_results(self, res, b=0):
         a0, a1 = int(res["cfg_start"][b]), int(res["cfg_start"][b + 1])
         return {
@@ -321,9 +330,7 @@ class EnsembleNFFSurface(_Base):
         res = self._get_engine().evaluate([structures.as_arrays(atoms)])
         self.results.update(self._fill_results(res, 0))
         if "surface_energy" in properties:
-            self.results["surface_energy"] = surface_energy_from_energy(
-                self.results["energy"], atoms.get_chemical_symbols(), self._require(self.chem_pots, "chemical potentials"),
-                self._require(self.offset_data, "offset data"), self.offset_units)
+            self.results["surface_energy"] = self.surface_energy_of(self.results["energy"], atoms)
         if hasattr(atoms, "results") and isinstance(atoms.results, dict):
             atoms.results.update(self.results)
 
@@ -341,9 +348,7 @@ class EnsembleNFFSurface(_Base):
         for b, atoms in enumerate(atoms_list):
             r = self._fill_results(res, b)
             if want_surface_energy:
-                r["surface_energy"] = surface_energy_from_energy(
-                    r["energy"], atoms.get_chemical_symbols(), self._require(self.chem_pots, "chemical potentials"),
-                    self._require(self.offset_data, "offset data"), self.offset_units)
+                r["surface_energy"] = self.surface_energy_of(r["energy"], atoms)
             out.append(r)
         return out
 
@@ -386,6 +391,106 @@ class EnsembleNFFSurface(_Base):
             r["converged"] = bool(info["converged"][b])
             out.append((relaxed, None, energy, oob, r))
         return out
+
+
+@dataclasses.dataclass
+class PourbaixAtom:
+    """Per-element data of the Pourbaix dissolution reaction (reference ``mcmc/pourbaix/atoms.py:25-66``)."""
+
+    symbol: str
+    dominant_species: str = ""
+    species_conc: float = 1e-6
+    num_e: int = 0
+    num_H: int = 0
+    atom_std_state_energy: float = 0.0
+    delta_G2_std: float = 0.0
+
+
+def _formula_counts(formula: str) -> Counter:
+    """Element counts of a plain formula string such as ``"OH"`` or ``"H2O"``."""
+    out = Counter()
+    for sym, num in re.findall(r"([A-Z][a-z]?)(\d*)", formula):
+        out[sym] += int(num) if num else 1
+    return out
+
+
+def pourbaix_potential_from_energy(energy: float, symbols, pourbaix_atoms: dict, temp: float = 0.0257, phi: float = 0.0,
+                                   pH: float = 7.0, adsorbate_corrections: dict | None = None) -> float:
+    """Pourbaix ("grand") potential of a slab with known potential energy — the arithmetic of the reference's
+    ``NFFPourbaix`` (``calculators.py:197-305``):
+    ``dG1 = sum_atoms E_std(atom) - (E_slab + adsorbate corrections)`` (``get_delta_G1``),
+    ``dG2 = sum_atoms [dG2_std - n_e phi - ln(10) n_H kT pH + kT ln(conc)]`` (``get_delta_G2``), result ``-(dG1 + dG2)``.
+    Adsorbate corrections count how many times the adsorbate formula fits into the slab formula; for O-H adsorbates the
+    hydrogens in excess of the oxygens are first attributed to water and removed (``calculators.py:254-268``)."""
+    counts = Counter(symbols)
+    sum_std = sum(n * pourbaix_atoms[a].atom_std_state_energy for a, n in counts.items())
+    slab_energy = float(np.ravel(energy)[0])
+    formula = Counter(counts)
+    for adsorbate, correction in (adsorbate_corrections or {}).items():
+        if "O" in adsorbate and "H" in adsorbate:
+            ho_diff = max(formula["H"] - formula["O"], 0)
+            if ho_diff > 0:
+                formula = Counter({k: v - {"H": 2, "O": 1}.get(k, 0) * ho_diff for k, v in formula.items()})
+        ads = _formula_counts(adsorbate)
+        div = min(formula[k] // n for k, n in ads.items()) if ads else 0
+        slab_energy += div * correction
+    dg1 = sum_std - slab_energy
+    dg2 = 0.0
+    for a, n in counts.items():
+        pa = pourbaix_atoms[a]
+        dg2 += n * (pa.delta_G2_std - pa.num_e * phi - np.log(10) * pa.num_H * temp * pH + temp * np.log(pa.species_conc))
+    return -(dg1 + dg2)
+
+
+class NFFPourbaix(EnsembleNFFSurface):
+    """Surface calculator whose ``surface_energy`` is the Pourbaix potential (reference ``NFFPourbaix``,
+    ``calculators.py:121-357``; there a single-model ``NeuralFF``, here any ensemble size on the same engine).
+    Parameters through ``set``: ``temperature`` (kT in eV), ``phi``, ``pH``, ``pourbaix_atoms`` (symbol ->
+    ``PourbaixAtom``), ``adsorbate_corrections`` (formula -> eV)."""
+
+    implemented_properties = (*EnsembleNFFSurface.implemented_properties, "pourbaix_potential")
+    name = "nff_pourbaix_mi355x"
+
+    def __init__(self, *args, temp: float = 0.0257, phi: float = 0.0, pH: float = 7.0, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.temp, self.phi, self.pH = temp, phi, pH
+        self.pourbaix_atoms: dict = {}
+        self.adsorbate_corrections: dict = {}
+
+    def set(self, **kwargs) -> dict:
+        changed = super().set(**kwargs)
+        for key, attr in (("temperature", "temp"), ("phi", "phi"), ("pH", "pH"), ("pourbaix_atoms", "pourbaix_atoms"),
+                          ("adsorbate_corrections", "adsorbate_corrections")):
+            if key in self.parameters:
+                setattr(self, attr, self.parameters[key])
+        return changed
+
+    def get_delta_G2_individual(self, atom) -> float:
+        pa = self.pourbaix_atoms[atom] if isinstance(atom, str) else atom
+        return pa.delta_G2_std - pa.num_e * self.phi - np.log(10) * pa.num_H * self.temp * self.pH \
+            + self.temp * np.log(pa.species_conc)
+
+    def get_delta_G2(self, atoms=None) -> float:
+        atoms = self.atoms if atoms is None else atoms
+        return sum(self.get_delta_G2_individual(a) for a in atoms.get_chemical_symbols())
+
+    def surface_energy_of(self, energy, atoms):
+        return pourbaix_potential_from_energy(energy, atoms.get_chemical_symbols(),
+                                              self._require(self.pourbaix_atoms, "Pourbaix atoms"), self.temp, self.phi,
+                                              self.pH, self.adsorbate_corrections)
+
+    def get_pourbaix_potential(self, atoms=None) -> float:
+        atoms = self.atoms if atoms is None else atoms
+        return self.surface_energy_of(self.get_potential_energy(atoms=atoms), atoms)
+
+    def get_surface_energy(self, atoms=None, **kwargs) -> float:
+        return self.get_pourbaix_potential(atoms)
+
+    def calculate(self, atoms=None, properties=implemented_properties, system_changes=all_changes):
+        super().calculate(atoms, properties, system_changes)
+        if "pourbaix_potential" in properties or "surface_energy" in properties:
+            self.results["pourbaix_potential"] = self.results.get(
+                "surface_energy", self.surface_energy_of(self.results["energy"], self.atoms if atoms is None else atoms))
 
 
 class TersoffSurfCalc(_Base):

@@ -252,6 +252,8 @@ class ChainEnsemble:
 
     # ---- energies --------------------------------------------------------------------------------------------------
     def _default_surface_energy(self, energy, struct):
+        if hasattr(self.calc, "surface_energy_of") and (getattr(self.calc, "pourbaix_atoms", None)):
+            return float(self.calc.surface_energy_of(energy, struct))
         chem_pots, offset_data = getattr(self.calc, "chem_pots", None), getattr(self.calc, "offset_data", None)
         if chem_pots and offset_data:
             from .calculators import surface_energy_from_energy

@@ -151,3 +151,44 @@ def test_edge_kernel_isa_keeps_loads_out_of_mfma_windows():
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "4 MFMA groups checked, 0 violations" in r.stdout, r.stdout
+
+
+def test_pourbaix_potential_arithmetic():
+    """``NFFPourbaix`` arithmetic (reference calculators.py:197-305) on hand-computed numbers: dG1 = sum E_std - (E_slab +
+    adsorbate corrections), dG2 = sum [dG2_std - n_e phi - ln10 n_H kT pH + kT ln conc], potential = -(dG1 + dG2)."""
+    P = calcs.PourbaixAtom
+    atoms = {"Sr": P("Sr", "Sr2+", species_conc=1e-6, num_e=2, num_H=0, atom_std_state_energy=-1.5, delta_G2_std=-5.8),
+             "O": P("O", "H2O", species_conc=1.0, num_e=-2, num_H=-2, atom_std_state_energy=-4.9, delta_G2_std=-2.46),
+             "H": P("H", "H+", species_conc=1.0, num_e=1, num_H=1, atom_std_state_energy=-3.4, delta_G2_std=0.0)}
+    symbols = ["Sr", "O", "O", "O", "H", "H", "H", "H"]          # O3 H4: one H in excess of O -> one H2O removed
+    kT, phi, pH, E = 0.0257, 0.3, 9.0, -40.0
+    corr = {"OH": 0.25}
+    got = calcs.pourbaix_potential_from_energy(E, symbols, atoms, kT, phi, pH, corr)
+    # formula after removing (H - O) = 1 water: Sr O2 H2 -> "OH" fits twice
+    e_slab = E + 2 * 0.25
+    dg1 = (-1.5 + 3 * -4.9 + 4 * -3.4) - e_slab
+    def g2(a):
+        return a.delta_G2_std - a.num_e * phi - np.log(10) * a.num_H * kT * pH + kT * np.log(a.species_conc)
+    dg2 = g2(atoms["Sr"]) + 3 * g2(atoms["O"]) + 4 * g2(atoms["H"])
+    assert got == pytest.approx(-(dg1 + dg2), abs=1e-12)
+    # no corrections, neutral conditions: the potential is linear in the slab energy with slope +1
+    a = calcs.pourbaix_potential_from_energy(-40.0, symbols, atoms, kT, 0.0, 7.0)
+    b = calcs.pourbaix_potential_from_energy(-39.0, symbols, atoms, kT, 0.0, 7.0)
+    assert b - a == pytest.approx(1.0, abs=1e-12)
+    assert calcs._formula_counts("H2O") == {"H": 2, "O": 1} and calcs._formula_counts("OH") == {"O": 1, "H": 1}
+
+
+def test_pourbaix_calculator_surface_without_gpu(golden):
+    """Parameter plumbing of the Pourbaix calculator (``set`` keys of the reference, calculators.py:307-336); the
+    surface energy hook is what the batched paths call."""
+    calc = calcs.NFFPourbaix(golden.blobs[:1], device="cuda:0")
+    P = calcs.PourbaixAtom
+    pa = {s: P(s, s, atom_std_state_energy=-1.0 * k, delta_G2_std=0.1 * k) for k, s in enumerate(("Sr", "Ti", "O"), 1)}
+    changed = calc.set(temperature=0.03, phi=0.5, pH=3.0, pourbaix_atoms=pa, adsorbate_corrections={})
+    assert set(changed) >= {"temperature", "phi", "pH", "pourbaix_atoms"}
+    assert (calc.temp, calc.phi, calc.pH) == (0.03, 0.5, 3.0)
+    assert "pourbaix_potential" in calc.implemented_properties and "surface_energy" in calc.implemented_properties
+    s = golden.structure("O36Sr12Ti12")
+    want = calcs.pourbaix_potential_from_energy(-467.5, s.get_chemical_symbols(), pa, 0.03, 0.5, 3.0, {})
+    assert calc.surface_energy_of(np.array([-467.5]), s) == pytest.approx(want)
+    assert calc.get_delta_G2(s) == pytest.approx(sum(calc.get_delta_G2_individual(x) for x in s.get_chemical_symbols()))
