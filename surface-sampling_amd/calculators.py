@@ -384,7 +384,8 @@ class EnsembleNFFSurface(_Base):
             r = self._fill_results(res, b)
             energy = float(r["energy"][0])
             max_force = float(np.abs(r["forces"]).max()) if a1 > a0 else 0.0
-            oob = bool(abs(energy) > self.ENERGY_THRESHOLD or max_force > self.MAX_FORCE_THRESHOLD)
+            oob = bool(not np.isfinite(energy) or not np.isfinite(max_force) or abs(energy) > self.ENERGY_THRESHOLD
+                       or max_force > self.MAX_FORCE_THRESHOLD)
             if oob:
                 energy = self.ENERGY_THRESHOLD
             r["n_steps"] = int(info["n_steps"][b])

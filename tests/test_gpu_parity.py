@@ -353,3 +353,30 @@ def test_repeatability_stress_many_chains(golden):
         finally:
             for k in env:
                 del os.environ[k]
+
+
+@pytest.mark.gpu
+def test_colliding_atoms_stay_finite_and_match_until_absurd(golden, oracle_mod, engine):
+    """Two atoms pushed towards each other: energies of 1e3 .. 1e8 eV still agree with the fp64 oracle to 1e-5 relative
+    (the matrix path splits fp32 into fp16 pieces; activations are clamped to the fp16 range before the split), and even
+    absurd overlaps return finite numbers, which the relaxation driver flags with the reference's +-1000 guard."""
+    from surface_sampling_amd.calculators import EnsembleNFFSurface
+
+    base = golden.structure("SrTiO3_2x2_pristine")
+    table, const = golden.offset_table()
+    for dmin, check in ((0.6, True), (0.4, True), (0.15, False)):
+        s = base.copy()
+        v = s.positions[8] - s.positions[7]
+        s.positions[8] = s.positions[7] + v / np.linalg.norm(v) * dmin
+        r = engine.evaluate([_arrays(s)])
+        e, f = float(r["energy"][0]), r["forces"]
+        assert np.isfinite(e) and np.isfinite(f).all()
+        if check:
+            ref = _oracle(golden, oracle_mod, s)
+            assert abs(e - ref["energy"]) <= 1e-5 * abs(ref["energy"])
+            assert np.abs(f - ref["forces"]).max() <= 1e-5 * np.abs(ref["forces"]).max()
+    calc = EnsembleNFFSurface(golden.blobs, device="cuda:0")
+    calc.set(offset=True, offset_data=golden.offset_data)
+    out = calc.relax_batch([s, base], relax_steps=1)
+    assert out[0][3] is True and out[0][2] == calc.ENERGY_THRESHOLD      # energy_oob, clamped energy
+    assert out[1][3] is False
