@@ -1,36 +1,41 @@
 // painn_node_mfma.hip — per-atom ("node") stages of PaiNN on the gfx950 matrix cores.
 //
-// The node stages are chains of small dense layers applied to every
-// atom of every chain and ensemble member: genuinely dense GEMMs with M = atoms (x3 Cartesian rows for
-// U/V), K, N in {128, 256, 384}.  gfx950 has no fp32-rate-above-vector matrix path (v_mfma_f32_32x32x2_f32 runs at the
-// fp32 vector rate, and measurably conflicts with the VALU; no xf32 exists), so the GEMMs run on the 16-bit matrix pipe
-// with fp32-level accuracy: both operands are split into two fp16 pieces x = h + l (h = fp16(x), l = fp16(x - h): 22
-// mantissa bits; fp16 subnormals are honoured by the matrix core) and the three products a_h w_l + a_l w_h + a_h w_h are
-// accumulated in fp32 on v_mfma_f32_32x32x16_f16 (gemm_acc16) -- 3 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles
-// per K = 16.  Weights are pre-split at vssr_create (pack_mfma_tiles16), activations are split in registers when a
-// fragment is read from its fp32 LDS tile (clamped to the fp16 range first: measured activations / adjoints of the
-// SrTiO3 models peak at ~160, tools/gpu_ranges.py).  -DVSSR_NODE_FP32 selects the fp32 MFMA path (gemm_acc).
+// The node stages are chains of small dense layers applied to every atom of every
+// chain and ensemble member: genuinely dense GEMMs with M = atoms (x3 Cartesian rows for U/V), K, N in {128, 256, 384}.
+// gfx950 has no fp32 matrix rate above the vector rate (v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate and
+// measurably conflicts with the VALU; no xf32 exists), so the GEMMs run on the 16-bit matrix pipe with fp32-level
+// accuracy: both operands are split into two fp16 pieces x = h + l (h = fp16(x), l = fp16(x - h): 22 mantissa bits;
+// fp16 subnormals are honoured by the matrix core) and the three products a_h w_l + a_l w_h + a_h w_h are accumulated in
+// fp32 on v_mfma_f32_16x16x32_f16.
 //
-// Structure of every kernel: one workgroup = 4 waves = a tile of 32 atoms of one ensemble member.
-//   * activations (A operand) live in LDS, row-major with a +4 float pad (conflict-free ds_read_b128);
-//   * weights (B operand) were re-packed at vssr_create into MFMA fragment order
-//       packed[tile][q][lane][4] = W[tile*32 + (lane&31)][(lane>>5)*(K/2) + 4q .. 4q+3]
-//     so each wave streams its own column tiles with one fully coalesced 1 KiB dwordx4 load per 4 k-steps,
-//     L2-resident (all workgroups read the same 0.7 MB per layer);
-//   * the k index is permuted identically on A and B (lane half h covers k in [h*K/2, (h+1)*K/2)), which
-//     only reorders the fp32 summation;
-//   * wave w owns output features [32w, 32w+32) of every section, so gates, norms and residuals that
-//     combine several GEMM outputs for the same (atom, feature) stay in one lane's registers.
+// Structure of every kernel: one workgroup = 8 waves = a tile of 32 atoms of one ensemble member.
+//   * activations (A operand) live in LDS as two fp16 planes (h and l, same bytes as an fp32 tile): every element is
+//     split ONCE by the thread that stores it (clamped to +-65504 first; measured activations / adjoints of the SrTiO3
+//     models peak at ~160, tools/gpu_ranges.py), and an A fragment is one ds_read_b128 per piece, no arithmetic;
+//   * weights (B operand) were pre-split at vssr_create into fragment order (pack_mfma_tiles16): a wave streams the
+//     pieces of its column tiles with coalesced 1 KiB dwordx4 loads, L2-resident (all workgroups read the same ~1 MB);
+//   * wave w owns output features [16w, 16w+16) of every section for all 32 atoms (two 16-row tiles), so gates, norms and
+//     residuals that combine several GEMM outputs for the same (atom, feature) stay in one lane's registers; with half
+//     the per-wave accumulator state of a 32-column layout two waves share a SIMD and hide each other's latencies;
+//   * residual inputs (s_msg, v_msg, vbar) are re-read from global memory (L2-hot) where the fp32 value is needed.
+// MFMA issue order follows the hazard rules of painn_edge_mfma.hip: the three products of a tile are a dependent chain,
+// so products are issued in rounds over >= 3 independent accumulators (K-interleaved partial accumulators for GEMMs with
+// two tiles), pinned with scheduling barriers, and no load is issued inside the MFMA block of a chunk group.
 #include "vssr_internal.h"
 
 namespace vssr {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TA = 32;           // atoms per workgroup
-constexpr int LDV = F + 4;       // LDS row stride for K = 128 operands
-constexpr int LDH = 2 * F + 4;   // K = 256
-constexpr int LDQ = 3 * F + 4;   // K = 384
+constexpr int TA = 32;            // atoms per workgroup
+constexpr int NW = 8;             // waves per workgroup
+constexpr int NTHREADS = 64 * NW;
+constexpr int PADH = 8;           // row pad of the fp16 planes (halves): conflict-free ds_read_b128 of 16 rows
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float swish(float x) { return x * sigm(x); }
@@ -38,56 +43,9 @@ __device__ __forceinline__ float dswish(float x) {
     float sg = sigm(x);
     return sg * fmaf(x, 1.f - sg, 1.f);
 }
-// row of accumulator register `reg` inside a 32x32 tile (MI355X guide: C/D layout of 32x32 MFMA)
-__device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
 // Weight pointers are read out of the ModelW table in memory, so the compiler would treat them as FLAT (flat loads
 // tick both vmcnt and lgkmcnt).  Loading through an explicit global address space pointer gives global_load.
-__device__ __forceinline__ float4 gload4(const float *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef float gf32x4 __attribute__((ext_vector_type(4)));
-    typedef const gf32x4 __attribute__((address_space(1))) *gptr;
-    const gf32x4 v = *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *reinterpret_cast<const float4 *>(p);
-#endif
-}
-
-// acc[t][c] += A(rows t*32.., K) * packed tile c
-template <int K, int NRT, int NCT>
-__device__ __forceinline__ void gemm_acc(const float *__restrict__ lds_a, int ld,
-                                         const float *const (&wp)[NCT], f32x16 (&acc)[NRT][NCT]) {
-    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
-    const float *a_base = lds_a + r * ld + half * (K / 2);
-#pragma unroll 2
-    for (int q = 0; q < K / 8; ++q) {
-        float bv[NCT][4], av[NRT][4];
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            float4 b = gload4(wp[c] + ((size_t)q * 64 + lane) * 4);
-            bv[c][0] = b.x; bv[c][1] = b.y; bv[c][2] = b.z; bv[c][3] = b.w;
-        }
-#pragma unroll
-        for (int t = 0; t < NRT; ++t) {
-            float4 a = *reinterpret_cast<const float4 *>(a_base + t * 32 * ld + 4 * q);
-            av[t][0] = a.x; av[t][1] = a.y; av[t][2] = a.z; av[t][3] = a.w;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < NRT; ++t)
-#pragma unroll
-                for (int c = 0; c < NCT; ++c)
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][s], bv[c][s], acc[t][c], 0, 0, 0);
-    }
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ u32x4 gload4u(const uint4 *p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const u32x4 __attribute__((address_space(1))) *gptr;
@@ -97,47 +55,79 @@ __device__ __forceinline__ u32x4 gload4u(const uint4 *p) {
 #endif
 }
 
-// 2-way fp16 split of 8 consecutive fp32 values into two MFMA operands (h and l pieces, 8 x fp16 each)
-__device__ __forceinline__ void split8(const float4 lo, const float4 hi, u32x4 (&o)[2]) {
-    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+// ---- activation tiles as fp16 planes -----------------------------------------------------------------------------------
+struct Planes {   // [rows][K] in two planes; ld = K + PADH halves
+    _Float16 *h, *l;
+    int ld;
+};
+__device__ __forceinline__ Planes make_planes(_Float16 *base, int rows, int K) {
+    return Planes{base, base + (size_t)rows * (K + PADH), K + PADH};
+}
+constexpr int plane_halves(int rows, int K) { return 2 * rows * (K + PADH); }
+
+__device__ __forceinline__ void split1(float x, _Float16 &h, _Float16 &l) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    h = (_Float16)xc;
+    l = (_Float16)(xc - (float)h);
+}
+__device__ __forceinline__ void store_split(const Planes &P, int row, int col, float x) {
+    _Float16 h, l;
+    split1(x, h, l);
+    P.h[row * P.ld + col] = h;
+    P.l[row * P.ld + col] = l;
+}
+// four consecutive columns at once (col multiple of 4): two 8-byte LDS stores
+__device__ __forceinline__ void store_split4(const Planes &P, int row, int col, float4 v) {
+    const f32x2 a = {__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f)};
+    const f32x2 b = {__builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f)};
+    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+    const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), f16x2);
+    const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), f16x2);
+    *reinterpret_cast<u32x2 *>(P.h + row * P.ld + col) = (u32x2){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+    *reinterpret_cast<u32x2 *>(P.l + row * P.ld + col) = (u32x2){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+
+// Cooperative tile load: NROWS rows of F floats from global, split, into plane columns [col0, col0 + F).  rowptr(row)
+// must always return a readable row (tail rows are clamped to the last atom; their results are never stored), so that
+// all loads are unconditional and issued back-to-back before the first LDS store.
+template <int NROWS, class RowPtr>
+__device__ __forceinline__ void load_rows_split(const Planes &P, int col0, RowPtr rowptr) {
+    constexpr int NIT = NROWS * (F / 4) / NTHREADS;
+    static_assert(NROWS * (F / 4) % NTHREADS == 0, "tile load must divide evenly");
+    float4 v[NIT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x2 xc = {__builtin_amdgcn_fmed3f(x[2 * j], -65504.f, 65504.f),
-                          __builtin_amdgcn_fmed3f(x[2 * j + 1], -65504.f, 65504.f)};
-        const f16x2 h = __builtin_convertvector(xc, f16x2);
-        const f16x2 l = __builtin_convertvector(xc - __builtin_convertvector(h, f32x2), f16x2);
-        o[0][j] = __builtin_bit_cast(unsigned, h);
-        o[1][j] = __builtin_bit_cast(unsigned, l);
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * NTHREADS;
+        v[it] = *reinterpret_cast<const float4 *>(rowptr(idx >> 5) + 4 * (idx & 31));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * NTHREADS;
+        store_split4(P, idx >> 5, col0 + 4 * (idx & 31), v[it]);
     }
 }
 
-// acc[t][c] += A(rows t*32.., K) * W tile c, fp16-split.  wq[c]: the tile's pieces, [K/16][2][64 lanes] uint4
-// (pack_mfma_tiles16).  Lane (r = lane & 31, half = lane >> 5) supplies row r / column r and k = 16 q + 8 half .. + 7.
-// Issue order (see painn_edge_mfma.hip, MFMA hazard rules): the three partial products of a tile form a dependent
-// accumulator chain, so products are issued in rounds over all independent accumulators; a GEMM with fewer than three
-// tiles gets NACC K-interleaved partial accumulators (summed at the end) so that a chain's producer is always >= 3
-// MFMAs back.  No load is issued inside the MFMA block of a chunk group.
+// ---- GEMM on the planes ------------------------------------------------------------------------------------------------
+// acc[t][c] += A(rows 16 t .. 16 t + 15, K) . W(column tile c)^T.  A fragment of lane (r = lane & 15, g = lane >> 4) for
+// chunk q: row 16 t + r, k = 32 q + 8 g .. + 7 -> one ds_read_b128 per piece.  wq[c]: pieces of a 16-column tile,
+// [K/32][2][64 lanes] uint4 (pack_mfma_tiles16).  D: lane holds column r, rows 4 g .. 4 g + 3 of the 16 x 16 tile.
 template <int K, int NRT, int NCT>
-__device__ __forceinline__ void gemm_acc16(const float *__restrict__ lds_a, int ld, const uint4 *const (&wq)[NCT],
-                                           f32x16 (&acc)[NRT][NCT]) {
-    constexpr int NT = NRT * NCT, NACC = NT >= 3 ? 1 : (NT == 2 ? 2 : 4);
+__device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)[NCT], f32x4 (&acc)[NRT][NCT]) {
+    constexpr int NT = NRT * NCT, NACC = NT >= 3 ? 1 : 2;
+    constexpr int NQ = K / 32;
+    static_assert(NQ % NACC == 0, "chunk groups");
     constexpr int wi[3] = {0, 1, 0}, ri[3] = {1, 0, 0};   // A-piece, W-piece: a_h w_l, a_l w_h, a_h w_h
-    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
-    const float *a_base = lds_a + r * ld + 8 * half;
-    f32x16 part[NACC][NRT][NCT];
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const _Float16 *ah = A.h + r * A.ld + 8 * g, *al = A.l + r * A.ld + 8 * g;
+    f32x4 part[NACC][NRT][NCT];
 #pragma unroll
     for (int j = 0; j < NACC; ++j)
 #pragma unroll
         for (int t = 0; t < NRT; ++t)
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                if (j == 0) part[0][t][c] = acc[t][c];
-                else
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) part[j][t][c][i] = 0.f;
-            }
+            for (int c = 0; c < NCT; ++c) part[j][t][c] = j == 0 ? acc[t][c] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int q0 = 0; q0 < K / 16; q0 += NACC) {
+    for (int q0 = 0; q0 < NQ; q0 += NACC) {
         u32x4 a[NACC][NRT][2], b[NACC][NCT][2];
 #pragma unroll
         for (int j = 0; j < NACC; ++j) {
@@ -148,8 +138,8 @@ __device__ __forceinline__ void gemm_acc16(const float *__restrict__ lds_a, int 
                 for (int pc = 0; pc < 2; ++pc) b[j][c][pc] = gload4u(wq[c] + ((size_t)(q * 2 + pc) * 64 + lane));
 #pragma unroll
             for (int t = 0; t < NRT; ++t) {
-                const float *ap = a_base + t * 32 * ld + 16 * q;
-                split8(*reinterpret_cast<const float4 *>(ap), *reinterpret_cast<const float4 *>(ap + 4), a[j][t]);
+                a[j][t][0] = *reinterpret_cast<const u32x4 *>(ah + t * 16 * A.ld + 32 * q);
+                a[j][t][1] = *reinterpret_cast<const u32x4 *>(al + t * 16 * A.ld + 32 * q);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -161,7 +151,7 @@ __device__ __forceinline__ void gemm_acc16(const float *__restrict__ lds_a, int 
                 for (int t = 0; t < NRT; ++t)
 #pragma unroll
                     for (int c = 0; c < NCT; ++c) {
-                        part[j][t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        part[j][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                             __builtin_bit_cast(f16x8, a[j][t][wi[k]]), __builtin_bit_cast(f16x8, b[j][c][ri[k]]),
                             part[j][t][c], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
@@ -177,222 +167,221 @@ __device__ __forceinline__ void gemm_acc16(const float *__restrict__ lds_a, int 
         }
 }
 
-// weight-tile pointers of the two paths: tile index and K select the 32-column tile of a packed matrix
-#ifdef VSSR_NODE_FP32
-#define WTILE(name, tile, K) (W.p##name + (size_t)(tile) * 32 * (K))
-#define WPTR const float *
-#define GEMM gemm_acc
-#else
-#define WTILE(name, tile, K) (W.q##name + (size_t)(tile) * 8 * (K))
-#define WPTR const uint4 *
-#define GEMM gemm_acc16
-#endif
-
 template <int NRT, int NCT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NRT][NCT]) {
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRT][NCT]) {
 #pragma unroll
     for (int t = 0; t < NRT; ++t)
 #pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][c][i] = 0.f;
+        for (int c = 0; c < NCT; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// Cooperative tile load: NROWS rows of F floats.  rowptr(row) must always return a readable row
-// (tail rows are clamped to the last atom; their results are never stored), so that all loads are
-// unconditional and issued back-to-back before the first LDS store (no per-element branch / vmcnt(0)).
-template <int NROWS, class RowPtr>
-__device__ __forceinline__ void load_rows(float *lds, int ld, int col0, RowPtr rowptr) {
-    constexpr int NIT = NROWS * (F / 4) / 256;
-    float4 v[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        int idx = threadIdx.x + it * 256;
-        v[it] = *reinterpret_cast<const float4 *>(rowptr(idx >> 5) + 4 * (idx & 31));
+// 16-column tile `tile` of a packed matrix with inner dimension K: K/32 chunks x 2 pieces x 64 lanes uint4
+#define WTILE(name, tile, K) (W.q##name + (size_t)(tile) * 4 * (K))
+
+// lane geometry shared by all kernels: wave w owns columns 16 w .. 16 w + 15; accumulator element (t, i) of a lane is
+// atom row 16 t + 4 (lane >> 4) + i and column 16 w + (lane & 15)
+struct LaneGeo {
+    int w, col, rbase;
+    __device__ __forceinline__ LaneGeo() {
+        const int lane = threadIdx.x & 63;
+        w = threadIdx.x >> 6;
+        col = 16 * w + (lane & 15);
+        rbase = 4 * (lane >> 4);
     }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        int idx = threadIdx.x + it * 256;
-        *reinterpret_cast<float4 *>(lds + (idx >> 5) * ld + col0 + 4 * (idx & 31)) = v[it];
-    }
-}
+    __device__ __forceinline__ int row(int t, int i) const { return 16 * t + rbase + i; }
+};
 
 // ---- message MLP forward: phi = W2 swish(W1 s + b1) + b2 ---------------------------------------------------
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(NTHREADS)
 k_msg_mlp_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
                float *__restrict__ phi) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *xs = lds;                 // [TA][LDV]
-    float *hs = lds + TA * LDV;      // [TA][LDV]
-    const int m = blockIdx.y, a0 = blockIdx.x * TA, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int half = lane >> 5, col = 32 * w + (lane & 31);
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    const Planes xs = make_planes(ldsh, TA, F), hs = make_planes(ldsh + plane_halves(TA, F), TA, F);
+    const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
-    load_rows<TA>(xs, LDV, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; });
+    load_rows_split<TA>(xs, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; });
     __syncthreads();
     {
-        f32x16 acc[1][1];
+        f32x4 acc[2][1];
         zero_acc(acc);
-        WPTR wp[1] = {WTILE(W1, w, F)};
-        GEMM<F, 1, 1>(xs, LDV, wp, acc);
-        float b = W.b1[col];
+        const uint4 *wp[1] = {WTILE(W1, L.w, F)};
+        gemm16<F, 2, 1>(xs, wp, acc);
+        const float b = W.b1[L.col];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hs[crow(i, half) * LDV + col] = swish(acc[0][0][i] + b);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) store_split(hs, L.row(t, i), L.col, swish(acc[t][0][i] + b));
     }
     __syncthreads();
-    f32x16 acc[1][3];
+    f32x4 acc[2][3];
     zero_acc(acc);
-    WPTR wp[3] = {WTILE(W2, w, F), WTILE(W2, 4 + w, F), WTILE(W2, 8 + w, F)};
-    GEMM<F, 1, 3>(hs, LDV, wp, acc);
+    const uint4 *wp[3] = {WTILE(W2, L.w, F), WTILE(W2, NW + L.w, F), WTILE(W2, 2 * NW + L.w, F)};
+    gemm16<F, 2, 3>(hs, wp, acc);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float b = W.b2[c * F + col];
+        const float b = W.b2[c * F + L.col];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int a = a0 + crow(i, half);
-            if (a < N) phi[(mN + a) * F3 + c * F + col] = acc[0][c][i] + b;
-        }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int a = a0 + L.row(t, i);
+                if (a < N) phi[(mN + a) * F3 + c * F + L.col] = acc[t][c][i] + b;
+            }
     }
 }
 
 // ---- message MLP reverse: sbar_in = sbar_msg + W1^T[(W2^T phibar) * swish'(W1 s + b1)] ------------------------------
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(NTHREADS)
 k_msg_mlp_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
                    const float *__restrict__ phibar, const float *__restrict__ sbar_msg, float *__restrict__ sbar_in) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *xs = lds;                 // [TA][LDV]  s tile, later h1bar
-    float *pb = lds + TA * LDV;      // [TA][LDQ]  phibar tile
-    const int m = blockIdx.y, a0 = blockIdx.x * TA, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int half = lane >> 5, col = 32 * w + (lane & 31);
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    const Planes xs = make_planes(ldsh, TA, F);                          // s tile, later h1bar
+    const Planes pb = make_planes(ldsh + plane_halves(TA, F), TA, F3);   // phibar tile
+    const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
-    load_rows<TA>(xs, LDV, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; });
+    load_rows_split<TA>(xs, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; });
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        load_rows<TA>(pb, LDQ, c * F, [&](int row) { return phibar + (mN + min(a0 + row, N - 1)) * F3 + c * F; });
+        load_rows_split<TA>(pb, c * F, [&](int row) { return phibar + (mN + min(a0 + row, N - 1)) * F3 + c * F; });
     __syncthreads();
-    f32x16 h1[1][1], a1[1][1];
+    f32x4 h1[2][1], a1[2][1];
     zero_acc(h1);
     zero_acc(a1);
     {
-        WPTR wp[1] = {WTILE(W1, w, F)};
-        GEMM<F, 1, 1>(xs, LDV, wp, h1);
-        WPTR wq[1] = {WTILE(W2t, w, F3)};
-        GEMM<F3, 1, 1>(pb, LDQ, wq, a1);
+        const uint4 *wp[1] = {WTILE(W1, L.w, F)};
+        gemm16<F, 2, 1>(xs, wp, h1);
+        const uint4 *wq[1] = {WTILE(W2t, L.w, F3)};
+        gemm16<F3, 2, 1>(pb, wq, a1);
     }
     __syncthreads();  // everyone is done reading xs
     {
-        float b = W.b1[col];
+        const float b = W.b1[L.col];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xs[crow(i, half) * LDV + col] = a1[0][0][i] * dswish(h1[0][0][i] + b);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) store_split(xs, L.row(t, i), L.col, a1[t][0][i] * dswish(h1[t][0][i] + b));
     }
     __syncthreads();
-    f32x16 acc[1][1];
+    f32x4 acc[2][1];
     zero_acc(acc);
-    WPTR wp[1] = {WTILE(W1t, w, F)};
-    GEMM<F, 1, 1>(xs, LDV, wp, acc);
+    const uint4 *wp[1] = {WTILE(W1t, L.w, F)};
+    gemm16<F, 2, 1>(xs, wp, acc);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int a = a0 + crow(i, half);
-        if (a < N) sbar_in[(mN + a) * F + col] = sbar_msg[(mN + a) * F + col] + acc[0][0][i];
-    }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = a0 + L.row(t, i);
+            if (a < N) sbar_in[(mN + a) * F + L.col] = sbar_msg[(mN + a) * F + L.col] + acc[t][0][i];
+        }
 }
 
 // ---- update block -----------------------------------------------------------------------------------------------
-// LDS map (floats): vt [3*TA][LDV] | hs [TA][LDH] | as [TA][LDV]   (contiguous; the reverse pass overlays it)
+// LDS map (halves): vt [3*TA][F] | hs [TA][2F] | as [TA][F], two planes each (the reverse pass overlays it)
 constexpr int OFF_VT = 0;
-constexpr int OFF_HS = 3 * TA * LDV;
-constexpr int OFF_AS = OFF_HS + TA * LDH;
-constexpr int UPD_LDS_FLOATS = OFF_AS + TA * LDV;   // 25 216 floats = 100 864 B
+constexpr int OFF_HS = plane_halves(3 * TA, F);
+constexpr int OFF_AS = OFF_HS + plane_halves(TA, 2 * F);
+constexpr int UPD_LDS_HALVES = OFF_AS + plane_halves(TA, F);   // 51 712 halves = 103 424 B
+static_assert(plane_halves(TA, F3) <= OFF_HS, "qb overlays vt");
+static_assert(plane_halves(3 * TA, 2 * F) <= UPD_LDS_HALVES, "[Ubar | Vbar] overlays the whole region");
 
 struct UpdRegs {
-    f32x16 uv[3][2];   // [x][0] = U v, [x][1] = V v   for feature `col`, 16 atoms (rows) per lane
-    f32x16 h3;         // pre-activation of the gate MLP
-    f32x16 gate[3];    // a_vv, a_sv, a_ss
-    float nrm[16], inner[16];
+    f32x4 uv[6][2];   // [2 x + t][0] = U v_x, [..][1] = V v_x for column `col`, atom rows 16 t + 4 g + i
+    f32x4 h3[2];      // pre-activation of the gate MLP
+    f32x4 gate[2][3]; // a_vv, a_sv, a_ss
+    f32x4 nrm[2], inner[2];
 };
 
 // Shared forward part: needs vt (v_msg tile, rows x*TA+atom) and hs[:, :F] (s_msg tile) loaded + synced.
-__device__ __forceinline__ void update_forward(const LayerW &W, float *lds, int w, int half, int col, UpdRegs &R) {
-    float *vt = lds + OFF_VT, *hs = lds + OFF_HS, *as_ = lds + OFF_AS;
+__device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, const LaneGeo &L, UpdRegs &R) {
+    const Planes vt = make_planes(ldsh + OFF_VT, 3 * TA, F), hs = make_planes(ldsh + OFF_HS, TA, 2 * F),
+                 as_ = make_planes(ldsh + OFF_AS, TA, F);
     zero_acc(R.uv);
     {
-        WPTR wp[2] = {WTILE(U, w, F), WTILE(V, w, F)};
-        GEMM<F, 3, 2>(vt, LDV, wp, R.uv);
+        const uint4 *wp[2] = {WTILE(U, L.w, F), WTILE(V, L.w, F)};
+        gemm16<F, 6, 2>(vt, wp, R.uv);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float n2 = 0.f, in = 0.f;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            float vv = R.uv[x][1][i];
-            n2 += fmaf(vv, vv, 1e-15f);
-            in = fmaf(R.uv[x][0][i], vv, in);
+        for (int i = 0; i < 4; ++i) {
+            float n2 = 0.f, in = 0.f;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const float vv = R.uv[2 * x + t][1][i];
+                n2 += fmaf(vv, vv, 1e-15f);
+                in = fmaf(R.uv[2 * x + t][0][i], vv, in);
+            }
+            R.nrm[t][i] = sqrtf(n2);
+            R.inner[t][i] = in;
+            store_split(hs, L.row(t, i), F + L.col, R.nrm[t][i]);
         }
-        R.nrm[i] = sqrtf(n2);
-        R.inner[i] = in;
-        hs[crow(i, half) * LDH + F + col] = R.nrm[i];
+    __syncthreads();
+    {
+        f32x4 acc[2][1];
+        zero_acc(acc);
+        const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F)};
+        gemm16<2 * F, 2, 1>(hs, wp, acc);
+        const float b = W.b3[L.col];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                R.h3[t][i] = acc[t][0][i] + b;
+                store_split(as_, L.row(t, i), L.col, swish(R.h3[t][i]));
+            }
     }
     __syncthreads();
     {
-        f32x16 acc[1][1];
-        zero_acc(acc);
-        WPTR wp[1] = {WTILE(W3, w, 2 * F)};
-        GEMM<2 * F, 1, 1>(hs, LDH, wp, acc);
-        float b = W.b3[col];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            R.h3[i] = acc[0][0][i] + b;
-            as_[crow(i, half) * LDV + col] = swish(R.h3[i]);
-        }
-    }
-    __syncthreads();
-    {
-        f32x16 acc[1][3];
-        zero_acc(acc);
-        WPTR wp[3] = {WTILE(W4, w, F), WTILE(W4, 4 + w, F), WTILE(W4, 8 + w, F)};
-        GEMM<F, 1, 3>(as_, LDV, wp, acc);
+        zero_acc(R.gate);
+        const uint4 *wp[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
+        gemm16<F, 2, 3>(as_, wp, R.gate);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float b = W.b4[c * F + col];
+            const float b = W.b4[c * F + L.col];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) R.gate[c][i] = acc[0][c][i] + b;
+            for (int t = 0; t < 2; ++t) R.gate[t][c] += (f32x4){b, b, b, b};
         }
     }
 }
 
-__device__ __forceinline__ void load_update_tiles(float *lds, const float *__restrict__ s_msg,
+__device__ __forceinline__ void load_update_tiles(_Float16 *ldsh, const float *__restrict__ s_msg,
                                                   const float *__restrict__ v_msg, size_t mN, int a0, int N) {
-    load_rows<3 * TA>(lds + OFF_VT, LDV, 0, [&](int row) {
+    const Planes vt = make_planes(ldsh + OFF_VT, 3 * TA, F), hs = make_planes(ldsh + OFF_HS, TA, 2 * F);
+    load_rows_split<3 * TA>(vt, 0, [&](int row) {
         int x = row / TA, a = min(a0 + (row % TA), N - 1);
         return v_msg + ((mN + a) * 3 + x) * F;
     });
-    load_rows<TA>(lds + OFF_HS, LDH, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
+    load_rows_split<TA>(hs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
 }
 
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(NTHREADS)
 k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
                   const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int m = blockIdx.y, a0 = blockIdx.x * TA, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int half = lane >> 5, col = 32 * w + (lane & 31);
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
-    load_update_tiles(lds, s_msg, v_msg, mN, a0, N);
+    load_update_tiles(ldsh, s_msg, v_msg, mN, a0, N);
     __syncthreads();
     UpdRegs R;
-    update_forward(W, lds, w, half, col, R);
-    const float *vt = lds + OFF_VT, *hs = lds + OFF_HS;
+    update_forward(W, ldsh, L, R);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int row = crow(i, half), a = a0 + row;
-        if (a >= N) continue;
-        size_t g = mN + a;
-        s_out[g * F + col] = fmaf(R.gate[1][i], R.inner[i], hs[row * LDH + col]) + R.gate[2][i];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int x = 0; x < 3; ++x)
-            v_out[(g * 3 + x) * F + col] = fmaf(R.gate[0][i], R.uv[x][0][i], vt[(x * TA + row) * LDV + col]);
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int a = a0 + L.row(t, i);
+            if (a >= N) continue;
+            const size_t g = mN + a;
+            s_out[g * F + L.col] = fmaf(R.gate[t][1][i], R.inner[t][i], s_msg[g * F + L.col]) + R.gate[t][2][i];
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+                v_out[(g * 3 + x) * F + L.col] = fmaf(R.gate[t][0][i], R.uv[2 * x + t][0][i], v_msg[(g * 3 + x) * F + L.col]);
+        }
 }
 
 // reverse: (sbar, vbar) of the block outputs -> (sbar_msg, vbar_msg) of its inputs.
@@ -401,93 +390,102 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
 //   h3bar = (W4^T qbar) * swish'(h3) ; [sbar_extra ; nbar] = W3^T h3bar
 //   Ubar_x = vbar_x a_vv + sbar a_sv Vv_x ; Vbar_x = sbar a_sv Uv_x + nbar Vv_x / |Vv|
 //   vbar_msg = vbar + U^T Ubar + V^T Vbar ; sbar_msg = sbar + sbar_extra
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(NTHREADS)
 k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
                   const float *__restrict__ v_msg, const float *__restrict__ sbar, const float *__restrict__ vbar,
                   float *__restrict__ sbar_msg, float *__restrict__ vbar_msg) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int m = blockIdx.y, a0 = blockIdx.x * TA, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int half = lane >> 5, col = 32 * w + (lane & 31);
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
-    load_update_tiles(lds, s_msg, v_msg, mN, a0, N);
+    load_update_tiles(ldsh, s_msg, v_msg, mN, a0, N);
     __syncthreads();
     UpdRegs R;
-    update_forward(W, lds, w, half, col, R);
+    update_forward(W, ldsh, L, R);
     // Every wave has passed the barrier in front of GEMM3, i.e. finished GEMM1/GEMM2: vt and hs are free.
-    float *qb = lds + OFF_VT;    // [TA][LDQ] overlays vt (12 416 <= 12 672 floats)
-    float sb[16];
+    const Planes qb = make_planes(ldsh + OFF_VT, TA, F3);    // overlays vt
+    f32x4 sb[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int row = crow(i, half);
-        size_t g = mN + min(a0 + row, N - 1);
-        sb[i] = sbar[g * F + col];
-        float abar_vv = 0.f;
-        if (!vbar_is_zero) {   // wave-uniform
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int x = 0; x < 3; ++x) abar_vv = fmaf(vbar[(g * 3 + x) * F + col], R.uv[x][0][i], abar_vv);
+        for (int i = 0; i < 4; ++i) {
+            const int row = L.row(t, i);
+            const size_t g = mN + min(a0 + row, N - 1);
+            sb[t][i] = sbar[g * F + L.col];
+            float abar_vv = 0.f;
+            if (!vbar_is_zero) {   // wave-uniform
+#pragma unroll
+                for (int x = 0; x < 3; ++x) abar_vv = fmaf(vbar[(g * 3 + x) * F + L.col], R.uv[2 * x + t][0][i], abar_vv);
+            }
+            store_split(qb, row, L.col, abar_vv);
+            store_split(qb, row, F + L.col, sb[t][i] * R.inner[t][i]);
+            store_split(qb, row, 2 * F + L.col, sb[t][i]);
         }
-        qb[row * LDQ + col] = abar_vv;
-        qb[row * LDQ + F + col] = sb[i] * R.inner[i];
-        qb[row * LDQ + 2 * F + col] = sb[i];
-    }
     __syncthreads();   // qb complete; every wave is past GEMM3, so `as` may be overwritten
-    float *hb = lds + OFF_AS;    // [TA][LDV] h3bar
+    const Planes hb = make_planes(ldsh + OFF_AS, TA, F);    // h3bar
     {
-        f32x16 acc[1][1];
+        f32x4 acc[2][1];
         zero_acc(acc);
-        WPTR wp[1] = {WTILE(W4t, w, F3)};
-        GEMM<F3, 1, 1>(qb, LDQ, wp, acc);
+        const uint4 *wp[1] = {WTILE(W4t, L.w, F3)};
+        gemm16<F3, 2, 1>(qb, wp, acc);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hb[crow(i, half) * LDV + col] = acc[0][0][i] * dswish(R.h3[i]);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) store_split(hb, L.row(t, i), L.col, acc[t][0][i] * dswish(R.h3[t][i]));
     }
     __syncthreads();
-    f32x16 hbar[1][2];   // [0] = d/d s_msg part, [1] = d/d norm part, both for feature `col`
+    f32x4 hbar[2][2];   // [t][0] = d/d s_msg part, [t][1] = d/d norm part, both for feature `col`
     zero_acc(hbar);
     {
-        WPTR wp[2] = {WTILE(W3t, w, F), WTILE(W3t, 4 + w, F)};
-        GEMM<F, 1, 2>(hb, LDV, wp, hbar);
+        const uint4 *wp[2] = {WTILE(W3t, L.w, F), WTILE(W3t, NW + L.w, F)};
+        gemm16<F, 2, 2>(hb, wp, hbar);
     }
     __syncthreads();   // all waves are done with qb / hb: the whole region becomes the [Ubar | Vbar] tile
-    float *ab = lds;     // [3*TA][LDH]: cols [0,F) = Ubar, [F,2F) = Vbar   (24 960 <= 25 216 floats)
+    const Planes ab = make_planes(ldsh, 3 * TA, 2 * F);     // cols [0,F) = Ubar, [F,2F) = Vbar
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int row = crow(i, half), a = a0 + row;
-        size_t g = mN + min(a, N - 1);
-        if (a < N) sbar_msg[g * F + col] = sb[i] + hbar[0][0][i];
-        float avv = R.gate[0][i], asv = R.gate[1][i];
-        float sc = hbar[0][1][i] / R.nrm[i];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            float vbo = vbar_is_zero ? 0.f : vbar[(g * 3 + x) * F + col];
-            float u = R.uv[x][0][i], v = R.uv[x][1][i];
-            float sa = sb[i] * asv;
-            ab[(x * TA + row) * LDH + col] = fmaf(vbo, avv, sa * v);
-            ab[(x * TA + row) * LDH + F + col] = fmaf(sa, u, sc * v);
+        for (int i = 0; i < 4; ++i) {
+            const int row = L.row(t, i), a = a0 + row;
+            const size_t g = mN + min(a, N - 1);
+            if (a < N) sbar_msg[g * F + L.col] = sb[t][i] + hbar[t][0][i];
+            const float avv = R.gate[t][0][i], asv = R.gate[t][1][i];
+            const float sc = hbar[t][1][i] / R.nrm[t][i];
+            const float sa = sb[t][i] * asv;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const float vbo = vbar_is_zero ? 0.f : vbar[(g * 3 + x) * F + L.col];
+                const float u = R.uv[2 * x + t][0][i], v = R.uv[2 * x + t][1][i];
+                store_split(ab, x * TA + row, L.col, fmaf(vbo, avv, sa * v));
+                store_split(ab, x * TA + row, F + L.col, fmaf(sa, u, sc * v));
+            }
         }
-    }
     __syncthreads();
-    f32x16 out[3][1];
+    f32x4 out[6][1];
     zero_acc(out);
     {
-        WPTR wp[1] = {WTILE(UVt, w, 2 * F)};
-        GEMM<2 * F, 3, 1>(ab, LDH, wp, out);
+        const uint4 *wp[1] = {WTILE(UVt, L.w, 2 * F)};
+        gemm16<2 * F, 6, 1>(ab, wp, out);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int row = crow(i, half), a = a0 + row;
-        if (a >= N) continue;
-        size_t g = mN + a;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            float vbo = vbar_is_zero ? 0.f : vbar[(g * 3 + x) * F + col];
-            vbar_msg[(g * 3 + x) * F + col] = vbo + out[x][0][i];
+        for (int i = 0; i < 4; ++i) {
+            const int a = a0 + L.row(t, i);
+            if (a >= N) continue;
+            const size_t g = mN + a;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const float vbo = vbar_is_zero ? 0.f : vbar[(g * 3 + x) * F + L.col];
+                vbar_msg[(g * 3 + x) * F + L.col] = vbo + out[2 * x + t][0][i];
+            }
         }
-    }
 }
 
 // ---- host: weight packing + launch helpers ------------------------------------------------------------------------
-// packed[tile][q][lane][t] = W[tile*32 + (lane&31)][(lane>>5)*(K/2) + 4q + t]   (W row-major [rows][K])
+// fp32 fragment order of the first (fp32 MFMA) implementation; still built by vssr_create, not used by these kernels
+//   packed[tile][q][lane][t] = W[tile*32 + (lane&31)][(lane>>5)*(K/2) + 4q + t]   (W row-major [rows][K])
 void pack_mfma_tiles(const float *Wsrc, int rows, int K, float *dst) {
     const int ntile = rows / 32, nq = K / 8;
     for (int tile = 0; tile < ntile; ++tile)
@@ -498,8 +496,8 @@ void pack_mfma_tiles(const float *Wsrc, int rows, int K, float *dst) {
                         Wsrc[(size_t)(tile * 32 + (lane & 31)) * K + (lane >> 5) * (K / 2) + 4 * q + t];
 }
 
-// fp16-split fragment order for v_mfma_f32_32x32x16_f16:
-//   dst[tile][q][piece][lane][j] = piece(W[tile*32 + (lane&31)][16 q + 8 (lane>>5) + 2 j]) | piece(W[..][.. + 1]) << 16
+// fp16-split fragment order for v_mfma_f32_16x16x32_f16, 16-column tiles:
+//   dst[tile][q][piece][lane][j] = piece(W[tile*16 + (lane&15)][32 q + 8 (lane>>4) + 2 j]) | piece(W[..][.. + 1]) << 16
 void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst) {
     auto split2 = [](float x, unsigned (&p)[2]) {
         const _Float16 h = (_Float16)x;
@@ -509,13 +507,13 @@ void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst) {
         memcpy(&lb, &l, 2);
         p[0] = hb; p[1] = lb;
     };
-    const int ntile = rows / 32, nq = K / 16;
+    const int ntile = rows / 16, nq = K / 32;
     for (int tile = 0; tile < ntile; ++tile)
         for (int q = 0; q < nq; ++q)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 4; ++j) {
-                    const size_t row = (size_t)tile * 32 + (lane & 31);
-                    const int k = 16 * q + 8 * (lane >> 5) + 2 * j;
+                    const size_t row = (size_t)tile * 16 + (lane & 15);
+                    const int k = 32 * q + 8 * (lane >> 4) + 2 * j;
                     unsigned p0[2], p1[2];
                     split2(Wsrc[row * K + k], p0);
                     split2(Wsrc[row * K + k + 1], p1);
@@ -526,9 +524,9 @@ void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst) {
 
 size_t node_mfma_lds_bytes(int which) {
     switch (which) {
-        case 0: return sizeof(float) * 2 * TA * LDV;            // msg mlp fwd
-        case 1: return sizeof(float) * (TA * LDV + TA * LDQ);   // msg mlp bwd
-        default: return sizeof(float) * UPD_LDS_FLOATS;         // update fwd / bwd
+        case 0: return sizeof(_Float16) * 2 * plane_halves(TA, F);                        // msg mlp fwd
+        case 1: return sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(TA, F3));   // msg mlp bwd
+        default: return sizeof(_Float16) * UPD_LDS_HALVES;                                // update fwd / bwd
     }
 }
 
@@ -545,23 +543,23 @@ int node_mfma_init(vssr_handle *h) {
 }
 
 void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in, float *phi) {
-    hipLaunchKernelGGL(k_msg_mlp_mfma, dim3((N + TA - 1) / TA, M), dim3(256), node_mfma_lds_bytes(0), st, N, l, MW,
+    hipLaunchKernelGGL(k_msg_mlp_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(0), st, N, l, MW,
                        s_in, phi);
 }
 void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in,
                              const float *phibar, const float *sbar_msg, float *sbar_in) {
-    hipLaunchKernelGGL(k_msg_mlp_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(256), node_mfma_lds_bytes(1), st, N, l, MW,
+    hipLaunchKernelGGL(k_msg_mlp_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(1), st, N, l, MW,
                        s_in, phibar, sbar_msg, sbar_in);
 }
 void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_msg,
                             const float *v_msg, float *s_out, float *v_out) {
-    hipLaunchKernelGGL(k_update_fwd_mfma, dim3((N + TA - 1) / TA, M), dim3(256), node_mfma_lds_bytes(2), st, N, l, MW,
+    hipLaunchKernelGGL(k_update_fwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(2), st, N, l, MW,
                        s_msg, v_msg, s_out, v_out);
 }
 void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zero, const ModelW *MW,
                             const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
                             float *sbar_msg, float *vbar_msg) {
-    hipLaunchKernelGGL(k_update_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(256), node_mfma_lds_bytes(2), st, N, l,
+    hipLaunchKernelGGL(k_update_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(2), st, N, l,
                        vbar_is_zero, MW, s_msg, v_msg, sbar, vbar, sbar_msg, vbar_msg);
 }
 
