@@ -340,22 +340,39 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
 
 // ---- ensemble reduction -----------------------------------------------------------------------------------------
 // forces: dE/dx_c = sum_{slots (c,n)} ( G[(n->c)] - G[(c->n)] ), G[(c->n)] lives at rev[slot].
-__global__ void k_finalize_forces(int N, int M, int n_groups, GraphView G, const int *__restrict__ counters,
-                                  const float4 *__restrict__ gbar, long long gbar_stride, double units_per_ev,
+// Partial edge gradients of the feature-slice groups -> one buffer per model (group 0, in place): a streaming,
+// coalesced pass in fixed group order, so that the gather through `rev` below touches one buffer per model only.
+__global__ void k_reduce_gbar_groups(int M, int n_groups, const int *__restrict__ counters, float4 *__restrict__ gbar,
+                                     long long gbar_stride) {
+    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (counters[2] || slot >= counters[0]) return;
+    for (int m = 0; m < M; ++m) {
+        float4 *g0 = gbar + (size_t)(m * n_groups) * gbar_stride + slot;
+        float4 acc = *g0;
+        for (int grp = 1; grp < n_groups; ++grp) {
+            const float4 v = g0[(size_t)grp * gbar_stride];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z;
+        }
+        *g0 = acc;
+    }
+}
+
+// forces = - sum_slots (G[slot] - G[rev[slot]]) per model, then ensemble mean / std.  gbar_model_stride: distance between
+// the (group-reduced) buffers of consecutive models.
+__global__ void k_finalize_forces(int N, int M, GraphView G, const int *__restrict__ counters,
+                                  const float4 *__restrict__ gbar, long long gbar_model_stride, double units_per_ev,
                                   float *__restrict__ forces, float *__restrict__ forces_std) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N || counters[2]) return;
     double fm[3] = {0, 0, 0}, f2[3] = {0, 0, 0};
     for (int m = 0; m < M; ++m) {
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        for (int grp = 0; grp < n_groups; ++grp) {   // partial edge gradients of the feature-slice groups
-            const float4 *gb = gbar + (size_t)(m * n_groups + grp) * gbar_stride;
-            for (int e = G.row_start[c]; e < G.row_start[c + 1]; ++e) {
-                int r = G.rev[e];
-                if (r < 0) continue;
-                float4 a = gb[e], b = gb[r];
-                g0 += a.x - b.x; g1 += a.y - b.y; g2 += a.z - b.z;
-            }
+        const float4 *gb = gbar + (size_t)m * gbar_model_stride;
+        for (int e = G.row_start[c]; e < G.row_start[c + 1]; ++e) {
+            int r = G.rev[e];
+            if (r < 0) continue;
+            float4 a = gb[e], b = gb[r];
+            g0 += a.x - b.x; g1 += a.y - b.y; g2 += a.z - b.z;
         }
         double f[3] = {-(double)g0 / units_per_ev, -(double)g1 / units_per_ev, -(double)g2 / units_per_ev};
         for (int x = 0; x < 3; ++x) { fm[x] += f[x]; f2[x] += f[x] * f[x]; }
@@ -564,11 +581,14 @@ int painn_run(vssr_handle *h, uint32_t want) {
         }
     }
     P.begin(KC_FINALIZE, st);
-    if (want & VSSR_WANT_FORCES)
-        hipLaunchKernelGGL(k_finalize_forces, dim3((N + 127) / 128), dim3(128), 0, st, N, M, n_groups, G, counters,
-                           sv.gbar,
-                           (long long)h->slot_cap, h->units_per_ev, h->d_forces.as<float>(),
+    if (want & VSSR_WANT_FORCES) {
+        if (n_groups > 1)
+            hipLaunchKernelGGL(k_reduce_gbar_groups, dim3((unsigned)((h->slot_cap + 255) / 256)), dim3(256), 0, st, M, n_groups,
+                               counters, sv.gbar, (long long)h->slot_cap);
+        hipLaunchKernelGGL(k_finalize_forces, dim3((N + 127) / 128), dim3(128), 0, st, N, M, G, counters, sv.gbar,
+                           (long long)h->slot_cap * n_groups, h->units_per_ev, h->d_forces.as<float>(),
                            h->d_forces_std.as<float>());
+    }
     hipLaunchKernelGGL(k_finalize_energy, dim3(h->n_cfg), dim3(256), 0, st, N, M, G.cfg_start, Z, sv.e_atom,
                        h->units_per_ev, h->has_offset ? h->offset_per_z.as<double>() : (const double *)nullptr,
                        h->offset_const, h->d_energy.as<float>(), h->d_energy_std.as<float>(),

@@ -370,7 +370,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 // slices, so the per-slot edge gradient G[m][group][slot] is accumulated by the SAME lane in a fixed order
 // (deterministic read-modify-write, L2 resident); finalize adds the groups.
 constexpr int BWD_THREADS = 512;
-constexpr int SLICES_PER_WG = 4;
+constexpr int SLICES_PER_WG = 1;   // measured: 1 -> 6.3 ms, 2 -> 6.7, 4 -> 7.1 per step (L2 locality of the tables); finalize reduces the 8 partial buffers in a streaming pass
 constexpr int NSG = NSLICE / SLICES_PER_WG;   // slice groups = partial edge-gradient buffers per model
 constexpr int ROWB = FS * 4 + 4;              // LDS row: [feature][sbar, vbar_x, vbar_y, vbar_z] + pad
 
