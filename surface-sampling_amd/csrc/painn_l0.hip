@@ -13,7 +13,7 @@
 // The per-edge work drops from 2 x 384 x 24 MACs per model (forward) to 7 x 24 (reverse) / 0 (forward): the layer-0
 // launches of the neighbor-sum kernels disappear.  Ab / Ac depend only on the weights: built once at vssr_create.
 // k runs in the table order kappa = kq * 6 + ks  <->  k = kq + 4 ks  used by the rho / drho tables (nbr.hip).
-#include "vssr_internal.h"
+#include "mfma16.h"
 
 namespace vssr {
 
@@ -42,81 +42,133 @@ k_l0_accum(int nz, GraphView G, const int *__restrict__ counters, const int *__r
     for (int z = 0; z < nz; ++z) T[((size_t)i * nz + z) * TBLK + comp * KP + kap] = acc[z];
 }
 
-constexpr int L0T = 8;   // atoms per block in the per-atom kernels (each table element is loaded once per L0T atoms)
+// ---- per-atom contractions on the matrix pipe (fp16 2-way split, see painn_node_mfma.hip / mfma16.h) -------------------------
+// Species z is one K-chunk of 32: its 24 table entries + 8 zeros.  Weight tiles per (model, species, section) were packed
+// at vssr_create (l0_pack_tables): forward  B = A_z[f][kappa]  (8 column tiles of 16 features, 1 chunk),
+//                                  reverse  B = A_z[kappa][f]  (2 column tiles of 16 kappas, 4 chunks of 32 features).
+constexpr int L0_TILE_U4 = 1024;   // uint4 per (model, species, section) in either packed table
 
-// ---- forward: s_msg0, v_msg0 for every model; block = (tile of L0T atoms, model), thread = feature ---------------------
-__global__ void __launch_bounds__(128)
-k_l0_fwd(int N, int nz, const int *__restrict__ counters, const int *__restrict__ Z, const int *__restrict__ zlist,
-         const ModelW *__restrict__ MW, const float *__restrict__ l0A /*[M][n_embed][2][24][F]*/, int n_embed,
-         const float *__restrict__ T, float *__restrict__ s_msg, float *__restrict__ v_msg) {
-    __shared__ float Ts[L0T][L0_MAX_SPECIES * TBLK];
+// forward: s_msg0 = Emb[Z] + T[:, 0] . Ab ,  v_msg0[x] = T[:, 1 + x] . Ac  for every model; workgroup = 32 atoms (the T
+// planes are model independent and are reused for all M models), wave w = features 16 w .. 16 w + 15
+__global__ void __launch_bounds__(NTHREADS)
+k_l0_fwd16(int N, int M, int nz, const int *__restrict__ counters, const int *__restrict__ Z,
+           const int *__restrict__ zlist, const ModelW *__restrict__ MW, const uint4 *__restrict__ A16, int n_embed,
+           const float *__restrict__ T, float *__restrict__ s_msg, float *__restrict__ v_msg) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     if (counters[2]) return;
-    const int i0 = blockIdx.x * L0T, m = blockIdx.y, f = threadIdx.x;
-    for (int t = f; t < L0T * nz * TBLK; t += 128) {
-        const int a = t / (nz * TBLK), r = t % (nz * TBLK);
-        Ts[a][r] = T[(size_t)min(i0 + a, N - 1) * nz * TBLK + r];
+    const int K = 32 * nz, a0 = blockIdx.x * TA;
+    const Planes Ts = make_planes(ldsh, TA, K), Tv = make_planes(ldsh + plane_halves(TA, K), 3 * TA, K);
+    const LaneGeo L;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    // T[(i nz + z) 96 + comp 24 + kappa] -> planes; the 8 pad entries of every species chunk are zero
+    for (int t = threadIdx.x; t < TA * nz * 4 * 32; t += NTHREADS) {
+        const int kap = t & 31, comp = (t >> 5) & 3, z = (t >> 7) % nz, a = t / (128 * nz);
+        const float val = kap < KP ? T[((size_t)min(a0 + a, N - 1) * nz + z) * TBLK + comp * KP + kap] : 0.f;
+        if (comp == 0) store_split(Ts, a, 32 * z + kap, val);
+        else store_split(Tv, (comp - 1) * TA + a, 32 * z + kap, val);
     }
     __syncthreads();
-    float s[L0T], vx[L0T], vy[L0T], vz[L0T];
+    for (int m = 0; m < M; ++m) {
+        f32x4 acc[8];   // tiles 0, 1: scalar rows ; 2 + 2 x + t: component x, rows 16 t ..
 #pragma unroll
-    for (int a = 0; a < L0T; ++a) {
-        s[a] = MW[m].embed[(size_t)Z[min(i0 + a, N - 1)] * F + f];
-        vx[a] = 0.f; vy[a] = 0.f; vz[a] = 0.f;
-    }
-    for (int z = 0; z < nz; ++z) {
-        const float *Ab = l0A + (((size_t)m * n_embed + zlist[z]) * 2 + 0) * KP * F + f;
-        const float *Ac = Ab + (size_t)KP * F;
-        for (int k = 0; k < KP; ++k) {
-            const float ab = Ab[k * F], ac = Ac[k * F];
+        for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int q = 0; q < nz; ++q) {
+            const uint4 *wb = A16 + (((size_t)m * n_embed + zlist[q]) * 2) * L0_TILE_U4 + (size_t)L.w * 128 + lane;
+            u32x4 b[2][2], a[8][2];
 #pragma unroll
-            for (int a = 0; a < L0T; ++a) {
-                const float *t0 = Ts[a] + z * TBLK;
-                s[a] = fmaf(ab, t0[k], s[a]);
-                vx[a] = fmaf(ac, t0[KP + k], vx[a]);
-                vy[a] = fmaf(ac, t0[2 * KP + k], vy[a]);
-                vz[a] = fmaf(ac, t0[3 * KP + k], vz[a]);
+            for (int sec = 0; sec < 2; ++sec)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) b[sec][pc] = gload4u(wb + sec * L0_TILE_U4 + pc * 64);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const Planes &P = t < 2 ? Ts : Tv;
+                const int row = (t < 2 ? 16 * t : 16 * (t - 2)) + r;
+                a[t][0] = *reinterpret_cast<const u32x4 *>(P.h + row * P.ld + 32 * q + 8 * g);
+                a[t][1] = *reinterpret_cast<const u32x4 *>(P.l + row * P.ld + 32 * q + 8 * g);
             }
-        }
-    }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int a = 0; a < L0T; ++a) {
-        if (i0 + a >= N) break;
-        const size_t g = (size_t)m * N + i0 + a;
-        s_msg[g * F + f] = s[a];
-        v_msg[(g * 3 + 0) * F + f] = vx[a];
-        v_msg[(g * 3 + 1) * F + f] = vy[a];
-        v_msg[(g * 3 + 2) * F + f] = vz[a];
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    acc[t] = mfma16(a[t][k == 1 ? 1 : 0], b[t < 2 ? 0 : 1][k == 0 ? 1 : 0], acc[t]);   // a_h w_l, a_l w_h, a_h w_h
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int a_ = a0 + L.row(t, i);
+                if (a_ >= N) continue;
+                const size_t gI = (size_t)m * N + a_;
+                s_msg[gI * F + L.col] = MW[m].embed[(size_t)Z[a_] * F + L.col] + acc[t][i];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) v_msg[(gI * 3 + x) * F + L.col] = acc[2 + 2 * x + t][i];
+            }
     }
 }
 
-// ---- reverse, per atom: Q_n,z[comp][kappa] = sum_f A_z[f][kappa] X_comp[f], X = [sbar; vbar_x; vbar_y; vbar_z] --------------
-__global__ void __launch_bounds__(96)
-k_l0_q(int N, int nz, const int *__restrict__ counters, const int *__restrict__ zlist,
-       const float *__restrict__ l0At /*[M][n_embed][2][F][24]*/, int n_embed, const float *__restrict__ sbar_msg,
-       const float *__restrict__ vbar_msg, float *__restrict__ Q /*[M][N][nz][4][24]*/) {
-    __shared__ float X[4][F][L0T];
+// reverse, per atom: Q_n,z[comp][kappa] = sum_f A_z[f][kappa] X_comp[f], X = [sbar; vbar_x; vbar_y; vbar_z].  Workgroup =
+// (32 atoms, model); the 2 nz column tiles (species x kappa half) are spread over the 8 waves.
+__global__ void __launch_bounds__(NTHREADS)
+k_l0_q16(int N, int nz, const int *__restrict__ counters, const int *__restrict__ zlist, const uint4 *__restrict__ At16,
+         int n_embed, const float *__restrict__ sbar_msg, const float *__restrict__ vbar_msg,
+         float *__restrict__ Q /*[M][N][nz][4][24]*/) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     if (counters[2]) return;
-    const int i0 = blockIdx.x * L0T, m = blockIdx.y, comp = threadIdx.x / KP, kap = threadIdx.x % KP;
-    for (int t = threadIdx.x; t < L0T * 4 * F; t += 96) {
-        const int a = t / (4 * F), c4 = (t / F) % 4, f = t % F;
-        const size_t g = (size_t)m * N + min(i0 + a, N - 1);
-        X[c4][f][a] = c4 == 0 ? sbar_msg[g * F + f] : vbar_msg[(g * 3 + (c4 - 1)) * F + f];
-    }
+    const int a0 = blockIdx.x * TA, m = blockIdx.y;
+    const size_t mN = (size_t)m * N;
+    const Planes Xs = make_planes(ldsh, TA, F), Xv = make_planes(ldsh + plane_halves(TA, F), 3 * TA, F);
+    load_rows_split<TA>(Xs, 0, [&](int row) { return sbar_msg + (mN + min(a0 + row, N - 1)) * F; });
+    load_rows_split<3 * TA>(Xv, 0, [&](int row) {
+        int x = row / TA, a = min(a0 + (row % TA), N - 1);
+        return vbar_msg + ((mN + a) * 3 + x) * F;
+    });
     __syncthreads();
-    for (int z = 0; z < nz; ++z) {
-        const float *At = l0At + (((size_t)m * n_embed + zlist[z]) * 2 + (comp == 0 ? 0 : 1)) * F * KP + kap;
-        float acc[L0T];
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    for (int ct = w; ct < 2 * nz; ct += NW) {
+        const int q = ct >> 1, hf = ct & 1;
+        const uint4 *wb = At16 + (((size_t)m * n_embed + zlist[q]) * 2) * L0_TILE_U4 + (size_t)hf * 512 + lane;
+        f32x4 acc[8];
 #pragma unroll
-        for (int a = 0; a < L0T; ++a) acc[a] = 0.f;
-#pragma unroll 4
-        for (int f = 0; f < F; ++f) {
-            const float w = At[f * KP];
+        for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int c = 0; c < F / 32; ++c) {
+            u32x4 b[2][2], a[8][2];
 #pragma unroll
-            for (int a = 0; a < L0T; ++a) acc[a] = fmaf(w, X[comp][f][a], acc[a]);
+            for (int sec = 0; sec < 2; ++sec)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) b[sec][pc] = gload4u(wb + sec * L0_TILE_U4 + (c * 2 + pc) * 64);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const Planes &P = t < 2 ? Xs : Xv;
+                const int row = (t < 2 ? 16 * t : 16 * (t - 2)) + r;
+                a[t][0] = *reinterpret_cast<const u32x4 *>(P.h + row * P.ld + 32 * c + 8 * g);
+                a[t][1] = *reinterpret_cast<const u32x4 *>(P.l + row * P.ld + 32 * c + 8 * g);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    acc[t] = mfma16(a[t][k == 1 ? 1 : 0], b[t < 2 ? 0 : 1][k == 0 ? 1 : 0], acc[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
+        const int kap = 16 * hf + r;
+        if (kap < KP) {
 #pragma unroll
-        for (int a = 0; a < L0T; ++a)
-            if (i0 + a < N) Q[((((size_t)m * N + i0 + a) * nz + z) * 4 + comp) * KP + kap] = acc[a];
+            for (int t = 0; t < 8; ++t) {
+                const int comp = t < 2 ? 0 : 1 + (t - 2) / 2, tt = t < 2 ? t : (t - 2) & 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int a_ = a0 + 16 * tt + 4 * g + i;
+                    if (a_ < N) Q[((((size_t)m * N + a_) * nz + q) * 4 + comp) * KP + kap] = acc[t][i];
+                }
+            }
+        }
     }
 }
 
@@ -213,6 +265,34 @@ void l0_build_tables(const float *blob_embed, const float *W1, const float *b1, 
     }
 }
 
+// fp16-split fragment-order copies of one model's tables (pack_mfma_tiles16, painn_node_mfma.hip):
+//   A16 [n_embed][2][1024 uint4]: matrix [F features][32 kappa (24 + zeros)]  -> forward B operand
+//   At16[n_embed][2][1024 uint4]: matrix [32 kappa (24 + zeros)][F features]  -> reverse B operand
+void l0_pack_tables(const float *A /*[n_embed][2][24][F]*/, int n_embed, unsigned *A16, unsigned *At16) {
+    std::vector<float> fk((size_t)F * 32), kf((size_t)32 * F);
+    for (int z = 0; z < n_embed; ++z)
+        for (int sec = 0; sec < 2; ++sec) {
+            std::fill(fk.begin(), fk.end(), 0.f);
+            std::fill(kf.begin(), kf.end(), 0.f);
+            for (int kap = 0; kap < KP; ++kap)
+                for (int f = 0; f < F; ++f) {
+                    const float v = A[(((size_t)z * 2 + sec) * KP + kap) * F + f];
+                    fk[(size_t)f * 32 + kap] = v;
+                    kf[(size_t)kap * F + f] = v;
+                }
+            const size_t o = ((size_t)z * 2 + sec) * L0_TILE_U4 * 4;
+            pack_mfma_tiles16(fk.data(), F, 32, A16 + o);
+            pack_mfma_tiles16(kf.data(), 32, F, At16 + o);
+        }
+}
+size_t l0_packed_dwords(int n_embed) { return (size_t)n_embed * 2 * L0_TILE_U4 * 4; }
+
+int l0_mfma_init(vssr_handle *h) {
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_l0_fwd16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_l0_q16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return VSSR_OK;
+}
+
 int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_msg) {
     const int N = h->n_atoms, M = h->n_models, nz = h->l0_nz;
     hipStream_t st = h->stream;
@@ -221,8 +301,9 @@ int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_ms
         return set_err(h, VSSR_E_NOMEM, "layer-0 factorisation buffers: out of device memory");
     hipLaunchKernelGGL(k_l0_accum, dim3(N), dim3(96), 0, st, nz, G, h->d_counters.as<int>(), h->d_Z.as<int>(),
                        h->d_zmap.as<int>(), h->d_l0T.as<float>());
-    hipLaunchKernelGGL(k_l0_fwd, dim3((N + L0T - 1) / L0T, M), dim3(128), 0, st, N, nz, h->d_counters.as<int>(), h->d_Z.as<int>(),
-                       h->d_zlist.as<int>(), h->model_table.as<ModelW>(), h->d_l0A.as<float>(), h->n_embed,
+    const size_t lds_fwd = sizeof(_Float16) * (plane_halves(TA, 32 * nz) + plane_halves(3 * TA, 32 * nz));
+    hipLaunchKernelGGL(k_l0_fwd16, dim3((N + TA - 1) / TA), dim3(NTHREADS), lds_fwd, st, N, M, nz, h->d_counters.as<int>(),
+                       h->d_Z.as<int>(), h->d_zlist.as<int>(), h->model_table.as<ModelW>(), h->d_l0A.as<uint4>(), h->n_embed,
                        h->d_l0T.as<float>(), s_msg, v_msg);
     return VSSR_OK;
 }
@@ -231,8 +312,9 @@ int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const fl
                    float4 *gbar, long long gbar_stride, int n_groups) {
     const int N = h->n_atoms, M = h->n_models, nz = h->l0_nz;
     hipStream_t st = h->stream;
-    hipLaunchKernelGGL(k_l0_q, dim3((N + L0T - 1) / L0T, M), dim3(96), 0, st, N, nz, h->d_counters.as<int>(), h->d_zlist.as<int>(),
-                       h->d_l0At.as<float>(), h->n_embed, sbar_msg, vbar_msg, h->d_l0Q.as<float>());
+    const size_t lds_q = sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(3 * TA, F));
+    hipLaunchKernelGGL(k_l0_q16, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), lds_q, st, N, nz, h->d_counters.as<int>(),
+                       h->d_zlist.as<int>(), h->d_l0At.as<uint4>(), h->n_embed, sbar_msg, vbar_msg, h->d_l0Q.as<float>());
     hipLaunchKernelGGL(k_l0_bwd, dim3((N + 3) / 4), dim3(256), 0, st, N, M, nz, first_write, h->excl_vol, G,
                        h->d_counters.as<int>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_l0Q.as<float>(), gbar,
                        gbar_stride, n_groups);

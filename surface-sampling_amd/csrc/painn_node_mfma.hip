@@ -21,91 +21,9 @@
 // MFMA issue order follows the hazard rules of painn_edge_mfma.hip: the three products of a tile are a dependent chain,
 // so products are issued in rounds over >= 3 independent accumulators (K-interleaved partial accumulators for GEMMs with
 // two tiles), pinned with scheduling barriers, and no load is issued inside the MFMA block of a chunk group.
-#include "vssr_internal.h"
+#include "mfma16.h"
 
 namespace vssr {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-constexpr int TA = 32;            // atoms per workgroup
-constexpr int NW = 8;             // waves per workgroup
-constexpr int NTHREADS = 64 * NW;
-constexpr int PADH = 8;           // row pad of the fp16 planes (halves): conflict-free ds_read_b128 of 16 rows
-
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float swish(float x) { return x * sigm(x); }
-__device__ __forceinline__ float dswish(float x) {
-    float sg = sigm(x);
-    return sg * fmaf(x, 1.f - sg, 1.f);
-}
-
-// Weight pointers are read out of the ModelW table in memory, so the compiler would treat them as FLAT (flat loads
-// tick both vmcnt and lgkmcnt).  Loading through an explicit global address space pointer gives global_load.
-__device__ __forceinline__ u32x4 gload4u(const uint4 *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const u32x4 __attribute__((address_space(1))) *gptr;
-    return *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
-#else
-    return *reinterpret_cast<const u32x4 *>(p);
-#endif
-}
-
-// ---- activation tiles as fp16 planes -----------------------------------------------------------------------------------
-struct Planes {   // [rows][K] in two planes; ld = K + PADH halves
-    _Float16 *h, *l;
-    int ld;
-};
-__device__ __forceinline__ Planes make_planes(_Float16 *base, int rows, int K) {
-    return Planes{base, base + (size_t)rows * (K + PADH), K + PADH};
-}
-constexpr int plane_halves(int rows, int K) { return 2 * rows * (K + PADH); }
-
-__device__ __forceinline__ void split1(float x, _Float16 &h, _Float16 &l) {
-    const float xc = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
-    h = (_Float16)xc;
-    l = (_Float16)(xc - (float)h);
-}
-__device__ __forceinline__ void store_split(const Planes &P, int row, int col, float x) {
-    _Float16 h, l;
-    split1(x, h, l);
-    P.h[row * P.ld + col] = h;
-    P.l[row * P.ld + col] = l;
-}
-// four consecutive columns at once (col multiple of 4): two 8-byte LDS stores
-__device__ __forceinline__ void store_split4(const Planes &P, int row, int col, float4 v) {
-    const f32x2 a = {__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f)};
-    const f32x2 b = {__builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f)};
-    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-    const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), f16x2);
-    const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), f16x2);
-    *reinterpret_cast<u32x2 *>(P.h + row * P.ld + col) = (u32x2){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
-    *reinterpret_cast<u32x2 *>(P.l + row * P.ld + col) = (u32x2){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
-}
-
-// Cooperative tile load: NROWS rows of F floats from global, split, into plane columns [col0, col0 + F).  rowptr(row)
-// must always return a readable row (tail rows are clamped to the last atom; their results are never stored), so that
-// all loads are unconditional and issued back-to-back before the first LDS store.
-template <int NROWS, class RowPtr>
-__device__ __forceinline__ void load_rows_split(const Planes &P, int col0, RowPtr rowptr) {
-    constexpr int NIT = NROWS * (F / 4) / NTHREADS;
-    static_assert(NROWS * (F / 4) % NTHREADS == 0, "tile load must divide evenly");
-    float4 v[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = threadIdx.x + it * NTHREADS;
-        v[it] = *reinterpret_cast<const float4 *>(rowptr(idx >> 5) + 4 * (idx & 31));
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = threadIdx.x + it * NTHREADS;
-        store_split4(P, idx >> 5, col0 + 4 * (idx & 31), v[it]);
-    }
-}
 
 // ---- GEMM on the planes ------------------------------------------------------------------------------------------------
 // acc[t][c] += A(rows 16 t .. 16 t + 15, K) . W(column tile c)^T.  A fragment of lane (r = lane & 15, g = lane >> 4) for
@@ -177,19 +95,6 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRT][NCT]) {
 
 // 16-column tile `tile` of a packed matrix with inner dimension K: K/32 chunks x 2 pieces x 64 lanes uint4
 #define WTILE(name, tile, K) (W.q##name + (size_t)(tile) * 4 * (K))
-
-// lane geometry shared by all kernels: wave w owns columns 16 w .. 16 w + 15; accumulator element (t, i) of a lane is
-// atom row 16 t + 4 (lane >> 4) + i and column 16 w + (lane & 15)
-struct LaneGeo {
-    int w, col, rbase;
-    __device__ __forceinline__ LaneGeo() {
-        const int lane = threadIdx.x & 63;
-        w = threadIdx.x >> 6;
-        col = 16 * w + (lane & 15);
-        rbase = 4 * (lane >> 4);
-    }
-    __device__ __forceinline__ int row(int t, int i) const { return 16 * t + rbase + i; }
-};
 
 // ---- message MLP forward: phi = W2 swish(W1 s + b1) + b2 ---------------------------------------------------
 __global__ void __launch_bounds__(NTHREADS)

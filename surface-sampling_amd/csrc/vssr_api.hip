@@ -213,10 +213,14 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
             const float *bd = hb + o;
             l0_build_tables(hb, W1, b1, W2, b2, Wd, bd, NE, A.data() + per_model * m, At.data() + per_model * m);
         }
-        if (h->d_l0A.ensure(A.size() * sizeof(float)) || h->d_l0At.ensure(At.size() * sizeof(float)))
-            return set_err(h, VSSR_E_NOMEM, "layer-0 tables: out of device memory");
-        VSSR_HIP(h, hipMemcpy(h->d_l0A.p, A.data(), A.size() * sizeof(float), hipMemcpyHostToDevice));
-        VSSR_HIP(h, hipMemcpy(h->d_l0At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
+        // the kernels read the fp16-split fragment-order copies (painn_l0.hip); the fp32 tables stay on the host
+        const size_t pk = l0_packed_dwords(NE);
+        std::vector<unsigned> A16(pk * M), At16(pk * M);
+        for (int m = 0; m < M; ++m) l0_pack_tables(A.data() + per_model * m, NE, A16.data() + pk * m, At16.data() + pk * m);
+        if (h->d_l0A.ensure(A16.size() * sizeof(unsigned)) || h->d_l0At.ensure(At16.size() * sizeof(unsigned)))
+            return set_err(h, VSSR_E_NOMEM, "layer-0 tables");
+        VSSR_HIP(h, hipMemcpy(h->d_l0A.p, A16.data(), A16.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        VSSR_HIP(h, hipMemcpy(h->d_l0At.p, At16.data(), At16.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
     if (h->model_table.ensure(sizeof(ModelW) * M)) return set_err(h, VSSR_E_NOMEM, "model table");
     VSSR_HIP(h, hipMemcpy(h->model_table.p, table.data(), sizeof(ModelW) * M, hipMemcpyHostToDevice));
@@ -309,6 +313,7 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     if (!rc) rc = upload_weights(h, cfg);
     if (!rc) rc = node_mfma_init(h);
     if (!rc) rc = edge_mfma_init(h);
+    if (!rc) rc = l0_mfma_init(h);
     if (const char *e = getenv("VSSR_EDGE_IMPL")) h->edge_impl = (strcmp(e, "gather") == 0) ? 0 : 1;
     if (const char *e = getenv("VSSR_L0_FACTORISE")) h->l0_enabled = atoi(e);
     if (!rc && cfg->offset_per_z) {

@@ -238,6 +238,9 @@ void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst /*[rows
 void build_wd16(const float *Wd, const float *bd, unsigned *dst /*[3F][4][2][4]*/);
 void l0_build_tables(const float *blob_embed, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *Wd, const float *bd, int n_embed, float *A, float *At);
+void l0_pack_tables(const float *A, int n_embed, unsigned *A16, unsigned *At16);
+size_t l0_packed_dwords(int n_embed);
+int l0_mfma_init(vssr_handle *h);
 int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_msg);
 int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const float *sbar_msg, const float *vbar_msg,
                    float4 *gbar, long long gbar_stride, int n_groups);
