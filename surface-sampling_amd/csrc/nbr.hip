@@ -249,7 +249,8 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
                             const int *__restrict__ cfg_start, const float4 *__restrict__ edge,
                             const int *__restrict__ counters, float rc, float excl_sigma, int excl_power,
                             float4 *__restrict__ erec, float *__restrict__ rho, float *__restrict__ drho,
-                            float2 *__restrict__ dist2, uint4 *__restrict__ rho16, uint4 *__restrict__ drho16) {
+                            float2 *__restrict__ dist2, uint4 *__restrict__ rho16, uint4 *__restrict__ drho16,
+                            const int *__restrict__ Z, const int *__restrict__ zmap, unsigned char *__restrict__ zslot) {
     if (counters[2]) return;
     const int i = blockIdx.x;                 // centre atom
     const int a0 = cfg_start[atom_cfg[i]];
@@ -291,6 +292,9 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
         r[5] = fc;      // envelope (bias column) replicated in every quarter: the edge kernels fold bd * fc into the
         dr[5] = dfc;    // accumulator init instead of spending a sixth MFMA k-step on it
         if (kq == 0) {
+            // species index of the neighbor (layer-0 factorisation, painn_l0.hip); pads / unmapped species: 255
+            const int zi = valid ? zmap[Z[j]] : -1;
+            zslot[slot] = (unsigned char)(zi >= 0 ? zi : 255);
             erec[slot] = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, __int_as_float(valid ? j - a0 : 0));
             dist2[slot] = valid ? make_float2(inv, -(float)excl_power * powf(excl_sigma * inv, (float)excl_power) * inv)
                                 : make_float2(-1.f, 0.f);
@@ -333,7 +337,8 @@ int build_neighbors(vssr_handle *h, double cutoff) {
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
         if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
             h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float2) * h->slot_cap) ||
-            h->d_rho16.ensure(sizeof(uint4) * 8 * h->slot_cap) || h->d_drho16.ensure(sizeof(uint4) * 8 * h->slot_cap))
+            h->d_rho16.ensure(sizeof(uint4) * 8 * h->slot_cap) || h->d_drho16.ensure(sizeof(uint4) * 8 * h->slot_cap) ||
+            h->d_zslot.ensure((size_t)h->slot_cap))
             return set_err(h, VSSR_E_NOMEM, "edge geometry tables: out of device memory");
         // the last slot of the capacity is never used by the CSR (counters[2] flags slots > cap - 64): it is the
         // all-zero table entry that exhausted lanes of the edge kernels read
@@ -345,7 +350,7 @@ int build_neighbors(vssr_handle *h, double cutoff) {
                            h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,
                            h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),
                            h->d_drho.as<float>(), h->d_dist.as<float2>(), h->d_rho16.as<uint4>(),
-                           h->d_drho16.as<uint4>());
+                           h->d_drho16.as<uint4>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_zslot.as<unsigned char>());
     }
     h->prof.end(st);
     VSSR_HIP(h, hipMemcpyAsync(h->h_counters, h->d_counters.as<int>(), sizeof(int) * 4,

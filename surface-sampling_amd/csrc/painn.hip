@@ -492,6 +492,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
     G.dist2 = h->d_dist.as<float2>();
     G.rho16 = h->d_rho16.as<uint4>();
     G.drho16 = h->d_drho16.as<uint4>();
+    G.zslot = h->d_zslot.as<unsigned char>();
     const ModelW *MW = h->model_table.as<ModelW>();
     const int *counters = h->d_counters.as<int>();
     const int *Z = h->d_Z.as<int>();

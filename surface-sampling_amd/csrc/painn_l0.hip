@@ -22,22 +22,31 @@ constexpr int TBLK = 4 * KP;        // floats per (atom, species) block: [scalar
 
 // ---- T_i,z : one block of 96 threads per centre; thread = (component, kappa) ------------------------------------------
 __global__ void __launch_bounds__(96)
-k_l0_accum(int nz, GraphView G, const int *__restrict__ counters, const int *__restrict__ Z,
-           const int *__restrict__ zmap, float *__restrict__ T) {
+k_l0_accum(int nz, GraphView G, const int *__restrict__ counters, float *__restrict__ T) {
     if (counters[2]) return;
     const int i = blockIdx.x, comp = threadIdx.x / KP, kap = threadIdx.x % KP;
-    const int a0 = G.cfg_start[G.atom_cfg[i]];
     float acc[L0_MAX_SPECIES];
 #pragma unroll
     for (int z = 0; z < L0_MAX_SPECIES; ++z) acc[z] = 0.f;
-    for (int e = G.row_start[i]; e < G.row_start[i + 1]; ++e) {
-        const float4 er = G.erec[e];
-        const float r = G.rho[(size_t)e * KP + kap];          // pads: rho = 0
-        const int zi = zmap[Z[a0 + __float_as_int(er.w)]];
-        const float u = comp == 0 ? 1.f : comp == 1 ? er.x : comp == 2 ? er.y : er.z;
-        const float val = r * u;
+    // slot counts are multiples of 4: four slots per iteration, all loads independent (species index from the per-slot
+    // table written by k_edge_geom); the sum order over slots stays ascending
+    for (int e = G.row_start[i]; e < G.row_start[i + 1]; e += 4) {
+        float4 er[4];
+        float r[4];
+        int zi[4];
 #pragma unroll
-        for (int z = 0; z < L0_MAX_SPECIES; ++z) acc[z] += (z == zi) ? val : 0.f;
+        for (int u = 0; u < 4; ++u) {
+            er[u] = G.erec[e + u];
+            r[u] = G.rho[(size_t)(e + u) * KP + kap];          // pads: rho = 0
+            zi[u] = G.zslot[e + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float uu = comp == 0 ? 1.f : comp == 1 ? er[u].x : comp == 2 ? er[u].y : er[u].z;
+            const float val = r[u] * uu;
+#pragma unroll
+            for (int z = 0; z < L0_MAX_SPECIES; ++z) acc[z] += (z == zi[u]) ? val : 0.f;
+        }
     }
     for (int z = 0; z < nz; ++z) T[((size_t)i * nz + z) * TBLK + comp * KP + kap] = acc[z];
 }
@@ -299,8 +308,7 @@ int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_ms
     if (h->d_l0T.ensure(sizeof(float) * (size_t)N * nz * TBLK) ||
         h->d_l0Q.ensure(sizeof(float) * (size_t)M * N * nz * TBLK))
         return set_err(h, VSSR_E_NOMEM, "layer-0 factorisation buffers: out of device memory");
-    hipLaunchKernelGGL(k_l0_accum, dim3(N), dim3(96), 0, st, nz, G, h->d_counters.as<int>(), h->d_Z.as<int>(),
-                       h->d_zmap.as<int>(), h->d_l0T.as<float>());
+    hipLaunchKernelGGL(k_l0_accum, dim3(N), dim3(96), 0, st, nz, G, h->d_counters.as<int>(), h->d_l0T.as<float>());
     const size_t lds_fwd = sizeof(_Float16) * (plane_halves(TA, 32 * nz) + plane_halves(3 * TA, 32 * nz));
     hipLaunchKernelGGL(k_l0_fwd16, dim3((N + TA - 1) / TA), dim3(NTHREADS), lds_fwd, st, N, M, nz, h->d_counters.as<int>(),
                        h->d_Z.as<int>(), h->d_zlist.as<int>(), h->model_table.as<ModelW>(), h->d_l0A.as<uint4>(), h->n_embed,

@@ -62,6 +62,7 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const float *drho;       // [slots][4][6]  d rho / d d, same order
     const uint4 *rho16;      // [slots][4][2] operand-ready 2-way fp16 split of rho (32 B per (slot, quarter)), see nbr.hip
     const uint4 *drho16;     // same for d rho / d d
+    const unsigned char *zslot;   // [slots] species index (zmap) of the neighbor, 255 for pads / unmapped
     const float2 *dist2;     // [slots] {1 / edge length (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
 };
 
@@ -181,7 +182,7 @@ struct vssr_handle {
     std::vector<int> h_n_atoms, h_cfg_start;
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
     vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
-    vssr::DevBuf d_erec, d_rho, d_drho, d_dist, d_rho16, d_drho16;
+    vssr::DevBuf d_erec, d_rho, d_drho, d_dist, d_rho16, d_drho16, d_zslot;
     // layer-0 species factorisation (painn_l0.hip)
     int l0_enabled = 1, l0_nz = 0;
     bool l0_used = false;                // last run used the factorised layer 0
