@@ -206,12 +206,20 @@ k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
             int s0, s1, s2;
             unpack_shift(edge_S[e], s0, s1, s2);
             const int want = pack_shift(-s0, -s1, -s2);
-            for (int e2 = row_start[j]; e2 < row_start[j + 1]; ++e2) {
-                if (__float_as_int(edge[e2].w) == i && edge_S[e2] == want) {
+            // j's row is sorted by neighbor index (pads, index -1, at its end): binary search to the first entry with
+            // neighbor i, then walk the (few) periodic images of that pair
+            int lo = row_start[j], hi = row_start[j + 1];
+            const int row_end = hi;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const int jm = __float_as_int(edge[mid].w);
+                if (jm >= 0 && jm < i) lo = mid + 1; else hi = mid;
+            }
+            for (int e2 = lo; e2 < row_end && __float_as_int(edge[e2].w) == i; ++e2)
+                if (edge_S[e2] == want) {
                     found = e2;
                     break;
                 }
-            }
         }
         rev[e] = found;
     }
