@@ -309,7 +309,16 @@ def test_fallback_paths_large_chain_many_species_and_forced_gather(golden, oracl
     r9 = eng.evaluate([_arrays(many)])
     ref9 = _oracle(golden, oracle_mod, many)
     assert abs(float(r9["energy"][0]) - ref9["energy"]) <= 3e-4 and np.abs(r9["forces"] - ref9["forces"]).max() <= 5e-4
+    # (2b) six species: still factorised (<= 8), the matrix-pipe layer-0 kernels run with K = 32 x 6 per chunk group
+    six = small.copy()
+    six.numbers[:3] = np.array([1, 6, 7], np.int32)
+    r6 = eng.evaluate([_arrays(six), _arrays(small)])
+    ref6 = _oracle(golden, oracle_mod, six)
+    a0, a1 = r6["cfg_start"][0], r6["cfg_start"][1]
+    assert abs(float(r6["energy"][0]) - ref6["energy"]) <= 3e-4 and np.abs(r6["forces"][a0:a1] - ref6["forces"]).max() <= 5e-4
+    assert eng.profile_read is not None
     ref_small = eng.evaluate([_arrays(small)])
+    assert float(ref_small["energy"][0]) == float(r6["energy"][1])   # neighbors in the batch do not change a chain
     eng.close()
     # (3) debug knobs select the other code paths; results agree to fp32 re-association noise
     for var, val in (("VSSR_EDGE_IMPL", "gather"), ("VSSR_L0_FACTORISE", "0")):
