@@ -389,18 +389,6 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
 }
 
 // ---- host: weight packing + launch helpers ------------------------------------------------------------------------
-// fp32 fragment order of the first (fp32 MFMA) implementation; still built by vssr_create, not used by these kernels
-//   packed[tile][q][lane][t] = W[tile*32 + (lane&31)][(lane>>5)*(K/2) + 4q + t]   (W row-major [rows][K])
-void pack_mfma_tiles(const float *Wsrc, int rows, int K, float *dst) {
-    const int ntile = rows / 32, nq = K / 8;
-    for (int tile = 0; tile < ntile; ++tile)
-        for (int q = 0; q < nq; ++q)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int t = 0; t < 4; ++t)
-                    dst[(((size_t)tile * nq + q) * 64 + lane) * 4 + t] =
-                        Wsrc[(size_t)(tile * 32 + (lane & 31)) * K + (lane >> 5) * (K / 2) + 4 * q + t];
-}
-
 // fp16-split fragment order for v_mfma_f32_16x16x32_f16, 16-column tiles:
 //   dst[tile][q][piece][lane][j] = piece(W[tile*16 + (lane&15)][32 q + 8 (lane>>4) + 2 j]) | piece(W[..][.. + 1]) << 16
 void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst) {

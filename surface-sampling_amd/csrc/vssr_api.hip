@@ -83,10 +83,7 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
                        (unsigned long long)cfg->weights_len, blob_len);
     // device image per model: [blob][transposed copies]
     const size_t t_per_layer = (size_t)F * F + (size_t)F * F3 + 2 * (size_t)F * F + (size_t)2 * F * F + (size_t)F * F3;
-    // packed (MFMA fragment order) copies: W1, W2, U, V, W3, W4 forward; W1^T, W2^T, W4^T, W3^T, [U;V]^T reverse
-    const size_t p_per_layer = 2 * ((size_t)F * F + (size_t)F3 * F + (size_t)F * 2 * F + (size_t)F3 * F) +
-                               2 * (size_t)F * F + (size_t)F * 2 * F;
-    const size_t img_len = blob_len + L * (t_per_layer + p_per_layer) + (size_t)F * H;
+    const size_t img_len = blob_len + L * t_per_layer + (size_t)F * H;
     std::vector<float> img(img_len * M);
     std::vector<ModelW> table(M);
     if (h->weights.ensure(img.size() * sizeof(float)))
@@ -125,21 +122,7 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
             Lw.U = db + u; Lw.Ut = db + ut; Lw.V = db + v; Lw.Vt = db + vt;
             Lw.W3 = db + w3; Lw.W3t = db + w3t; Lw.b3 = db + b3;
             Lw.W4 = db + w4; Lw.W4t = db + w4t; Lw.b4 = db + b4;
-            // MFMA fragment-order copies
-            size_t pw1 = taket((size_t)F * F), pw2 = taket((size_t)F3 * F), pu = taket((size_t)F * F);
-            size_t pv = taket((size_t)F * F), pw3 = taket((size_t)F * 2 * F), pw4 = taket((size_t)F3 * F);
-            size_t pw1t = taket((size_t)F * F), pw2t = taket((size_t)F * F3), pw4t = taket((size_t)F * F3);
-            size_t pw3t = taket((size_t)2 * F * F), puvt = taket((size_t)F * 2 * F);
-            pack_mfma_tiles(hb + w1, F, F, hb + pw1);
-            pack_mfma_tiles(hb + w2, F3, F, hb + pw2);
-            pack_mfma_tiles(hb + u, F, F, hb + pu);
-            pack_mfma_tiles(hb + v, F, F, hb + pv);
-            pack_mfma_tiles(hb + w3, F, 2 * F, hb + pw3);
-            pack_mfma_tiles(hb + w4, F3, F, hb + pw4);
-            pack_mfma_tiles(hb + w1t, F, F, hb + pw1t);       // W1^T is [F in -> rows][F]
-            pack_mfma_tiles(hb + w2t, F, F3, hb + pw2t);      // W2^T: rows = F hidden, K = 3F
-            pack_mfma_tiles(hb + w4t, F, F3, hb + pw4t);      // W4^T: rows = F hidden, K = 3F
-            pack_mfma_tiles(hb + w3t, 2 * F, F, hb + pw3t);   // W3^T: rows = 2F inputs, K = F
+            // fp16-split MFMA fragment-order copies of the eleven node-GEMM matrices (painn_node_mfma.hip)
             {   // [U;V]^T: rows g (input feature of U/V), K = 2F: k<F -> U[k][g], k>=F -> V[k-F][g]
                 std::vector<float> uvt((size_t)F * 2 * F);
                 for (int g = 0; g < F; ++g)
@@ -147,7 +130,6 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
                         uvt[(size_t)g * 2 * F + k] = hb[u + (size_t)k * F + g];
                         uvt[(size_t)g * 2 * F + F + k] = hb[v + (size_t)k * F + g];
                     }
-                pack_mfma_tiles(uvt.data(), F, 2 * F, hb + puvt);
                 // fp16-split copies, same order as the q* pointers are assigned below
                 unsigned *q = node16.data() + ((size_t)m * L + l) * node16_per_layer;
                 auto put16 = [&](const float *src, int rows, int K) {
@@ -158,9 +140,6 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
                 put16(hb + w3, F, 2 * F); put16(hb + w4, F3, F); put16(hb + w1t, F, F); put16(hb + w2t, F, F3);
                 put16(hb + w4t, F, F3); put16(hb + w3t, 2 * F, F); put16(uvt.data(), F, 2 * F);
             }
-            Lw.pW1 = db + pw1; Lw.pW2 = db + pw2; Lw.pU = db + pu; Lw.pV = db + pv; Lw.pW3 = db + pw3;
-            Lw.pW4 = db + pw4; Lw.pW1t = db + pw1t; Lw.pW2t = db + pw2t; Lw.pW4t = db + pw4t;
-            Lw.pW3t = db + pw3t; Lw.pUVt = db + puvt;
         }
         size_t w5 = take((size_t)H * F), b5 = take(H), w6 = take(H), b6 = take(1);
         size_t w5t = taket((size_t)F * H);

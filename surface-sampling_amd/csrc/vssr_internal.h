@@ -30,14 +30,8 @@ struct LayerW {
     const float *U, *Ut, *V, *Vt;  // [F][F]
     const float *W3, *W3t, *b3;  // [F][2F], transposed [2F][F]
     const float *W4, *W4t, *b4;  // [3F][F], transposed [F][3F]
-    // MFMA fragment-order copies (painn_node_mfma.hip: packed[tile][q][lane][4])
-    const float *pW1, *pW2;      // forward:  W1 (4 tiles, K=F), W2 (12 tiles, K=F)
-    const float *pU, *pV;        //           U, V (4 tiles each, K=F)
-    const float *pW3, *pW4;      //           W3 (4 tiles, K=2F), W4 (12 tiles, K=F)
-    const float *pW1t, *pW2t;    // reverse:  W1^T (4 tiles, K=F), W2^T (4 tiles, K=3F)
-    const float *pW4t, *pW3t;    //           W4^T (4 tiles, K=3F), W3^T (8 tiles, K=F)
-    const float *pUVt;           //           [U;V]^T (4 tiles, K=2F)
-    // the same eleven matrices as 2-way fp16 pieces in v_mfma_f32_32x32x16_f16 B-fragment order (pack_mfma_tiles16)
+    // W1, W2, U, V, W3, W4 (forward) and W1^T, W2^T, W4^T, W3^T, [U;V]^T (reverse) as 2-way fp16 pieces in
+    // v_mfma_f32_16x16x32_f16 B-fragment order (pack_mfma_tiles16), 16-column tiles
     const uint4 *qW1, *qW2, *qU, *qV, *qW3, *qW4, *qW1t, *qW2t, *qW4t, *qW3t, *qUVt;
     const uint4 *wd16;           // radial-filter weights, 2-way fp16 split in MFMA A-operand order: [3F rows][4 quarters][h, l]
 };
@@ -224,7 +218,6 @@ int tersoff_run(vssr_handle *h, uint32_t want);
 // lock-step FIRE relaxation (relax.hip)
 int relax_fire(vssr_handle *h, const vssr_fire_params *fp, const uint8_t *fixed_host, uint32_t want);
 // MFMA node stages (painn_node_mfma.hip)
-void pack_mfma_tiles(const float *Wsrc, int rows, int K, float *dst);
 int node_mfma_init(vssr_handle *h);
 void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in, float *phi);
 void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in,
