@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256)
 k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
       const int *__restrict__ cfg_start, const double *__restrict__ cell, const int *__restrict__ nimg, double rc2,
       int *__restrict__ deg, const int *__restrict__ row_start, float4 *__restrict__ edge,
-      int *__restrict__ edge_S, long long slot_cap) {
+      int *__restrict__ edge_S, long long slot_cap, unsigned long long *__restrict__ hits_buf, int hits_stride) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -87,7 +87,15 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
         // pass revisits only the hits instead of all (2 n0 + 1)(2 n1 + 1)(2 n2 + 1) images again
         int cnt = 0;
         unsigned long long hits = 0ull;
-        if (have) {
+        // hits_buf (optional scratch, every configuration scans <= 64 images): the counting pass stores the masks, the
+        // fill pass replays them instead of repeating the fp64 search
+        unsigned long long *hslot = hits_buf ? hits_buf + (size_t)i * hits_stride + (j - a0) : nullptr;
+        if (FILL && hslot) {
+            if (have) {
+                hits = *hslot;
+                cnt = __builtin_popcountll(hits);
+            }
+        } else if (have) {
             int img = 0;
             for (int s0 = -n0; s0 <= n0; ++s0)
                 for (int s1 = -n1; s1 <= n1; ++s1)
@@ -102,6 +110,7 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
                             if (img < 64) hits |= 1ull << img;
                         }
                     }
+            if (!FILL && hslot) *hslot = hits;
         }
         int total;
         const int off = wave_excl_scan(cnt, lane, total);
@@ -324,6 +333,12 @@ int build_neighbors(vssr_handle *h, double cutoff) {
     if (h->d_edge.ensure(sizeof(float4) * h->slot_cap) || h->d_edge_S.ensure(sizeof(int) * h->slot_cap) ||
         h->d_rev.ensure(sizeof(int) * h->slot_cap))
         return set_err(h, VSSR_E_NOMEM, "edge buffers: out of device memory");
+    // scratch for the hit masks of the counting pass (skipped for very large single configurations / thin cells)
+    unsigned long long *hits_buf = nullptr;
+    const int hits_stride = (h->max_cfg_atoms + 63) & ~63;
+    if (h->max_images <= 64 && (size_t)n * hits_stride * 8 <= ((size_t)1 << 30) &&
+        !h->d_hits.ensure((size_t)n * hits_stride * 8))
+        hits_buf = h->d_hits.as<unsigned long long>();
     h->prof.begin(KC_NBR, st);
     dim3 blk(128), grd((n + 127) / 128);
     dim3 wblk(256), wgrd((n + 3) / 4);   // one wave per centre
@@ -333,13 +348,13 @@ int build_neighbors(vssr_handle *h, double cutoff) {
     hipLaunchKernelGGL(k_nbr<false>, wgrd, wblk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_nimg.as<int>(),
                        cutoff * cutoff, h->d_deg.as<int>(), (const int *)nullptr, (float4 *)nullptr,
-                       (int *)nullptr, (long long)0);
+                       (int *)nullptr, (long long)0, hits_buf, hits_stride);
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, n, h->d_deg.as<int>(),
                        h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap);
     hipLaunchKernelGGL(k_nbr<true>, wgrd, wblk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_nimg.as<int>(),
                        cutoff * cutoff, h->d_deg.as<int>(), h->d_row_start.as<int>(),
-                       h->d_edge.as<float4>(), h->d_edge_S.as<int>(), (long long)h->slot_cap);
+                       h->d_edge.as<float4>(), h->d_edge_S.as<int>(), (long long)h->slot_cap, hits_buf, hits_stride);
     hipLaunchKernelGGL(k_rev, wgrd, wblk, 0, st, n, h->d_row_start.as<int>(), h->d_edge.as<float4>(),
                        h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>());
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices

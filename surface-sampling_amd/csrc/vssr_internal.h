@@ -148,6 +148,7 @@ struct vssr_handle {
     int edge_impl = 1;  // 1 = LDS-slice + MFMA edge kernels for chains that fit LDS; 0 forces the gather kernels
                         // (VSSR_EDGE_IMPL=gather: debug knob, also the automatic path for very large chains)
     int max_cfg_atoms = 0;
+    int max_images = 0;          // largest number of periodic images any configuration of the batch scans per pair
 
     // configuration
     int n_models = 0, n_rbf = 20, num_conv = 3, n_embed = 100, readout_hidden = 64;
@@ -177,6 +178,7 @@ struct vssr_handle {
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
     vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
     vssr::DevBuf d_erec, d_rho, d_drho, d_dist, d_rho16, d_drho16, d_zslot;
+    vssr::DevBuf d_hits;         // neighbor search: per (centre, candidate) 64-bit hit masks of the counting pass
     // layer-0 species factorisation (painn_l0.hip)
     int l0_enabled = 1, l0_nz = 0;
     bool l0_used = false;                // last run used the factorised layer 0
