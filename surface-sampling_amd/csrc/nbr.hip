@@ -163,41 +163,44 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
     }
 }
 
-// exclusive scan of padded degrees -> row_start ; counters[0] = slots, [1] = real edges
-__global__ void k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start,
-                            int *__restrict__ counters, long long slot_cap) {
-    __shared__ long long part[1024];
-    __shared__ long long part_real[1024];
-    int t = threadIdx.x, nt = blockDim.x;
-    int chunk = (n + nt - 1) / nt;
-    int b = t * chunk, e = min(n, b + chunk);
-    long long s = 0, sr = 0;
-    for (int i = b; i < e; ++i) {
-        s += (deg[i] + 3) & ~3;
-        sr += deg[i];
-    }
-    part[t] = s;
-    part_real[t] = sr;
-    __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {  // inclusive Hillis-Steele
-        long long v = (t >= off) ? part[t - off] : 0;
-        long long vr = (t >= off) ? part_real[t - off] : 0;
+// exclusive scan of padded degrees -> row_start ; counters[0] = slots, [1] = real edges.  One workgroup walks the array in
+// tiles of 1024 with coalesced loads: wave-level shuffles + one LDS exchange per tile, running prefix carried in registers.
+__global__ void __launch_bounds__(1024)
+k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int *__restrict__ counters,
+            long long slot_cap) {
+    __shared__ int wsum[16], wreal[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    long long run = 0, run_real = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + t;
+        const int d = i < n ? deg[i] : 0;
+        const int p = (d + 3) & ~3;
+        int x = p, xr = d;                       // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off, 64), yr = __shfl_up(xr, off, 64);
+            if (lane >= off) { x += y; xr += yr; }
+        }
+        if (lane == 63) { wsum[w] = x; wreal[w] = xr; }
         __syncthreads();
-        part[t] += v;
-        part_real[t] += vr;
+        int woff = 0, tile = 0, tile_real = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int v = wsum[k];
+            if (k < w) woff += v;
+            tile += v;
+            tile_real += wreal[k];
+        }
+        if (i < n) row_start[i] = (int)(run + woff + x - p);
+        run += tile;
+        run_real += tile_real;
         __syncthreads();
     }
-    long long run = part[t] - s;
-    for (int i = b; i < e; ++i) {
-        row_start[i] = (int)run;
-        run += (deg[i] + 3) & ~3;
-    }
-    if (t == nt - 1) {
-        long long total = part[t];
-        row_start[n] = (int)total;
-        counters[0] = (int)total;
-        counters[1] = (int)part_real[t];
-        counters[2] = (total > slot_cap - 64 || total > 2147483000LL) ? 1 : 0;
+    if (t == 0) {
+        row_start[n] = (int)run;
+        counters[0] = (int)run;
+        counters[1] = (int)run_real;
+        counters[2] = (run > slot_cap - 64 || run > 2147483000LL) ? 1 : 0;
     }
 }
 
