@@ -340,7 +340,7 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
 
 // ---- ensemble reduction -----------------------------------------------------------------------------------------
 // forces: dE/dx_c = sum_{slots (c,n)} ( G[(n->c)] - G[(c->n)] ), G[(c->n)] lives at rev[slot].
-// Partial edge gradients of the feature-slice groups -> one buffer per model (group 0, in place): a streaming,
+// Partial edge gradients of the feature slices (one buffer per workgroup group) -> one buffer per model (group 0, in place): a streaming,
 // coalesced pass in fixed group order, so that the gather through `rev` below touches one buffer per model only.
 __global__ void k_reduce_gbar_groups(int M, int n_groups, const int *__restrict__ counters, float4 *__restrict__ gbar,
                                      long long gbar_stride) {

@@ -1,21 +1,19 @@
-// painn_edge_mfma.hip — the neighbor-sum ("message") stage of PaiNN on gfx950: LDS-staged
-// feature slices + the radial filter on the fp32 matrix cores.
+// painn_edge_mfma.hip — the neighbor-sum ("message") stage of PaiNN on gfx950, layers >= 1, forward and reverse:
+// LDS-staged feature slices + the radial filter on the 16-bit matrix cores with fp32-level accuracy.
 //
 // Math (nff MessageBlock / DistanceEmbed):
 //   w_e = (Wd rbf(d_e) + bd) fcut(d_e) = Wd_ext . rho(d_e),  rho = [sin(n pi d/rc)/d * fc]_{n=1..20} ++ [fc]
 //   s_i += sum_e phi_j[b] w_e[b] ;  v_i += sum_e ( phi_j[c] w_e[c] u_e + phi_j[a] w_e[a] v_j )
 //
-// Decomposition: one workgroup = (chain, 16-feature slice, ensemble member).  It stages the slice of
-// phi and v of ALL atoms of its chain in LDS once (exactly the compulsory HBM bytes of SURVEY §8(d):
-// every phi/v element is read by one workgroup only), then walks the chain's padded CSR.  The filter
-// GEMM  [slots x 24] . [24 x 16]  runs on v_mfma_f32_16x16x4_f32 with slots as rows, so a lane holds the
-// filter values of ITS lane-group's 4 slots for ITS feature: each 16-lane group streams its own centre
-// atom (4 slots per step), accumulates ds / dv in registers and writes the centre once.  No atomics, no
-// cross-lane reduction; summation order per centre is the CSR order regardless of batching.
-//   A operand (rho) comes from the per-slot table written once per evaluation by k_edge_geom (nbr.hip) in
-//   A-fragment order (PMC showed the kernel is instruction-issue bound: recomputing sincos per slice x
-//   model x layer cost ~110 of ~360 instructions per step); unit vectors / local neighbor ids likewise.
-//   B operand (Wd_ext slice) lives in 18 VGPRs for the whole kernel.
+// Decomposition: one workgroup = (chain, 16-feature slice, ensemble member).  It stages the slice of phi and v of ALL
+// atoms of its chain in LDS once (exactly the compulsory HBM bytes of SURVEY §8(d): every phi/v element is read by one
+// workgroup only), then walks the chain's padded CSR in steps of 16 slots per wave (4 streams x 4 slots).  The filter
+// tile D[16 features][16 slots] = Wd_ext . rho runs on v_mfma_f32_16x16x32_f16 (fp16 2-way split, three products):
+// weights are the A operand (resident in registers), rho the B operand, read as operand-ready pieces from the per-slot
+// table that k_edge_geom (nbr.hip) writes once per evaluation; unit vectors / local neighbor ids come from the same
+// pass.  Lane (p, fq) owns slot p and features 4 fq .. 4 fq + 3: it gathers the neighbor's values from the LDS tile,
+// forms the messages in registers and accumulates them; a centre is written once, after a 4-lane DPP reduction.  No
+// atomics; the summation order per centre is the CSR order regardless of batching.
 // Chains larger than the LDS capacity (N > ~400) fall back to the gather kernels in painn.hip.
 #include "vssr_internal.h"
 
@@ -366,9 +364,10 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 //   dE/du(n->c) = sum_f  phi_c[c] w[c] vbar_n            (dw = Wd_ext . d rho/dd)
 // Same slot-major lane layout as the forward kernel: lane (p, fq) owns slot p and features 4fq..4fq+3, so
 // the sums over features are 4 in-lane terms + a reduction over the 4 feature quarters (lanes p, p+16,
-// p+32, p+48).  One workgroup = (chain, model, group of SLICES_PER_WG feature slices): it loops over its
-// slices, so the per-slot edge gradient G[m][group][slot] is accumulated by the SAME lane in a fixed order
-// (deterministic read-modify-write, L2 resident); finalize adds the groups.
+// p+32, p+48).  One workgroup = (chain, model, group of SLICES_PER_WG feature slices) with its own partial edge-gradient
+// buffer G[m][group][slot]: within a layer every slot is written once per group, across layers the SAME lane adds to
+// it in a fixed order (deterministic read-modify-write, old value prefetched one step ahead); finalize reduces the
+// groups in a streaming pass.
 constexpr int BWD_THREADS = 512;
 constexpr int SLICES_PER_WG = 1;   // measured: 1 -> 6.3 ms, 2 -> 6.7, 4 -> 7.1 per step (L2 locality of the tables); finalize reduces the 8 partial buffers in a streaming pass
 constexpr int NSG = NSLICE / SLICES_PER_WG;   // slice groups = partial edge-gradient buffers per model

@@ -161,7 +161,7 @@ struct vssr_handle {
 
     // weights
     vssr::DevBuf weights;        // all model blobs + transposed copies
-    vssr::DevBuf wd16;           // bf16-split radial-filter weights in MFMA operand order
+    vssr::DevBuf wd16;           // fp16-split radial-filter weights in MFMA operand order
     vssr::DevBuf node16;         // fp16-split node-GEMM weights in MFMA fragment order
     vssr::DevBuf model_table;    // ModelW[n_models]
     vssr::DevBuf offset_per_z;   // double[n_embed]
