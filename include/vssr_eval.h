@@ -23,7 +23,8 @@
  * Conventions
  *   - All arrays are caller-allocated and borrowed only for the duration of the call.
  *   - Positions are double [N][3] (Angstrom), cell is double[9] with rows = lattice vectors,
- *     pbc is uint8[3].  Results are float32 (the model computes in fp32, like the reference).
+ *     pbc is uint8[3].  Results are float32 (fp32 state and fp32-level arithmetic, like the reference: matrix products
+ *     run as exact-split fp16 pieces with fp32 accumulation).
  *   - A batch is a list of independent configurations (Markov chains), concatenated:
  *     n_atoms[B], then Z / pos / forces concatenated in chain order.
  *   - Status codes: 0 ok, <0 error (see VSSR_E_*); vssr_last_error() gives the message.

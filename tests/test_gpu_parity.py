@@ -389,3 +389,32 @@ def test_colliding_atoms_stay_finite_and_match_until_absurd(golden, oracle_mod, 
     out = calc.relax_batch([s, base], relax_steps=1)
     assert out[0][3] is True and out[0][2] == calc.ENERGY_THRESHOLD      # energy_oob, clamped energy
     assert out[1][3] is False
+
+
+@pytest.mark.gpu
+def test_degenerate_chains_in_one_batch(golden, oracle_mod, engine):
+    """A batch mixing a normal slab with chains that have no edges at all (atoms further apart than the cutoff), a
+    single-atom chain, and a non-periodic 4-atom cluster: every kernel must cope with empty CSR rows, tiles of one atom
+    and zero-slot chains; results equal the oracle's and do not disturb the neighbours in the batch."""
+    from surface_sampling_amd import structures
+
+    Z = structures.ATOMIC_NUMBERS
+    box = np.diag([30.0, 30.0, 30.0])
+    far = structures.Structure(np.array([Z["Sr"], Z["O"], Z["Ti"]], np.int32),
+                               np.array([[2.0, 2.0, 2.0], [12.0, 12.0, 12.0], [22.0, 22.0, 22.0]]), box, np.array([True] * 3))
+    one = structures.Structure(np.array([Z["O"]], np.int32), np.array([[1.0, 1.0, 1.0]]), box, np.array([True] * 3))
+    cluster = structures.Structure(np.array([Z["Ti"], Z["O"], Z["O"], Z["Sr"]], np.int32),
+                                   np.array([[0.0, 0.0, 0.0], [1.9, 0.0, 0.0], [0.0, 1.9, 0.0], [2.2, 2.2, 1.0]]), box,
+                                   np.array([False] * 3))
+    slab = golden.structure("SrTiO3_2x2_pristine")
+    chains = [far, slab, one, cluster]
+    res = engine.evaluate([_arrays(s) for s in chains])
+    assert np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()
+    for b, s in enumerate(chains):
+        a0, a1 = res["cfg_start"][b], res["cfg_start"][b + 1]
+        ref = _oracle(golden, oracle_mod, s)
+        assert abs(float(res["energy"][b]) - ref["energy"]) <= E_TOL, (b, float(res["energy"][b]), ref["energy"])
+        assert np.abs(res["forces"][a0:a1] - ref["forces"]).max() <= F_TOL
+    assert np.abs(res["forces"][: len(far)]).max() == 0.0           # isolated atoms feel nothing
+    alone = engine.evaluate([_arrays(slab)])
+    assert float(alone["energy"][0]) == float(res["energy"][1])
