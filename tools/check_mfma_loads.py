@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Build-time check of the MFMA / load ordering rule of the edge kernels (see mfma_load_fence in painn_edge_mfma.hip):
-in the emitted gfx950 ISA no load (LDS, global, scratch, flat) may sit between the first MFMA of a step and the
-'; mfma_load_fence' marker that follows it.  Usage: check_mfma_loads.py [file.hip ...]  (exit code 1 on violation)."""
+"""Build-time check of the MFMA / load ordering rules (see mfma_load_fence in painn_edge_mfma.hip) on the emitted gfx950
+ISA.  Rule 1 (files with fences): no load (LDS, global, scratch, flat) may sit between the first MFMA of a step and the
+'; mfma_load_fence' marker that follows it.  Rule 2 (every file): no load inside a dense MFMA block, i.e. between two
+MFMAs that are at most DENSE_GAP instructions apart.  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
 import os, re, subprocess, sys, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "surface-sampling_amd", "csrc")
 LOAD = re.compile(r"^\s*(ds_read|ds_load|global_load|buffer_load|scratch_load|flat_load)")
+DENSE_GAP = 6
+DEFAULT_FILES = ("painn_edge_mfma.hip", "painn_node_mfma.hip", "painn_l0.hip")
 
 
 def check(hip):
@@ -44,10 +47,34 @@ def check(hip):
             if open_group is not None and kernel and "edge" in kernel and "mfma" in kernel:
                 print(f"note: {kernel}: MFMA group at line {open_group} without a following fence")
             open_group = None
-    print(f"{os.path.basename(hip)}: {groups} MFMA groups checked, {bad} violations")
+    # rule 2: dense MFMA blocks must be free of loads
+    kernel, last_mfma, pending, dense_blocks = None, None, [], 0
+    instr_idx = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\w+):", l)
+        if m:
+            kernel, last_mfma, pending = m.group(1), None, []
+        t = l.strip()
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+            continue
+        instr_idx += 1
+        if t.startswith("v_mfma"):
+            if last_mfma is not None and instr_idx - last_mfma <= DENSE_GAP:
+                dense_blocks += 1
+                if pending:
+                    bad += 1
+                    print(f"VIOLATION in {kernel}: load inside a dense MFMA block near line {i}:")
+                    for j in pending[:4]:
+                        print("    ", lines[j].strip())
+            last_mfma, pending = instr_idx, []
+        elif LOAD.match(l) and last_mfma is not None and instr_idx - last_mfma <= DENSE_GAP:
+            pending.append(i)
+        elif last_mfma is not None and instr_idx - last_mfma > DENSE_GAP:
+            pending = []
+    print(f"{os.path.basename(hip)}: {groups} MFMA groups checked, {dense_blocks} dense MFMA pairs, {bad} violations")
     return bad
 
 
 if __name__ == "__main__":
-    files = sys.argv[1:] or [os.path.join(CSRC, "painn_edge_mfma.hip")]
+    files = sys.argv[1:] or [os.path.join(CSRC, f) for f in DEFAULT_FILES]
     sys.exit(1 if sum(check(f) for f in files) else 0)
