@@ -1,0 +1,71 @@
+"""The one-shot C-ABI entry points, driven through raw ctypes exactly as INTEGRATION.md shows a maintainer of the
+reference would bind them (no helper classes of this package on the call path except the struct definitions)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def test_vssr_eval_and_eval_batch_through_raw_ctypes(golden):
+    from surface_sampling_amd import backend
+
+    lib = backend.load_library()
+    table, const = golden.offset_table()
+    engine = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    blobs = [np.ascontiguousarray(b, np.float32) for b in golden.blobs]
+    ptrs = (C.POINTER(C.c_float) * len(blobs))(*[_f32(b) for b in blobs])
+    tab = np.ascontiguousarray(table, np.float64)
+    cfg = backend.PainnConfig(C.sizeof(backend.PainnConfig), 0, len(blobs), ptrs, blobs[0].size, 128, 20, 3, 100, 64, 5.0, 1,
+                              12, 1.5, 23.0605, tab.ctypes.data_as(C.POINTER(C.c_double)), float(const))
+    h = C.c_void_p()
+    assert lib.vssr_create(C.byref(cfg), C.byref(h)) == 0, lib.vssr_last_error(None)
+    try:
+        structs = [golden.structure("O36Sr12Ti12"), golden.structure("O44Sr12Ti16")]
+        want = backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD
+        ref = engine.evaluate([(s.numbers, s.positions, s.cell, s.pbc) for s in structs])
+        # ---- vssr_eval: one configuration ----------------------------------------------------------------------------------
+        s = structs[0]
+        Z = np.ascontiguousarray(s.numbers, np.int32)
+        pos = np.ascontiguousarray(s.positions, np.float64)
+        cell = np.ascontiguousarray(s.cell, np.float64)
+        pbc = np.ascontiguousarray(s.pbc, np.uint8)
+        E, Es = np.zeros(1, np.float32), np.zeros(1, np.float32)
+        F, Fs = np.zeros((len(Z), 3), np.float32), np.zeros((len(Z), 3), np.float32)
+        out = backend.Out(_f32(E), _f32(Es), _f32(F), _f32(Fs), None, None)
+        rc = lib.vssr_eval(h, len(Z), Z.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_double)),
+                           cell.ctypes.data_as(C.POINTER(C.c_double)), pbc.ctypes.data_as(C.POINTER(C.c_uint8)), want,
+                           C.byref(out))
+        assert rc == 0, lib.vssr_last_error(h)
+        assert abs(float(E[0]) - (-467.525604)) <= 2e-4                  # reference notebook value
+        assert float(E[0]) == float(ref["energy"][0]) and np.array_equal(F, ref["forces"][: len(Z)])
+        assert float(Es[0]) == float(ref["energy_std"][0])
+        # ---- vssr_eval_batch: two configurations, concatenated arrays ------------------------------------------------------------
+        n_atoms = np.array([len(x) for x in structs], np.int32)
+        Zb = np.ascontiguousarray(np.concatenate([x.numbers for x in structs]), np.int32)
+        posb = np.ascontiguousarray(np.concatenate([x.positions for x in structs]), np.float64)
+        cellb = np.ascontiguousarray(np.stack([x.cell for x in structs]), np.float64)
+        pbcb = np.ascontiguousarray(np.stack([x.pbc for x in structs]), np.uint8)
+        Eb, Esb = np.zeros(2, np.float32), np.zeros(2, np.float32)
+        Fb, Fsb = np.zeros((len(Zb), 3), np.float32), np.zeros((len(Zb), 3), np.float32)
+        Em = np.zeros((2, len(blobs)), np.float32)
+        outb = backend.Out(_f32(Eb), _f32(Esb), _f32(Fb), _f32(Fsb), _f32(Em), None)
+        rc = lib.vssr_eval_batch(h, 2, n_atoms.ctypes.data_as(C.POINTER(C.c_int32)), Zb.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 posb.ctypes.data_as(C.POINTER(C.c_double)), cellb.ctypes.data_as(C.POINTER(C.c_double)),
+                                 pbcb.ctypes.data_as(C.POINTER(C.c_uint8)), want | backend.WANT_PER_MODEL, C.byref(outb))
+        assert rc == 0, lib.vssr_last_error(h)
+        assert np.array_equal(Eb, ref["energy"]) and np.array_equal(Fb, ref["forces"]) and np.array_equal(Fsb, ref["forces_std"])
+        assert np.allclose(Em.mean(axis=1), Eb, atol=2e-4) and Em.std() > 0
+        # ---- error reporting: bad argument -> negative status + message ---------------------------------------------------------
+        rc = lib.vssr_eval(h, -1, Z.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_double)),
+                           cell.ctypes.data_as(C.POINTER(C.c_double)), pbc.ctypes.data_as(C.POINTER(C.c_uint8)), want,
+                           C.byref(out))
+        assert rc < 0 and lib.vssr_last_error(h)
+    finally:
+        lib.vssr_destroy(h)
+        engine.close()
