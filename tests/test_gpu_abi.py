@@ -69,3 +69,31 @@ def test_vssr_eval_and_eval_batch_through_raw_ctypes(golden):
     finally:
         lib.vssr_destroy(h)
         engine.close()
+
+
+def test_resident_batch_set_positions_and_profiler(golden):
+    """The split API a relaxation loop uses: upload once, then set_positions / run / download per step — results equal a
+    fresh upload of the moved structure; the per-class profiler counts the launches of each step."""
+    from surface_sampling_amd import backend
+
+    table, const = golden.offset_table()
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    try:
+        s0 = golden.structure("SrTiO3_2x2_pristine")
+        s1 = golden.structure("O40Sr16Ti12")
+        eng.upload([(s.numbers, s.positions, s.cell, s.pbc) for s in (s0, s1)])
+        eng.profile_enable(True)
+        eng.profile_reset()
+        rng = np.random.default_rng(0)
+        moved = [s.positions + rng.normal(0, 0.02, s.positions.shape) for s in (s0, s1)]
+        eng.set_positions(np.concatenate(moved))
+        eng.run()
+        got = eng.download()
+        prof = eng.profile_read()
+        assert prof["neighbor_list"]["launches"] == 1 and prof["edge_message_bwd"]["launches"] == 2
+        assert prof["update_bwd"]["launches"] == 3 and all(v["total_ms"] >= 0 for v in prof.values())
+        fresh = eng.evaluate([(s.numbers, p, s.cell, s.pbc) for s, p in zip((s0, s1), moved)])
+        assert np.array_equal(got["energy"], fresh["energy"]) and np.array_equal(got["forces"], fresh["forces"])
+        assert eng.stats()["atoms"] == len(s0) + len(s1)
+    finally:
+        eng.close()
