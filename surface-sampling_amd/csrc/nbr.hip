@@ -152,8 +152,8 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
         run += total;
     }
     if (FILL) {
-        const int padded = (run + 3) & ~3;
-        const long long slot = base + run + lane;
+        const int padded = max((run + 3) & ~3, 4);   // at least one quad per centre (an isolated atom gets 4 pads): the edge
+        const long long slot = base + run + lane;    // kernels complete at most one centre per step
         if (lane < padded - run && slot < slot_cap) {
             edge[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
             edge_S[slot] = pack_shift(0, 0, 0);
@@ -174,7 +174,7 @@ k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int
     for (int base = 0; base < n; base += 1024) {
         const int i = base + t;
         const int d = i < n ? deg[i] : 0;
-        const int p = (d + 3) & ~3;
+        const int p = i < n ? max((d + 3) & ~3, 4) : 0;
         int x = p, xr = d;                       // inclusive scan inside the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {

@@ -47,6 +47,18 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void mfma_pre_fence(u32x4 &a, u32x4 &b) {
     asm volatile("; mfma_pre_fence" : "+v"(a), "+v"(b) : : "memory");
 }
+// Everything a step consumes from global memory is "used" here, at the top of the step, BEFORE the conditional memory
+// operations of a completed centre (result stores, prefetch of the next centre) are issued.  vmcnt retires in order and
+// the compiler must pick one count for both sides of a branch: with the conditional operations issued after the table
+// loads it could only wait for everything (measured in the ISA: s_waitcnt vmcnt(0) right behind freshly issued stores /
+// prefetches on every step).  With them issued first they are older than the next table loads and every wait is exact.
+__device__ __forceinline__ void arrival_fence(u32x4 &a, u32x4 &b, float4 &r) {
+    asm volatile("; arrival_fence" : "+v"(a), "+v"(b), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w) : : "memory");
+}
+__device__ __forceinline__ void arrival_fence(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, float4 &r, float2 &q, float &g) {
+    asm volatile("; arrival_fence" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w),
+                 "+v"(q.x), "+v"(q.y), "+v"(g) : : "memory");
+}
 __device__ __forceinline__ void mfma_load_fence(int &index, float &a, float &b, float &c) {
     asm volatile("; mfma_load_fence" : "+v"(index), "+v"(a), "+v"(b), "+v"(c));
 }
@@ -134,9 +146,13 @@ __device__ __forceinline__ float quad_sum(float x) {
 }
 // (a hand-written v_add_f32_dpp variant was tried and dropped: the compiler's wait-count / hazard bookkeeping does not
 // look inside inline asm, and the kernel produced run-to-run differences while table loads were in flight)
+// The sums are consumed only by the quad's first lane inside a branch; without the (empty) asm the compiler sinks the
+// second add into that branch and keeps a separate v_mov_b32_dpp outside (a DPP read of a lane the branch disabled
+// returns 0): 3 instructions per value instead of 2.  The asm pins the complete sum in front of the branch.
 __device__ __forceinline__ void quad_sum4(float (&x)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = quad_sum(x[r]);
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
 }
 
 // sum over the four 16-lane rows (lanes l, l^16, l^32, l^48), result in every lane: the gfx950 row-swap instructions
@@ -269,10 +285,12 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
         er[0] = erec[min(sl, last_slot)];
     }
 
-    // A centre that is complete is written exactly once (also covers centres without any neighbor): reduce the 4
-    // slot lanes of the quad, add the residual from the staged slices (no global loads), one float4 store per row.
+    // A centre that is complete is written exactly once: reduce the 4 slot lanes of the quad, add the residual from the
+    // staged slices (no global loads), one float4 store per row.  Every centre owns at least one quad of slots (the
+    // neighbor build pads an isolated atom with 4 zero-weight slots), so at most one centre completes per step and a
+    // plain `if` suffices: no loop-carried register rotation in the hot loop.
     auto flush_complete = [&]() {
-        while (c < c_last && pos >= cend) {
+        if (c < c_last && pos >= cend) {
             float4 so, vxo, vyo, vzo;
             quad_sum4(ds); quad_sum4(dvx); quad_sum4(dvy); quad_sum4(dvz);
             so = make_float4(ds[0], ds[1], ds[2], ds[3]);
@@ -298,12 +316,12 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             cend = c < c_last ? rs[c + 1] : stream_end;
         }
     };
-    flush_complete();   // leading centres without neighbors
-
     const float *trow = tile + (4 * fq) * LY::NSEG;
     while (__any(pos < stream_end)) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: ping-pong the unit-vector registers
+            arrival_fence(rq[0], rq[1], er[ph]);
+            flush_complete();   // centre completed by the previous step
             // gather this slot's neighbor row: 4 features x NSEG values, contiguous in LDS
             float tv[4 * LY::NSEG];
             {
@@ -350,9 +368,9 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 #pragma unroll
             for (int r = 1; r < 4; ++r) message(r);
             if (pos < stream_end) pos += 4;
-            flush_complete();
         }
     }
+    flush_complete();   // last centre of the stream
 }
 
 // ======================================================================================================
@@ -373,10 +391,15 @@ constexpr int SLICES_PER_WG = 1;   // measured: 1 -> 6.3 ms, 2 -> 6.7, 4 -> 7.1 
 constexpr int NSG = NSLICE / SLICES_PER_WG;   // slice groups = partial edge-gradient buffers per model
 constexpr int ROWB = FS * 4 + 4;              // LDS row: [feature][sbar, vbar_x, vbar_y, vbar_z] + pad
 
-size_t edge_bwd_lds_bytes(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * ROWB + max_atoms + 4); }
+constexpr int BWD_STREAMS = (BWD_THREADS / 64) * 4;
+constexpr int CEN_FLOATS = BWD_STREAMS * 4 * 6 * 4;   // current-centre store: [stream][feature quarter][phi a, b, c, v x, y, z] float4
+__host__ __device__ inline size_t bwd_rs_floats(int max_atoms) { return ((size_t)max_atoms + 1 + 3) & ~(size_t)3; }
+size_t edge_bwd_lds_bytes(int max_atoms) {
+    return sizeof(float) * ((size_t)max_atoms * ROWB + bwd_rs_floats(max_atoms) + CEN_FLOATS);
+}
 int edge_bwd_groups() { return NSG; }
 
-__global__ void __launch_bounds__(BWD_THREADS)
+__global__ void __launch_bounds__(BWD_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))   // one workgroup per CU (LDS): use the 256 VGPRs
 k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, GraphView G,
                 const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms,
                 const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
@@ -399,7 +422,7 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
 
     const int lane = tid & 63, wave = tid >> 6, p = lane & 15, fq = lane >> 4, e = p & 3;
     const int sid = wave * 4 + (p >> 2);
-    constexpr int nstreams = (BWD_THREADS / 64) * 4;
+    constexpr int nstreams = BWD_STREAMS;
     const int slot0 = rs[0], slots = rs[Nc] - slot0;
     auto first_centre = [&](int sidx) {
         const int target = slot0 + (int)(((long long)slots * sidx) / nstreams);
@@ -418,6 +441,19 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
     float4 *gb = gbar + (size_t)(m * n_groups + sg) * gbar_stride;
     const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 2;
     const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 2;
+
+    // which gradient component the reduce-scatter of the hot loop leaves in this lane's row: the same swap network run
+    // once on tags (0, 1, 2 and 3 = the zero filler), so the mapping never depends on a reading of the ISA manual
+    int gcomp_id;
+    {
+        unsigned t0 = 0u, t1 = 1u, t2 = 2u, t3 = 3u;
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+        const auto a = __builtin_amdgcn_permlane32_swap(t0, t1, false, false);
+        const auto bq = __builtin_amdgcn_permlane32_swap(t2, t3, false, false);
+        const auto cq = __builtin_amdgcn_permlane16_swap(a[0], bq[0], false, false);
+        gcomp_id = (a[0] == a[1] && bq[0] == bq[1] && cq[0] == cq[1]) ? (int)cq[0] : 3;
+        if (!(a[0] == a[1] && bq[0] == bq[1] && cq[0] == cq[1])) __builtin_trap();
+    }
 
     for (int si = 0; si < SLICES_PER_WG; ++si) {
         const int fs = sg * SLICES_PER_WG + si;
@@ -459,35 +495,47 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
         }
         __syncthreads();
 
-        // ---- per-centre data of this lane's 4 features: phi_c (a, b, c) and v_c; prefetched one centre ahead ------------
-        float4 pca = make_float4(0.f, 0.f, 0.f, 0.f), pcb, pcc, vcx = pca, vcy = pca, vcz = pca;
-        float4 npca = pca, npcb = pca, npcc = pca, nvcx = pca, nvcy = pca, nvcz = pca;
-        auto load_centre = [&](int cc, float4 &a, float4 &bq, float4 &cq, float4 &x, float4 &y, float4 &z) {
+        // ---- per-centre data of this lane's 4 features: phi_c (a, b, c) and v_c -------------------------------------------
+        // The CURRENT centre's values live in a small LDS record per (stream, feature quarter) and are re-read every step
+        // next to the neighbor gathers (6 broadcast ds_read_b128); the NEXT centre's values are in flight in registers
+        // and are parked in the record when the stream moves on.  (Keeping both sets in registers made the compiler
+        // rotate ~50 registers per completed centre and wait on the prefetch it had just issued.)
+        const int cen_idx = (int)((size_t)max_atoms * ROWB + bwd_rs_floats(max_atoms)) + (sid * 4 + fq) * 24;   // float index in tile[]
+        f32x4 *cen = reinterpret_cast<f32x4 *>(tile + cen_idx);
+        f32x4 nx[6];   // (ext vectors: arrays of HIP float4 stay in scratch memory)
+        auto load_centre = [&](int cc) {
             const size_t ga = mN + a0 + min(cc, Nc - 1);
             const float *pr = phi + ga * F3 + fcol;
-            a = *reinterpret_cast<const float4 *>(pr);
-            bq = *reinterpret_cast<const float4 *>(pr + F);
-            cq = *reinterpret_cast<const float4 *>(pr + 2 * F);
-            x = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 0) * F + fcol);
-            y = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 1) * F + fcol);
-            z = *reinterpret_cast<const float4 *>(v_in + (ga * 3 + 2) * F + fcol);
+            nx[0] = *reinterpret_cast<const f32x4 *>(pr);
+            nx[1] = *reinterpret_cast<const f32x4 *>(pr + F);
+            nx[2] = *reinterpret_cast<const f32x4 *>(pr + 2 * F);
+            nx[3] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 0) * F + fcol);
+            nx[4] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 1) * F + fcol);
+            nx[5] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 2) * F + fcol);
+        };
+        auto park_centre = [&]() {   // the quad's 4 slot lanes hold identical values: any of them may write
+#pragma unroll
+            for (int q = 0; q < 6; ++q) cen[q] = nx[q];
         };
         int c = c_first, pos = stream_begin;
         int cend = c < c_last ? rs[c + 1] : stream_end;
-        load_centre(c, pca, pcb, pcc, vcx, vcy, vcz);
-        load_centre(c + 1, npca, npcb, npcc, nvcx, nvcy, nvcz);
+        load_centre(c);
+        park_centre();
+        load_centre(c + 1);
         float accb[4] = {0.f, 0.f, 0.f, 0.f}, accc[4] = {0.f, 0.f, 0.f, 0.f};
         float accx[4] = {0.f, 0.f, 0.f, 0.f}, accy[4] = {0.f, 0.f, 0.f, 0.f}, accz[4] = {0.f, 0.f, 0.f, 0.f};
 
+        // at most one centre completes per step (>= 4 slots per centre, see forward)
         auto flush_complete = [&]() {
-            while (c < c_last && pos >= cend) {
+            if (c < c_last && pos >= cend) {
                 float4 pa, pb, pc2, ox, oy, oz;
                 quad_sum4(accb); quad_sum4(accc); quad_sum4(accx); quad_sum4(accy); quad_sum4(accz);
                 const float (&tb)[4] = accb, (&tc)[4] = accc, (&tx)[4] = accx, (&ty)[4] = accy, (&tz)[4] = accz;
                 if (e == 0) {
                     const size_t ga = mN + a0 + c;
-                    const float vx_[4] = {vcx.x, vcx.y, vcx.z, vcx.w}, vy_[4] = {vcy.x, vcy.y, vcy.z, vcy.w};
-                    const float vz_[4] = {vcz.x, vcz.y, vcz.z, vcz.w}, pa_[4] = {pca.x, pca.y, pca.z, pca.w};
+                    const f32x4 cv[6] = {cen[0], cen[1], cen[2], cen[3], cen[4], cen[5]};   // record of the completed centre
+                    const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
+                    const float vz_[4] = {cv[5].x, cv[5].y, cv[5].z, cv[5].w}, pa_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
                     float a_[4], x_[4], y_[4], z_[4];
                     const float *res = tile + c * ROWB + (4 * fq) * 4;   // [r][sbar, vbar_x, vbar_y, vbar_z]
 #pragma unroll
@@ -515,12 +563,11 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                 for (int r = 0; r < 4; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
                 ++c;
                 cend = c < c_last ? rs[c + 1] : stream_end;
-                pca = npca; pcb = npcb; pcc = npcc; vcx = nvcx; vcy = nvcy; vcz = nvcz;
-                load_centre(c + 1, npca, npcb, npcc, nvcx, nvcy, nvcz);
+                park_centre();
+                __builtin_amdgcn_sched_barrier(0);   // the old values leave their registers before the loads that refill them are issued
+                load_centre(c + 1);
             }
         };
-        flush_complete();
-
         // table entries of this lane's slot; exhausted streams read the all-zero entry.  rho / drho pieces are single
         // buffered (the next step's loads are issued right after the MFMAs that consume them), the small records
         // (unit vector + neighbor id, distance) are double buffered.
@@ -543,13 +590,15 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
         // partial edge gradient written by the previous slice for this lane's slot: fetched one step ahead so that the
         // read-modify-write never stalls the step (a slot is visited once per slice, so the early read is safe)
         const bool first_write = layer_first && si == 0;
-        float4 gold = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!first_write) gold = gb[min(pos + e, last_slot)];
+        float *gcomp = reinterpret_cast<float *>(gb) + gcomp_id;   // component this row ends up with (3: none)
+        float gold = gcomp[(size_t)min(pos + e, last_slot) * 4];
         const float *trow = tile + (4 * fq) * 4;
 
         while (__any(pos < stream_end)) {
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
+                arrival_fence(rq[0], rq[1], dq[0], dq[1], er[ph], dd[ph], gold);
+                flush_complete();   // centre completed by the previous step
                 float tb[16];
                 {
                     const float4 *row = reinterpret_cast<const float4 *>(trow + __float_as_int(er[ph].w) * ROWB);
@@ -558,6 +607,17 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                         const float4 t4 = row[q];
                         tb[4 * q] = t4.x; tb[4 * q + 1] = t4.y; tb[4 * q + 2] = t4.z; tb[4 * q + 3] = t4.w;
                     }
+                }
+                // (the record's index passes through an empty asm: otherwise the compiler forwards the parked registers to these
+                // reads on the completing lanes, hoists the reads of the other lanes into the tail of the previous step and
+                // shuffles / waits on the registers of the prefetch it has just issued)
+                f32x4 cv[6];
+                {
+                    int ci = cen_idx;   // (the INDEX is laundered: a laundered pointer loses its LDS address space -> flat loads)
+                    asm volatile("" : "+v"(ci));
+                    const f32x4 *cr = reinterpret_cast<const f32x4 *>(tile + ci);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) cv[q] = cr[q];
                 }
                 mfma_pre_fence(rq[0], rq[1]);   // gathers are issued before the first MFMA
                 mfma_pre_fence(dq[0], dq[1]);
@@ -572,10 +632,10 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                 const f32x4 *aw = awd, *ad = awd + NSEC;
                 __builtin_amdgcn_sched_barrier(0);
                 const float ux = er[ph].x, uy = er[ph].y, uz = er[ph].z;   // unit vector c -> n ; edge (n -> c) has -u
-                const float pcb_[4] = {pcb.x, pcb.y, pcb.z, pcb.w}, pcc_[4] = {pcc.x, pcc.y, pcc.z, pcc.w};
-                const float pca_[4] = {pca.x, pca.y, pca.z, pca.w};
-                const float vx_[4] = {vcx.x, vcx.y, vcx.z, vcx.w}, vy_[4] = {vcy.x, vcy.y, vcy.z, vcy.w};
-                const float vz_[4] = {vcz.x, vcz.y, vcz.z, vcz.w};
+                const float pcb_[4] = {cv[1].x, cv[1].y, cv[1].z, cv[1].w}, pcc_[4] = {cv[2].x, cv[2].y, cv[2].z, cv[2].w};
+                const float pca_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
+                const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
+                const float vz_[4] = {cv[5].x, cv[5].y, cv[5].z, cv[5].w};
                 float dpart = 0.f, ub0 = 0.f, ub1 = 0.f, ub2 = 0.f;
                 auto feature = [&](int r) {
                     const float sbn = tb[4 * r], vb0 = tb[4 * r + 1], vb1 = tb[4 * r + 2], vb2 = tb[4 * r + 3];
@@ -600,26 +660,38 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                 mfma_load_fence(nquad, accb[0], accc[0], dpart, ub0);
                 fetch_tables(nquad);
                 fetch_rec(nquad, ph ^ 1);
+                const float gold_next = gcomp[(size_t)min(nquad + e, last_slot) * 4];   // old partial gradient of the next slot (ignored on the first write)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 1; r < 4; ++r) feature(r);
-                // sum over the 4 feature quarters (lanes p, p+16, p+32, p+48): fixed order, all lanes get the total (xrow_sum)
-                dpart = xrow_sum(dpart); ub0 = xrow_sum(ub0); ub1 = xrow_sum(ub1); ub2 = xrow_sum(ub2);
-                if (fq == 0 && pos < stream_end && dd[ph].x > 0.f) {   // one lane per real slot writes its gradient
+                // Gradient of edge (n -> c), unit vector -u:  g = -(dE/dd) u + (ub - (ub.u) u) / d, linear in (dpart, ub).
+                // The map is applied to the lane's partial sums BEFORE the reduction over the 4 feature quarters (lanes
+                // p, p+16, p+32, p+48), so only 3 values cross lanes, and the reduction is a reduce-scatter on the
+                // gfx950 row swaps: swap32 pairs (g0, g1) / (g2, 0) -> rows {0,1} hold half sums of g0 / g2, rows {2,3} of
+                // g1 / 0; swap16 of the two -> row 0 = g0, row 1 = g2, row 2 = g1 (complete sums, fixed order): 3 swaps +
+                // 3 adds for the whole quantity, and row r writes one component.
+                {
                     const float invd = dd[ph].x;
-                    const float db = dpart;
-                    // edge (n -> c): unit vector -u ; g = db (-u) + (ub - (ub.u) u) / d
                     const float dotu = fmaf(ub2, uz, fmaf(ub1, uy, ub0 * ux));
-                    const float g0 = fmaf(-db, ux, (ub0 - dotu * ux) * invd) + gold.x;
-                    const float g1 = fmaf(-db, uy, (ub1 - dotu * uy) * invd) + gold.y;
-                    const float g2 = fmaf(-db, uz, (ub2 - dotu * uz) * invd) + gold.z;
-                    gb[pos + e] = make_float4(g0, g1, g2, 0.f);
+                    float g0 = fmaf(-dpart, ux, fmaf(-dotu, ux, ub0) * invd);
+                    float g1 = fmaf(-dpart, uy, fmaf(-dotu, uy, ub1) * invd);
+                    float g2 = fmaf(-dpart, uz, fmaf(-dotu, uz, ub2) * invd);
+                    const auto h01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(g0), __float_as_uint(g1), false, false);
+                    const auto h2z = __builtin_amdgcn_permlane32_swap(__float_as_uint(g2), 0u, false, false);
+                    const float A = __uint_as_float(h01[0]) + __uint_as_float(h01[1]);
+                    const float B = __uint_as_float(h2z[0]) + __uint_as_float(h2z[1]);
+                    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(A), __float_as_uint(B), false, false);
+                    const float gsum = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+                    // three rows of a real slot write one component each; every other lane writes the spare entry, so the
+                    // store is unconditional and the memory-operation count of a step does not depend on the path
+                    const bool real = gcomp_id < 3 && pos < stream_end && invd > 0.f;
+                    gcomp[(size_t)(real ? pos + e : zero_slot) * 4] = gsum + (first_write ? 0.f : gold);
+                    gold = gold_next;
                 }
-                if (!first_write) gold = gb[min(nquad + e, last_slot)];   // index from the fence: never hoisted into the MFMAs
                 if (pos < stream_end) pos += 4;
-                flush_complete();
             }
         }
+        flush_complete();   // last centre of the stream
     }
 }
 
