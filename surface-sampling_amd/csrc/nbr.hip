@@ -255,14 +255,21 @@ __device__ __forceinline__ void split2_f16(float x, unsigned &h, unsigned &l) {
     h = __builtin_bit_cast(unsigned short, hh);
     l = __builtin_bit_cast(unsigned short, ll);
 }
-__device__ __forceinline__ void write_f16_record(const float (&v)[5], float env, uint4 *__restrict__ rec) {
+// Table layout (rho16 / drho16), in 16-byte units: unit(slot, kq, piece) = (slot >> 2) * 32 + piece * 16 + kq * 4 + (slot & 3).
+// The edge kernels always consume an aligned quad of 4 slots with 4 consecutive lanes; with the quad's entries interleaved
+// like this those 4 lanes read 64 contiguous bytes (one L1 access) instead of 4 accesses 128 bytes apart: the kernels
+// were bound by the L1 tag-lookup rate (~1 access / clock / CU; PMC: TA busy 80-90 %), not by bytes.
+__device__ __forceinline__ size_t f16_unit(size_t slot, int kq, int piece) {
+    return (slot >> 2) * 32 + (size_t)piece * 16 + (size_t)kq * 4 + (slot & 3);
+}
+__device__ __forceinline__ void write_f16_record(const float (&v)[5], float env, uint4 *__restrict__ tab, size_t slot, int kq) {
     unsigned h[6], l[6];
 #pragma unroll
     for (int k = 0; k < 5; ++k) split2_f16(v[k], h[k], l[k]);
     split2_f16(env, h[5], l[5]);
     auto pk = [](unsigned lo, unsigned hi) { return lo | (hi << 16); };
-    rec[0] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), 0u);
-    rec[1] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), 0u);
+    tab[f16_unit(slot, kq, 0)] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), 0u);
+    tab[f16_unit(slot, kq, 1)] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), 0u);
 }
 
 __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
@@ -306,8 +313,8 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
         }
         {
             const float rv[5] = {r[0], r[1], r[2], r[3], r[4]}, dv[5] = {dr[0], dr[1], dr[2], dr[3], dr[4]};
-            write_f16_record(rv, fc, rho16 + ((size_t)slot * 4 + kq) * 2);
-            write_f16_record(dv, dfc, drho16 + ((size_t)slot * 4 + kq) * 2);
+            write_f16_record(rv, fc, rho16, (size_t)slot, kq);
+            write_f16_record(dv, dfc, drho16, (size_t)slot, kq);
         }
         r[5] = fc;      // envelope (bias column) replicated in every quarter: the edge kernels fold bd * fc into the
         dr[5] = dfc;    // accumulator init instead of spending a sixth MFMA k-step on it
@@ -370,8 +377,9 @@ int build_neighbors(vssr_handle *h, double cutoff) {
         // all-zero table entry that exhausted lanes of the edge kernels read
         VSSR_HIP(h, hipMemsetAsync(h->d_rho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
         VSSR_HIP(h, hipMemsetAsync(h->d_drho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
-        VSSR_HIP(h, hipMemsetAsync(h->d_rho16.as<uint4>() + 8 * (size_t)(h->slot_cap - 1), 0, 8 * sizeof(uint4), st));
-        VSSR_HIP(h, hipMemsetAsync(h->d_drho16.as<uint4>() + 8 * (size_t)(h->slot_cap - 1), 0, 8 * sizeof(uint4), st));
+        // fp16 tables: the last complete QUAD of the capacity is the all-zero entry (quad-interleaved layout, f16_unit)
+        VSSR_HIP(h, hipMemsetAsync(h->d_rho16.as<uint4>() + 32 * (size_t)((h->slot_cap >> 2) - 1), 0, 32 * sizeof(uint4), st));
+        VSSR_HIP(h, hipMemsetAsync(h->d_drho16.as<uint4>() + 32 * (size_t)((h->slot_cap >> 2) - 1), 0, 32 * sizeof(uint4), st));
         hipLaunchKernelGGL(k_edge_geom, dim3(n), dim3(64), 0, st, n, h->d_row_start.as<int>(), h->d_atom_cfg.as<int>(),
                            h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,
                            h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),

@@ -59,6 +59,15 @@ __device__ __forceinline__ void arrival_fence(u32x4 &a, u32x4 &b, u32x4 &c, u32x
     asm volatile("; arrival_fence" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w),
                  "+v"(q.x), "+v"(q.y), "+v"(g) : : "memory");
 }
+// Explicit register copy.  The table buffers are refilled (for the step after next) in the middle of the step that consumes
+// them; small values that stay live to the end of the step are first moved out with a real v_mov, so that the buffer is
+// dead when its refill is issued and the load can land in the same registers (otherwise the loop-carried buffer needs a
+// copy of the freshly loaded value at the loop end -- and a wait for it).
+__device__ __forceinline__ float take(float src) {
+    float d;
+    asm("v_mov_b32 %0, %1" : "=v"(d) : "v"(src));
+    return d;
+}
 __device__ __forceinline__ void mfma_load_fence(int &index, float &a, float &b, float &c) {
     asm volatile("; mfma_load_fence" : "+v"(index), "+v"(a), "+v"(b), "+v"(c));
 }
@@ -269,21 +278,25 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int fcol = fs * FS + 4 * fq;            // first of this lane's 4 global feature columns
 
     // table entry of this lane's slot; exhausted streams read the reserved all-zero entry (filter = 0)
-    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 2;
+    // quad-interleaved table (nbr.hip f16_unit): unit = quad * 32 + piece * 16 + fq * 4 + e -> the 4 slot lanes of a quad read
+    // 64 contiguous bytes
+    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;
+    const int zero_quad = (zero_slot + 1) / 4 - 1;   // zero_slot = capacity - 1; the last complete quad is all zero
     const float4 *erec = G.erec;
     const int last_slot = max(rs[Nc] - 1, 0);     // records are always read from inside the chain (finite values)
 
-    // rho pieces of the current step (single buffer: the next step's loads are issued right after the MFMAs that read
-    // them and complete during the message arithmetic); unit vector / neighbor id double-buffered
-    u32x4 rq[2];
+    // Two table buffers (rho pieces, unit vector + neighbor id), one per step parity: buffer ph is consumed by the step of
+    // parity ph and refilled right after that step's MFMAs for the step after next, so a table load has ~1.6 steps to
+    // arrive (L2 / HBM latency is of the order of one step).
+    u32x4 rq[2][2];
     float4 er[2];
-    {
-        const int sl = pos + e;
-        const size_t tsl = pos < stream_end ? sl : zero_slot;
-        const u32x4 *rp = rho_lane + tsl * 8;
-        rq[0] = rp[0]; rq[1] = rp[1];
-        er[0] = erec[min(sl, last_slot)];
-    }
+    auto fetch = [&](int buf, int quad, int sl) {   // sl = quad + e (passed separately: it comes out of the load fence)
+        const u32x4 *rp = rho_lane + (size_t)(quad < stream_end ? (sl >> 2) : zero_quad) * 32;
+        rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
+        er[buf] = erec[min(sl, last_slot)];
+    };
+    fetch(0, pos, pos + e);
+    fetch(1, pos + 4, pos + 4 + e);
 
     // A centre that is complete is written exactly once: reduce the 4 slot lanes of the quad, add the residual from the
     // staged slices (no global loads), one float4 store per row.  Every centre owns at least one quad of slots (the
@@ -320,30 +333,31 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     while (__any(pos < stream_end)) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: ping-pong the unit-vector registers
-            arrival_fence(rq[0], rq[1], er[ph]);
+            arrival_fence(rq[ph][0], rq[ph][1], er[ph]);
+            const float ux = take(er[ph].x), uy = take(er[ph].y), uz = take(er[ph].z);
+            const int jn = __float_as_int(take(er[ph].w));
             flush_complete();   // centre completed by the previous step
             // gather this slot's neighbor row: 4 features x NSEG values, contiguous in LDS
             float tv[4 * LY::NSEG];
             {
-                const float4 *row = reinterpret_cast<const float4 *>(trow + __float_as_int(er[ph].w) * LY::ROW);
+                const float4 *row = reinterpret_cast<const float4 *>(trow + jn * LY::ROW);
 #pragma unroll
                 for (int q = 0; q < LY::NSEG; ++q) {
                     const float4 t4 = row[q];
                     tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
                 }
             }
-            mfma_pre_fence(rq[0], rq[1]);   // gathers are issued before the first MFMA
+            mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
             // ---- filter GEMM  D[feature][slot] = Wd_ext[feature][k] rho[k][slot]  (bias . fc included) ---------------
             f32x4 acc[LY::NSEC];
             {
                 const u32x4 (*wp[LY::NSEC])[2], (*rp3[LY::NSEC])[2];
 #pragma unroll
-                for (int s2 = 0; s2 < LY::NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq; }
+                for (int s2 = 0; s2 < LY::NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; }
                 filter_tiles<LY::NSEC>(wp, rp3, acc);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- messages of this lane's slot for its 4 features (filter = 0 exactly for pads / foreign slots) -----------
-            const float ux = er[ph].x, uy = er[ph].y, uz = er[ph].z;
             auto message = [&](int r) {
                 const float *tr = tv + r * LY::NSEG;
                 const float wa = acc[0][r], wb = acc[1][r], wc = acc[2][r];
@@ -355,15 +369,10 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                 dvz[r] = fmaf(ma, tr[5], dvz[r]);
             };
             message(0);   // consumes every accumulator tile
-            // next step's table entries (in flight during the rest of the message arithmetic); see mfma_load_fence
-            int nsl = pos + 4 + e;
+            // table entries of the step after next, into the buffer this step has just consumed; see mfma_load_fence
+            int nsl = pos + 8 + e;
             mfma_load_fence(nsl, ds[0], dvx[0], dvy[0]);
-            {
-                const size_t tsl = pos + 4 < stream_end ? nsl : zero_slot;
-                const u32x4 *rp = rho_lane + tsl * 8;
-                rq[0] = rp[0]; rq[1] = rp[1];
-                er[ph ^ 1] = erec[min(nsl, last_slot)];
-            }
+            fetch(ph, pos + 8, nsl);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 1; r < 4; ++r) message(r);
@@ -386,7 +395,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 // buffer G[m][group][slot]: within a layer every slot is written once per group, across layers the SAME lane adds to
 // it in a fixed order (deterministic read-modify-write, old value prefetched one step ahead); finalize reduces the
 // groups in a streaming pass.
-constexpr int BWD_THREADS = 512;
+constexpr int BWD_THREADS = 256;   // 4 waves: two workgroups share a CU (81 KB of LDS each at 272 atoms), one stages its slice while the other computes (6.4 -> 6.0 ms / step)
 constexpr int SLICES_PER_WG = 1;   // measured: 1 -> 6.3 ms, 2 -> 6.7, 4 -> 7.1 per step (L2 locality of the tables); finalize reduces the 8 partial buffers in a streaming pass
 constexpr int NSG = NSLICE / SLICES_PER_WG;   // slice groups = partial edge-gradient buffers per model
 constexpr int ROWB = FS * 4 + 4;              // LDS row: [feature][sbar, vbar_x, vbar_y, vbar_z] + pad
@@ -439,8 +448,9 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
     const int last_slot = max(rs[Nc] - 1, 0);
     const LayerW &W = MW[m].layer[l];
     float4 *gb = gbar + (size_t)(m * n_groups + sg) * gbar_stride;
-    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 2;
-    const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 2;
+    const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;   // quad-interleaved tables, see forward
+    const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 4 + e;
+    const int zero_quad = (zero_slot + 1) / 4 - 1;
 
     // which gradient component the reduce-scatter of the hot loop leaves in this lane's row: the same swap network run
     // once on tags (0, 1, 2 and 3 = the zero filler), so the mapping never depends on a reading of the ISA manual
@@ -568,40 +578,41 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                 load_centre(c + 1);
             }
         };
-        // table entries of this lane's slot; exhausted streams read the all-zero entry.  rho / drho pieces are single
-        // buffered (the next step's loads are issued right after the MFMAs that consume them), the small records
-        // (unit vector + neighbor id, distance) are double buffered.
-        u32x4 rq[2], dq[2];
+        // Table entries of this lane's slot; exhausted streams read the all-zero entry.  Two buffers, one per step parity:
+        // buffer ph is consumed by the step of parity ph and refilled right after that step's MFMAs for the step after next
+        // (~1.6 steps for a load to arrive).  The old partial edge gradient of the slot (written by the previous layer for
+        // this lane's slot; a slot is visited once per launch, so the early read is safe) travels with the tables.
+        const bool first_write = layer_first && si == 0;
+        float *gcomp = reinterpret_cast<float *>(gb) + gcomp_id;   // component this row ends up with (3: none)
+        u32x4 rq[2][2], dq[2][2];
         float4 er[2];
         float2 dd[2];
-        auto fetch_tables = [&](int quad) {
-            const size_t off = (size_t)(quad < stream_end ? quad + e : zero_slot) * 8;
+        float gold[2];
+        auto fetch = [&](int buf, int quad) {
+            const size_t off = (size_t)(quad < stream_end ? (quad >> 2) : zero_quad) * 32;
             const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
-            rq[0] = rp[0]; rq[1] = rp[1];
-            dq[0] = dp[0]; dq[1] = dp[1];
-        };
-        auto fetch_rec = [&](int quad, int buf) {
+            rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
+            dq[buf][0] = dp[0]; dq[buf][1] = dp[16];
             const int sl = min(quad + e, last_slot);
             er[buf] = G.erec[sl];
             dd[buf] = G.dist2[sl];
+            gold[buf] = gcomp[(size_t)sl * 4];   // (ignored on the first write)
         };
-        fetch_tables(pos);
-        fetch_rec(pos, 0);
-        // partial edge gradient written by the previous slice for this lane's slot: fetched one step ahead so that the
-        // read-modify-write never stalls the step (a slot is visited once per slice, so the early read is safe)
-        const bool first_write = layer_first && si == 0;
-        float *gcomp = reinterpret_cast<float *>(gb) + gcomp_id;   // component this row ends up with (3: none)
-        float gold = gcomp[(size_t)min(pos + e, last_slot) * 4];
+        fetch(0, pos);
+        fetch(1, pos + 4);
         const float *trow = tile + (4 * fq) * 4;
 
         while (__any(pos < stream_end)) {
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
-                arrival_fence(rq[0], rq[1], dq[0], dq[1], er[ph], dd[ph], gold);
+                arrival_fence(rq[ph][0], rq[ph][1], dq[ph][0], dq[ph][1], er[ph], dd[ph], gold[ph]);
+                const float ux = take(er[ph].x), uy = take(er[ph].y), uz = take(er[ph].z);   // unit vector c -> n ; edge (n -> c) has -u
+                const int jn = __float_as_int(take(er[ph].w));
+                const float invd = take(dd[ph].x), gold_cur = take(gold[ph]);
                 flush_complete();   // centre completed by the previous step
                 float tb[16];
                 {
-                    const float4 *row = reinterpret_cast<const float4 *>(trow + __float_as_int(er[ph].w) * ROWB);
+                    const float4 *row = reinterpret_cast<const float4 *>(trow + jn * ROWB);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float4 t4 = row[q];
@@ -619,19 +630,18 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
 #pragma unroll
                     for (int q = 0; q < 6; ++q) cv[q] = cr[q];
                 }
-                mfma_pre_fence(rq[0], rq[1]);   // gathers are issued before the first MFMA
-                mfma_pre_fence(dq[0], dq[1]);
+                mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
+                mfma_pre_fence(dq[ph][0], dq[ph][1]);
                 // filter and its radial derivative for this lane's slot and 4 features (bias . fc / bias . fc' included)
                 f32x4 awd[2 * NSEC];   // tiles [0, NSEC): filter w, [NSEC, 2 NSEC): radial derivative dw
                 {
                     const u32x4 (*wp[2 * NSEC])[2], (*rp3[2 * NSEC])[2];
 #pragma unroll
-                    for (int s2 = 0; s2 < NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq; wp[NSEC + s2] = &wA[s2]; rp3[NSEC + s2] = &dq; }
+                    for (int s2 = 0; s2 < NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; wp[NSEC + s2] = &wA[s2]; rp3[NSEC + s2] = &dq[ph]; }
                     filter_tiles<2 * NSEC>(wp, rp3, awd);
                 }
                 const f32x4 *aw = awd, *ad = awd + NSEC;
                 __builtin_amdgcn_sched_barrier(0);
-                const float ux = er[ph].x, uy = er[ph].y, uz = er[ph].z;   // unit vector c -> n ; edge (n -> c) has -u
                 const float pcb_[4] = {cv[1].x, cv[1].y, cv[1].z, cv[1].w}, pcc_[4] = {cv[2].x, cv[2].y, cv[2].z, cv[2].w};
                 const float pca_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
                 const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
@@ -656,11 +666,9 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                     ub0 = fmaf(mc, vb0, ub0); ub1 = fmaf(mc, vb1, ub1); ub2 = fmaf(mc, vb2, ub2);
                 };
                 feature(0);   // consumes every accumulator tile
-                int nquad = pos + 4;
+                int nquad = pos + 8;   // the step after next, into the buffer this step has just consumed
                 mfma_load_fence(nquad, accb[0], accc[0], dpart, ub0);
-                fetch_tables(nquad);
-                fetch_rec(nquad, ph ^ 1);
-                const float gold_next = gcomp[(size_t)min(nquad + e, last_slot) * 4];   // old partial gradient of the next slot (ignored on the first write)
+                fetch(ph, nquad);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 1; r < 4; ++r) feature(r);
@@ -671,7 +679,6 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                 // g1 / 0; swap16 of the two -> row 0 = g0, row 1 = g2, row 2 = g1 (complete sums, fixed order): 3 swaps +
                 // 3 adds for the whole quantity, and row r writes one component.
                 {
-                    const float invd = dd[ph].x;
                     const float dotu = fmaf(ub2, uz, fmaf(ub1, uy, ub0 * ux));
                     float g0 = fmaf(-dpart, ux, fmaf(-dotu, ux, ub0) * invd);
                     float g1 = fmaf(-dpart, uy, fmaf(-dotu, uy, ub1) * invd);
@@ -685,8 +692,7 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
                     // three rows of a real slot write one component each; every other lane writes the spare entry, so the
                     // store is unconditional and the memory-operation count of a step does not depend on the path
                     const bool real = gcomp_id < 3 && pos < stream_end && invd > 0.f;
-                    gcomp[(size_t)(real ? pos + e : zero_slot) * 4] = gsum + (first_write ? 0.f : gold);
-                    gold = gold_next;
+                    gcomp[(size_t)(real ? pos + e : zero_slot) * 4] = gsum + (first_write ? 0.f : gold_cur);
                 }
                 if (pos < stream_end) pos += 4;
             }

@@ -54,7 +54,7 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const float4 *erec;      // [slots] {u_x, u_y, u_z, bitcast(j local to its chain)} ; pads: u = 0, j = 0
     const float *rho;        // [slots][4][6]  radial basis * envelope in MFMA A-fragment order: [kq][ks] = rho_{kq+4ks}
     const float *drho;       // [slots][4][6]  d rho / d d, same order
-    const uint4 *rho16;      // [slots][4][2] operand-ready 2-way fp16 split of rho (32 B per (slot, quarter)), see nbr.hip
+    const uint4 *rho16;      // operand-ready 2-way fp16 split of rho, quad-interleaved: [slot / 4][piece h, l][quarter][slot % 4] x 16 B (nbr.hip f16_unit)
     const uint4 *drho16;     // same for d rho / d d
     const unsigned char *zslot;   // [slots] species index (zmap) of the neighbor, 255 for pads / unmapped
     const float2 *dist2;     // [slots] {1 / edge length (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
