@@ -152,8 +152,8 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
         run += total;
     }
     if (FILL) {
-        const int padded = max((run + 3) & ~3, 4);   // at least one quad per centre (an isolated atom gets 4 pads): the edge
-        const long long slot = base + run + lane;    // kernels complete at most one centre per step
+        const int padded = max((run + 3) & ~3, 8);   // at least two quads per centre (an isolated atom gets 8 pads): the edge
+        const long long slot = base + run + lane;    // kernels prefetch two steps ahead across at most one centre boundary
         if (lane < padded - run && slot < slot_cap) {
             edge[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
             edge_S[slot] = pack_shift(0, 0, 0);
@@ -174,7 +174,7 @@ k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int
     for (int base = 0; base < n; base += 1024) {
         const int i = base + t;
         const int d = i < n ? deg[i] : 0;
-        const int p = i < n ? max((d + 3) & ~3, 4) : 0;
+        const int p = i < n ? max((d + 3) & ~3, 8) : 0;
         int x = p, xr = d;                       // inclusive scan inside the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -329,6 +329,29 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
     }
 }
 
+// Work list of the MFMA edge kernels: per chain, the centres sorted by padded slot count (descending; ties by index) as
+// {centre (chain-local), first slot, padded slot count, 0}.  Four consecutive entries form a "bundle" that one wave
+// walks in lock step (4 slots per centre and step), so the four centres finish within the same step and their results
+// are reduced / written with all lanes active.  One workgroup per chain, O(N^2) ranking on LDS broadcasts.
+__global__ void __launch_bounds__(256)
+k_bundle_sort(const int *__restrict__ cfg_start, const int *__restrict__ row_start, const int *__restrict__ counters,
+              int4 *__restrict__ bundle) {
+    extern __shared__ int sdeg[];
+    if (counters[2]) return;
+    const int b = blockIdx.x, a0 = cfg_start[b], n = cfg_start[b + 1] - a0;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) sdeg[c] = row_start[a0 + c + 1] - row_start[a0 + c];
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const int d = sdeg[c];
+        int rank = 0;
+        for (int o = 0; o < n; ++o) {
+            const int od = sdeg[o];
+            rank += (od > d || (od == d && o < c)) ? 1 : 0;
+        }
+        bundle[a0 + rank] = make_int4(c, row_start[a0 + c], d, 0);
+    }
+}
+
 // Enqueue the neighbor build on the handle's stream (no host synchronisation).  If the slot
 // capacity is exceeded, counters[2] is set on the device, every consumer kernel exits early on
 // that flag, and the host (vssr_batch_download / vssr_synchronize) grows the buffers and reruns.
@@ -371,7 +394,7 @@ int build_neighbors(vssr_handle *h, double cutoff) {
         if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
             h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float2) * h->slot_cap) ||
             h->d_rho16.ensure(sizeof(uint4) * 8 * h->slot_cap) || h->d_drho16.ensure(sizeof(uint4) * 8 * h->slot_cap) ||
-            h->d_zslot.ensure((size_t)h->slot_cap))
+            h->d_zslot.ensure((size_t)h->slot_cap) || h->d_bundle.ensure(sizeof(int4) * (size_t)n))
             return set_err(h, VSSR_E_NOMEM, "edge geometry tables: out of device memory");
         // the last slot of the capacity is never used by the CSR (counters[2] flags slots > cap - 64): it is the
         // all-zero table entry that exhausted lanes of the edge kernels read
@@ -385,6 +408,10 @@ int build_neighbors(vssr_handle *h, double cutoff) {
                            h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),
                            h->d_drho.as<float>(), h->d_dist.as<float2>(), h->d_rho16.as<uint4>(),
                            h->d_drho16.as<uint4>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_zslot.as<unsigned char>());
+        if ((size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024)   // chains of the MFMA edge kernels (LDS slices) are far smaller
+            hipLaunchKernelGGL(k_bundle_sort, dim3(h->n_cfg), dim3(256), (size_t)h->max_cfg_atoms * sizeof(int), st,
+                               h->d_cfg_start.as<int>(), h->d_row_start.as<int>(), h->d_counters.as<int>(),
+                               h->d_bundle.as<int4>());
     }
     h->prof.end(st);
     VSSR_HIP(h, hipMemcpyAsync(h->h_counters, h->d_counters.as<int>(), sizeof(int) * 4,

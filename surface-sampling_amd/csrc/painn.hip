@@ -493,6 +493,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
     G.rho16 = h->d_rho16.as<uint4>();
     G.drho16 = h->d_drho16.as<uint4>();
     G.zslot = h->d_zslot.as<unsigned char>();
+    G.bundle = h->d_bundle.as<int4>();
     const ModelW *MW = h->model_table.as<ModelW>();
     const int *counters = h->d_counters.as<int>();
     const int *Z = h->d_Z.as<int>();

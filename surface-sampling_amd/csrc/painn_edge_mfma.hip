@@ -175,6 +175,60 @@ __device__ __forceinline__ float xrow_sum(float x) {
     return __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
 }
 
+// ---- work decomposition of both kernels: bundles ---------------------------------------------------------------------------
+// The neighbor build sorts the centres of every chain by padded slot count (G.bundle, nbr.hip k_bundle_sort).  Four
+// consecutive entries form a bundle; a wave walks one bundle at a time, its 4 CSR streams (lanes p >> 2) taking one centre
+// each, 4 slots per stream and step.  Centres of a bundle have (nearly) the same slot count, so all four complete in the
+// same step (L = slot count of the longest / 4 steps; a shorter centre runs its last steps on the all-zero table entry):
+// the completion code -- cross-lane reduction, residual, stores, accumulator reset -- runs once per bundle with all lanes
+// active and behind a wave-uniform branch.  (Before: every stream walked its own run of centres, each completion ran
+// with a quarter of the lanes and made the compiler copy every accumulator on every step.)  Bundles are dealt to the NW
+// waves of the workgroup in snake order (w, 2 NW - 1 - w, 2 NW + w, ...), which balances a monotone sequence.
+// Every centre owns >= 8 slots (nbr.hip), i.e. L >= 2: a table prefetch two steps ahead crosses at most one bundle
+// boundary.  Entries of upcoming bundles are loaded two bundles ahead (one unconditional load per bundle).
+template <int NW>
+struct BundleWalk {
+    const int4 *tab;   // entries of this chain
+    int Nc, wave, st;  // st: stream (lane quad) inside the wave
+    int nj;            // bundles of this wave
+    int j, t, Lc, Ln;  // current bundle (index into the wave's list), step inside it, steps of current / next bundle
+    int4 cur, nxt, pend;
+
+    __device__ __forceinline__ int bundle_of(int jj) const { return jj * NW + ((jj & 1) ? NW - 1 - wave : wave); }
+    __device__ __forceinline__ int4 load(int jj) const {   // always a load (clamped address): the count of memory operations is path-independent
+        const int idx = 4 * bundle_of(jj) + st;
+        const int4 v = tab[min(idx, Nc - 1)];
+        return (jj < nj && idx < Nc) ? v : make_int4(-1, 0, 0, 0);
+    }
+    __device__ __forceinline__ static int steps(const int4 &q) { return max(__builtin_amdgcn_readfirstlane(q.z) >> 2, 2); }
+    __device__ __forceinline__ void init(const int4 *table, int n, int w, int stream) {
+        tab = table; Nc = n; wave = w; st = stream;
+        const int NB = (n + 3) >> 2, full = NB / NW, rem = NB - full * NW;
+        nj = full + ((((full & 1) ? NW - 1 - w : w) < rem) ? 1 : 0);
+        j = 0; t = 0;
+        cur = load(0); nxt = load(1); pend = load(2);
+        // stream 0 of a bundle holds its longest centre (descending order); lane 0 of the wave belongs to stream 0
+        Lc = steps(cur); Ln = steps(nxt);
+    }
+    // first slot of this stream's quad `ahead` steps from now (ahead <= 2) and whether it holds real slots
+    __device__ __forceinline__ int quad_ahead(int ahead, bool &valid) const {
+        const int tt = t + ahead;
+        const bool in_cur = tt < Lc;   // wave-uniform
+        const int4 &q = in_cur ? cur : nxt;
+        const int ts = in_cur ? tt : tt - Lc;
+        valid = 4 * ts < q.z;
+        return q.y + 4 * ts;
+    }
+    // bundle complete: move on; returns true when the wave has no bundle left
+    __device__ __forceinline__ bool advance() {
+        ++j;
+        if (j == nj) return true;
+        cur = nxt; nxt = pend; pend = load(j + 2);
+        t = 0; Lc = Ln; Ln = steps(nxt);
+        return false;
+    }
+};
+
 // Lane roles ("slot-major"): p = lane & 15 is the slot position inside the step's 16-slot tile, stream = p >> 2
 // (4 independent CSR streams per wave, 4 slots each per step), e = p & 3 the slot inside the quad, and
 // fq = lane >> 4 selects features 4 fq .. 4 fq + 3 of the slice.  With the WEIGHTS as MFMA A operand
@@ -205,7 +259,6 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     // (NSEG + 1) * 4 float4 per atom; loads are issued in batches of 4 per thread before any LDS store so that
     // the L2 / HBM round trips overlap (one workgroup per CU: nothing else hides them)
     float *s_tile = tile + (size_t)max_atoms * LY::ROW;                      // [atom][FS]
-    int *rs = reinterpret_cast<int *>(s_tile + (size_t)max_atoms * FS);      // [Nc + 1] row_start of this chain
     {
         constexpr int PER_ATOM = (LY::NSEG + 1) * 4;   // float4 per atom: NSEG slice segments + the s slice
         const int total = Nc * PER_ATOM;
@@ -236,13 +289,10 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             for (int u = 0; u < 4; ++u)
                 if (base + u * EDGE_THREADS < total) put(base + u * EDGE_THREADS, v4[u]);
         }
-        for (int idx = tid; idx <= Nc; idx += EDGE_THREADS) rs[idx] = G.row_start[a0 + idx];
     }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, p = lane & 15, fq = lane >> 4, e = p & 3;
-    const int sid = wave * 4 + (p >> 2);                      // stream id inside the workgroup
-    const int nstreams = (EDGE_THREADS / 64) * 4;
     // ---- A operand: Wd_ext[section row = feature (lane & 15)][k = 4 ks + (lane >> 4)] ---------------------------
     const LayerW &W = MW[m].layer[l];
     // A operand: fp16 pieces (h, l) of the filter weights of feature row p, quarter fq: 2 x 16 B per section, bias
@@ -256,87 +306,77 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
         for (int i3 = 0; i3 < 2; ++i3) wA[s][i3] = wsrc[i3];
     }
 
-    // ---- every stream walks a contiguous run of CSR slots, cut at centre boundaries, ~equal slot counts ---------
-    const int slot0 = rs[0], slots = rs[Nc] - slot0;
-    auto first_centre = [&](int sidx) {   // first centre whose slots start at or after the sidx-th slot quantile
-        const int target = slot0 + (int)(((long long)slots * sidx) / nstreams);
-        int lo = 0, hi = Nc;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (rs[mid] < target) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-    const int c_first = sid == 0 ? 0 : first_centre(sid);
-    const int c_last = sid == nstreams - 1 ? Nc : first_centre(sid + 1);   // centres [c_first, c_last)
-    int c = c_first;
-    int pos = rs[c_first];
-    const int stream_end = rs[c_last];
-    int cend = c < c_last ? rs[c + 1] : stream_end;               // end of the current centre
+    // ---- work list: bundles of 4 centres of (nearly) equal slot count, see BundleWalk --------------------------------
+    BundleWalk<EDGE_THREADS / 64> bw;
+    bw.init(G.bundle + a0, Nc, __builtin_amdgcn_readfirstlane(wave), p >> 2);
+    if (bw.nj == 0) return;   // (no barrier below)
+    const int last_slot = max(G.row_start[a0 + Nc] - 1, 0);     // records are always read from inside the chain (finite values)
     float ds[4] = {0.f, 0.f, 0.f, 0.f}, dvx[4] = {0.f, 0.f, 0.f, 0.f}, dvy[4] = {0.f, 0.f, 0.f, 0.f},
           dvz[4] = {0.f, 0.f, 0.f, 0.f};
     const int fcol = fs * FS + 4 * fq;            // first of this lane's 4 global feature columns
 
-    // table entry of this lane's slot; exhausted streams read the reserved all-zero entry (filter = 0)
     // quad-interleaved table (nbr.hip f16_unit): unit = quad * 32 + piece * 16 + fq * 4 + e -> the 4 slot lanes of a quad read
-    // 64 contiguous bytes
+    // 64 contiguous bytes; exhausted streams read the reserved all-zero quad (filter = 0)
     const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;
     const int zero_quad = (zero_slot + 1) / 4 - 1;   // zero_slot = capacity - 1; the last complete quad is all zero
     const float4 *erec = G.erec;
-    const int last_slot = max(rs[Nc] - 1, 0);     // records are always read from inside the chain (finite values)
 
     // Two table buffers (rho pieces, unit vector + neighbor id), one per step parity: buffer ph is consumed by the step of
     // parity ph and refilled right after that step's MFMAs for the step after next, so a table load has ~1.6 steps to
     // arrive (L2 / HBM latency is of the order of one step).
     u32x4 rq[2][2];
     float4 er[2];
-    auto fetch = [&](int buf, int quad, int sl) {   // sl = quad + e (passed separately: it comes out of the load fence)
-        const u32x4 *rp = rho_lane + (size_t)(quad < stream_end ? (sl >> 2) : zero_quad) * 32;
+    auto fetch = [&](int buf, int quad_first_slot, bool valid) {   // quad_first_slot: first slot of the stream's quad
+        const u32x4 *rp = rho_lane + (size_t)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
-        er[buf] = erec[min(sl, last_slot)];
+        er[buf] = erec[min(quad_first_slot + e, last_slot)];
     };
-    fetch(0, pos, pos + e);
-    fetch(1, pos + 4, pos + 4 + e);
+    {
+        bool v0, v1;
+        const int q0 = bw.quad_ahead(0, v0), q1 = bw.quad_ahead(1, v1);
+        fetch(0, q0, v0);
+        fetch(1, q1, v1);
+    }
 
-    // A centre that is complete is written exactly once: reduce the 4 slot lanes of the quad, add the residual from the
-    // staged slices (no global loads), one float4 store per row.  Every centre owns at least one quad of slots (the
-    // neighbor build pads an isolated atom with 4 zero-weight slots), so at most one centre completes per step and a
-    // plain `if` suffices: no loop-carried register rotation in the hot loop.
-    auto flush_complete = [&]() {
-        if (c < c_last && pos >= cend) {
-            float4 so, vxo, vyo, vzo;
-            quad_sum4(ds); quad_sum4(dvx); quad_sum4(dvy); quad_sum4(dvz);
-            so = make_float4(ds[0], ds[1], ds[2], ds[3]);
-            vxo = make_float4(dvx[0], dvx[1], dvx[2], dvx[3]);
-            vyo = make_float4(dvy[0], dvy[1], dvy[2], dvy[3]);
-            vzo = make_float4(dvz[0], dvz[1], dvz[2], dvz[3]);
-            if (e == 0) {
-                const size_t ga = mN + a0 + c;
-                const float4 sr = *reinterpret_cast<const float4 *>(s_tile + c * FS + 4 * fq);
-                so.x += sr.x; so.y += sr.y; so.z += sr.z; so.w += sr.w;
-                const float *vc = tile + c * LY::ROW + (4 * fq) * LY::NSEG;
-                vxo.x += vc[3]; vxo.y += vc[9]; vxo.z += vc[15]; vxo.w += vc[21];
-                vyo.x += vc[4]; vyo.y += vc[10]; vyo.z += vc[16]; vyo.w += vc[22];
-                vzo.x += vc[5]; vzo.y += vc[11]; vzo.z += vc[17]; vzo.w += vc[23];
-                *reinterpret_cast<float4 *>(s_msg + ga * F + fcol) = so;
-                *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 0) * F + fcol) = vxo;
-                *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 1) * F + fcol) = vyo;
-                *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 2) * F + fcol) = vzo;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { ds[r] = 0.f; dvx[r] = 0.f; dvy[r] = 0.f; dvz[r] = 0.f; }
-            ++c;
-            cend = c < c_last ? rs[c + 1] : stream_end;
+    // The 4 centres of a bundle complete in the same step: reduce the 4 slot lanes of every quad, add the residual from
+    // the staged slices (no global loads), one float4 store per row; all lanes take part.
+    auto flush_bundle = [&]() {
+        float4 so, vxo, vyo, vzo;
+        quad_sum4(ds); quad_sum4(dvx); quad_sum4(dvy); quad_sum4(dvz);
+        so = make_float4(ds[0], ds[1], ds[2], ds[3]);
+        vxo = make_float4(dvx[0], dvx[1], dvx[2], dvx[3]);
+        vyo = make_float4(dvy[0], dvy[1], dvy[2], dvy[3]);
+        vzo = make_float4(dvz[0], dvz[1], dvz[2], dvz[3]);
+        const int c = bw.cur.x;
+        if (e == 0 && c >= 0) {
+            const size_t ga = mN + a0 + c;
+            const float4 sr = *reinterpret_cast<const float4 *>(s_tile + c * FS + 4 * fq);
+            so.x += sr.x; so.y += sr.y; so.z += sr.z; so.w += sr.w;
+            const float *vc = tile + c * LY::ROW + (4 * fq) * LY::NSEG;
+            vxo.x += vc[3]; vxo.y += vc[9]; vxo.z += vc[15]; vxo.w += vc[21];
+            vyo.x += vc[4]; vyo.y += vc[10]; vyo.z += vc[16]; vyo.w += vc[22];
+            vzo.x += vc[5]; vzo.y += vc[11]; vzo.z += vc[17]; vzo.w += vc[23];
+            *reinterpret_cast<float4 *>(s_msg + ga * F + fcol) = so;
+            *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 0) * F + fcol) = vxo;
+            *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 1) * F + fcol) = vyo;
+            *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 2) * F + fcol) = vzo;
         }
-    };
-    const float *trow = tile + (4 * fq) * LY::NSEG;
-    while (__any(pos < stream_end)) {
 #pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: ping-pong the unit-vector registers
+        for (int r = 0; r < 4; ++r) { ds[r] = 0.f; dvx[r] = 0.f; dvy[r] = 0.f; dvz[r] = 0.f; }
+    };
+
+    const float *trow = tile + (4 * fq) * LY::NSEG;
+    bool done = false;
+    while (!done) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: one table buffer per step parity
             arrival_fence(rq[ph][0], rq[ph][1], er[ph]);
             const float ux = take(er[ph].x), uy = take(er[ph].y), uz = take(er[ph].z);
             const int jn = __float_as_int(take(er[ph].w));
-            flush_complete();   // centre completed by the previous step
+            if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
+                flush_bundle();
+                if (bw.advance()) { done = true; break; }
+            }
             // gather this slot's neighbor row: 4 features x NSEG values, contiguous in LDS
             float tv[4 * LY::NSEG];
             {
@@ -370,16 +410,16 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             };
             message(0);   // consumes every accumulator tile
             // table entries of the step after next, into the buffer this step has just consumed; see mfma_load_fence
-            int nsl = pos + 8 + e;
-            mfma_load_fence(nsl, ds[0], dvx[0], dvy[0]);
-            fetch(ph, pos + 8, nsl);
+            bool nv;
+            int nq = bw.quad_ahead(2, nv);
+            mfma_load_fence(nq, ds[0], dvx[0], dvy[0]);
+            fetch(ph, nq, nv);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 1; r < 4; ++r) message(r);
-            if (pos < stream_end) pos += 4;
+            ++bw.t;
         }
     }
-    flush_complete();   // last centre of the stream
 }
 
 // ======================================================================================================
@@ -402,14 +442,13 @@ constexpr int ROWB = FS * 4 + 4;              // LDS row: [feature][sbar, vbar_x
 
 constexpr int BWD_STREAMS = (BWD_THREADS / 64) * 4;
 constexpr int CEN_FLOATS = BWD_STREAMS * 4 * 6 * 4;   // current-centre store: [stream][feature quarter][phi a, b, c, v x, y, z] float4
-__host__ __device__ inline size_t bwd_rs_floats(int max_atoms) { return ((size_t)max_atoms + 1 + 3) & ~(size_t)3; }
-size_t edge_bwd_lds_bytes(int max_atoms) {
-    return sizeof(float) * ((size_t)max_atoms * ROWB + bwd_rs_floats(max_atoms) + CEN_FLOATS);
-}
+size_t edge_bwd_lds_bytes(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * ROWB + CEN_FLOATS); }
 int edge_bwd_groups() { return NSG; }
 
-__global__ void __launch_bounds__(BWD_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))   // one workgroup per CU (LDS): use the 256 VGPRs
-k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, GraphView G,
+// FIRST: the launch writes the partial edge-gradient buffers for the first time (last layer): nothing to add to.
+template <bool FIRST>
+__global__ void __launch_bounds__(BWD_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))   // two workgroups per CU = 2 waves per SIMD: use the 256 VGPRs
+k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms,
                 const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
                 const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
@@ -421,36 +460,18 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
     const int per_chain = NSG * n_models;
     const int t = rest % per_chain, b = (rest / per_chain) * 8 + xcd;
     if (b >= G.n_cfg) return;
-    const int sg = t % NSG, m = t / NSG;
+    const int fs = t % NSG, m = t / NSG;   // feature slice = partial-gradient group
     const int a0 = G.cfg_start[b], Nc = G.cfg_start[b + 1] - a0;
     const size_t mN = (size_t)m * N;
     const int tid = threadIdx.x;
-    int *rs = reinterpret_cast<int *>(tile + (size_t)max_atoms * ROWB);
-    for (int idx = tid; idx <= Nc; idx += BWD_THREADS) rs[idx] = G.row_start[a0 + idx];
-    __syncthreads();
-
     const int lane = tid & 63, wave = tid >> 6, p = lane & 15, fq = lane >> 4, e = p & 3;
-    const int sid = wave * 4 + (p >> 2);
-    constexpr int nstreams = BWD_STREAMS;
-    const int slot0 = rs[0], slots = rs[Nc] - slot0;
-    auto first_centre = [&](int sidx) {
-        const int target = slot0 + (int)(((long long)slots * sidx) / nstreams);
-        int lo = 0, hi = Nc;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (rs[mid] < target) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-    const int c_first = sid == 0 ? 0 : first_centre(sid);
-    const int c_last = sid == nstreams - 1 ? Nc : first_centre(sid + 1);
-    const int stream_begin = rs[c_first], stream_end = rs[c_last];
-    const int last_slot = max(rs[Nc] - 1, 0);
+    const int last_slot = max(G.row_start[a0 + Nc] - 1, 0);
     const LayerW &W = MW[m].layer[l];
-    float4 *gb = gbar + (size_t)(m * n_groups + sg) * gbar_stride;
+    float4 *gb = gbar + (size_t)(m * n_groups + fs) * gbar_stride;
     const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;   // quad-interleaved tables, see forward
     const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 4 + e;
     const int zero_quad = (zero_slot + 1) / 4 - 1;
+    const int fcol = fs * FS + 4 * fq;
 
     // which gradient component the reduce-scatter of the hot loop leaves in this lane's row: the same swap network run
     // once on tags (0, 1, 2 and 3 = the zero filler), so the mapping never depends on a reading of the ISA manual
@@ -465,239 +486,243 @@ k_edge_bwd_mfma(int N, int l, int layer_first, const ModelW *__restrict__ MW, Gr
         if (!(a[0] == a[1] && bq[0] == bq[1] && cq[0] == cq[1])) __builtin_trap();
     }
 
-    for (int si = 0; si < SLICES_PER_WG; ++si) {
-        const int fs = sg * SLICES_PER_WG + si;
-        const int fcol = fs * FS + 4 * fq;
-        __syncthreads();   // previous slice's gathers are done
-        // ---- stage [atom][f][sbar, vbar_x, vbar_y, vbar_z] of this slice ------------------------------------------
-        {
-            const int total = Nc * 16;   // 4 segments x 4 float4 per atom
-            for (int base = tid; base < total; base += 4 * BWD_THREADS) {
-                float4 v4[4];
+    // ---- stage [atom][f][sbar, vbar_x, vbar_y, vbar_z] of this slice ------------------------------------------
+    {
+        const int total = Nc * 16;   // 4 segments x 4 float4 per atom
+        for (int base = tid; base < total; base += 4 * BWD_THREADS) {
+            float4 v4[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = min(base + u * BWD_THREADS, total - 1);
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(base + u * BWD_THREADS, total - 1);
+                const int atom = idx >> 4, seg = (idx >> 2) & 3, q4 = idx & 3;
+                const size_t ga = mN + a0 + atom;
+                const float *src = seg == 0 ? sbar_msg + ga * F + fs * FS + q4 * 4
+                                            : vbar_msg + (ga * 3 + (seg - 1)) * F + fs * FS + q4 * 4;
+                v4[u] = *reinterpret_cast<const float4 *>(src);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * BWD_THREADS;
+                if (idx < total) {
                     const int atom = idx >> 4, seg = (idx >> 2) & 3, q4 = idx & 3;
-                    const size_t ga = mN + a0 + atom;
-                    const float *src = seg == 0 ? sbar_msg + ga * F + fs * FS + q4 * 4
-                                                : vbar_msg + (ga * 3 + (seg - 1)) * F + fs * FS + q4 * 4;
-                    v4[u] = *reinterpret_cast<const float4 *>(src);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = base + u * BWD_THREADS;
-                    if (idx < total) {
-                        const int atom = idx >> 4, seg = (idx >> 2) & 3, q4 = idx & 3;
-                        float *dst = tile + atom * ROWB + (q4 * 4) * 4 + seg;
-                        dst[0] = v4[u].x; dst[4] = v4[u].y; dst[8] = v4[u].z; dst[12] = v4[u].w;
-                    }
+                    float *dst = tile + atom * ROWB + (q4 * 4) * 4 + seg;
+                    dst[0] = v4[u].x; dst[4] = v4[u].y; dst[8] = v4[u].z; dst[12] = v4[u].w;
                 }
             }
         }
-        // ---- A operand: Wd_ext rows of this slice ------------------------------------------------------------------
-        u32x4 wA[NSEC][2];   // fp16 pieces (h, l) of the slice's filter rows, bias column included (build_wd16)
+    }
+    // ---- A operand: Wd_ext rows of this slice ------------------------------------------------------------------
+    u32x4 wA[NSEC][2];   // fp16 pieces (h, l) of the slice's filter rows, bias column included (build_wd16)
 #pragma unroll
-        for (int s2 = 0; s2 < NSEC; ++s2) {
-            const int row = s2 * F + fs * FS + p;
-            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 2;
+    for (int s2 = 0; s2 < NSEC; ++s2) {
+        const int row = s2 * F + fs * FS + p;
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 2;
 #pragma unroll
-            for (int i3 = 0; i3 < 2; ++i3) wA[s2][i3] = wsrc[i3];
+        for (int i3 = 0; i3 < 2; ++i3) wA[s2][i3] = wsrc[i3];
+    }
+    __syncthreads();
+
+    BundleWalk<BWD_THREADS / 64> bw;   // work list: bundles of 4 centres, see the forward kernel
+    bw.init(G.bundle + a0, Nc, __builtin_amdgcn_readfirstlane(wave), p >> 2);
+    if (bw.nj == 0) return;   // (no barrier below)
+
+    // ---- per-centre data of this lane's 4 features: phi_c (a, b, c) and v_c -------------------------------------------
+    // The CURRENT centre's values live in a small LDS record per (stream, feature quarter) and are re-read every step
+    // next to the neighbor gathers (6 broadcast ds_read_b128); the NEXT bundle's values are in flight in registers
+    // and are parked in the record when the wave moves on.  (Keeping both sets in registers made the compiler
+    // rotate ~50 registers per completed centre and wait on the prefetch it had just issued.)
+    const int cen_idx = max_atoms * ROWB + ((wave * 4 + (p >> 2)) * 4 + fq) * 24;   // float index in tile[]
+    f32x4 *cen = reinterpret_cast<f32x4 *>(tile + cen_idx);
+    f32x4 nx[6];   // (ext vectors: arrays of HIP float4 stay in scratch memory)
+    auto load_centre = [&](int cc) {   // always a load (any valid row for streams without a centre)
+        const size_t ga = mN + a0 + min(max(cc, 0), Nc - 1);
+        const float *pr = phi + ga * F3 + fcol;
+        nx[0] = *reinterpret_cast<const f32x4 *>(pr);
+        nx[1] = *reinterpret_cast<const f32x4 *>(pr + F);
+        nx[2] = *reinterpret_cast<const f32x4 *>(pr + 2 * F);
+        nx[3] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 0) * F + fcol);
+        nx[4] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 1) * F + fcol);
+        nx[5] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 2) * F + fcol);
+    };
+    auto park_centre = [&]() {   // the quad's 4 slot lanes hold identical values: any of them may write
+#pragma unroll
+        for (int q = 0; q < 6; ++q) cen[q] = nx[q];
+    };
+    load_centre(bw.cur.x);
+    park_centre();
+    load_centre(bw.nxt.x);
+    float accb[4] = {0.f, 0.f, 0.f, 0.f}, accc[4] = {0.f, 0.f, 0.f, 0.f};
+    float accx[4] = {0.f, 0.f, 0.f, 0.f}, accy[4] = {0.f, 0.f, 0.f, 0.f}, accz[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // the 4 centres of a bundle complete in the same step: all lanes reduce, the first lane of every quad writes
+    auto flush_bundle = [&]() {
+        float4 pa, pb, pc2, ox, oy, oz;
+        quad_sum4(accb); quad_sum4(accc); quad_sum4(accx); quad_sum4(accy); quad_sum4(accz);
+        const float (&tb)[4] = accb, (&tc)[4] = accc, (&tx)[4] = accx, (&ty)[4] = accy, (&tz)[4] = accz;
+        const int c = bw.cur.x;
+        if (e == 0 && c >= 0) {
+            const size_t ga = mN + a0 + c;
+            const f32x4 cv[6] = {cen[0], cen[1], cen[2], cen[3], cen[4], cen[5]};   // record of the completed centre
+            const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
+            const float vz_[4] = {cv[5].x, cv[5].y, cv[5].z, cv[5].w}, pa_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
+            float a_[4], x_[4], y_[4], z_[4];
+            const float *res = tile + c * ROWB + (4 * fq) * 4;   // [r][sbar, vbar_x, vbar_y, vbar_z]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a_[r] = fmaf(vz_[r], tz[r], fmaf(vy_[r], ty[r], vx_[r] * tx[r]));
+                x_[r] = fmaf(pa_[r], tx[r], res[4 * r + 1]);
+                y_[r] = fmaf(pa_[r], ty[r], res[4 * r + 2]);
+                z_[r] = fmaf(pa_[r], tz[r], res[4 * r + 3]);
+            }
+            pa = make_float4(a_[0], a_[1], a_[2], a_[3]);
+            pb = make_float4(tb[0], tb[1], tb[2], tb[3]);
+            pc2 = make_float4(tc[0], tc[1], tc[2], tc[3]);
+            ox = make_float4(x_[0], x_[1], x_[2], x_[3]);
+            oy = make_float4(y_[0], y_[1], y_[2], y_[3]);
+            oz = make_float4(z_[0], z_[1], z_[2], z_[3]);
+            float *pbp = phibar + ga * F3 + fcol;
+            *reinterpret_cast<float4 *>(pbp) = pa;
+            *reinterpret_cast<float4 *>(pbp + F) = pb;
+            *reinterpret_cast<float4 *>(pbp + 2 * F) = pc2;
+            *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 0) * F + fcol) = ox;
+            *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 1) * F + fcol) = oy;
+            *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 2) * F + fcol) = oz;
         }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
+    };
 
-        // ---- per-centre data of this lane's 4 features: phi_c (a, b, c) and v_c -------------------------------------------
-        // The CURRENT centre's values live in a small LDS record per (stream, feature quarter) and are re-read every step
-        // next to the neighbor gathers (6 broadcast ds_read_b128); the NEXT centre's values are in flight in registers
-        // and are parked in the record when the stream moves on.  (Keeping both sets in registers made the compiler
-        // rotate ~50 registers per completed centre and wait on the prefetch it had just issued.)
-        const int cen_idx = (int)((size_t)max_atoms * ROWB + bwd_rs_floats(max_atoms)) + (sid * 4 + fq) * 24;   // float index in tile[]
-        f32x4 *cen = reinterpret_cast<f32x4 *>(tile + cen_idx);
-        f32x4 nx[6];   // (ext vectors: arrays of HIP float4 stay in scratch memory)
-        auto load_centre = [&](int cc) {
-            const size_t ga = mN + a0 + min(cc, Nc - 1);
-            const float *pr = phi + ga * F3 + fcol;
-            nx[0] = *reinterpret_cast<const f32x4 *>(pr);
-            nx[1] = *reinterpret_cast<const f32x4 *>(pr + F);
-            nx[2] = *reinterpret_cast<const f32x4 *>(pr + 2 * F);
-            nx[3] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 0) * F + fcol);
-            nx[4] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 1) * F + fcol);
-            nx[5] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 2) * F + fcol);
-        };
-        auto park_centre = [&]() {   // the quad's 4 slot lanes hold identical values: any of them may write
-#pragma unroll
-            for (int q = 0; q < 6; ++q) cen[q] = nx[q];
-        };
-        int c = c_first, pos = stream_begin;
-        int cend = c < c_last ? rs[c + 1] : stream_end;
-        load_centre(c);
-        park_centre();
-        load_centre(c + 1);
-        float accb[4] = {0.f, 0.f, 0.f, 0.f}, accc[4] = {0.f, 0.f, 0.f, 0.f};
-        float accx[4] = {0.f, 0.f, 0.f, 0.f}, accy[4] = {0.f, 0.f, 0.f, 0.f}, accz[4] = {0.f, 0.f, 0.f, 0.f};
+    // Table entries of this lane's slot; exhausted streams read the all-zero quad.  Two buffers, one per step parity:
+    // buffer ph is consumed by the step of parity ph and refilled right after that step's MFMAs for the step after next
+    // (~1.6 steps for a load to arrive).  The old partial edge gradient of the slot (written by the previous layer for
+    // this lane's slot; a slot is visited once per launch, so the early read is safe) travels with the tables.
+    float *gcomp = reinterpret_cast<float *>(gb) + gcomp_id;   // component this row ends up with (3: none)
+    u32x4 rq[2][2], dq[2][2];
+    float4 er[2];
+    float2 dd[2];
+    float gold[2] = {0.f, 0.f};
+    auto fetch = [&](int buf, int quad_first_slot, bool valid) {
+        const size_t off = (size_t)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;
+        const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
+        rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
+        dq[buf][0] = dp[0]; dq[buf][1] = dp[16];
+        const int sl = min(quad_first_slot + e, last_slot);
+        er[buf] = G.erec[sl];
+        dd[buf] = G.dist2[sl];
+        if (!FIRST) gold[buf] = gcomp[(size_t)sl * 4];
+    };
+    {
+        bool v0, v1;
+        const int q0 = bw.quad_ahead(0, v0), q1 = bw.quad_ahead(1, v1);
+        fetch(0, q0, v0);
+        fetch(1, q1, v1);
+    }
+    const float *trow = tile + (4 * fq) * 4;
 
-        // at most one centre completes per step (>= 4 slots per centre, see forward)
-        auto flush_complete = [&]() {
-            if (c < c_last && pos >= cend) {
-                float4 pa, pb, pc2, ox, oy, oz;
-                quad_sum4(accb); quad_sum4(accc); quad_sum4(accx); quad_sum4(accy); quad_sum4(accz);
-                const float (&tb)[4] = accb, (&tc)[4] = accc, (&tx)[4] = accx, (&ty)[4] = accy, (&tz)[4] = accz;
-                if (e == 0) {
-                    const size_t ga = mN + a0 + c;
-                    const f32x4 cv[6] = {cen[0], cen[1], cen[2], cen[3], cen[4], cen[5]};   // record of the completed centre
-                    const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
-                    const float vz_[4] = {cv[5].x, cv[5].y, cv[5].z, cv[5].w}, pa_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
-                    float a_[4], x_[4], y_[4], z_[4];
-                    const float *res = tile + c * ROWB + (4 * fq) * 4;   // [r][sbar, vbar_x, vbar_y, vbar_z]
+    bool done = false;
+    while (!done) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        a_[r] = fmaf(vz_[r], tz[r], fmaf(vy_[r], ty[r], vx_[r] * tx[r]));
-                        x_[r] = fmaf(pa_[r], tx[r], res[4 * r + 1]);
-                        y_[r] = fmaf(pa_[r], ty[r], res[4 * r + 2]);
-                        z_[r] = fmaf(pa_[r], tz[r], res[4 * r + 3]);
-                    }
-                    pa = make_float4(a_[0], a_[1], a_[2], a_[3]);
-                    pb = make_float4(tb[0], tb[1], tb[2], tb[3]);
-                    pc2 = make_float4(tc[0], tc[1], tc[2], tc[3]);
-                    ox = make_float4(x_[0], x_[1], x_[2], x_[3]);
-                    oy = make_float4(y_[0], y_[1], y_[2], y_[3]);
-                    oz = make_float4(z_[0], z_[1], z_[2], z_[3]);
-                    float *pbp = phibar + ga * F3 + fcol;
-                    *reinterpret_cast<float4 *>(pbp) = pa;
-                    *reinterpret_cast<float4 *>(pbp + F) = pb;
-                    *reinterpret_cast<float4 *>(pbp + 2 * F) = pc2;
-                    *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 0) * F + fcol) = ox;
-                    *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 1) * F + fcol) = oy;
-                    *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 2) * F + fcol) = oz;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
-                ++c;
-                cend = c < c_last ? rs[c + 1] : stream_end;
-                park_centre();
+        for (int ph = 0; ph < 2; ++ph) {
+            arrival_fence(rq[ph][0], rq[ph][1], dq[ph][0], dq[ph][1], er[ph], dd[ph], gold[ph]);
+            const float ux = take(er[ph].x), uy = take(er[ph].y), uz = take(er[ph].z);   // unit vector c -> n ; edge (n -> c) has -u
+            const int jn = __float_as_int(take(er[ph].w));
+            const float invd = take(dd[ph].x), gold_cur = FIRST ? 0.f : take(gold[ph]);
+            if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
+                flush_bundle();
+                if (bw.advance()) { done = true; break; }
+                park_centre();                       // centre data of the bundle that starts now
                 __builtin_amdgcn_sched_barrier(0);   // the old values leave their registers before the loads that refill them are issued
-                load_centre(c + 1);
+                load_centre(bw.nxt.x);
             }
-        };
-        // Table entries of this lane's slot; exhausted streams read the all-zero entry.  Two buffers, one per step parity:
-        // buffer ph is consumed by the step of parity ph and refilled right after that step's MFMAs for the step after next
-        // (~1.6 steps for a load to arrive).  The old partial edge gradient of the slot (written by the previous layer for
-        // this lane's slot; a slot is visited once per launch, so the early read is safe) travels with the tables.
-        const bool first_write = layer_first && si == 0;
-        float *gcomp = reinterpret_cast<float *>(gb) + gcomp_id;   // component this row ends up with (3: none)
-        u32x4 rq[2][2], dq[2][2];
-        float4 er[2];
-        float2 dd[2];
-        float gold[2];
-        auto fetch = [&](int buf, int quad) {
-            const size_t off = (size_t)(quad < stream_end ? (quad >> 2) : zero_quad) * 32;
-            const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
-            rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
-            dq[buf][0] = dp[0]; dq[buf][1] = dp[16];
-            const int sl = min(quad + e, last_slot);
-            er[buf] = G.erec[sl];
-            dd[buf] = G.dist2[sl];
-            gold[buf] = gcomp[(size_t)sl * 4];   // (ignored on the first write)
-        };
-        fetch(0, pos);
-        fetch(1, pos + 4);
-        const float *trow = tile + (4 * fq) * 4;
-
-        while (__any(pos < stream_end)) {
+            bool real_slot;
+            const int my_slot = bw.quad_ahead(0, real_slot) + e;
+            float tb[16];
+            {
+                const float4 *row = reinterpret_cast<const float4 *>(trow + jn * ROWB);
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
-                arrival_fence(rq[ph][0], rq[ph][1], dq[ph][0], dq[ph][1], er[ph], dd[ph], gold[ph]);
-                const float ux = take(er[ph].x), uy = take(er[ph].y), uz = take(er[ph].z);   // unit vector c -> n ; edge (n -> c) has -u
-                const int jn = __float_as_int(take(er[ph].w));
-                const float invd = take(dd[ph].x), gold_cur = take(gold[ph]);
-                flush_complete();   // centre completed by the previous step
-                float tb[16];
-                {
-                    const float4 *row = reinterpret_cast<const float4 *>(trow + jn * ROWB);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 t4 = row[q];
-                        tb[4 * q] = t4.x; tb[4 * q + 1] = t4.y; tb[4 * q + 2] = t4.z; tb[4 * q + 3] = t4.w;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t4 = row[q];
+                    tb[4 * q] = t4.x; tb[4 * q + 1] = t4.y; tb[4 * q + 2] = t4.z; tb[4 * q + 3] = t4.w;
                 }
-                // (the record's index passes through an empty asm: otherwise the compiler forwards the parked registers to these
-                // reads on the completing lanes, hoists the reads of the other lanes into the tail of the previous step and
-                // shuffles / waits on the registers of the prefetch it has just issued)
-                f32x4 cv[6];
-                {
-                    int ci = cen_idx;   // (the INDEX is laundered: a laundered pointer loses its LDS address space -> flat loads)
-                    asm volatile("" : "+v"(ci));
-                    const f32x4 *cr = reinterpret_cast<const f32x4 *>(tile + ci);
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) cv[q] = cr[q];
-                }
-                mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
-                mfma_pre_fence(dq[ph][0], dq[ph][1]);
-                // filter and its radial derivative for this lane's slot and 4 features (bias . fc / bias . fc' included)
-                f32x4 awd[2 * NSEC];   // tiles [0, NSEC): filter w, [NSEC, 2 NSEC): radial derivative dw
-                {
-                    const u32x4 (*wp[2 * NSEC])[2], (*rp3[2 * NSEC])[2];
-#pragma unroll
-                    for (int s2 = 0; s2 < NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; wp[NSEC + s2] = &wA[s2]; rp3[NSEC + s2] = &dq[ph]; }
-                    filter_tiles<2 * NSEC>(wp, rp3, awd);
-                }
-                const f32x4 *aw = awd, *ad = awd + NSEC;
-                __builtin_amdgcn_sched_barrier(0);
-                const float pcb_[4] = {cv[1].x, cv[1].y, cv[1].z, cv[1].w}, pcc_[4] = {cv[2].x, cv[2].y, cv[2].z, cv[2].w};
-                const float pca_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
-                const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
-                const float vz_[4] = {cv[5].x, cv[5].y, cv[5].z, cv[5].w};
-                float dpart = 0.f, ub0 = 0.f, ub1 = 0.f, ub2 = 0.f;
-                auto feature = [&](int r) {
-                    const float sbn = tb[4 * r], vb0 = tb[4 * r + 1], vb1 = tb[4 * r + 2], vb2 = tb[4 * r + 3];
-                    const float wB = aw[1][r], wC = aw[2][r];
-                    const float dB = ad[1][r], dC = ad[2][r];
-                    const float pn = -fmaf(vb2, uz, fmaf(vb1, uy, vb0 * ux));   // vbar_n . u_(n->c)
-                    accb[r] = fmaf(wB, sbn, accb[r]);
-                    accc[r] = fmaf(wC, pn, accc[r]);
-                    dpart = fmaf(pcb_[r] * sbn, dB, dpart);
-                    dpart = fmaf(pcc_[r] * pn, dC, dpart);
-                    const float wAa = aw[0][r], dA = ad[0][r];
-                    const float q = fmaf(vb2, vz_[r], fmaf(vb1, vy_[r], vb0 * vx_[r]));
-                    accx[r] = fmaf(wAa, vb0, accx[r]);
-                    accy[r] = fmaf(wAa, vb1, accy[r]);
-                    accz[r] = fmaf(wAa, vb2, accz[r]);
-                    dpart = fmaf(pca_[r] * q, dA, dpart);
-                    const float mc = pcc_[r] * wC;
-                    ub0 = fmaf(mc, vb0, ub0); ub1 = fmaf(mc, vb1, ub1); ub2 = fmaf(mc, vb2, ub2);
-                };
-                feature(0);   // consumes every accumulator tile
-                int nquad = pos + 8;   // the step after next, into the buffer this step has just consumed
-                mfma_load_fence(nquad, accb[0], accc[0], dpart, ub0);
-                fetch(ph, nquad);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 1; r < 4; ++r) feature(r);
-                // Gradient of edge (n -> c), unit vector -u:  g = -(dE/dd) u + (ub - (ub.u) u) / d, linear in (dpart, ub).
-                // The map is applied to the lane's partial sums BEFORE the reduction over the 4 feature quarters (lanes
-                // p, p+16, p+32, p+48), so only 3 values cross lanes, and the reduction is a reduce-scatter on the
-                // gfx950 row swaps: swap32 pairs (g0, g1) / (g2, 0) -> rows {0,1} hold half sums of g0 / g2, rows {2,3} of
-                // g1 / 0; swap16 of the two -> row 0 = g0, row 1 = g2, row 2 = g1 (complete sums, fixed order): 3 swaps +
-                // 3 adds for the whole quantity, and row r writes one component.
-                {
-                    const float dotu = fmaf(ub2, uz, fmaf(ub1, uy, ub0 * ux));
-                    float g0 = fmaf(-dpart, ux, fmaf(-dotu, ux, ub0) * invd);
-                    float g1 = fmaf(-dpart, uy, fmaf(-dotu, uy, ub1) * invd);
-                    float g2 = fmaf(-dpart, uz, fmaf(-dotu, uz, ub2) * invd);
-                    const auto h01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(g0), __float_as_uint(g1), false, false);
-                    const auto h2z = __builtin_amdgcn_permlane32_swap(__float_as_uint(g2), 0u, false, false);
-                    const float A = __uint_as_float(h01[0]) + __uint_as_float(h01[1]);
-                    const float B = __uint_as_float(h2z[0]) + __uint_as_float(h2z[1]);
-                    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(A), __float_as_uint(B), false, false);
-                    const float gsum = __uint_as_float(q[0]) + __uint_as_float(q[1]);
-                    // three rows of a real slot write one component each; every other lane writes the spare entry, so the
-                    // store is unconditional and the memory-operation count of a step does not depend on the path
-                    const bool real = gcomp_id < 3 && pos < stream_end && invd > 0.f;
-                    gcomp[(size_t)(real ? pos + e : zero_slot) * 4] = gsum + (first_write ? 0.f : gold_cur);
-                }
-                if (pos < stream_end) pos += 4;
             }
+            // (the record's index passes through an empty asm: otherwise the compiler forwards the parked registers to these
+            // reads, hoists them into the tail of the previous step and shuffles / waits on the registers of the prefetch
+            // it has just issued)
+            f32x4 cv[6];
+            {
+                int ci = cen_idx;   // (the INDEX is laundered: a laundered pointer loses its LDS address space -> flat loads)
+                asm volatile("" : "+v"(ci));
+                const f32x4 *cr = reinterpret_cast<const f32x4 *>(tile + ci);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) cv[q] = cr[q];
+            }
+            mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
+            mfma_pre_fence(dq[ph][0], dq[ph][1]);
+            // filter and its radial derivative for this lane's slot and 4 features (bias . fc / bias . fc' included)
+            f32x4 awd[2 * NSEC];   // tiles [0, NSEC): filter w, [NSEC, 2 NSEC): radial derivative dw
+            {
+                const u32x4 (*wp[2 * NSEC])[2], (*rp3[2 * NSEC])[2];
+#pragma unroll
+                for (int s2 = 0; s2 < NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; wp[NSEC + s2] = &wA[s2]; rp3[NSEC + s2] = &dq[ph]; }
+                filter_tiles<2 * NSEC>(wp, rp3, awd);
+            }
+            const f32x4 *aw = awd, *ad = awd + NSEC;
+            __builtin_amdgcn_sched_barrier(0);
+            const float pcb_[4] = {cv[1].x, cv[1].y, cv[1].z, cv[1].w}, pcc_[4] = {cv[2].x, cv[2].y, cv[2].z, cv[2].w};
+            const float pca_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
+            const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
+            const float vz_[4] = {cv[5].x, cv[5].y, cv[5].z, cv[5].w};
+            float dpart = 0.f, ub0 = 0.f, ub1 = 0.f, ub2 = 0.f;
+            auto feature = [&](int r) {
+                const float sbn = tb[4 * r], vb0 = tb[4 * r + 1], vb1 = tb[4 * r + 2], vb2 = tb[4 * r + 3];
+                const float wB = aw[1][r], wC = aw[2][r];
+                const float dB = ad[1][r], dC = ad[2][r];
+                const float pn = -fmaf(vb2, uz, fmaf(vb1, uy, vb0 * ux));   // vbar_n . u_(n->c)
+                accb[r] = fmaf(wB, sbn, accb[r]);
+                accc[r] = fmaf(wC, pn, accc[r]);
+                dpart = fmaf(pcb_[r] * sbn, dB, dpart);
+                dpart = fmaf(pcc_[r] * pn, dC, dpart);
+                const float wAa = aw[0][r], dA = ad[0][r];
+                const float q = fmaf(vb2, vz_[r], fmaf(vb1, vy_[r], vb0 * vx_[r]));
+                accx[r] = fmaf(wAa, vb0, accx[r]);
+                accy[r] = fmaf(wAa, vb1, accy[r]);
+                accz[r] = fmaf(wAa, vb2, accz[r]);
+                dpart = fmaf(pca_[r] * q, dA, dpart);
+                const float mc = pcc_[r] * wC;
+                ub0 = fmaf(mc, vb0, ub0); ub1 = fmaf(mc, vb1, ub1); ub2 = fmaf(mc, vb2, ub2);
+            };
+            feature(0);   // consumes every accumulator tile
+            bool nv;
+            int nq = bw.quad_ahead(2, nv);   // the step after next, into the buffer this step has just consumed
+            mfma_load_fence(nq, accb[0], accc[0], dpart, ub0);
+            fetch(ph, nq, nv);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) feature(r);
+            // Gradient of edge (n -> c), unit vector -u:  g = -(dE/dd) u + (ub - (ub.u) u) / d, linear in (dpart, ub).
+            // The map is applied to the lane's partial sums BEFORE the reduction over the 4 feature quarters (lanes
+            // p, p+16, p+32, p+48), so only 3 values cross lanes, and the reduction is a reduce-scatter on the
+            // gfx950 row swaps: swap32 pairs (g0, g1) / (g2, 0) -> rows {0,1} hold half sums of g0 / g2, rows {2,3} of
+            // g1 / 0; swap16 of the two -> row 0 = g0, row 1 = g2, row 2 = g1 (complete sums, fixed order): 3 swaps +
+            // 3 adds for the whole quantity, and row r writes one component.
+            {
+                const float dotu = fmaf(ub2, uz, fmaf(ub1, uy, ub0 * ux));
+                float g0 = fmaf(-dpart, ux, fmaf(-dotu, ux, ub0) * invd);
+                float g1 = fmaf(-dpart, uy, fmaf(-dotu, uy, ub1) * invd);
+                float g2 = fmaf(-dpart, uz, fmaf(-dotu, uz, ub2) * invd);
+                const auto h01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(g0), __float_as_uint(g1), false, false);
+                const auto h2z = __builtin_amdgcn_permlane32_swap(__float_as_uint(g2), 0u, false, false);
+                const float A = __uint_as_float(h01[0]) + __uint_as_float(h01[1]);
+                const float B = __uint_as_float(h2z[0]) + __uint_as_float(h2z[1]);
+                const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(A), __float_as_uint(B), false, false);
+                const float gsum = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+                // three rows of a real slot write one component each; every other lane writes the spare entry, so the
+                // store is unconditional and the memory-operation count of a step does not depend on the path
+                const bool real = gcomp_id < 3 && real_slot && invd > 0.f;
+                gcomp[(size_t)(real ? my_slot : zero_slot) * 4] = gsum + gold_cur;
+            }
+            ++bw.t;
         }
-        flush_complete();   // last centre of the stream
     }
 }
 
@@ -725,7 +750,8 @@ void launch_excl_vol(hipStream_t st, int N, int M, const GraphView &G, const int
 
 int edge_mfma_init(vssr_handle *h) {
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return VSSR_OK;
 }
 
@@ -737,8 +763,12 @@ void launch_edge_bwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int la
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
                           float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups) {
     dim3 grid(((n_cfg + 7) / 8) * 8 * NSG * M), blk(BWD_THREADS);
-    hipLaunchKernelGGL(k_edge_bwd_mfma, grid, blk, edge_bwd_lds_bytes(max_atoms), st, N, l, layer_first, MW, G, counters,
-                       zero_slot, M, max_atoms, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
+    if (layer_first)
+        hipLaunchKernelGGL(k_edge_bwd_mfma<true>, grid, blk, edge_bwd_lds_bytes(max_atoms), st, N, l, MW, G, counters,
+                           zero_slot, M, max_atoms, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
+    else
+        hipLaunchKernelGGL(k_edge_bwd_mfma<false>, grid, blk, edge_bwd_lds_bytes(max_atoms), st, N, l, MW, G, counters,
+                           zero_slot, M, max_atoms, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
 }
 
 void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,

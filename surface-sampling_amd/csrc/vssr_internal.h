@@ -58,6 +58,7 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const uint4 *drho16;     // same for d rho / d d
     const unsigned char *zslot;   // [slots] species index (zmap) of the neighbor, 255 for pads / unmapped
     const float2 *dist2;     // [slots] {1 / edge length (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
+    const int4 *bundle;      // [n_atoms] per chain: centres sorted by padded degree (descending): {centre (chain-local), first slot, padded slot count, 0}
 };
 
 struct StateView {  // activations of all models: index [m][atom][...]
@@ -177,7 +178,7 @@ struct vssr_handle {
     std::vector<int> h_n_atoms, h_cfg_start;
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
     vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
-    vssr::DevBuf d_erec, d_rho, d_drho, d_dist, d_rho16, d_drho16, d_zslot;
+    vssr::DevBuf d_erec, d_rho, d_drho, d_dist, d_rho16, d_drho16, d_zslot, d_bundle;
     vssr::DevBuf d_hits;         // neighbor search: per (centre, candidate) 64-bit hit masks of the counting pass
     // layer-0 species factorisation (painn_l0.hip)
     int l0_enabled = 1, l0_nz = 0;
