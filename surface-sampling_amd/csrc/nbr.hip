@@ -262,14 +262,21 @@ __device__ __forceinline__ void split2_f16(float x, unsigned &h, unsigned &l) {
 __device__ __forceinline__ size_t f16_unit(size_t slot, int kq, int piece) {
     return (slot >> 2) * 32 + (size_t)piece * 16 + (size_t)kq * 4 + (slot & 3);
 }
-__device__ __forceinline__ void write_f16_record(const float (&v)[5], float env, uint4 *__restrict__ tab, size_t slot, int kq) {
+// The two spare K entries of a quarter (the weight side is zero there) carry the per-slot scalars of the edge kernels:
+// entry 6 = one of {u_x, u_y, u_z, 1/d} (quarter 0..3) as fp16 pieces h | l -- a selector tile on the matrix pipe hands all
+// four to every lane of the slot (painn_edge_mfma.hip, 22-bit values) -- and entry 7 of the H piece = the chain-local
+// neighbor index as a raw 16-bit integer (a finite fp16 pattern below 0x7C00).  No separate record loads in the hot loops.
+__device__ __forceinline__ void write_f16_record(const float (&v)[5], float env, uint4 *__restrict__ tab, size_t slot, int kq,
+                                                 float spare, unsigned jbits) {
     unsigned h[6], l[6];
 #pragma unroll
     for (int k = 0; k < 5; ++k) split2_f16(v[k], h[k], l[k]);
     split2_f16(env, h[5], l[5]);
     auto pk = [](unsigned lo, unsigned hi) { return lo | (hi << 16); };
-    tab[f16_unit(slot, kq, 0)] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), 0u);
-    tab[f16_unit(slot, kq, 1)] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), 0u);
+    unsigned sh, sl;
+    split2_f16(spare, sh, sl);
+    tab[f16_unit(slot, kq, 0)] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), pk(sh, jbits));
+    tab[f16_unit(slot, kq, 1)] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), pk(sl, 0u));
 }
 
 __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
@@ -313,8 +320,9 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
         }
         {
             const float rv[5] = {r[0], r[1], r[2], r[3], r[4]}, dv[5] = {dr[0], dr[1], dr[2], dr[3], dr[4]};
-            write_f16_record(rv, fc, rho16, (size_t)slot, kq);
-            write_f16_record(dv, dfc, drho16, (size_t)slot, kq);
+            const float scal = kq == 0 ? ed.x * inv : kq == 1 ? ed.y * inv : kq == 2 ? ed.z * inv : (valid ? inv : -1.f);
+            write_f16_record(rv, fc, rho16, (size_t)slot, kq, scal, (unsigned)min(valid ? j - a0 : 0, 0x7BFF));
+            write_f16_record(dv, dfc, drho16, (size_t)slot, kq, 0.f, 0u);
         }
         r[5] = fc;      // envelope (bias column) replicated in every quarter: the edge kernels fold bd * fc into the
         dr[5] = dfc;    // accumulator init instead of spending a sixth MFMA k-step on it

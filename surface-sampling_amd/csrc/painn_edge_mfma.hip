@@ -52,12 +52,11 @@ __device__ __forceinline__ void mfma_pre_fence(u32x4 &a, u32x4 &b) {
 // the compiler must pick one count for both sides of a branch: with the conditional operations issued after the table
 // loads it could only wait for everything (measured in the ISA: s_waitcnt vmcnt(0) right behind freshly issued stores /
 // prefetches on every step).  With them issued first they are older than the next table loads and every wait is exact.
-__device__ __forceinline__ void arrival_fence(u32x4 &a, u32x4 &b, float4 &r) {
-    asm volatile("; arrival_fence" : "+v"(a), "+v"(b), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w) : : "memory");
+__device__ __forceinline__ void arrival_fence(u32x4 &a, u32x4 &b) {
+    asm volatile("; arrival_fence" : "+v"(a), "+v"(b) : : "memory");
 }
-__device__ __forceinline__ void arrival_fence(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, float4 &r, float2 &q, float &g) {
-    asm volatile("; arrival_fence" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w),
-                 "+v"(q.x), "+v"(q.y), "+v"(g) : : "memory");
+__device__ __forceinline__ void arrival_fence(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, float &g) {
+    asm volatile("; arrival_fence" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(g) : : "memory");
 }
 // Explicit register copy.  The table buffers are refilled (for the step after next) in the middle of the step that consumes
 // them; small values that stay live to the end of the step are first moved out with a real v_mov, so that the buffer is
@@ -99,6 +98,31 @@ __device__ __forceinline__ void filter_tiles(const u32x4 (*const (&w)[NT])[2], c
             acc[t] = mfma_f16((*w[t])[wi[k]], (*r[t])[ri[k]], acc[t]);
             if (NT < 3) asm volatile("s_nop 7");   // two tiles (layer-0 fallback path): keep the chain producer 2 MFMAs + 16 wait states back
             __builtin_amdgcn_sched_barrier(0);       // fixed tile order inside the round as well
+        }
+    }
+}
+
+// The same rounds plus the selector tile: sel has a single 1.0 per lane (K entry 6 of quarter fq on feature row i with
+// i % 4 == fq), so D_sel[4 q + r][slot] = entry 6 of quarter r of the slot's record = {u_x, u_y, u_z, 1/d}[r]: lane (slot p,
+// any quarter) receives the four per-slot scalars in its 4 accumulator registers, h piece + l piece (22 bits), without
+// a record load and without cross-lane traffic.  Two products (round 0: l, round 2: h).
+template <int NT>
+__device__ __forceinline__ void filter_tiles_sel(const u32x4 (*const (&w)[NT])[2], const u32x4 (*const (&r)[NT])[2], f32x4 (&acc)[NT],
+                                                 const u32x4 &sel, const u32x4 (&rs)[2], f32x4 &accsel) {
+    constexpr int wi[3] = {0, 1, 0}, ri[3] = {1, 0, 0};   // Wh rl, Wl rh, Wh rh
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accsel = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = mfma_f16((*w[t])[wi[k]], (*r[t])[ri[k]], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);       // fixed tile order inside the round as well
+        }
+        if (k != 1) {
+            accsel = mfma_f16(sel, rs[ri[k]], accsel);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -310,7 +334,6 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     BundleWalk<EDGE_THREADS / 64> bw;
     bw.init(G.bundle + a0, Nc, __builtin_amdgcn_readfirstlane(wave), p >> 2);
     if (bw.nj == 0) return;   // (no barrier below)
-    const int last_slot = max(G.row_start[a0 + Nc] - 1, 0);     // records are always read from inside the chain (finite values)
     float ds[4] = {0.f, 0.f, 0.f, 0.f}, dvx[4] = {0.f, 0.f, 0.f, 0.f}, dvy[4] = {0.f, 0.f, 0.f, 0.f},
           dvz[4] = {0.f, 0.f, 0.f, 0.f};
     const int fcol = fs * FS + 4 * fq;            // first of this lane's 4 global feature columns
@@ -319,17 +342,15 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     // 64 contiguous bytes; exhausted streams read the reserved all-zero quad (filter = 0)
     const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;
     const int zero_quad = (zero_slot + 1) / 4 - 1;   // zero_slot = capacity - 1; the last complete quad is all zero
-    const float4 *erec = G.erec;
+    const u32x4 sel = {0u, 0u, 0u, fq == (p & 3) ? 0x3C00u : 0u};   // selector tile (filter_tiles_sel): 1.0 at K entry 6
 
-    // Two table buffers (rho pieces, unit vector + neighbor id), one per step parity: buffer ph is consumed by the step of
-    // parity ph and refilled right after that step's MFMAs for the step after next, so a table load has ~1.6 steps to
-    // arrive (L2 / HBM latency is of the order of one step).
+    // Two table buffers (rho pieces; they also carry the unit vector and the neighbor id of the slot), one per step parity:
+    // buffer ph is consumed by the step of parity ph and refilled right after that step's MFMAs for the step after next,
+    // so a table load has ~1.6 steps to arrive (L2 / HBM latency is of the order of one step).
     u32x4 rq[2][2];
-    float4 er[2];
     auto fetch = [&](int buf, int quad_first_slot, bool valid) {   // quad_first_slot: first slot of the stream's quad
         const u32x4 *rp = rho_lane + (size_t)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
-        er[buf] = erec[min(quad_first_slot + e, last_slot)];
     };
     {
         bool v0, v1;
@@ -370,9 +391,8 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     while (!done) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: one table buffer per step parity
-            arrival_fence(rq[ph][0], rq[ph][1], er[ph]);
-            const float ux = take(er[ph].x), uy = take(er[ph].y), uz = take(er[ph].z);
-            const int jn = __float_as_int(take(er[ph].w));
+            arrival_fence(rq[ph][0], rq[ph][1]);
+            const int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
             if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
                 flush_bundle();
                 if (bw.advance()) { done = true; break; }
@@ -389,14 +409,15 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             }
             mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
             // ---- filter GEMM  D[feature][slot] = Wd_ext[feature][k] rho[k][slot]  (bias . fc included) ---------------
-            f32x4 acc[LY::NSEC];
+            f32x4 acc[LY::NSEC], usel;
             {
                 const u32x4 (*wp[LY::NSEC])[2], (*rp3[LY::NSEC])[2];
 #pragma unroll
                 for (int s2 = 0; s2 < LY::NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; }
-                filter_tiles<LY::NSEC>(wp, rp3, acc);
+                filter_tiles_sel<LY::NSEC>(wp, rp3, acc, sel, rq[ph], usel);
             }
             __builtin_amdgcn_sched_barrier(0);
+            const float ux = usel[0], uy = usel[1], uz = usel[2];   // unit vector of this lane's slot
             // ---- messages of this lane's slot for its 4 features (filter = 0 exactly for pads / foreign slots) -----------
             auto message = [&](int r) {
                 const float *tr = tv + r * LY::NSEG;
@@ -466,6 +487,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, p = lane & 15, fq = lane >> 4, e = p & 3;
     const int last_slot = max(G.row_start[a0 + Nc] - 1, 0);
+    const u32x4 sel = {0u, 0u, 0u, fq == (p & 3) ? 0x3C00u : 0u};   // selector tile (filter_tiles_sel): 1.0 at K entry 6
     const LayerW &W = MW[m].layer[l];
     float4 *gb = gbar + (size_t)(m * n_groups + fs) * gbar_stride;
     const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;   // quad-interleaved tables, see forward
@@ -598,18 +620,13 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     // this lane's slot; a slot is visited once per launch, so the early read is safe) travels with the tables.
     float *gcomp = reinterpret_cast<float *>(gb) + gcomp_id;   // component this row ends up with (3: none)
     u32x4 rq[2][2], dq[2][2];
-    float4 er[2];
-    float2 dd[2];
     float gold[2] = {0.f, 0.f};
     auto fetch = [&](int buf, int quad_first_slot, bool valid) {
         const size_t off = (size_t)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;
         const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
         dq[buf][0] = dp[0]; dq[buf][1] = dp[16];
-        const int sl = min(quad_first_slot + e, last_slot);
-        er[buf] = G.erec[sl];
-        dd[buf] = G.dist2[sl];
-        if (!FIRST) gold[buf] = gcomp[(size_t)sl * 4];
+        if (!FIRST) gold[buf] = gcomp[(size_t)min(quad_first_slot + e, last_slot) * 4];
     };
     {
         bool v0, v1;
@@ -623,10 +640,9 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     while (!done) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
-            arrival_fence(rq[ph][0], rq[ph][1], dq[ph][0], dq[ph][1], er[ph], dd[ph], gold[ph]);
-            const float ux = take(er[ph].x), uy = take(er[ph].y), uz = take(er[ph].z);   // unit vector c -> n ; edge (n -> c) has -u
-            const int jn = __float_as_int(take(er[ph].w));
-            const float invd = take(dd[ph].x), gold_cur = FIRST ? 0.f : take(gold[ph]);
+            arrival_fence(rq[ph][0], rq[ph][1], dq[ph][0], dq[ph][1], gold[ph]);
+            const int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
+            const float gold_cur = FIRST ? 0.f : take(gold[ph]);
             if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
                 flush_bundle();
                 if (bw.advance()) { done = true; break; }
@@ -659,15 +675,16 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
             mfma_pre_fence(dq[ph][0], dq[ph][1]);
             // filter and its radial derivative for this lane's slot and 4 features (bias . fc / bias . fc' included)
-            f32x4 awd[2 * NSEC];   // tiles [0, NSEC): filter w, [NSEC, 2 NSEC): radial derivative dw
+            f32x4 awd[2 * NSEC], usel;   // tiles [0, NSEC): filter w, [NSEC, 2 NSEC): radial derivative dw; usel: per-slot scalars
             {
                 const u32x4 (*wp[2 * NSEC])[2], (*rp3[2 * NSEC])[2];
 #pragma unroll
                 for (int s2 = 0; s2 < NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; wp[NSEC + s2] = &wA[s2]; rp3[NSEC + s2] = &dq[ph]; }
-                filter_tiles<2 * NSEC>(wp, rp3, awd);
+                filter_tiles_sel<2 * NSEC>(wp, rp3, awd, sel, rq[ph], usel);
             }
             const f32x4 *aw = awd, *ad = awd + NSEC;
             __builtin_amdgcn_sched_barrier(0);
+            const float ux = usel[0], uy = usel[1], uz = usel[2], invd = usel[3];   // unit vector c -> n (edge (n -> c) has -u), 1 / d
             const float pcb_[4] = {cv[1].x, cv[1].y, cv[1].z, cv[1].w}, pcc_[4] = {cv[2].x, cv[2].y, cv[2].z, cv[2].w};
             const float pca_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
             const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
