@@ -155,7 +155,7 @@ void build_wd16(const float *Wd, const float *bd, unsigned *dst) {
 
 constexpr int FS = 16;           // features per slice
 constexpr int NSLICE = F / FS;   // 8
-constexpr int EDGE_THREADS = 768;   // 12 waves = 48 CSR streams per workgroup, 3 waves per SIMD (<= 168 VGPRs per lane)
+constexpr int EDGE_THREADS = 1024;   // 16 waves = 4 per SIMD (120 VGPRs): measured 512 -> 2.54, 768 -> 2.17, 1024 -> 2.03 ms / step
 
 // LDS slice layout: tile[atom][feature f][NSEG] with NSEG = {a, b, c, v_x, v_y, v_z}: the values a lane needs for its 4
 // features of one neighbor are 96 contiguous bytes = 6 ds_read_b128.  (Layer 0 never comes here: it is either
