@@ -30,15 +30,36 @@ k_l0_accum(int nz, GraphView G, const int *__restrict__ counters, float *__restr
     for (int z = 0; z < L0_MAX_SPECIES; ++z) acc[z] = 0.f;
     // slot counts are multiples of 4: four slots per iteration, all loads independent (species index from the per-slot
     // table written by k_edge_geom); the sum order over slots stays ascending
-    for (int e = G.row_start[i]; e < G.row_start[i + 1]; e += 4) {
+    // the per-slot record and species index are the same for every thread of the block: read through the constant
+    // address space (scalar loads) instead of 96 identical vector accesses -- the kernel is bound by the L1 access rate
+    auto erec_c = [&](int idx) -> float4 {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const f32x4 __attribute__((address_space(4))) *cp;
+        const f32x4 v = reinterpret_cast<cp>(reinterpret_cast<uintptr_t>(G.erec))[idx];
+        return make_float4(v.x, v.y, v.z, v.w);
+#else
+        return G.erec[idx];
+#endif
+    };
+    auto zslot_c = [&](int word) -> unsigned {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const unsigned __attribute__((address_space(4))) *cp;
+        return reinterpret_cast<cp>(reinterpret_cast<uintptr_t>(G.zslot))[word];
+#else
+        return reinterpret_cast<const unsigned *>(G.zslot)[word];
+#endif
+    };
+    const int e_begin = __builtin_amdgcn_readfirstlane(G.row_start[i]), e_end = __builtin_amdgcn_readfirstlane(G.row_start[i + 1]);
+    for (int e = e_begin; e < e_end; e += 4) {   // (rows start at multiples of 4: the 4 species bytes are one aligned word)
         float4 er[4];
         float r[4];
         int zi[4];
+        const unsigned zw = zslot_c(e >> 2);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            er[u] = G.erec[e + u];
+            er[u] = erec_c(e + u);
             r[u] = G.rho[(size_t)(e + u) * KP + kap];          // pads: rho = 0
-            zi[u] = G.zslot[e + u];
+            zi[u] = (zw >> (8 * u)) & 255;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -198,16 +219,27 @@ k_l0_bwd(int N, int M, int nz, int first_write, int excl_vol, GraphView G, const
         const float4 er = G.erec[e];
         const float2 dd = G.dist2[e];
         const float *rp = G.rho + (size_t)e * KP + kq * 6, *dp = G.drho + (size_t)e * KP + kq * 6;
-        float rho[6], drho[6];
+        float rho[6], drho[6];   // 24-byte records, 8-byte aligned: float2 loads (the kernel is bound by the L1 access rate)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { rho[k] = rp[k]; drho[k] = dp[k]; }
+        for (int k = 0; k < 3; ++k) {
+            const float2 r2 = reinterpret_cast<const float2 *>(rp)[k], d2 = reinterpret_cast<const float2 *>(dp)[k];
+            rho[2 * k] = r2.x; rho[2 * k + 1] = r2.y; drho[2 * k] = d2.x; drho[2 * k + 1] = d2.y;
+        }
         const int n = a0 + __float_as_int(er.w);
         for (int m = 0; m < M; ++m) {
             const float *q = Q + ((((size_t)m * N + n) * nz + zc) * 4) * KP + kq * 6;
             float d0 = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+            float qv[4][6];
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float2 t2 = reinterpret_cast<const float2 *>(q + cq * KP)[k];
+                    qv[cq][2 * k] = t2.x; qv[cq][2 * k + 1] = t2.y;
+                }
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const float q0 = q[k], qx = q[KP + k], qy = q[2 * KP + k], qz = q[3 * KP + k];
+                const float q0 = qv[0][k], qx = qv[1][k], qy = qv[2][k], qz = qv[3][k];
                 d0 = fmaf(drho[k], q0, d0);
                 dx = fmaf(drho[k], qx, dx); dy = fmaf(drho[k], qy, dy); dz = fmaf(drho[k], qz, dz);
                 bx = fmaf(rho[k], qx, bx); by = fmaf(rho[k], qy, by); bz = fmaf(rho[k], qz, bz);
