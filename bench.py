@@ -75,7 +75,7 @@ def reverse_pass_flops(n_slots, n_models):
 def measured_traffic(kernel):
     """HBM bytes per launch from committed PMC passes (profiles/: FETCH_SIZE, WRITE_SIZE in KB, separate passes;
     FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM for 16-B/lane streams).  None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_edge_kernels_v6.json")
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_edge_kernels_v7.json")
     if not os.path.exists(path):
         return None
     raw = json.load(open(path))
@@ -218,8 +218,8 @@ def main():
                        "parallelism": f"chains sharded x{world}, RCCL all_gather of per-chain energies"},
             # The reverse neighbor pass is instruction / matrix-pipe bound, not HBM bound (its HBM view is given beside
             # it): `achieved` = fp32-precision algorithmic TFLOP/s (filter GEMVs + adjoint arithmetic, formulas above)
-            # against the fp32 peak of MI355X_MICROARCH.md; the filter runs as 6 bf16 partial products per GEMV on
-            # the bf16 MFMA pipe (3-way exact split, fp32-level accuracy), the rest on the fp32 VALU.
+            # against the fp32 peak of MI355X_MICROARCH.md; the filter runs as 3 fp16 partial products per GEMV on
+            # the 16-bit MFMA pipe (2-way split, fp32-level accuracy), the rest on the fp32 VALU.
             "roofline": {"bound": "mfma", "kernel": "edge_message_bwd (reverse neighbor pass, k_edge_bwd_mfma)",
                          "achieved": bwd["achieved_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": bwd["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS,
