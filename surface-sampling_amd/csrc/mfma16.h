@@ -89,6 +89,23 @@ __device__ __forceinline__ void load_rows_split(const Planes &P, int col0, RowPt
 }
 
 
+// ---- coalesced global I/O for data that lives in the accumulator layout --------------------------------------------------
+// In the accumulator layout a lane owns ONE column and 4 rows per tile: written or read directly, every dword access
+// moves 16 contiguous bytes per lane quad (a quarter of what an L1 access can carry), and the kernels' epilogues were bound
+// by the L1 access rate (update_fwd: 30 % of its time).  Results go through an fp32 tile in LDS instead
+// (T[row][FT], conflict-free for the accumulator layout), and a cooperative pass moves whole rows as float4 per lane.
+constexpr int FT = F + 4;   // row stride of the staging tile (floats): rows stay 16-byte aligned, 4 rows apart = 16 banks apart
+template <int NROWS, class Fn>
+__device__ __forceinline__ void stage_rows(const float *T, Fn fn) {   // fn(row, first column, the tile's 4 values)
+    constexpr int NIT = NROWS * (F / 4) / NTHREADS;
+    static_assert(NROWS * (F / 4) % NTHREADS == 0, "tile pass must divide evenly");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * NTHREADS, row = idx >> 5, c4 = idx & 31;
+        fn(row, 4 * c4, *reinterpret_cast<const float4 *>(T + row * FT + 4 * c4));
+    }
+}
+
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }

@@ -275,18 +275,27 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
     __syncthreads();
     UpdRegs R;
     update_forward(W, ldsh, L, R);
+    // Every wave has passed the barrier in front of GEMM3: vt and hs are free.  The increments go through an fp32 tile
+    // that overlays them (rows [0, TA): s, rows TA (1 + x) + atom: v_x); the residual is added in the coalesced pass.
+    float *T = reinterpret_cast<float *>(ldsh);
+    static_assert(4 * TA * FT * sizeof(float) <= OFF_AS * sizeof(_Float16), "staging tile overlays vt + hs only");
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int a = a0 + L.row(t, i);
-            if (a >= N) continue;
-            const size_t g = mN + a;
-            s_out[g * F + L.col] = fmaf(R.gate[t][1][i], R.inner[t][i], s_msg[g * F + L.col]) + R.gate[t][2][i];
+            const int row = L.row(t, i);
+            T[row * FT + L.col] = fmaf(R.gate[t][1][i], R.inner[t][i], R.gate[t][2][i]);
 #pragma unroll
-            for (int x = 0; x < 3; ++x)
-                v_out[(g * 3 + x) * F + L.col] = fmaf(R.gate[t][0][i], R.uv[2 * x + t][0][i], v_msg[(g * 3 + x) * F + L.col]);
+            for (int x = 0; x < 3; ++x) T[(TA * (1 + x) + row) * FT + L.col] = R.gate[t][0][i] * R.uv[2 * x + t][0][i];
         }
+    __syncthreads();
+    stage_rows<4 * TA>(T, [&](int row, int col, const float4 &d) {
+        const int q = row / TA, a = a0 + row % TA;   // q = 0: s, 1..3: v_x, v_y, v_z
+        if (a >= N) return;
+        const size_t off = q == 0 ? (mN + a) * F + col : ((mN + a) * 3 + (q - 1)) * F + col;
+        const float4 r = *reinterpret_cast<const float4 *>((q == 0 ? s_msg : v_msg) + off);
+        *reinterpret_cast<float4 *>((q == 0 ? s_out : v_out) + off) = make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
+    });
 }
 
 // reverse: (sbar, vbar) of the block outputs -> (sbar_msg, vbar_msg) of its inputs.
@@ -354,7 +363,6 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
         for (int i = 0; i < 4; ++i) {
             const int row = L.row(t, i), a = a0 + row;
             const size_t g = mN + min(a, N - 1);
-            if (a < N) sbar_msg[g * F + L.col] = sb[t][i] + hbar[t][0][i];
             const float avv = R.gate[t][0][i], asv = R.gate[t][1][i];
             const float sc = hbar[t][1][i] / R.nrm[t][i];
             const float sa = sb[t][i] * asv;
@@ -373,19 +381,30 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
         const uint4 *wp[1] = {WTILE(UVt, L.w, 2 * F)};
         gemm16<2 * F, 6, 1>(ab, wp, out);
     }
+    __syncthreads();   // every wave is done with the [Ubar | Vbar] planes: the region becomes the fp32 output tile
+    float *T = reinterpret_cast<float *>(ldsh);   // rows [0, TA): sbar_msg, rows TA (1 + x) + atom: increment of vbar_msg_x
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int a = a0 + L.row(t, i);
-            if (a >= N) continue;
-            const size_t g = mN + a;
+            const int row = L.row(t, i);
+            T[row * FT + L.col] = sb[t][i] + hbar[t][0][i];
 #pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                const float vbo = vbar_is_zero ? 0.f : vbar[(g * 3 + x) * F + L.col];
-                vbar_msg[(g * 3 + x) * F + L.col] = vbo + out[2 * x + t][0][i];
-            }
+            for (int x = 0; x < 3; ++x) T[(TA * (1 + x) + row) * FT + L.col] = out[2 * x + t][0][i];
         }
+    __syncthreads();
+    stage_rows<4 * TA>(T, [&](int row, int col, const float4 &d) {
+        const int q = row / TA, a = a0 + row % TA;
+        if (a >= N) return;
+        if (q == 0) {
+            *reinterpret_cast<float4 *>(sbar_msg + (mN + a) * F + col) = d;
+        } else {
+            const size_t off = ((mN + a) * 3 + (q - 1)) * F + col;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!vbar_is_zero) r = *reinterpret_cast<const float4 *>(vbar + off);
+            *reinterpret_cast<float4 *>(vbar_msg + off) = make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
+        }
+    });
 }
 
 // ---- host: weight packing + launch helpers ------------------------------------------------------------------------
