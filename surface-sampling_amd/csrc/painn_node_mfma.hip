@@ -23,6 +23,22 @@
 // two tiles), pinned with scheduling barriers, and no load is issued inside the MFMA block of a chunk group.
 #include "mfma16.h"
 
+#ifdef PHASE_TIMING   // debug build only (tools/gpu_phase.py): wall-clock ticks between phase marks, first thread of every workgroup
+__device__ unsigned long long g_phase[64];
+#define PH_INIT unsigned long long ph_t = wall_clock64();
+#define PH_RESET ph_t = wall_clock64();
+#define PH(k) { const unsigned long long ph_n = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_phase[k], ph_n - ph_t); ph_t = wall_clock64(); }
+extern "C" int vssr_debug_phases(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define PH_INIT
+#define PH_RESET
+#define PH(k)
+#endif
+
 namespace vssr {
 
 // ---- GEMM on the planes ------------------------------------------------------------------------------------------------
@@ -201,14 +217,17 @@ struct UpdRegs {
 };
 
 // Shared forward part: needs vt (v_msg tile, rows x*TA+atom) and hs[:, :F] (s_msg tile) loaded + synced.
+template <int PHB>   // PHB: first phase-timing slot (debug builds)
 __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, const LaneGeo &L, UpdRegs &R) {
     const Planes vt = make_planes(ldsh + OFF_VT, 3 * TA, F), hs = make_planes(ldsh + OFF_HS, TA, 2 * F),
                  as_ = make_planes(ldsh + OFF_AS, TA, F);
     zero_acc(R.uv);
+    PH_INIT
     {
         const uint4 *wp[2] = {WTILE(U, L.w, F), WTILE(V, L.w, F)};
         gemm16<F, 6, 2>(vt, wp, R.uv);
     }
+    PH(PHB + 1)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -224,7 +243,9 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
             R.inner[t][i] = in;
             store_split(hs, L.row(t, i), F + L.col, R.nrm[t][i]);
         }
+    PH(PHB + 2)
     __syncthreads();
+    PH(PHB + 3)
     {
         f32x4 acc[2][1];
         zero_acc(acc);
@@ -239,7 +260,9 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
                 store_split(as_, L.row(t, i), L.col, swish(R.h3[t][i]));
             }
     }
+    PH(PHB + 4)
     __syncthreads();
+    PH(PHB + 5)
     {
         zero_acc(R.gate);
         const uint4 *wp[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
@@ -251,6 +274,7 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
             for (int t = 0; t < 2; ++t) R.gate[t][c] += (f32x4){b, b, b, b};
         }
     }
+    PH(PHB + 6)
 }
 
 __device__ __forceinline__ void load_update_tiles(_Float16 *ldsh, const float *__restrict__ s_msg,
@@ -271,10 +295,13 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
     const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
+    PH_INIT
     load_update_tiles(ldsh, s_msg, v_msg, mN, a0, N);
     __syncthreads();
+    PH(0)
     UpdRegs R;
-    update_forward(W, ldsh, L, R);
+    update_forward<0>(W, ldsh, L, R);
+    PH_RESET
     // Every wave has passed the barrier in front of GEMM3: vt and hs are free.  The increments go through an fp32 tile
     // that overlays them (rows [0, TA): s, rows TA (1 + x) + atom: v_x); the residual is added in the coalesced pass.
     float *T = reinterpret_cast<float *>(ldsh);
@@ -289,6 +316,7 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
             for (int x = 0; x < 3; ++x) T[(TA * (1 + x) + row) * FT + L.col] = R.gate[t][0][i] * R.uv[2 * x + t][0][i];
         }
     __syncthreads();
+    PH(7)
     stage_rows<4 * TA>(T, [&](int row, int col, const float4 &d) {
         const int q = row / TA, a = a0 + row % TA;   // q = 0: s, 1..3: v_x, v_y, v_z
         if (a >= N) return;
@@ -296,6 +324,7 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
         const float4 r = *reinterpret_cast<const float4 *>((q == 0 ? s_msg : v_msg) + off);
         *reinterpret_cast<float4 *>((q == 0 ? s_out : v_out) + off) = make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
     });
+    PH(8)
 }
 
 // reverse: (sbar, vbar) of the block outputs -> (sbar_msg, vbar_msg) of its inputs.
@@ -313,10 +342,13 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
+    PH_INIT
     load_update_tiles(ldsh, s_msg, v_msg, mN, a0, N);
     __syncthreads();
+    PH(16)
     UpdRegs R;
-    update_forward(W, ldsh, L, R);
+    update_forward<16>(W, ldsh, L, R);
+    PH_RESET
     // Every wave has passed the barrier in front of GEMM3, i.e. finished GEMM1/GEMM2: vt and hs are free.
     const Planes qb = make_planes(ldsh + OFF_VT, TA, F3);    // overlays vt
     f32x4 sb[2];
@@ -336,7 +368,9 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
             store_split(qb, row, F + L.col, sb[t][i] * R.inner[t][i]);
             store_split(qb, row, 2 * F + L.col, sb[t][i]);
         }
+    PH(23)
     __syncthreads();   // qb complete; every wave is past GEMM3, so `as` may be overwritten
+    PH(24)
     const Planes hb = make_planes(ldsh + OFF_AS, TA, F);    // h3bar
     {
         f32x4 acc[2][1];
@@ -348,14 +382,18 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
 #pragma unroll
             for (int i = 0; i < 4; ++i) store_split(hb, L.row(t, i), L.col, acc[t][0][i] * dswish(R.h3[t][i]));
     }
+    PH(25)
     __syncthreads();
+    PH(26)
     f32x4 hbar[2][2];   // [t][0] = d/d s_msg part, [t][1] = d/d norm part, both for feature `col`
     zero_acc(hbar);
     {
         const uint4 *wp[2] = {WTILE(W3t, L.w, F), WTILE(W3t, NW + L.w, F)};
         gemm16<F, 2, 2>(hb, wp, hbar);
     }
+    PH(27)
     __syncthreads();   // all waves are done with qb / hb: the whole region becomes the [Ubar | Vbar] tile
+    PH(28)
     const Planes ab = make_planes(ldsh, 3 * TA, 2 * F);     // cols [0,F) = Ubar, [F,2F) = Vbar
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -374,14 +412,18 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
                 store_split(ab, x * TA + row, F + L.col, fmaf(sa, u, sc * v));
             }
         }
+    PH(29)
     __syncthreads();
+    PH(30)
     f32x4 out[6][1];
     zero_acc(out);
     {
         const uint4 *wp[1] = {WTILE(UVt, L.w, 2 * F)};
         gemm16<2 * F, 6, 1>(ab, wp, out);
     }
+    PH(31)
     __syncthreads();   // every wave is done with the [Ubar | Vbar] planes: the region becomes the fp32 output tile
+    PH(32)
     float *T = reinterpret_cast<float *>(ldsh);   // rows [0, TA): sbar_msg, rows TA (1 + x) + atom: increment of vbar_msg_x
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -405,6 +447,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
             *reinterpret_cast<float4 *>(vbar_msg + off) = make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
         }
     });
+    PH(33)
 }
 
 // ---- host: weight packing + launch helpers ------------------------------------------------------------------------
