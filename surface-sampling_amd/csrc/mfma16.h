@@ -106,6 +106,24 @@ __device__ __forceinline__ void stage_rows(const float *T, Fn fn) {   // fn(row,
     }
 }
 
+// same pass with a residual operand from global memory: all loads of the pass are issued before the first store
+template <int NROWS, class Ld, class St>
+__device__ __forceinline__ void stage_rows_residual(const float *T, Ld ld, St st) {   // ld(row, col) -> float4 ; st(row, col, tile, residual)
+    constexpr int NIT = NROWS * (F / 4) / NTHREADS;
+    static_assert(NROWS * (F / 4) % NTHREADS == 0, "tile pass must divide evenly");
+    float4 r[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * NTHREADS;
+        r[it] = ld(idx >> 5, 4 * (idx & 31));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * NTHREADS, row = idx >> 5, c4 = idx & 31;
+        st(row, 4 * c4, *reinterpret_cast<const float4 *>(T + row * FT + 4 * c4), r[it]);
+    }
+}
+
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }

@@ -317,13 +317,17 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
         }
     __syncthreads();
     PH(7)
-    stage_rows<4 * TA>(T, [&](int row, int col, const float4 &d) {
-        const int q = row / TA, a = a0 + row % TA;   // q = 0: s, 1..3: v_x, v_y, v_z
-        if (a >= N) return;
-        const size_t off = q == 0 ? (mN + a) * F + col : ((mN + a) * 3 + (q - 1)) * F + col;
-        const float4 r = *reinterpret_cast<const float4 *>((q == 0 ? s_msg : v_msg) + off);
-        *reinterpret_cast<float4 *>((q == 0 ? s_out : v_out) + off) = make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
-    });
+    auto gofs = [&](int row, int col) -> size_t {   // q = row / TA: 0 = s, 1..3 = v_x, v_y, v_z (tail rows clamped to the last atom)
+        const int q = row / TA, a = min(a0 + row % TA, N - 1);
+        return q == 0 ? (mN + a) * F + col : ((mN + a) * 3 + (q - 1)) * F + col;
+    };
+    stage_rows_residual<4 * TA>(
+        T, [&](int row, int col) { return *reinterpret_cast<const float4 *>((row < TA ? s_msg : v_msg) + gofs(row, col)); },
+        [&](int row, int col, const float4 &d, const float4 &r) {
+            if (a0 + row % TA >= N) return;
+            *reinterpret_cast<float4 *>((row < TA ? s_out : v_out) + gofs(row, col)) =
+                make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
+        });
     PH(8)
 }
 
@@ -343,7 +347,29 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
     PH_INIT
+    f32x4 sb[2];   // sbar in the accumulator layout: requested first, needed after the forward recomputation
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sb[t][i] = sbar[(mN + min(a0 + L.row(t, i), N - 1)) * F + L.col];
     load_update_tiles(ldsh, s_msg, v_msg, mN, a0, N);
+    // vbar of the tile (96 rows, fp32) stays in LDS behind the planes for the whole kernel: it is needed three times in the
+    // accumulator layout (one column per lane), where direct global reads are scalar, uncoalesced and latency-exposed
+    float *VB = reinterpret_cast<float *>(ldsh + UPD_LDS_HALVES);   // [x * TA + atom][FT]
+    if (!vbar_is_zero) {
+        constexpr int NIT = 3 * TA * (F / 4) / NTHREADS;
+        float4 vv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * NTHREADS, row = idx >> 5, c4 = idx & 31;
+            vv[it] = *reinterpret_cast<const float4 *>(vbar + ((mN + min(a0 + row % TA, N - 1)) * 3 + row / TA) * F + 4 * c4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * NTHREADS, row = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<float4 *>(VB + row * FT + 4 * c4) = vv[it];
+        }
+    }
     __syncthreads();
     PH(16)
     UpdRegs R;
@@ -351,18 +377,15 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     PH_RESET
     // Every wave has passed the barrier in front of GEMM3, i.e. finished GEMM1/GEMM2: vt and hs are free.
     const Planes qb = make_planes(ldsh + OFF_VT, TA, F3);    // overlays vt
-    f32x4 sb[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = L.row(t, i);
-            const size_t g = mN + min(a0 + row, N - 1);
-            sb[t][i] = sbar[g * F + L.col];
             float abar_vv = 0.f;
             if (!vbar_is_zero) {   // wave-uniform
 #pragma unroll
-                for (int x = 0; x < 3; ++x) abar_vv = fmaf(vbar[(g * 3 + x) * F + L.col], R.uv[2 * x + t][0][i], abar_vv);
+                for (int x = 0; x < 3; ++x) abar_vv = fmaf(VB[(x * TA + row) * FT + L.col], R.uv[2 * x + t][0][i], abar_vv);
             }
             store_split(qb, row, L.col, abar_vv);
             store_split(qb, row, F + L.col, sb[t][i] * R.inner[t][i]);
@@ -399,14 +422,13 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = L.row(t, i), a = a0 + row;
-            const size_t g = mN + min(a, N - 1);
+            const int row = L.row(t, i);
             const float avv = R.gate[t][0][i], asv = R.gate[t][1][i];
             const float sc = hbar[t][1][i] / R.nrm[t][i];
             const float sa = sb[t][i] * asv;
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
-                const float vbo = vbar_is_zero ? 0.f : vbar[(g * 3 + x) * F + L.col];
+                const float vbo = vbar_is_zero ? 0.f : VB[(x * TA + row) * FT + L.col];
                 const float u = R.uv[2 * x + t][0][i], v = R.uv[2 * x + t][1][i];
                 store_split(ab, x * TA + row, L.col, fmaf(vbo, avv, sa * v));
                 store_split(ab, x * TA + row, F + L.col, fmaf(sa, u, sc * v));
@@ -443,7 +465,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
         } else {
             const size_t off = ((mN + a) * 3 + (q - 1)) * F + col;
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!vbar_is_zero) r = *reinterpret_cast<const float4 *>(vbar + off);
+            if (!vbar_is_zero) r = *reinterpret_cast<const float4 *>(VB + (row - TA) * FT + col);
             *reinterpret_cast<float4 *>(vbar_msg + off) = make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
         }
     });
@@ -481,7 +503,8 @@ size_t node_mfma_lds_bytes(int which) {
     switch (which) {
         case 0: return sizeof(_Float16) * 2 * plane_halves(TA, F);                        // msg mlp fwd
         case 1: return sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(TA, F3));   // msg mlp bwd
-        default: return sizeof(_Float16) * UPD_LDS_HALVES;                                // update fwd / bwd
+        case 2: return sizeof(_Float16) * UPD_LDS_HALVES;                                 // update fwd
+        default: return sizeof(_Float16) * UPD_LDS_HALVES + sizeof(float) * 3 * TA * FT;  // update bwd: planes + fp32 vbar tile
     }
 }
 
@@ -493,7 +516,7 @@ int node_mfma_init(vssr_handle *h) {
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(2)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)node_mfma_lds_bytes(2)));
+                                    (int)node_mfma_lds_bytes(3)));
     return VSSR_OK;
 }
 
@@ -514,7 +537,7 @@ void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *M
 void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zero, const ModelW *MW,
                             const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
                             float *sbar_msg, float *vbar_msg) {
-    hipLaunchKernelGGL(k_update_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(2), st, N, l,
+    hipLaunchKernelGGL(k_update_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(3), st, N, l,
                        vbar_is_zero, MW, s_msg, v_msg, sbar, vbar, sbar_msg, vbar_msg);
 }
 
