@@ -1,0 +1,23 @@
+"""Single-chain latency of the drop-in path (one evaluation per call, host arrays in / out), and small batches."""
+import os, sys, time
+import numpy as np
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import bench
+from surface_sampling_amd import backend
+from surface_sampling_amd.calculators import stoich_offset_table
+blobs, S, offset_data = bench.load_golden()
+table, const = stoich_offset_table(offset_data)
+chains = bench.build_chains(S, 0, 64)
+eng = backend.PainnEngine(blobs, device=0, offset_per_z=table, offset_const=const)
+for nb in (1, 4, 16, 64):
+    batch = [(s.numbers, s.positions, s.cell, s.pbc) for s in chains[:nb]]
+    for _ in range(5):
+        eng.evaluate(batch)
+    t0 = time.perf_counter()
+    n = 50
+    for _ in range(n):
+        eng.evaluate(batch)
+    dt = (time.perf_counter() - t0) / n
+    print(f"batch {nb:3d}: {1e3 * dt:7.3f} ms per call  -> {nb / dt:9.1f} evaluations/s")
+eng.close()
