@@ -216,21 +216,28 @@ struct BundleWalk {
     int Nc, wave, st;  // st: stream (lane quad) inside the wave
     int nj;            // bundles of this wave
     int j, t, Lc, Ln;  // current bundle (index into the wave's list), step inside it, steps of current / next bundle
-    int4 cur, nxt, pend;
+    int4 cur, nxt, pend;   // pend: raw entry of the bundle after next, in flight since the previous switch
+    bool pend_ok;          // ... and whether this stream has a centre in it
 
     __device__ __forceinline__ int bundle_of(int jj) const { return jj * NW + ((jj & 1) ? NW - 1 - wave : wave); }
-    __device__ __forceinline__ int4 load(int jj) const {   // always a load (clamped address): the count of memory operations is path-independent
+    // always a load (clamped address): the count of memory operations is path-independent.  The value is only looked at
+    // one bundle later (select()), so the load never stalls the switch that issues it.
+    __device__ __forceinline__ int4 load(int jj, bool &ok) const {
         const int idx = 4 * bundle_of(jj) + st;
-        const int4 v = tab[min(idx, Nc - 1)];
-        return (jj < nj && idx < Nc) ? v : make_int4(-1, 0, 0, 0);
+        ok = jj < nj && idx < Nc;
+        return tab[min(idx, Nc - 1)];
     }
+    __device__ __forceinline__ static int4 select(const int4 &v, bool ok) { return ok ? v : make_int4(-1, 0, 0, 0); }
     __device__ __forceinline__ static int steps(const int4 &q) { return max(__builtin_amdgcn_readfirstlane(q.z) >> 2, 2); }
     __device__ __forceinline__ void init(const int4 *table, int n, int w, int stream) {
         tab = table; Nc = n; wave = w; st = stream;
         const int NB = (n + 3) >> 2, full = NB / NW, rem = NB - full * NW;
         nj = full + ((((full & 1) ? NW - 1 - w : w) < rem) ? 1 : 0);
         j = 0; t = 0;
-        cur = load(0); nxt = load(1); pend = load(2);
+        bool ok0, ok1;
+        const int4 r0 = load(0, ok0), r1 = load(1, ok1);
+        pend = load(2, pend_ok);
+        cur = select(r0, ok0); nxt = select(r1, ok1);
         // stream 0 of a bundle holds its longest centre (descending order); lane 0 of the wave belongs to stream 0
         Lc = steps(cur); Ln = steps(nxt);
     }
@@ -247,7 +254,8 @@ struct BundleWalk {
     __device__ __forceinline__ bool advance() {
         ++j;
         if (j == nj) return true;
-        cur = nxt; nxt = pend; pend = load(j + 2);
+        cur = nxt; nxt = select(pend, pend_ok);
+        pend = load(j + 2, pend_ok);
         t = 0; Lc = Ln; Ln = steps(nxt);
         return false;
     }
