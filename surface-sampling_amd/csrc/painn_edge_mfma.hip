@@ -250,14 +250,14 @@ struct BundleWalk {
         valid = 4 * ts < q.z;
         return q.y + 4 * ts;
     }
-    // bundle complete: move on; returns true when the wave has no bundle left
-    __device__ __forceinline__ bool advance() {
+    // bundle complete: move on.  Past the wave's last bundle the entries are empty (no centre, no real slot, 2 steps): the
+    // hot loops test `j < nj` only between iterations, so a finished wave runs at most a few empty steps instead of
+    // leaving the loop from its middle (an exit there makes the compiler's memory waits conservative on every step).
+    __device__ __forceinline__ void advance() {
         ++j;
-        if (j == nj) return true;
         cur = nxt; nxt = select(pend, pend_ok);
         pend = load(j + 2, pend_ok);
         t = 0; Lc = Ln; Ln = steps(nxt);
-        return false;
     }
 };
 
@@ -395,15 +395,14 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     };
 
     const float *trow = tile + (4 * fq) * LY::NSEG;
-    bool done = false;
-    while (!done) {
+    while (bw.j < bw.nj) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: one table buffer per step parity
             arrival_fence(rq[ph][0], rq[ph][1]);
             const int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
             if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
                 flush_bundle();
-                if (bw.advance()) { done = true; break; }
+                bw.advance();
             }
             // gather this slot's neighbor row: 4 features x NSEG values, contiguous in LDS
             float tv[4 * LY::NSEG];
@@ -644,8 +643,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     }
     const float *trow = tile + (4 * fq) * 4;
 
-    bool done = false;
-    while (!done) {
+    while (bw.j < bw.nj) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             arrival_fence(rq[ph][0], rq[ph][1], dq[ph][0], dq[ph][1], gold[ph]);
@@ -653,7 +651,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             const float gold_cur = FIRST ? 0.f : take(gold[ph]);
             if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
                 flush_bundle();
-                if (bw.advance()) { done = true; break; }
+                bw.advance();
                 park_centre();                       // centre data of the bundle that starts now
                 __builtin_amdgcn_sched_barrier(0);   // the old values leave their registers before the loads that refill them are issued
                 load_centre(bw.nxt.x);
