@@ -287,7 +287,15 @@ __device__ __forceinline__ void load_update_tiles(_Float16 *ldsh, const float *_
     load_rows_split<TA>(hs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
 }
 
-__global__ void __launch_bounds__(NTHREADS)
+// Forward kernel with a compact LDS layout (70 KB instead of 103 KB): TWO workgroups share a CU, so the barriers and the
+// latency-bound phases of one overlap the matrix work of the other (the kernel needs 128 VGPRs: 4 waves per SIMD fit).
+//   [0, VT): v tile (h | l planes, 96 rows)  -- after GEMM1: |Vv| plane at 0, swish(h3) plane behind it, at the end the
+//   [VT, VT + XS): s tile (32 rows)             fp32 output tile over everything
+constexpr int CF_XS = plane_halves(3 * TA, F);                    // halves
+constexpr int CF_LDS_HALVES = CF_XS + plane_halves(TA, F);        // 34 816 halves = 69 632 B
+static_assert(2 * plane_halves(TA, F) <= CF_XS, "|Vv| and swish planes overlay the v tile");
+static_assert(4 * TA * FT * sizeof(float) <= CF_LDS_HALVES * sizeof(_Float16), "output tile overlays the planes");
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))   // two workgroups per CU
 k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
                   const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
@@ -295,28 +303,78 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
     const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
-    PH_INIT
-    load_update_tiles(ldsh, s_msg, v_msg, mN, a0, N);
+    const Planes vt = make_planes(ldsh, 3 * TA, F), xs = make_planes(ldsh + CF_XS, TA, F);
+    const Planes nr = make_planes(ldsh, TA, F), as_ = make_planes(ldsh + plane_halves(TA, F), TA, F);   // overlays of vt
+    load_rows_split<3 * TA>(vt, 0, [&](int row) {
+        int x = row / TA, a = min(a0 + (row % TA), N - 1);
+        return v_msg + ((mN + a) * 3 + x) * F;
+    });
+    load_rows_split<TA>(xs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
     __syncthreads();
-    PH(0)
-    UpdRegs R;
-    update_forward<0>(W, ldsh, L, R);
-    PH_RESET
-    // Every wave has passed the barrier in front of GEMM3: vt and hs are free.  The increments go through an fp32 tile
-    // that overlays them (rows [0, TA): s, rows TA (1 + x) + atom: v_x); the residual is added in the coalesced pass.
+    f32x4 uv[6][2];   // [2 x + t][0] = U v_x, [..][1] = V v_x
+    zero_acc(uv);
+    {
+        const uint4 *wp[2] = {WTILE(U, L.w, F), WTILE(V, L.w, F)};
+        gemm16<F, 6, 2>(vt, wp, uv);
+    }
+    f32x4 h3[2][1];   // gate MLP, first layer: the s half of [s ; |Vv|] now, the |Vv| half after the barrier
+    zero_acc(h3);
+    {
+        const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F)};
+        gemm16<F, 2, 1>(xs, wp, h3);
+    }
+    __syncthreads();   // every wave is done with the v tile
+    f32x4 inner[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float n2 = 0.f, in = 0.f;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const float vv = uv[2 * x + t][1][i];
+                n2 += fmaf(vv, vv, 1e-15f);
+                in = fmaf(uv[2 * x + t][0][i], vv, in);
+            }
+            inner[t][i] = in;
+            store_split(nr, L.row(t, i), L.col, sqrtf(n2));
+        }
+    __syncthreads();
+    {
+        const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F) + (F / 32) * 2 * 64};   // chunks F/32 .. 2F/32 - 1 of the same column tile
+        gemm16<F, 2, 1>(nr, wp, h3);
+        const float b = W.b3[L.col];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) store_split(as_, L.row(t, i), L.col, swish(h3[t][0][i] + b));
+    }
+    __syncthreads();
+    f32x4 gate[2][3];   // a_vv, a_sv, a_ss
+    zero_acc(gate);
+    {
+        const uint4 *wp[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
+        gemm16<F, 2, 3>(as_, wp, gate);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float b = W.b4[c * F + L.col];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) gate[t][c] += (f32x4){b, b, b, b};
+        }
+    }
+    __syncthreads();   // every wave is done with the planes: the region becomes the fp32 output tile
+    // increments (rows [0, TA): s, rows TA (1 + x) + atom: v_x); the residual is added in the coalesced pass
     float *T = reinterpret_cast<float *>(ldsh);
-    static_assert(4 * TA * FT * sizeof(float) <= OFF_AS * sizeof(_Float16), "staging tile overlays vt + hs only");
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = L.row(t, i);
-            T[row * FT + L.col] = fmaf(R.gate[t][1][i], R.inner[t][i], R.gate[t][2][i]);
+            T[row * FT + L.col] = fmaf(gate[t][1][i], inner[t][i], gate[t][2][i]);
 #pragma unroll
-            for (int x = 0; x < 3; ++x) T[(TA * (1 + x) + row) * FT + L.col] = R.gate[t][0][i] * R.uv[2 * x + t][0][i];
+            for (int x = 0; x < 3; ++x) T[(TA * (1 + x) + row) * FT + L.col] = gate[t][0][i] * uv[2 * x + t][0][i];
         }
     __syncthreads();
-    PH(7)
     auto gofs = [&](int row, int col) -> size_t {   // q = row / TA: 0 = s, 1..3 = v_x, v_y, v_z (tail rows clamped to the last atom)
         const int q = row / TA, a = min(a0 + row % TA, N - 1);
         return q == 0 ? (mN + a) * F + col : ((mN + a) * 3 + (q - 1)) * F + col;
@@ -328,7 +386,6 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
             *reinterpret_cast<float4 *>((row < TA ? s_out : v_out) + gofs(row, col)) =
                 make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
         });
-    PH(8)
 }
 
 // reverse: (sbar, vbar) of the block outputs -> (sbar_msg, vbar_msg) of its inputs.
@@ -503,7 +560,7 @@ size_t node_mfma_lds_bytes(int which) {
     switch (which) {
         case 0: return sizeof(_Float16) * 2 * plane_halves(TA, F);                        // msg mlp fwd
         case 1: return sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(TA, F3));   // msg mlp bwd
-        case 2: return sizeof(_Float16) * UPD_LDS_HALVES;                                 // update fwd
+        case 2: return sizeof(_Float16) * CF_LDS_HALVES;                                  // update fwd (compact layout)
         default: return sizeof(_Float16) * UPD_LDS_HALVES + sizeof(float) * 3 * TA * FT;  // update bwd: planes + fp32 vbar tile
     }
 }
