@@ -10,8 +10,14 @@ chains: site occupations are ``[B, S]`` arrays, proposals / acceptances are draw
 how chains are batched or sharded over GPUs, and the B proposed slabs are relaxed in one lock-step device call
 (``EnsembleNFFSurface.relax_batch``).  "before"/"after" states are simply the old and the new arrays.
 
+Canonical sampling (``MCMC.step_canonical`` ``mcmc/mcmc.py:190-231``: ``SwitchProposal`` ``mcmc/events/proposal.py:154-197``
+-> ``get_complementary_idx`` ``mcmc/slab.py:168-232`` with uniform weights, ``Exchange`` ``mcmc/events/event.py:138-156``) is
+the same array arithmetic: two different "types" present on the lattice (a species or "None" for empty sites), one site of
+each, adsorbates exchanged.  The per-atom-energy (Boltzmann) and distance-decay site weights of the reference's proposal are
+not covered.
+
 Single-atom adsorbates only (the SrTiO3 / GaN configurations of BASELINE.json); the reference's multi-atom
-``ATOM_GROUPS`` are not covered.  Canonical (switch) moves are not covered either.
+``ATOM_GROUPS`` are not covered.
 """
 from __future__ import annotations
 
@@ -216,6 +222,39 @@ class ChainEnsemble:
         end = np.where(k < start, k, k + 1)
         return site, end, start, u[:, 2]
 
+    # ---- proposal: vectorised SwitchProposal.get_action (uniform weights) -------------------------------------------
+    def propose_switch(self, step: int, state: ChainState | None = None):
+        """Per chain: an ordered pair of DIFFERENT types present on the lattice (species codes, ``n_ads`` = "None" for
+        empty sites; ``random.sample(types, 2)``, ``mcmc/slab.py:60-71``), then a uniformly random site of each type
+        (``mcmc/slab.py:217-222``).  Returns ``(site1 [B], site2 [B], type1 [B], type2 [B], valid [B], u_acc [B])``;
+        ``valid`` is False for chains with fewer than two types on the lattice (the reference cannot propose there).
+        The reference collects the sites of a species with ``itertools.groupby`` over the site order, which keeps only
+        the last consecutive run of a species; ALL sites of the species are candidates here."""
+        st = state or self.state
+        u = chain_uniforms(self.seed, self.chain_ids, step)
+        B, S = st.species.shape
+        codes = np.arange(self.n_ads + 1)
+        counts = (st.species[:, :, None] == codes[None, None, :]).sum(axis=1)          # [B, n_ads + 1]
+        present = counts > 0
+        T = present.sum(axis=1)
+        valid = T >= 2
+        Tm = np.maximum(T, 2)
+        k = np.minimum((u[:, 0] * (Tm * (Tm - 1))).astype(np.int64), Tm * (Tm - 1) - 1)   # ordered pairs, uniform
+        i1, i2 = k // (Tm - 1), k % (Tm - 1)
+        i2 = i2 + (i2 >= i1)
+        rank = np.cumsum(present, axis=1) - 1                                           # index among the present types
+        type1 = np.argmax(present & (rank == i1[:, None]), axis=1)
+        type2 = np.argmax(present & (rank == i2[:, None]), axis=1)
+
+        def pick(type_code, uu):
+            mask = st.species == type_code[:, None]
+            n = np.maximum(mask.sum(axis=1), 1)
+            j = np.minimum((uu * n).astype(np.int64), n - 1)
+            return np.argmax(mask & ((np.cumsum(mask, axis=1) - 1) == j[:, None]), axis=1)
+
+        site1, site2 = pick(type1, u[:, 1]), pick(type2, u[:, 3])
+        return site1, site2, type1, type2, valid, u[:, 2]
+
     # ---- vectorised change_site ------------------------------------------------------------------------------------
     def apply(self, state: ChainState, site, end_code) -> ChainState:
         """The "after" state: remove what is on the site, adsorb ``end_code`` (``n_ads`` = desorb only)."""
@@ -305,16 +344,45 @@ class ChainEnsemble:
         self.relaxed = [ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, self.relaxed)]
         return accept
 
-    def sweep(self, i: int = 0, sweep_size: int = 20, temperature: float | None = None) -> dict:
-        """``MCMC.sweep`` (``mcmc/mcmc.py:268-299``): ``sweep_size`` steps; per-chain summary."""
+    # ---- one Exchange event + Metropolis for every chain ------------------------------------------------------------
+    def step_canonical(self, temperature: float | None = None) -> np.ndarray:
+        """``MCMC.step_canonical`` (``mcmc/mcmc.py:190-231``) for all chains at once: the adsorbates of two sites of
+        different type are exchanged (two ``change_site`` calls, ``mcmc/events/event.py:138-156``), the composition is
+        conserved.  Chains without two different types keep their state.  Returns the accept mask."""
+        temp = self.temp if temperature is None else float(temperature)
+        if self.state.energy is None:
+            self.initialize()
+        self.step_count += 1
+        before = self.state
+        site1, site2, type1, type2, valid, u_acc = self.propose_switch(self.step_count, before)
+        after = self.apply(self.apply(before, site1, type2), site2, type1)
+        moved = np.flatnonzero(valid)
+        after.energy = before.energy.copy()
+        relaxed_after = list(self.relaxed)
+        if len(moved):
+            e, r = self.evaluate(after, moved)
+            after.energy[moved] = e
+            for b, rb in zip(moved, r):
+                relaxed_after[int(b)] = rb
+        accept = metropolis_accept(before.energy, after.energy, temp, u_acc) & valid
+        a2 = accept[:, None]
+        self.state = ChainState(np.where(a2, after.species, before.species), np.where(a2, after.order, before.order),
+                                np.where(accept, after.counter, before.counter),
+                                np.where(accept, after.energy, before.energy))
+        self.relaxed = [ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, self.relaxed)]
+        return accept
+
+    def sweep(self, i: int = 0, sweep_size: int = 20, temperature: float | None = None, canonical: bool = False) -> dict:
+        """``MCMC.sweep`` (``mcmc/mcmc.py:268-299``): ``sweep_size`` steps (semigrand, or exchange moves when
+        ``canonical``); per-chain summary."""
         n_acc = np.zeros(len(self.chain_ids), np.int64)
         for _ in range(sweep_size):
-            n_acc += self.step_semigrand(temperature)
+            n_acc += self.step_canonical(temperature) if canonical else self.step_semigrand(temperature)
         return {"energy": self.state.energy.copy(), "adsorption_count": self.num_adsorbates(),
                 "acceptance_rate": n_acc / float(sweep_size), "species": self.state.species.copy()}
 
     def run(self, total_sweeps: int = 10, sweep_size: int = 20, start_temp: float = 1.0, perform_annealing: bool = True,
-            alpha: float = 0.99, multiple_anneal: bool = False, anneal_schedule=None) -> dict:
+            alpha: float = 0.99, multiple_anneal: bool = False, anneal_schedule=None, canonical: bool = False) -> dict:
         """``MCMC.run`` (``mcmc/mcmc.py:301-420``) without the file outputs: temperature schedule + sweeps."""
         if anneal_schedule is not None:
             temps = list(anneal_schedule)
@@ -324,7 +392,7 @@ class ChainEnsemble:
             temps = [start_temp] * total_sweeps
         hist = {"energy": [], "adsorption_count": [], "acceptance_rate": [], "temperature": temps}
         for i in range(total_sweeps):
-            r = self.sweep(i, sweep_size, temps[i])
+            r = self.sweep(i, sweep_size, temps[i], canonical=canonical)
             for k in ("energy", "adsorption_count", "acceptance_rate"):
                 hist[k].append(r[k])
         return hist

@@ -243,3 +243,80 @@ def test_run_with_annealing_returns_per_chain_history():
     assert len(hist["energy"]) == 3 and hist["energy"][0].shape == (6,)
     assert ((hist["acceptance_rate"][0] >= 0) & (hist["acceptance_rate"][0] <= 1)).all()
     assert ens.step_count == 15
+
+
+# ---- canonical (switch) moves: mirrors tests/events/test_proposal.py:79-110, tests/test_slab.py:153-183, ----------------
+# ---- tests/events/test_event.py:84-131 of the reference ----------------------------------------------------------------
+def _seeded_ensemble(n_chains=64, n_sites=8, seed=11):
+    ens, _ = _toy(n_chains, n_sites=n_sites, seed=seed)
+    rng = np.random.default_rng(5)
+    # random starting occupations: species codes 0..n_ads (n_ads = empty), adsorption order = site order
+    sp = rng.integers(0, ens.n_ads + 1, size=(n_chains, n_sites)).astype(np.int16)
+    sp[0] = ens.n_ads                      # chain 0: empty lattice (one type only)
+    sp[1] = 0                              # chain 1: full lattice of one species (one type only)
+    order = np.where(sp != ens.n_ads, np.cumsum(sp != ens.n_ads, axis=1), 0)
+    ens.state = mc.ChainState(sp, order.astype(np.int64), (order.max(axis=1) + 1).astype(np.int64))
+    return ens
+
+
+def test_switch_proposal_picks_two_sites_of_different_type():
+    ens = _seeded_ensemble()
+    for step in range(1, 30):
+        s1, s2, t1, t2, valid, u = ens.propose_switch(step)
+        b = np.arange(len(s1))
+        assert not valid[0] and not valid[1] and valid[2:].sum() > 0
+        v = np.flatnonzero(valid)
+        assert (t1[v] != t2[v]).all() and (s1[v] != s2[v]).all()
+        assert (ens.state.species[b, s1][v] == t1[v]).all() and (ens.state.species[b, s2][v] == t2[v]).all()
+        assert ((u >= 0) & (u < 1)).all()
+
+
+def test_switch_proposal_is_uniform_over_ordered_type_pairs_and_sites():
+    ens, _ = _toy(1, n_sites=5, seed=2)
+    ens.state.species[0] = [0, 1, 1, ens.n_ads, 0]      # types present: 0 (sites 0, 4), 1 (sites 1, 2), None (site 3)
+    ens.state.order[0] = [1, 2, 3, 0, 4]
+    ens.state.counter[0] = 5
+    pairs, sites = {}, {}
+    n = 6000
+    for step in range(n):
+        s1, s2, t1, t2, valid, _ = ens.propose_switch(step)
+        assert valid[0]
+        pairs[(int(t1[0]), int(t2[0]))] = pairs.get((int(t1[0]), int(t2[0])), 0) + 1
+        sites[int(s1[0])] = sites.get(int(s1[0]), 0) + 1
+    assert len(pairs) == 6 and all(abs(c / n - 1 / 6) < 0.02 for c in pairs.values())
+    # site of type 1 / 2: uniform inside the type -> sites 0, 1, 2, 4 each 1/6, site 3 ("None", alone) 1/3
+    for site, want in {0: 1 / 6, 1: 1 / 6, 2: 1 / 6, 4: 1 / 6, 3: 1 / 3}.items():
+        assert abs(sites[site] / n - want) < 0.02
+
+
+def test_exchange_conserves_composition_and_is_restored_on_rejection():
+    ens = _seeded_ensemble(n_chains=32)
+    ens.initialize()
+    before = ens.state.copy()
+    comp0 = np.sort(before.species, axis=1)
+    acc = ens.step_canonical(temperature=1e-9)              # practically only downhill moves are accepted
+    assert np.array_equal(np.sort(ens.state.species, axis=1), comp0)             # composition conserved
+    rej = ~acc
+    assert np.array_equal(ens.state.species[rej], before.species[rej])           # Event.backward
+    assert np.array_equal(ens.state.order[rej], before.order[rej])
+    assert np.allclose(ens.state.energy[rej], before.energy[rej])
+    changed = (ens.state.species != before.species).any(axis=1)
+    assert np.array_equal(changed, acc)                                          # an accepted exchange moves two sites
+    assert ((ens.state.species != before.species).sum(axis=1)[acc] == 2).all()
+    assert not acc[0] and not acc[1]                                             # one type only: nothing to exchange
+    # always-accept limit (TestingCriterion): every valid chain moves
+    ens2 = _seeded_ensemble(n_chains=32)
+    ens2.initialize()
+    acc2 = ens2.step_canonical(temperature=1e12)
+    assert acc2[2:].all()
+
+
+def test_canonical_trajectories_do_not_depend_on_batching():
+    whole = _seeded_ensemble(n_chains=16, seed=4)
+    whole.run(total_sweeps=2, sweep_size=5, perform_annealing=False, canonical=True)
+    part, _ = _toy(8, n_sites=8, first_chain=8, seed=4)
+    ref = _seeded_ensemble(n_chains=16, seed=4)
+    part.state = mc.ChainState(ref.state.species[8:].copy(), ref.state.order[8:].copy(), ref.state.counter[8:].copy())
+    part.run(total_sweeps=2, sweep_size=5, perform_annealing=False, canonical=True)
+    assert np.array_equal(whole.state.species[8:], part.state.species)
+    assert np.allclose(whole.state.energy[8:], part.state.energy)
