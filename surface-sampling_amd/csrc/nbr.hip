@@ -179,18 +179,28 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
 }
 
 // exclusive scan of padded degrees -> row_start ; counters[0] = slots, [1] = real edges.  One workgroup walks the array in
-// tiles of 1024 with coalesced loads: wave-level shuffles + one LDS exchange per tile, running prefix carried in registers.
+// tiles of 4096 (4 consecutive atoms per thread, int4 loads): wave-level shuffles + one LDS exchange per tile, running
+// prefix carried in registers.
 __global__ void __launch_bounds__(1024)
 k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int *__restrict__ counters,
             long long slot_cap) {
     __shared__ int wsum[16], wreal[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     long long run = 0, run_real = 0;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + t;
-        const int d = i < n ? deg[i] : 0;
-        const int p = i < n ? max((d + 3) & ~3, 8) : 0;
-        int x = p, xr = d;                       // inclusive scan inside the wave
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + 4 * t;
+        int d[4], pd[4];
+        if (i0 + 3 < n) {
+            const int4 v = *reinterpret_cast<const int4 *>(deg + i0);   // (deg is 256-byte aligned, i0 a multiple of 4)
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = i0 + u < n ? deg[i0 + u] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pd[u] = i0 + u < n ? max((d[u] + 3) & ~3, 8) : 0;
+        const int p = pd[0] + pd[1] + pd[2] + pd[3];
+        int x = p, xr = d[0] + d[1] + d[2] + d[3];   // inclusive scan of the thread sums inside the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int y = __shfl_up(x, off, 64), yr = __shfl_up(xr, off, 64);
@@ -206,7 +216,12 @@ k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int
             tile += v;
             tile_real += wreal[k];
         }
-        if (i < n) row_start[i] = (int)(run + woff + x - p);
+        int o = (int)(run + woff + x - p);   // first slot of this thread's first atom
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u < n) row_start[i0 + u] = o;
+            o += pd[u];
+        }
         run += tile;
         run_real += tile_real;
         __syncthreads();
@@ -324,7 +339,7 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
         float sn = kq == 0 ? s1 : kq == 1 ? s2 : kq == 2 ? s3 : s4;
         float cn = kq == 0 ? c1 : kq == 1 ? c2 : kq == 2 ? c3 : c4;
         float nf = (float)(kq + 1);
-        float *r = rho + (size_t)slot * 24 + kq * 6, *dr = drho + (size_t)slot * 24 + kq * 6;
+        float r[6], dr[6];   // this quarter's values; stored below as three 8-byte pieces per table (24-byte records)
 #pragma unroll
         for (int ks = 0; ks < 5; ++ks) {
             const float rb = sn * inv;
@@ -333,14 +348,23 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
             const float sn2 = fmaf(sn, c4, cn * s4), cn2 = fmaf(cn, c4, -sn * s4);
             sn = sn2; cn = cn2; nf += 4.f;
         }
+        r[5] = fc;      // envelope (bias column) replicated in every quarter
+        dr[5] = dfc;
+        {
+            float2 *rg = reinterpret_cast<float2 *>(rho + (size_t)slot * 24 + kq * 6);
+            float2 *dg = reinterpret_cast<float2 *>(drho + (size_t)slot * 24 + kq * 6);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                rg[q] = make_float2(r[2 * q], r[2 * q + 1]);
+                dg[q] = make_float2(dr[2 * q], dr[2 * q + 1]);
+            }
+        }
         {
             const float rv[5] = {r[0], r[1], r[2], r[3], r[4]}, dv[5] = {dr[0], dr[1], dr[2], dr[3], dr[4]};
             const float scal = kq == 0 ? ed.x * inv : kq == 1 ? ed.y * inv : kq == 2 ? ed.z * inv : (valid ? inv : -1.f);
             write_f16_record(rv, fc, rho16, (size_t)slot, kq, scal, (unsigned)min(valid ? j - a0 : 0, 0x7BFF));
             write_f16_record(dv, dfc, drho16, (size_t)slot, kq, 0.f, 0u);
         }
-        r[5] = fc;      // envelope (bias column) replicated in every quarter: the edge kernels fold bd * fc into the
-        dr[5] = dfc;    // accumulator init instead of spending a sixth MFMA k-step on it
         if (kq == 0) {
             // species index of the neighbor (layer-0 factorisation, painn_l0.hip); pads / unmapped species: 255
             const int zi = valid ? zmap[Z[j]] : -1;
