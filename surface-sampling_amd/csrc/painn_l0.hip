@@ -203,32 +203,45 @@ k_l0_q16(int N, int nz, const int *__restrict__ counters, const int *__restrict_
 }
 
 // ---- reverse, per slot: dE/dr of the edge (n -> c) stored at slot (c, n); one wave per centre, lane = (slot, kq) ------------
+// Walks the row of atom n and produces the gradient of the REVERSE edges (c' -> n) of its slots (n -> c'): they need
+// Q[n][species of c'], i.e. only the row owner's own blocks (M x nz x 384 B, staged once per wave in LDS) instead of a
+// 1.15 KB gather per slot from a different atom (the previous formulation: 3.3 GB of L2 gathers per launch).  Same
+// distance, hence the same radial values; unit vector negated; the result is written to slot rev[e'].
 __global__ void __launch_bounds__(256)
 k_l0_bwd(int N, int M, int nz, int first_write, int excl_vol, GraphView G, const int *__restrict__ counters,
-         const int *__restrict__ Z, const int *__restrict__ zmap, const float *__restrict__ Q,
-         float4 *__restrict__ gbar, long long gbar_group_stride, int n_groups) {
-    const int lane = threadIdx.x & 63, sl = lane >> 2, kq = lane & 3;
-    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (c >= N || counters[2]) return;
-    const int a0 = G.cfg_start[G.atom_cfg[c]];
-    const int zc = zmap[Z[c]];
-    const int e0 = G.row_start[c], e1 = G.row_start[c + 1];
+         const float *__restrict__ Q, float4 *__restrict__ gbar, long long gbar_group_stride, int n_groups) {
+    extern __shared__ __attribute__((aligned(16))) float qs_all[];   // [wave][m][species][4][24]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane >> 2, kq = lane & 3;
+    const int n = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (n >= N || counters[2]) return;
+    const int per_model = nz * TBLK;
+    float *qs = qs_all + (size_t)wave * M * per_model;
+    for (int m = 0; m < M; ++m) {
+        const float4 *src = reinterpret_cast<const float4 *>(Q + ((size_t)m * N + n) * per_model);
+        for (int i = lane; i < per_model / 4; i += 64) reinterpret_cast<float4 *>(qs + m * per_model)[i] = src[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // one wave writes and reads its own block: LDS operations of a wave execute in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int e0 = G.row_start[n], e1 = G.row_start[n + 1];
     for (int eb = e0; eb < e1; eb += 16) {
         const int e = min(eb + sl, e1 - 1);
         const bool live = eb + sl < e1;
         const float4 er = G.erec[e];
         const float2 dd = G.dist2[e];
+        const int zi = G.zslot[e];          // species index of c' (255: pad)
+        const int re = G.rev[e];            // slot of (c' -> n)
         const float *rp = G.rho + (size_t)e * KP + kq * 6, *dp = G.drho + (size_t)e * KP + kq * 6;
-        float rho[6], drho[6];   // 24-byte records, 8-byte aligned: float2 loads (the kernel is bound by the L1 access rate)
+        float rho[6], drho[6];   // 24-byte records, 8-byte aligned
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float2 r2 = reinterpret_cast<const float2 *>(rp)[k], d2 = reinterpret_cast<const float2 *>(dp)[k];
             rho[2 * k] = r2.x; rho[2 * k + 1] = r2.y; drho[2 * k] = d2.x; drho[2 * k + 1] = d2.y;
         }
-        const int n = a0 + __float_as_int(er.w);
+        const bool real = live && zi < nz && re >= 0 && dd.x > 0.f;
+        const int zq = zi < nz ? zi : 0;
         for (int m = 0; m < M; ++m) {
-            const float *q = Q + ((((size_t)m * N + n) * nz + zc) * 4) * KP + kq * 6;
-            float d0 = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+            const float *q = qs + m * per_model + zq * TBLK + kq * 6;
             float qv[4][6];
 #pragma unroll
             for (int cq = 0; cq < 4; ++cq)
@@ -237,6 +250,7 @@ k_l0_bwd(int N, int M, int nz, int first_write, int excl_vol, GraphView G, const
                     const float2 t2 = reinterpret_cast<const float2 *>(q + cq * KP)[k];
                     qv[cq][2 * k] = t2.x; qv[cq][2 * k + 1] = t2.y;
                 }
+            float d0 = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const float q0 = qv[0][k], qx = qv[1][k], qy = qv[2][k], qz = qv[3][k];
@@ -245,14 +259,14 @@ k_l0_bwd(int N, int M, int nz, int first_write, int excl_vol, GraphView G, const
                 bx = fmaf(rho[k], qx, bx); by = fmaf(rho[k], qy, by); bz = fmaf(rho[k], qz, bz);
             }
             // reduce the 4 radial quarters (lanes 4 sl .. 4 sl + 3): fixed order, DPP
-            auto qs = [](float x) {
+            auto qsum = [](float x) {
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
                 return x;
             };
-            d0 = qs(d0); dx = qs(dx); dy = qs(dy); dz = qs(dz); bx = qs(bx); by = qs(by); bz = qs(bz);
-            if (live && kq == 0 && dd.x > 0.f) {
-                const float ux = er.x, uy = er.y, uz = er.z;   // unit vector c -> n; the edge (n -> c) has -u
+            d0 = qsum(d0); dx = qsum(dx); dy = qsum(dy); dz = qsum(dz); bx = qsum(bx); by = qsum(by); bz = qsum(bz);
+            if (real && kq == 0) {
+                const float ux = -er.x, uy = -er.y, uz = -er.z;   // unit vector c' -> n; the edge (n -> c') has -u
                 float db = d0 - (dx * ux + dy * uy + dz * uz);
                 if (excl_vol) db += dd.y;
                 const float invd = dd.x;
@@ -262,10 +276,10 @@ k_l0_bwd(int N, int M, int nz, int first_write, int excl_vol, GraphView G, const
                 float g2 = fmaf(-db, uz, (bz - dotu * uz) * invd);
                 float4 *gb = gbar + (size_t)m * n_groups * gbar_group_stride;   // group 0 of model m
                 if (!first_write) {
-                    const float4 old = gb[e];
+                    const float4 old = gb[re];
                     g0 += old.x; g1 += old.y; g2 += old.z;
                 }
-                gb[e] = make_float4(g0, g1, g2, 0.f);
+                gb[re] = make_float4(g0, g1, g2, 0.f);
             }
         }
     }
@@ -355,9 +369,10 @@ int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const fl
     const size_t lds_q = sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(3 * TA, F));
     hipLaunchKernelGGL(k_l0_q16, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), lds_q, st, N, nz, h->d_counters.as<int>(),
                        h->d_zlist.as<int>(), h->d_l0At.as<uint4>(), h->n_embed, sbar_msg, vbar_msg, h->d_l0Q.as<float>());
-    hipLaunchKernelGGL(k_l0_bwd, dim3((N + 3) / 4), dim3(256), 0, st, N, M, nz, first_write, h->excl_vol, G,
-                       h->d_counters.as<int>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_l0Q.as<float>(), gbar,
-                       gbar_stride, n_groups);
+    if (sizeof(float) * 4 * M * nz * TBLK > 48 * 1024)   // (3 models x 3 species: 13.8 KB)
+        VSSR_HIP(h, hipFuncSetAttribute((const void *)k_l0_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_l0_bwd, dim3((N + 3) / 4), dim3(256), sizeof(float) * 4 * M * nz * TBLK, st, N, M, nz, first_write,
+                       h->excl_vol, G, h->d_counters.as<int>(), h->d_l0Q.as<float>(), gbar, gbar_stride, n_groups);
     return VSSR_OK;
 }
 
