@@ -359,27 +359,38 @@ __global__ void k_reduce_gbar_groups(int M, int n_groups, const int *__restrict_
 
 // forces = - sum_slots (G[slot] - G[rev[slot]]) per model, then ensemble mean / std.  gbar_model_stride: distance between
 // the (group-reduced) buffers of consecutive models.
-__global__ void k_finalize_forces(int N, int M, GraphView G, const int *__restrict__ counters,
-                                  const float4 *__restrict__ gbar, long long gbar_model_stride, double units_per_ev,
-                                  float *__restrict__ forces, float *__restrict__ forces_std) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per centre, lanes over its slots: the row's gradients are read as contiguous float4 (thread-per-atom reads were
+// one L1 access per lane), the reverse slots are gathered, and the 3 x M partial sums are combined by a fixed shuffle tree.
+__global__ void __launch_bounds__(256)
+k_finalize_forces(int N, int M, GraphView G, const int *__restrict__ counters,
+                  const float4 *__restrict__ gbar, long long gbar_model_stride, double units_per_ev,
+                  float *__restrict__ forces, float *__restrict__ forces_std) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= N || counters[2]) return;
+    const int e0 = G.row_start[c], e1 = G.row_start[c + 1];
     double fm[3] = {0, 0, 0}, f2[3] = {0, 0, 0};
     for (int m = 0; m < M; ++m) {
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
         const float4 *gb = gbar + (size_t)m * gbar_model_stride;
-        for (int e = G.row_start[c]; e < G.row_start[c + 1]; ++e) {
-            int r = G.rev[e];
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const int r = G.rev[e];
             if (r < 0) continue;
-            float4 a = gb[e], b = gb[r];
+            const float4 a = gb[e], b = gb[r];
             g0 += a.x - b.x; g1 += a.y - b.y; g2 += a.z - b.z;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            g0 += __shfl_xor(g0, off, 64); g1 += __shfl_xor(g1, off, 64); g2 += __shfl_xor(g2, off, 64);
         }
         double f[3] = {-(double)g0 / units_per_ev, -(double)g1 / units_per_ev, -(double)g2 / units_per_ev};
         for (int x = 0; x < 3; ++x) { fm[x] += f[x]; f2[x] += f[x] * f[x]; }
     }
-    for (int x = 0; x < 3; ++x) {
-        double mu = fm[x] / M;
-        double var = f2[x] / M - mu * mu;
+    if (lane < 3) {
+        const int x = lane;
+        const double fmx = x == 0 ? fm[0] : x == 1 ? fm[1] : fm[2], f2x = x == 0 ? f2[0] : x == 1 ? f2[1] : f2[2];
+        double mu = fmx / M;
+        double var = f2x / M - mu * mu;
         forces[3 * c + x] = (float)mu;
         if (forces_std) forces_std[3 * c + x] = (float)sqrt(var > 0 ? var : 0.0);
     }
@@ -587,7 +598,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
         if (n_groups > 1)
             hipLaunchKernelGGL(k_reduce_gbar_groups, dim3((unsigned)((h->slot_cap + 255) / 256)), dim3(256), 0, st, M, n_groups,
                                counters, sv.gbar, (long long)h->slot_cap);
-        hipLaunchKernelGGL(k_finalize_forces, dim3((N + 127) / 128), dim3(128), 0, st, N, M, G, counters, sv.gbar,
+        hipLaunchKernelGGL(k_finalize_forces, dim3((N + 3) / 4), dim3(256), 0, st, N, M, G, counters, sv.gbar,
                            (long long)h->slot_cap * n_groups, h->units_per_ev, h->d_forces.as<float>(),
                            h->d_forces_std.as<float>());
     }
