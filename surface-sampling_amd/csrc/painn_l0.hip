@@ -21,13 +21,15 @@ constexpr int KP = 24;              // padded radial index
 constexpr int TBLK = 4 * KP;        // floats per (atom, species) block: [scalar, x, y, z][24]
 
 // ---- T_i,z : one block of 96 threads per centre; thread = (component, kappa) ------------------------------------------
+template <int NZ>   // number of species of the batch (the per-slot select runs over exactly these)
 __global__ void __launch_bounds__(96)
-k_l0_accum(int nz, GraphView G, const int *__restrict__ counters, float *__restrict__ T) {
+k_l0_accum(GraphView G, const int *__restrict__ counters, float *__restrict__ T) {
+    constexpr int nz = NZ;
     if (counters[2]) return;
     const int i = blockIdx.x, comp = threadIdx.x / KP, kap = threadIdx.x % KP;
-    float acc[L0_MAX_SPECIES];
+    float acc[NZ];
 #pragma unroll
-    for (int z = 0; z < L0_MAX_SPECIES; ++z) acc[z] = 0.f;
+    for (int z = 0; z < NZ; ++z) acc[z] = 0.f;
     // slot counts are multiples of 4: four slots per iteration, all loads independent (species index from the per-slot
     // table written by k_edge_geom); the sum order over slots stays ascending
     // the per-slot record and species index are the same for every thread of the block: read through the constant
@@ -66,10 +68,11 @@ k_l0_accum(int nz, GraphView G, const int *__restrict__ counters, float *__restr
             const float uu = comp == 0 ? 1.f : comp == 1 ? er[u].x : comp == 2 ? er[u].y : er[u].z;
             const float val = r[u] * uu;
 #pragma unroll
-            for (int z = 0; z < L0_MAX_SPECIES; ++z) acc[z] += (z == zi[u]) ? val : 0.f;
+            for (int z = 0; z < NZ; ++z) acc[z] += (z == zi[u]) ? val : 0.f;
         }
     }
-    for (int z = 0; z < nz; ++z) T[((size_t)i * nz + z) * TBLK + comp * KP + kap] = acc[z];
+#pragma unroll
+    for (int z = 0; z < NZ; ++z) T[((size_t)i * nz + z) * TBLK + comp * KP + kap] = acc[z];
 }
 
 // ---- per-atom contractions on the matrix pipe (fp16 2-way split, see painn_node_mfma.hip / mfma16.h) -------------------------
@@ -354,7 +357,20 @@ int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_ms
     if (h->d_l0T.ensure(sizeof(float) * (size_t)N * nz * TBLK) ||
         h->d_l0Q.ensure(sizeof(float) * (size_t)M * N * nz * TBLK))
         return set_err(h, VSSR_E_NOMEM, "layer-0 factorisation buffers: out of device memory");
-    hipLaunchKernelGGL(k_l0_accum, dim3(N), dim3(96), 0, st, nz, G, h->d_counters.as<int>(), h->d_l0T.as<float>());
+    {
+        const int *cnt = h->d_counters.as<int>();
+        float *T = h->d_l0T.as<float>();
+        switch (nz) {
+            case 1: hipLaunchKernelGGL(k_l0_accum<1>, dim3(N), dim3(96), 0, st, G, cnt, T); break;
+            case 2: hipLaunchKernelGGL(k_l0_accum<2>, dim3(N), dim3(96), 0, st, G, cnt, T); break;
+            case 3: hipLaunchKernelGGL(k_l0_accum<3>, dim3(N), dim3(96), 0, st, G, cnt, T); break;
+            case 4: hipLaunchKernelGGL(k_l0_accum<4>, dim3(N), dim3(96), 0, st, G, cnt, T); break;
+            case 5: hipLaunchKernelGGL(k_l0_accum<5>, dim3(N), dim3(96), 0, st, G, cnt, T); break;
+            case 6: hipLaunchKernelGGL(k_l0_accum<6>, dim3(N), dim3(96), 0, st, G, cnt, T); break;
+            case 7: hipLaunchKernelGGL(k_l0_accum<7>, dim3(N), dim3(96), 0, st, G, cnt, T); break;
+            default: hipLaunchKernelGGL(k_l0_accum<L0_MAX_SPECIES>, dim3(N), dim3(96), 0, st, G, cnt, T); break;
+        }
+    }
     const size_t lds_fwd = sizeof(_Float16) * (plane_halves(TA, 32 * nz) + plane_halves(3 * TA, 32 * nz));
     hipLaunchKernelGGL(k_l0_fwd16, dim3((N + TA - 1) / TA), dim3(NTHREADS), lds_fwd, st, N, M, nz, h->d_counters.as<int>(),
                        h->d_Z.as<int>(), h->d_zlist.as<int>(), h->model_table.as<ModelW>(), h->d_l0A.as<uint4>(), h->n_embed,
