@@ -418,3 +418,34 @@ def test_degenerate_chains_in_one_batch(golden, oracle_mod, engine):
     assert np.abs(res["forces"][: len(far)]).max() == 0.0           # isolated atoms feel nothing
     alone = engine.evaluate([_arrays(slab)])
     assert float(alone["energy"][0]) == float(res["energy"][1])
+
+
+@pytest.mark.gpu
+def test_odd_chain_sizes_through_the_bundle_walk(golden, oracle_mod, engine):
+    """The MFMA edge kernels walk bundles of 4 centres sorted by slot count, dealt to the waves in snake order
+    (painn_edge_mfma.hip BundleWalk).  Chain sizes that are not multiples of 4, fewer bundles than waves, very uneven
+    coordination numbers (slab fragments in a big periodic box) and all of them mixed in one ragged batch must give the
+    oracle's energies and forces and must not depend on what else is in the batch."""
+    from surface_sampling_amd import structures
+
+    slab = golden.structure("SrTiO3_2x2_pristine")
+    rng = np.random.default_rng(7)
+    chains = []
+    for n_keep in (57, 41, 13, 6, 5, 3, 2):
+        keep = np.sort(rng.choice(len(slab), size=n_keep, replace=False))
+        chains.append(structures.Structure(slab.numbers[keep], slab.positions[keep], slab.cell, slab.pbc))
+    # a fragment in a large box: surface-like atoms with few neighbours next to fully coordinated ones
+    box = slab.cell.copy()
+    box[0, 0] *= 3.0
+    box[1, 1] *= 3.0
+    chains.append(structures.Structure(slab.numbers, slab.positions, box, slab.pbc))
+    res = engine.evaluate([_arrays(s) for s in chains])
+    assert np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()
+    for b, s in enumerate(chains):
+        a0, a1 = res["cfg_start"][b], res["cfg_start"][b + 1]
+        ref = _oracle(golden, oracle_mod, s)
+        assert abs(float(res["energy"][b]) - ref["energy"]) <= E_TOL, (b, len(s), float(res["energy"][b]), ref["energy"])
+        assert np.abs(res["forces"][a0:a1] - ref["forces"]).max() <= F_TOL, (b, len(s))
+        alone = engine.evaluate([_arrays(s)])
+        assert float(alone["energy"][0]) == float(res["energy"][b])
+        assert np.array_equal(alone["forces"], res["forces"][a0:a1])
