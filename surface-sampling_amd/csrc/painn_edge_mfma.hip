@@ -7,13 +7,16 @@
 //
 // Decomposition: one workgroup = (chain, 16-feature slice, ensemble member).  It stages the slice of phi and v of ALL
 // atoms of its chain in LDS once (exactly the compulsory HBM bytes of SURVEY §8(d): every phi/v element is read by one
-// workgroup only), then walks the chain's padded CSR in steps of 16 slots per wave (4 streams x 4 slots).  The filter
-// tile D[16 features][16 slots] = Wd_ext . rho runs on v_mfma_f32_16x16x32_f16 (fp16 2-way split, three products):
-// weights are the A operand (resident in registers), rho the B operand, read as operand-ready pieces from the per-slot
-// table that k_edge_geom (nbr.hip) writes once per evaluation; unit vectors / local neighbor ids come from the same
-// pass.  Lane (p, fq) owns slot p and features 4 fq .. 4 fq + 3: it gathers the neighbor's values from the LDS tile,
-// forms the messages in registers and accumulates them; a centre is written once, after a 4-lane DPP reduction.  No
-// atomics; the summation order per centre is the CSR order regardless of batching.
+// workgroup only), then walks the chain's padded CSR in steps of 16 slots per wave: 4 streams x 4 slots, the 4 streams
+// being the 4 centres of a "bundle" of (nearly) equal slot count (BundleWalk below).  The filter tile
+// D[16 features][16 slots] = Wd_ext . rho runs on v_mfma_f32_16x16x32_f16 (fp16 2-way split, three products): weights are
+// the A operand (resident in registers), rho the B operand, read as operand-ready pieces from the quad-interleaved
+// per-slot table that k_edge_geom (nbr.hip) writes once per evaluation; the slot's unit vector, 1 / d and neighbor index
+// ride in the spare K entries of the same table (selector tile, filter_tiles_sel).  Lane (p, fq) owns slot p and features
+// 4 fq .. 4 fq + 3: it gathers the neighbor's values from the LDS tile, forms the messages in registers and accumulates
+// them; a centre is written once, after a 4-lane DPP reduction.  No atomics; the summation order per centre is the CSR
+// order regardless of batching.  What bounds these kernels and what was tried: DESIGN.md section 5,
+// profiles/r01/NOTES_edge_r1b.md.
 // Chains larger than the LDS capacity (N > ~400) fall back to the gather kernels in painn.hip.
 #include "vssr_internal.h"
 
