@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split this GPU's chains over S engines (own HIP streams) that run concurrently; default 1 keeps "
+                         "the per-kernel launch durations of the roofline free of overlap (DESIGN.md section 5)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,21 +150,28 @@ def main():
     first, count = chain_range(world * B, world, rank)   # block partition of the global chain list
     chains = build_chains(S, first, count)
 
-    eng = backend.PainnEngine(blobs, device=local_rank, offset_per_z=table, offset_const=const)
-    eng.upload([(s.numbers, s.positions, s.cell, s.pbc) for s in chains])   # inputs resident in HBM
+    n_str = max(1, min(args.streams, count))
+    engs = []
+    for k in range(n_str):   # block partition of this rank's chains over its engines
+        lo, hi = (k * count) // n_str, ((k + 1) * count) // n_str
+        e = backend.PainnEngine(blobs, device=local_rank, offset_per_z=table, offset_const=const)
+        e.upload([(s.numbers, s.positions, s.cell, s.pbc) for s in chains[lo:hi]])   # inputs resident in HBM
+        engs.append(e)
     want = backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD
     dev = torch.device("cuda", local_rank)
     gathered = torch.empty(world * count * 2, dtype=torch.float32, device=dev) if world > 1 else None
 
     def step():
-        eng.run(want)
+        for e in engs:
+            e.run(want)
         if world > 1:   # the path's only exchange: per-chain (E_mean, E_std) to every rank
-            res = eng.download(backend.WANT_ENERGY | backend.WANT_STD)
-            mine = torch.from_numpy(np.concatenate([res["energy"], res["energy_std"]])).to(dev)
+            parts = [e.download(backend.WANT_ENERGY | backend.WANT_STD) for e in engs]
+            mine = torch.from_numpy(np.concatenate([p["energy"] for p in parts] + [p["energy_std"] for p in parts])).to(dev)
             dist.all_gather_into_tensor(gathered, mine)
 
     def fence():
-        eng.synchronize()
+        for e in engs:
+            e.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -169,24 +179,33 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    eng.profile_enable(True)
-    eng.profile_reset()
+    for e in engs:
+        e.profile_enable(True)
+        e.profile_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile_enable(False)
+    prof = {}
+    for e in engs:   # HIP-event times of every engine's own stream, summed per kernel class
+        for name, v in e.profile_read().items():
+            acc = prof.setdefault(name, {"launches": 0, "total_ms": 0.0})
+            acc["launches"] += v["launches"]
+            acc["total_ms"] += v["total_ms"]
+        e.profile_enable(False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    stats = eng.stats()
-    res = eng.download(want)
-    if not (np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()):
-        raise SystemExit("non-finite results in the timed region")
+    stats = {"atoms": 0, "edges": 0, "slots": 0}
+    for e in engs:
+        for k, v in e.stats().items():
+            stats[k] += v
+        res = e.download(want)
+        if not (np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()):
+            raise SystemExit("non-finite results in the timed region")
 
     if rank == 0:
         total_evals = world * count * args.steps
@@ -202,10 +221,11 @@ def main():
                     "algorithmic_bytes_per_launch": nbytes,
                     "achieved_GBps": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
 
-        bwd = kernel_view("edge_message_bwd", reverse_pass_flops(stats["slots"], M),
-                          reverse_pass_bytes(stats["atoms"], stats["edges"], M))
-        fwd = kernel_view("edge_message_fwd", neighbor_sum_flops(stats["slots"], M),
-                          neighbor_sum_bytes(stats["atoms"], stats["edges"], M))
+        # (per launch = per engine: with --streams S a launch covers 1/S of this GPU's chains and overlaps the other engines)
+        bwd = kernel_view("edge_message_bwd", reverse_pass_flops(stats["slots"], M) / n_str,
+                          reverse_pass_bytes(stats["atoms"], stats["edges"], M) / n_str)
+        fwd = kernel_view("edge_message_fwd", neighbor_sum_flops(stats["slots"], M) / n_str,
+                          neighbor_sum_bytes(stats["atoms"], stats["edges"], M) / n_str)
         step_ms = sum(v["total_ms"] for v in prof.values()) / args.steps
         line = {
             "metric": "MC energy-evaluations/sec (SrTiO3(001) ~250-atom slabs, 3-model PaiNN ensemble E+F incl. neighbor list)",
@@ -215,6 +235,7 @@ def main():
             "config": {"workload": f"SrTiO3(001) PaiNN x3, {count} batched independent chains per GPU "
                                    f"(BASELINE configs[{3 if world == 1 else 4}]), 248-272 atoms/chain",
                        "chains_per_gpu": count, "atoms_per_gpu": stats["atoms"], "edges_per_gpu": stats["edges"],
+                       "streams_per_gpu": n_str,
                        "parallelism": f"chains sharded x{world}, RCCL all_gather of per-chain energies"},
             # The reverse neighbor pass is instruction / matrix-pipe bound, not HBM bound (its HBM view is given beside
             # it): `achieved` = fp32-precision algorithmic TFLOP/s (filter GEMVs + adjoint arithmetic, formulas above)
@@ -243,7 +264,8 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    eng.close()
+    for e in engs:
+        e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
