@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvssr_eval.so")
+# VSSR_EVAL_LIB selects another build of the same library (A/B measurements, tools/gpu_ab.sh); there is still no fallback
+LIB_PATH = os.environ.get("VSSR_EVAL_LIB") or os.path.join(_HERE, "libvssr_eval.so")
 
 WANT_ENERGY, WANT_FORCES, WANT_STD, WANT_PER_MODEL, WANT_PER_ATOM = 1, 2, 4, 8, 16
 WANT_ALL = WANT_ENERGY | WANT_FORCES | WANT_STD | WANT_PER_MODEL | WANT_PER_ATOM

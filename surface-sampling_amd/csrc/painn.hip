@@ -555,38 +555,61 @@ int painn_run(vssr_handle *h, uint32_t want) {
         launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
         P.end(st);
     }
-    P.begin(KC_READOUT, st);
-    hipLaunchKernelGGL(k_readout, g_tile, blk, 0, st, N, H, MW, sv.s_in[L], sv.e_excl, h->excl_vol, sv.e_atom,
-                       sv.sbar);
-    P.end(st);
+    // Readout.  With forces wanted (and the compiled readout width) it runs as the head of the last layer's reverse kernel;
+    // energy-only evaluations use the stand-alone kernel built from the same code (identical per-atom energies).
+    const bool fused = readout_mfma_supported(H);
+    const bool want_forces = (want & VSSR_WANT_FORCES) != 0;
+    const float *e_excl = h->excl_vol ? sv.e_excl : (const float *)nullptr;
+    if (!(fused && want_forces)) {
+        P.begin(KC_READOUT, st);
+        if (fused) launch_readout_mfma(st, N, M, MW, sv.s_in[L], e_excl, sv.e_atom);
+        else
+            hipLaunchKernelGGL(k_readout, g_tile, blk, 0, st, N, H, MW, sv.s_in[L], sv.e_excl, h->excl_vol, sv.e_atom,
+                               sv.sbar);
+        P.end(st);
+    }
 
-    if (want & VSSR_WANT_FORCES) {
+    if (want_forces) {
+        // Reverse pass.  update_bwd(l) carries the producer of its sbar input as its head: the readout (l = L - 1) or the
+        // reverse of the message MLP of layer l + 1 (painn_node_mfma.hip); the adjoint of s_msg alternates between two
+        // buffers so that a launch never reads the buffer it writes.
+        float *sb_buf[2] = {sv.sbar_msg, sv.sbar};
         for (int l = L - 1; l >= 0; --l) {
+            float *sbar_msg_l = fused ? sb_buf[(L - 1 - l) & 1] : sv.sbar_msg;
+            const float *sbar_msg_up = sb_buf[(L - l) & 1];   // adjoint of s_msg[l + 1] (fused path, l < L - 1)
             P.begin(KC_UPDATE_BWD, st);
-            launch_update_bwd_mfma(st, N, M, l, (int)(l == L - 1), MW, sv.s_msg[l], sv.v_msg[l], sv.sbar, sv.vbar,
-                                   sv.sbar_msg, sv.vbar_msg);
+            if (!fused)
+                launch_update_bwd_mfma(st, N, M, l, 0, (int)(l == L - 1), MW, sv.s_msg[l], sv.v_msg[l], sv.sbar, sv.vbar,
+                                       nullptr, nullptr, nullptr, nullptr, sbar_msg_l, sv.vbar_msg);
+            else if (l == L - 1)
+                launch_update_bwd_mfma(st, N, M, l, 1, 1, MW, sv.s_msg[l], sv.v_msg[l], nullptr, sv.vbar, sv.s_in[L], nullptr,
+                                       e_excl, sv.e_atom, sbar_msg_l, sv.vbar_msg);
+            else
+                launch_update_bwd_mfma(st, N, M, l, 2, 0, MW, sv.s_msg[l], sv.v_msg[l], sbar_msg_up, sv.vbar, sv.s_in[l + 1],
+                                       sv.phibar, nullptr, nullptr, sbar_msg_l, sv.vbar_msg);
             P.end(st);
+            sv.sbar_msg_l0 = sbar_msg_l;
             P.begin((l == 0 && l0_fact) ? KC_L0_BWD : KC_EDGE_BWD, st);
             int accumulate = (l != L - 1);
             if (l == 0 && l0_fact) {
-                rc = l0_run_reverse(h, G, (int)(L == 1), sv.sbar_msg, sv.vbar_msg, sv.gbar, (long long)h->slot_cap,
+                rc = l0_run_reverse(h, G, (int)(L == 1), sbar_msg_l, sv.vbar_msg, sv.gbar, (long long)h->slot_cap,
                                     n_groups);
                 if (rc) return rc;
             } else if (use_edge_mfma && l > 0)
                 launch_edge_bwd_mfma(st, N, h->n_cfg, M, l, (int)(l == L - 1), h->max_cfg_atoms, MW, G, counters,
-                                     (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l], sv.sbar_msg,
+                                     (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l], sbar_msg_l,
                                      sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap, n_groups);
             else if (l == 0)   // adds into partial buffer 0 of every model (model stride = n_groups buffers)
                 hipLaunchKernelGGL(k_edge_bwd<true>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                    h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
-                                   sv.sbar_msg, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
+                                   sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
                                    (long long)h->slot_cap * n_groups);
             else
                 hipLaunchKernelGGL(k_edge_bwd<false>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                    h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
-                                   sv.sbar_msg, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap);
+                                   sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap);
             P.end(st);
-            if (l > 0) {
+            if (l > 0 && !fused) {
                 P.begin(KC_MSG_MLP_BWD, st);
                 launch_msg_mlp_bwd_mfma(st, N, M, l, MW, sv.s_in[l], sv.phibar, sv.sbar_msg, sv.sbar);
                 P.end(st);

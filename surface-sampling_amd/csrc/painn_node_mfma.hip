@@ -45,11 +45,22 @@ namespace vssr {
 // acc[t][c] += A(rows 16 t .. 16 t + 15, K) . W(column tile c)^T.  A fragment of lane (r = lane & 15, g = lane >> 4) for
 // chunk q: row 16 t + r, k = 32 q + 8 g .. + 7 -> one ds_read_b128 per piece.  wq[c]: pieces of a 16-column tile,
 // [K/32][2][64 lanes] uint4 (pack_mfma_tiles16).  D: lane holds column r, rows 4 g .. 4 g + 3 of the 16 x 16 tile.
-template <int K, int NRT, int NCT>
+// gemm16<K, NRT, NCT, PF>.  PF = 0: chunk groups one after the other (load, wait, multiply) in a rolled loop -- the
+// smallest register footprint (update_fwd runs two workgroups per CU inside 128 registers).
+// PF = 1: software pipeline.  Measured per-phase timings (profiles/r02/NOTES_node_kernels.md): a chunk group cost ~0.65 us
+// wall whatever its matrix work (12 .. 36 MFMAs), i.e. the load -> wait -> MFMA round trip.  The weight pieces (global
+// memory, L2 latency several hundred cycles under load) of group i + 1 are requested BEFORE the matrix instructions of
+// group i are issued and land in the other half of a ping-pong register buffer; GEMMs with fewer than three tiles also
+// read the A fragments (LDS) of group i + 1 ahead.  The loop is fully unrolled (K is a template parameter) so that the
+// buffer halves are static registers.  Issue rules as before: loads are issued in front of an MFMA block, never inside
+// it; the block is pinned with scheduling barriers.
+template <int K, int NRT, int NCT, int PF = 0>
 __device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)[NCT], f32x4 (&acc)[NRT][NCT]) {
     constexpr int NT = NRT * NCT, NACC = NT >= 3 ? 1 : 2;
     constexpr int NQ = K / 32;
     static_assert(NQ % NACC == 0, "chunk groups");
+    constexpr int NG = NQ / NACC;
+    constexpr bool PFA = PF && NT < 3;   // A fragments one group ahead as well
     constexpr int wi[3] = {0, 1, 0}, ri[3] = {1, 0, 0};   // A-piece, W-piece: a_h w_l, a_l w_h, a_h w_h
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const _Float16 *ah = A.h + r * A.ld + 8 * g, *al = A.l + r * A.ld + 8 * g;
@@ -60,36 +71,83 @@ __device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)
         for (int t = 0; t < NRT; ++t)
 #pragma unroll
             for (int c = 0; c < NCT; ++c) part[j][t][c] = j == 0 ? acc[t][c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (PF == 0) {
 #pragma unroll 1
-    for (int q0 = 0; q0 < NQ; q0 += NACC) {
-        u32x4 a[NACC][NRT][2], b[NACC][NCT][2];
+        for (int q0 = 0; q0 < NQ; q0 += NACC) {
+            u32x4 a[NACC][NRT][2], b[NACC][NCT][2];
 #pragma unroll
-        for (int j = 0; j < NACC; ++j) {
-            const int q = q0 + j;
+            for (int j = 0; j < NACC; ++j) {
+                const int q = q0 + j;
 #pragma unroll
-            for (int c = 0; c < NCT; ++c)
+                for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                for (int pc = 0; pc < 2; ++pc) b[j][c][pc] = gload4u(wq[c] + ((size_t)(q * 2 + pc) * 64 + lane));
+                    for (int pc = 0; pc < 2; ++pc) b[j][c][pc] = gload4u(wq[c] + ((size_t)(q * 2 + pc) * 64 + lane));
 #pragma unroll
-            for (int t = 0; t < NRT; ++t) {
-                a[j][t][0] = *reinterpret_cast<const u32x4 *>(ah + t * 16 * A.ld + 32 * q);
-                a[j][t][1] = *reinterpret_cast<const u32x4 *>(al + t * 16 * A.ld + 32 * q);
+                for (int t = 0; t < NRT; ++t) {
+                    a[j][t][0] = *reinterpret_cast<const u32x4 *>(ah + t * 16 * A.ld + 32 * q);
+                    a[j][t][1] = *reinterpret_cast<const u32x4 *>(al + t * 16 * A.ld + 32 * q);
+                }
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < NACC; ++j)
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c) {
+                            part[j][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                __builtin_bit_cast(f16x8, a[j][t][wi[k]]), __builtin_bit_cast(f16x8, b[j][c][ri[k]]),
+                                part[j][t][c], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+        }
+    } else {
+        u32x4 b[2][NACC][NCT][2], a[PFA ? 2 : 1][NACC][NRT][2];
+        auto load_b = [&](int buf, int grp) {
 #pragma unroll
             for (int j = 0; j < NACC; ++j)
 #pragma unroll
-                for (int t = 0; t < NRT; ++t)
+                for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                    for (int c = 0; c < NCT; ++c) {
-                        part[j][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                            __builtin_bit_cast(f16x8, a[j][t][wi[k]]), __builtin_bit_cast(f16x8, b[j][c][ri[k]]),
-                            part[j][t][c], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    for (int pc = 0; pc < 2; ++pc)
+                        b[buf][j][c][pc] = gload4u(wq[c] + ((size_t)((grp * NACC + j) * 2 + pc) * 64 + lane));
+        };
+        auto load_a = [&](int buf, int grp) {
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) {
+                const int q = grp * NACC + j;
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) {
+                    a[buf][j][t][0] = *reinterpret_cast<const u32x4 *>(ah + t * 16 * A.ld + 32 * q);
+                    a[buf][j][t][1] = *reinterpret_cast<const u32x4 *>(al + t * 16 * A.ld + 32 * q);
+                }
+            }
+        };
+        load_b(0, 0);
+        if (PFA) load_a(0, 0);
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            const int cur = grp & 1, ca = PFA ? cur : 0;
+            if (grp + 1 < NG) load_b(cur ^ 1, grp + 1);
+            if (PFA) { if (grp + 1 < NG) load_a(cur ^ 1, grp + 1); }
+            else load_a(0, grp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < NACC; ++j)
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c) {
+                            part[j][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                __builtin_bit_cast(f16x8, a[ca][j][t][wi[k]]), __builtin_bit_cast(f16x8, b[cur][j][c][ri[k]]),
+                                part[j][t][c], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+        }
     }
 #pragma unroll
     for (int t = 0; t < NRT; ++t)
@@ -101,6 +159,9 @@ __device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)
         }
 }
 
+#ifndef UPD_PF
+#define UPD_PF 1   // pipelined GEMMs in the reverse update kernel (256-register budget)
+#endif
 template <int NRT, int NCT>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRT][NCT]) {
 #pragma unroll
@@ -202,42 +263,51 @@ k_msg_mlp_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__r
 
 // ---- update block -----------------------------------------------------------------------------------------------
 // LDS map (halves): vt [3*TA][F] | hs [TA][2F] | as [TA][F], two planes each (the reverse pass overlays it)
-constexpr int OFF_VT = 0;
-constexpr int OFF_HS = plane_halves(3 * TA, F);
-constexpr int OFF_AS = OFF_HS + plane_halves(TA, 2 * F);
-constexpr int UPD_LDS_HALVES = OFF_AS + plane_halves(TA, F);   // 51 712 halves = 103 424 B
-static_assert(plane_halves(TA, F3) <= OFF_HS, "qb overlays vt");
-static_assert(plane_halves(3 * TA, 2 * F) <= UPD_LDS_HALVES, "[Ubar | Vbar] overlays the whole region");
+// RT = 16-row tiles per wave = TA / 16.  RT = 2: 32 atoms per workgroup, one workgroup per CU (the weight stream from L2 is
+// amortised over 32 atoms); RT = 1: 16 atoms, half the LDS and accumulator registers, two workgroups per CU whose memory /
+// LDS / matrix phases overlap.
+template <int RT>
+struct UpdLds {
+    static constexpr int TA = 16 * RT;
+    static constexpr int OFF_VT = 0;
+    static constexpr int OFF_HS = plane_halves(3 * TA, F);
+    static constexpr int OFF_AS = OFF_HS + plane_halves(TA, 2 * F);
+    static constexpr int HALVES = OFF_AS + plane_halves(TA, F);   // RT = 2: 51 712 halves = 103 424 B
+    static_assert(plane_halves(TA, F3) <= OFF_HS, "qb overlays vt");
+    static_assert(plane_halves(3 * TA, 2 * F) <= HALVES, "[Ubar | Vbar] overlays the whole region");
+};
 
+template <int RT>
 struct UpdRegs {
-    f32x4 uv[6][2];   // [2 x + t][0] = U v_x, [..][1] = V v_x for column `col`, atom rows 16 t + 4 g + i
-    f32x4 h3[2];      // pre-activation of the gate MLP
-    f32x4 gate[2][3]; // a_vv, a_sv, a_ss
-    f32x4 nrm[2], inner[2];
+    f32x4 uv[3 * RT][2];   // [RT x + t][0] = U v_x, [..][1] = V v_x for column `col`, atom rows 16 t + 4 g + i
+    f32x4 h3[RT];          // pre-activation of the gate MLP
+    f32x4 gate[RT][3];     // a_vv, a_sv, a_ss
+    f32x4 nrm[RT], inner[RT];
 };
 
 // Shared forward part: needs vt (v_msg tile, rows x*TA+atom) and hs[:, :F] (s_msg tile) loaded + synced.
-template <int PHB>   // PHB: first phase-timing slot (debug builds)
-__device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, const LaneGeo &L, UpdRegs &R) {
+template <int RT, int PHB>   // PHB: first phase-timing slot (debug builds)
+__device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, const LaneGeo &L, UpdRegs<RT> &R) {
+    constexpr int TA = 16 * RT, OFF_VT = UpdLds<RT>::OFF_VT, OFF_HS = UpdLds<RT>::OFF_HS, OFF_AS = UpdLds<RT>::OFF_AS;
     const Planes vt = make_planes(ldsh + OFF_VT, 3 * TA, F), hs = make_planes(ldsh + OFF_HS, TA, 2 * F),
                  as_ = make_planes(ldsh + OFF_AS, TA, F);
     zero_acc(R.uv);
     PH_INIT
     {
         const uint4 *wp[2] = {WTILE(U, L.w, F), WTILE(V, L.w, F)};
-        gemm16<F, 6, 2>(vt, wp, R.uv);
+        gemm16<F, 3 * RT, 2, UPD_PF>(vt, wp, R.uv);
     }
     PH(PHB + 1)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float n2 = 0.f, in = 0.f;
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
-                const float vv = R.uv[2 * x + t][1][i];
+                const float vv = R.uv[RT * x + t][1][i];
                 n2 += fmaf(vv, vv, 1e-15f);
-                in = fmaf(R.uv[2 * x + t][0][i], vv, in);
+                in = fmaf(R.uv[RT * x + t][0][i], vv, in);
             }
             R.nrm[t][i] = sqrtf(n2);
             R.inner[t][i] = in;
@@ -247,13 +317,13 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
     __syncthreads();
     PH(PHB + 3)
     {
-        f32x4 acc[2][1];
+        f32x4 acc[RT][1];
         zero_acc(acc);
         const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F)};
-        gemm16<2 * F, 2, 1>(hs, wp, acc);
+        gemm16<2 * F, RT, 1, UPD_PF>(hs, wp, acc);
         const float b = W.b3[L.col];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 R.h3[t][i] = acc[t][0][i] + b;
@@ -266,24 +336,30 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
     {
         zero_acc(R.gate);
         const uint4 *wp[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
-        gemm16<F, 2, 3>(as_, wp, R.gate);
+        gemm16<F, RT, 3, UPD_PF>(as_, wp, R.gate);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float b = W.b4[c * F + L.col];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) R.gate[t][c] += (f32x4){b, b, b, b};
+            for (int t = 0; t < RT; ++t) R.gate[t][c] += (f32x4){b, b, b, b};
         }
     }
     PH(PHB + 6)
 }
 
-__device__ __forceinline__ void load_update_tiles(_Float16 *ldsh, const float *__restrict__ s_msg,
-                                                  const float *__restrict__ v_msg, size_t mN, int a0, int N) {
-    const Planes vt = make_planes(ldsh + OFF_VT, 3 * TA, F), hs = make_planes(ldsh + OFF_HS, TA, 2 * F);
+template <int RT>
+__device__ __forceinline__ void load_update_v(_Float16 *ldsh, const float *__restrict__ v_msg, size_t mN, int a0, int N) {
+    constexpr int TA = 16 * RT;
+    const Planes vt = make_planes(ldsh + UpdLds<RT>::OFF_VT, 3 * TA, F);
     load_rows_split<3 * TA>(vt, 0, [&](int row) {
         int x = row / TA, a = min(a0 + (row % TA), N - 1);
         return v_msg + ((mN + a) * 3 + x) * F;
     });
+}
+template <int RT>
+__device__ __forceinline__ void load_update_s(_Float16 *ldsh, const float *__restrict__ s_msg, size_t mN, int a0, int N) {
+    constexpr int TA = 16 * RT;
+    const Planes hs = make_planes(ldsh + UpdLds<RT>::OFF_HS, TA, 2 * F);
     load_rows_split<TA>(hs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
 }
 
@@ -388,31 +464,111 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
         });
 }
 
+// ---- readout on the matrix pipe ---------------------------------------------------------------
+// e_i = w6 . swish(W5 s_i + b5) + b6 (+ excluded volume) ; sbar_i = W5^T (w6 * swish'(W5 s_i + b5)).  Needs the s tile in
+// `xs` (planes, synced).  hp: planes [TA][RH] for the hidden adjoint; red: [RH / 16][TA] floats.  The same code serves the
+// energy-only kernel and the head of the fused reverse kernel, so both produce identical per-atom energies.
+constexpr int RH = 64;   // hidden width of the compiled matrix-pipe readout (other widths use k_readout, painn.hip)
+template <int RT, bool WANT_SBAR>
+__device__ __forceinline__ void readout_head(const ModelW &W, const Planes &xs, const Planes &hp, float *red, const LaneGeo &L,
+                                             int a0, int N, size_t mN, const float *__restrict__ e_excl,
+                                             float *__restrict__ e_atom, f32x4 (&sb)[RT]) {
+    constexpr int NCW = RH / 16;   // waves that own a column tile of the hidden layer
+    constexpr int TA = 16 * RT;
+    const int lane = threadIdx.x & 63;
+    if (L.w < NCW) {   // wave-uniform
+        f32x4 acc[RT][1];
+        zero_acc(acc);
+        const uint4 *wp[1] = {W.qW5 + (size_t)L.w * 4 * F};
+        gemm16<F, RT, 1>(xs, wp, acc);
+        const float b = W.b5[L.col], w6 = W.w6[L.col];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float hval = acc[t][0][i] + b;
+                float es = w6 * swish(hval);
+                if (WANT_SBAR) store_split(hp, L.row(t, i), L.col, w6 * dswish(hval));
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) es += __shfl_xor(es, off, 16);   // the tile's 16 hidden units, fixed order
+                if ((lane & 15) == 0) red[L.w * TA + L.row(t, i)] = es;
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x < TA) {
+        const int atom = a0 + threadIdx.x;
+        if (atom < N) {
+            float e = W.b6[0];
+#pragma unroll
+            for (int k = 0; k < NCW; ++k) e += red[k * TA + threadIdx.x];
+            if (e_excl) e += e_excl[mN + atom];
+            e_atom[mN + atom] = e;
+        }
+    }
+    if (WANT_SBAR) {
+        f32x4 acc[RT][1];
+        zero_acc(acc);
+        const uint4 *wp[1] = {W.qW5t + (size_t)L.w * 4 * RH};
+        gemm16<RH, RT, 1>(hp, wp, acc);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) sb[t] = acc[t][0];
+    }
+}
+
+// energy-only evaluations: readout of the final scalar features
+__global__ void __launch_bounds__(NTHREADS)
+k_readout_mfma(int N, const ModelW *__restrict__ MW, const float *__restrict__ s, const float *__restrict__ e_excl,
+               float *__restrict__ e_atom) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    const LaneGeo L;
+    const size_t mN = (size_t)m * N;
+    const Planes xs = make_planes(ldsh, TA, F), hp = make_planes(ldsh + plane_halves(TA, F), TA, RH);
+    float *red = reinterpret_cast<float *>(ldsh + plane_halves(TA, F) + plane_halves(TA, RH));
+    load_rows_split<TA>(xs, 0, [&](int row) { return s + (mN + min(a0 + row, N - 1)) * F; });
+    __syncthreads();
+    f32x4 sb[2];
+    readout_head<2, false>(MW[m], xs, hp, red, L, a0, N, mN, e_excl, e_atom, sb);
+}
+
 // reverse: (sbar, vbar) of the block outputs -> (sbar_msg, vbar_msg) of its inputs.
 // Adjoint algebra as in the oracle (oracle/painn_impl.inc, "update block^T"):
 //   abar_vv = sum_x vbar_x Uv_x ; qbar = [abar_vv, sbar*inner, sbar]
 //   h3bar = (W4^T qbar) * swish'(h3) ; [sbar_extra ; nbar] = W3^T h3bar
 //   Ubar_x = vbar_x a_vv + sbar a_sv Vv_x ; Vbar_x = sbar a_sv Uv_x + nbar Vv_x / |Vv|
 //   vbar_msg = vbar + U^T Ubar + V^T Vbar ; sbar_msg = sbar + sbar_extra
-__global__ void __launch_bounds__(NTHREADS)
+// The producer of sbar is fused in as the kernel's HEAD (the result is born in the accumulator layout the body wants, so it
+// never travels through HBM and the scalar, uncoalesced sbar reads / writes of separate kernels disappear):
+//   MODE 0: sbar is read from memory (readout widths other than RH);
+//   MODE 1: last layer -- the readout and its reverse (e_atom is written here; vbar is zero by construction);
+//   MODE 2: layer l < L - 1 -- the reverse of the message MLP of layer l + 1:
+//           sbar = sbar_msg(l+1) + W1^T[(W2^T phibar) * swish'(W1 s_in(l+1) + b1)]   (weights of layer l + 1)
+// s_next: MODE 1: final scalar features, MODE 2: s_in(l+1); sbar_src: MODE 0: sbar, MODE 2: sbar_msg(l+1) (a different
+// buffer than the sbar_msg this launch writes).
+template <int MODE, int RT>
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(RT == 1 ? 4 : 2, RT == 1 ? 4 : 2)))
 k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
-                  const float *__restrict__ v_msg, const float *__restrict__ sbar, const float *__restrict__ vbar,
-                  float *__restrict__ sbar_msg, float *__restrict__ vbar_msg) {
+                  const float *__restrict__ v_msg, const float *__restrict__ sbar_src, const float *__restrict__ vbar,
+                  const float *__restrict__ s_next, const float *__restrict__ phibar, const float *__restrict__ e_excl,
+                  float *__restrict__ e_atom, float *__restrict__ sbar_msg, float *__restrict__ vbar_msg) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    constexpr int TA = 16 * RT, OFF_VT = UpdLds<RT>::OFF_VT, OFF_AS = UpdLds<RT>::OFF_AS, UPD_LDS_HALVES = UpdLds<RT>::HALVES;
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
     PH_INIT
-    f32x4 sb[2];   // sbar in the accumulator layout: requested first, needed after the forward recomputation
+    f32x4 sb[RT];   // sbar in the accumulator layout
+    if (MODE != 1) {   // requested first, needed after the head / the forward recomputation
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sb[t][i] = sbar[(mN + min(a0 + L.row(t, i), N - 1)) * F + L.col];
-    load_update_tiles(ldsh, s_msg, v_msg, mN, a0, N);
+            for (int i = 0; i < 4; ++i) sb[t][i] = sbar_src[(mN + min(a0 + L.row(t, i), N - 1)) * F + L.col];
+    }
     // vbar of the tile (96 rows, fp32) stays in LDS behind the planes for the whole kernel: it is needed three times in the
     // accumulator layout (one column per lane), where direct global reads are scalar, uncoalesced and latency-exposed
     float *VB = reinterpret_cast<float *>(ldsh + UPD_LDS_HALVES);   // [x * TA + atom][FT]
+    if (MODE == 1) vbar_is_zero = 1;   // (the region hosts the readout scratch)
     if (!vbar_is_zero) {
         constexpr int NIT = 3 * TA * (F / 4) / NTHREADS;
         float4 vv[NIT];
@@ -427,22 +583,78 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
             *reinterpret_cast<float4 *>(VB + row * FT + 4 * c4) = vv[it];
         }
     }
-    __syncthreads();
+    load_update_s<RT>(ldsh, s_msg, mN, a0, N);
+    if (MODE == 0) {
+        load_update_v<RT>(ldsh, v_msg, mN, a0, N);
+        __syncthreads();
+    } else if (MODE == 1) {
+        // head: readout of s_next (tile in the `as` region; hidden adjoint + reduction scratch in the unused vbar region)
+        load_update_v<RT>(ldsh, v_msg, mN, a0, N);
+        const Planes xs = make_planes(ldsh + OFF_AS, TA, F);
+        const Planes hp = make_planes(ldsh + UPD_LDS_HALVES, TA, RH);
+        float *red = reinterpret_cast<float *>(ldsh + UPD_LDS_HALVES + plane_halves(TA, RH));
+        load_rows_split<TA>(xs, 0, [&](int row) { return s_next + (mN + min(a0 + row, N - 1)) * F; });
+        __syncthreads();
+        PH(40)
+        readout_head<RT, true>(MW[m], xs, hp, red, L, a0, N, mN, e_excl, e_atom, sb);
+        PH(41)
+        // (the body's first barrier orders the last reads of xs before anything overwrites the `as` region)
+    } else {
+        // head: reverse of the message MLP of layer l + 1.  phibar tile over the (not yet loaded) v tile, s_next / h1bar in
+        // the `as` region; the v tile follows once the head is done with the region.
+        const LayerW &Wn = MW[m].layer[l + 1];
+        const Planes xs = make_planes(ldsh + OFF_AS, TA, F), pb = make_planes(ldsh + OFF_VT, TA, F3);
+        load_rows_split<TA>(xs, 0, [&](int row) { return s_next + (mN + min(a0 + row, N - 1)) * F; });
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            load_rows_split<TA>(pb, c * F, [&](int row) { return phibar + (mN + min(a0 + row, N - 1)) * F3 + c * F; });
+        __syncthreads();
+        PH(42)
+        f32x4 h1[RT][1], a1[RT][1];
+        zero_acc(h1);
+        zero_acc(a1);
+        {
+            const uint4 *wp[1] = {Wn.qW1 + (size_t)L.w * 4 * F};
+            gemm16<F, RT, 1, UPD_PF>(xs, wp, h1);
+            const uint4 *wq[1] = {Wn.qW2t + (size_t)L.w * 4 * F3};
+            gemm16<F3, RT, 1, UPD_PF>(pb, wq, a1);
+        }
+        PH(43)
+        __syncthreads();   // everyone is done reading xs and pb
+        load_update_v<RT>(ldsh, v_msg, mN, a0, N);   // the v tile takes the place of the phibar tile
+        PH(44)
+        {
+            const float b = Wn.b1[L.col];
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) store_split(xs, L.row(t, i), L.col, a1[t][0][i] * dswish(h1[t][0][i] + b));
+        }
+        __syncthreads();
+        f32x4 acc[RT][1];
+        zero_acc(acc);
+        const uint4 *wp[1] = {Wn.qW1t + (size_t)L.w * 4 * F};
+        gemm16<F, RT, 1, UPD_PF>(xs, wp, acc);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) sb[t] += acc[t][0];
+        PH(45)
+        // (the body's first barrier orders the last reads of xs before anything overwrites the `as` region)
+    }
     PH(16)
-    UpdRegs R;
-    update_forward<16>(W, ldsh, L, R);
+    UpdRegs<RT> R;
+    update_forward<RT, 16>(W, ldsh, L, R);
     PH_RESET
     // Every wave has passed the barrier in front of GEMM3, i.e. finished GEMM1/GEMM2: vt and hs are free.
     const Planes qb = make_planes(ldsh + OFF_VT, TA, F3);    // overlays vt
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = L.row(t, i);
             float abar_vv = 0.f;
             if (!vbar_is_zero) {   // wave-uniform
 #pragma unroll
-                for (int x = 0; x < 3; ++x) abar_vv = fmaf(VB[(x * TA + row) * FT + L.col], R.uv[2 * x + t][0][i], abar_vv);
+                for (int x = 0; x < 3; ++x) abar_vv = fmaf(VB[(x * TA + row) * FT + L.col], R.uv[RT * x + t][0][i], abar_vv);
             }
             store_split(qb, row, L.col, abar_vv);
             store_split(qb, row, F + L.col, sb[t][i] * R.inner[t][i]);
@@ -453,30 +665,30 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     PH(24)
     const Planes hb = make_planes(ldsh + OFF_AS, TA, F);    // h3bar
     {
-        f32x4 acc[2][1];
+        f32x4 acc[RT][1];
         zero_acc(acc);
         const uint4 *wp[1] = {WTILE(W4t, L.w, F3)};
-        gemm16<F3, 2, 1>(qb, wp, acc);
+        gemm16<F3, RT, 1, UPD_PF>(qb, wp, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) store_split(hb, L.row(t, i), L.col, acc[t][0][i] * dswish(R.h3[t][i]));
     }
     PH(25)
     __syncthreads();
     PH(26)
-    f32x4 hbar[2][2];   // [t][0] = d/d s_msg part, [t][1] = d/d norm part, both for feature `col`
+    f32x4 hbar[RT][2];   // [t][0] = d/d s_msg part, [t][1] = d/d norm part, both for feature `col`
     zero_acc(hbar);
     {
         const uint4 *wp[2] = {WTILE(W3t, L.w, F), WTILE(W3t, NW + L.w, F)};
-        gemm16<F, 2, 2>(hb, wp, hbar);
+        gemm16<F, RT, 2, UPD_PF>(hb, wp, hbar);
     }
     PH(27)
     __syncthreads();   // all waves are done with qb / hb: the whole region becomes the [Ubar | Vbar] tile
     PH(28)
     const Planes ab = make_planes(ldsh, 3 * TA, 2 * F);     // cols [0,F) = Ubar, [F,2F) = Vbar
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = L.row(t, i);
@@ -486,7 +698,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
                 const float vbo = vbar_is_zero ? 0.f : VB[(x * TA + row) * FT + L.col];
-                const float u = R.uv[2 * x + t][0][i], v = R.uv[2 * x + t][1][i];
+                const float u = R.uv[RT * x + t][0][i], v = R.uv[RT * x + t][1][i];
                 store_split(ab, x * TA + row, L.col, fmaf(vbo, avv, sa * v));
                 store_split(ab, x * TA + row, F + L.col, fmaf(sa, u, sc * v));
             }
@@ -494,24 +706,24 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW,
     PH(29)
     __syncthreads();
     PH(30)
-    f32x4 out[6][1];
+    f32x4 out[3 * RT][1];
     zero_acc(out);
     {
         const uint4 *wp[1] = {WTILE(UVt, L.w, 2 * F)};
-        gemm16<2 * F, 6, 1>(ab, wp, out);
+        gemm16<2 * F, 3 * RT, 1, UPD_PF>(ab, wp, out);
     }
     PH(31)
     __syncthreads();   // every wave is done with the [Ubar | Vbar] planes: the region becomes the fp32 output tile
     PH(32)
     float *T = reinterpret_cast<float *>(ldsh);   // rows [0, TA): sbar_msg, rows TA (1 + x) + atom: increment of vbar_msg_x
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = L.row(t, i);
             T[row * FT + L.col] = sb[t][i] + hbar[t][0][i];
 #pragma unroll
-            for (int x = 0; x < 3; ++x) T[(TA * (1 + x) + row) * FT + L.col] = out[2 * x + t][0][i];
+            for (int x = 0; x < 3; ++x) T[(TA * (1 + x) + row) * FT + L.col] = out[RT * x + t][0][i];
         }
     __syncthreads();
     stage_rows<4 * TA>(T, [&](int row, int col, const float4 &d) {
@@ -561,9 +773,16 @@ size_t node_mfma_lds_bytes(int which) {
         case 0: return sizeof(_Float16) * 2 * plane_halves(TA, F);                        // msg mlp fwd
         case 1: return sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(TA, F3));   // msg mlp bwd
         case 2: return sizeof(_Float16) * CF_LDS_HALVES;                                  // update fwd (compact layout)
-        default: return sizeof(_Float16) * UPD_LDS_HALVES + sizeof(float) * 3 * TA * FT;  // update bwd: planes + fp32 vbar tile
+        case 4: return sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(TA, RH)) + sizeof(float) * (RH / 16) * TA;   // readout
+        case 5: return sizeof(_Float16) * UpdLds<1>::HALVES + sizeof(float) * 3 * 16 * FT;  // update bwd, 16-atom tiles
+        default: return sizeof(_Float16) * UpdLds<2>::HALVES + sizeof(float) * 3 * TA * FT;  // update bwd: planes + fp32 vbar tile
     }
 }
+static_assert(sizeof(_Float16) * plane_halves(16, RH) + sizeof(float) * (RH / 16) * 16 <= sizeof(float) * 3 * 16 * FT,
+              "readout scratch fits the vbar region");
+static int g_upd_rt = 2;   // atoms per update_bwd workgroup / 16 (VSSR_UPD_RT)
+
+bool readout_mfma_supported(int hidden) { return hidden == RH; }
 
 int node_mfma_init(vssr_handle *h) {
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -572,8 +791,16 @@ int node_mfma_init(vssr_handle *h) {
                                     (int)node_mfma_lds_bytes(1)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(2)));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)node_mfma_lds_bytes(3)));
+#define SET_UPD(MODE)                                                                                                     \
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma<MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)node_mfma_lds_bytes(3)));                                                       \
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)node_mfma_lds_bytes(5)));
+    SET_UPD(0) SET_UPD(1) SET_UPD(2)
+#undef SET_UPD
+    if (const char *e = getenv("VSSR_UPD_RT")) g_upd_rt = atoi(e) == 1 ? 1 : 2;
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_readout_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(4)));
     return VSSR_OK;
 }
 
@@ -591,11 +818,30 @@ void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *M
     hipLaunchKernelGGL(k_update_fwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(2), st, N, l, MW,
                        s_msg, v_msg, s_out, v_out);
 }
-void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zero, const ModelW *MW,
-                            const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
+void launch_readout_mfma(hipStream_t st, int N, int M, const ModelW *MW, const float *s, const float *e_excl,
+                         float *e_atom) {
+    hipLaunchKernelGGL(k_readout_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(4), st, N, MW, s,
+                       e_excl, e_atom);
+}
+// mode 0: sbar_src = sbar ; mode 1: s_next = final s, e_excl (or null), e_atom ; mode 2: s_next = s_in(l+1), phibar,
+// sbar_src = sbar_msg(l+1)
+void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int vbar_is_zero, const ModelW *MW,
+                            const float *s_msg, const float *v_msg, const float *sbar_src, const float *vbar,
+                            const float *s_next, const float *phibar, const float *e_excl, float *e_atom,
                             float *sbar_msg, float *vbar_msg) {
-    hipLaunchKernelGGL(k_update_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(3), st, N, l,
-                       vbar_is_zero, MW, s_msg, v_msg, sbar, vbar, sbar_msg, vbar_msg);
+    const int ta = 16 * g_upd_rt;
+    const dim3 grid((N + ta - 1) / ta, M), blk(NTHREADS);
+    const size_t lds = node_mfma_lds_bytes(g_upd_rt == 1 ? 5 : 3);
+    if (mode == 1) vbar_is_zero = 1;
+#define LAUNCH_UPD(MODE, RT)                                                                                              \
+    hipLaunchKernelGGL((k_update_bwd_mfma<MODE, RT>), grid, blk, lds, st, N, l, vbar_is_zero, MW, s_msg, v_msg, sbar_src, vbar, \
+                       s_next, phibar, e_excl, e_atom, sbar_msg, vbar_msg)
+    if (g_upd_rt == 1) {
+        if (mode == 1) LAUNCH_UPD(1, 1); else if (mode == 2) LAUNCH_UPD(2, 1); else LAUNCH_UPD(0, 1);
+    } else {
+        if (mode == 1) LAUNCH_UPD(1, 2); else if (mode == 2) LAUNCH_UPD(2, 2); else LAUNCH_UPD(0, 2);
+    }
+#undef LAUNCH_UPD
 }
 
 }  // namespace vssr

@@ -91,7 +91,8 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
     float *dbase = h->weights.as<float>();
     // fp16-split fragment-order copies of the node-GEMM weights: 22 F^2 elements x 4 B per (model, layer)
     const size_t node16_per_layer = (size_t)22 * F * F;   // dwords
-    std::vector<unsigned> node16(node16_per_layer * L * M);
+    const size_t node16_readout = (size_t)2 * H * F;      // W5 and W5^T (used when the width is a multiple of 32)
+    std::vector<unsigned> node16(node16_per_layer * L * M + node16_readout * M);
     for (int m = 0; m < M; ++m) {
         float *hb = img.data() + (size_t)m * img_len;
         float *db = dbase + (size_t)m * img_len;
@@ -145,6 +146,11 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
         size_t w5t = taket((size_t)F * H);
         transpose(hb + w5, H, F, hb + w5t);
         W.W5 = db + w5; W.W5t = db + w5t; W.b5 = db + b5; W.w6 = db + w6; W.b6 = db + b6;
+        if (H % 32 == 0) {   // fragment-order pieces of the readout matrices (matrix-pipe readout, painn_node_mfma.hip)
+            unsigned *q = node16.data() + node16_per_layer * L * M + node16_readout * m;
+            pack_mfma_tiles16(hb + w5, H, F, q);
+            pack_mfma_tiles16(hb + w5t, F, H, q + (size_t)H * F);
+        }
     }
     VSSR_HIP(h, hipMemcpy(dbase, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
     {   // node-GEMM weights as fp16 pieces (painn_node_mfma.hip)
@@ -159,6 +165,11 @@ static int upload_weights(vssr_handle *h, const vssr_painn_config *cfg) {
                 Lw.qW3 = next(F, 2 * F); Lw.qW4 = next(F3, F); Lw.qW1t = next(F, F); Lw.qW2t = next(F, F3);
                 Lw.qW4t = next(F, F3); Lw.qW3t = next(2 * F, F); Lw.qUVt = next(F, 2 * F);
             }
+        for (int m = 0; m < M; ++m) {
+            const uint4 *q = h->node16.as<uint4>() + (node16_per_layer * L * M + node16_readout * m) / 4;
+            table[m].qW5 = q;
+            table[m].qW5t = q + (size_t)H * F / 4;
+        }
     }
     {   // radial-filter weights split into fp16 pieces in MFMA operand order (painn_edge_mfma.hip), per model / layer
         const size_t per_layer16 = (size_t)F3 * 4 * 8;   // dwords
@@ -645,7 +656,7 @@ int vssr_debug_read(vssr_handle *h, const char *name, int32_t model, float *dst,
     else if ((l = layer_of("s_upd")) >= 0) { src = sv.s_in[l + 1]; per_atom = F; }
     else if ((l = layer_of("v_upd")) >= 0) { src = sv.v_in[l + 1]; per_atom = F3; }
     else if (nm == "e_atom") { src = sv.e_atom; per_atom = 1; }
-    else if (nm == "sbar_msg0") { src = sv.sbar_msg; per_atom = F; }   // reverse buffers hold the LAST layer processed
+    else if (nm == "sbar_msg0") { src = sv.sbar_msg_l0; per_atom = F; }   // reverse buffers hold the LAST layer processed
     else if (nm == "vbar_msg0") { src = sv.vbar_msg; per_atom = F3; }
     else return set_err(h, VSSR_E_BADARG, "unknown intermediate '%s'", name);
     size_t n = N * per_atom;

@@ -39,6 +39,7 @@ struct ModelW {
     const float *embed;  // [n_embed][F]
     LayerW layer[MAX_LAYERS];
     const float *W5, *W5t, *b5, *w6, *b6;  // [H][F], [F][H], [H], [H], [1]
+    const uint4 *qW5, *qW5t;               // readout matrices as fp16 pieces in MFMA fragment order (painn_node_mfma.hip)
 };
 
 struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by centre)
@@ -75,7 +76,8 @@ struct StateView {  // activations of all models: index [m][atom][...]
     // reverse
     float *sbar;                  // [M][N][F]     adjoint of s_in[l+1] / s_in[l]
     float *vbar;                  // [M][N][3][F]
-    float *sbar_msg;              // adjoint of s_msg[l]
+    float *sbar_msg;              // adjoint of s_msg[l] (the fused reverse kernels alternate between sbar_msg and sbar)
+    float *sbar_msg_l0;           // the buffer that holds the adjoint of s_msg[0] after a reverse pass
     float *vbar_msg;
     float *phibar;                // [M][N][3F]
     float4 *gbar;                 // [M][slots] dE/d r for the edge (j -> i) stored at slot (i, j)
@@ -227,8 +229,12 @@ void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *
                              const float *phibar, const float *sbar_msg, float *sbar_in);
 void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_msg,
                             const float *v_msg, float *s_out, float *v_out);
-void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int vbar_is_zero, const ModelW *MW,
-                            const float *s_msg, const float *v_msg, const float *sbar, const float *vbar,
+bool readout_mfma_supported(int hidden);
+void launch_readout_mfma(hipStream_t st, int N, int M, const ModelW *MW, const float *s, const float *e_excl,
+                         float *e_atom);
+void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int vbar_is_zero, const ModelW *MW,
+                            const float *s_msg, const float *v_msg, const float *sbar_src, const float *vbar,
+                            const float *s_next, const float *phibar, const float *e_excl, float *e_atom,
                             float *sbar_msg, float *vbar_msg);
 // layer-0 species factorisation (painn_l0.hip)
 void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst /*[rows/32][K/16][2][64][4]*/);

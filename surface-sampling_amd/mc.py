@@ -130,26 +130,36 @@ def metropolis_accept(prev_energy, curr_energy, temperature: float, u) -> np.nda
     return np.asarray(u, float) < prob
 
 
+def geometric_schedule(start_temp: float, total_sweeps: int, alpha: float) -> list:
+    """Simulated-annealing temperatures ``T_i = start_temp * alpha**i`` for ``total_sweeps`` sweeps."""
+    return (float(start_temp) * np.power(float(alpha), np.arange(int(total_sweeps)))).tolist()
+
+
+# One cooling / reheating cycle of the reference's "multiple anneal" mode as data: (kind, T_from, T_to, sweeps); ``None``
+# stands for the temperature the cycle was entered with (``mcmc/utils/sampling.py:48-62`` lists the same four legs).
+REFERENCE_ANNEAL_CYCLE = (("ramp", None, 0.10, 100), ("ramp", 0.10, 0.08, 200), ("hold", 0.08, 0.08, 200),
+                          ("ramp", 0.08, None, 10))
+
+
+def cyclic_schedule(start_temp: float, total_sweeps: int, cycle=REFERENCE_ANNEAL_CYCLE) -> list:
+    """``start_temp`` followed by repetitions of ``cycle`` (linear ramps / plateaus), cut to ``total_sweeps`` entries."""
+    legs = []
+    for kind, t0, t1, n in cycle:
+        a = start_temp if t0 is None else t0
+        b = start_temp if t1 is None else t1
+        legs.append(np.full(n, a) if kind == "hold" else np.linspace(a, b, n))
+    one = np.concatenate(legs)
+    reps = max(1, -(-(int(total_sweeps) - 1) // len(one)))
+    return np.concatenate([[float(start_temp)], np.tile(one, reps)])[:int(total_sweeps)].tolist()
+
+
 def create_anneal_schedule(start_temp: float = 1.0, total_sweeps: int = 1000, alpha: float = 0.99,
                            multiple_anneal: bool = False) -> list:
-    """Temperature per sweep (``mcmc/utils/sampling.py:10-67`` without the plot / csv side effects)."""
-    temps = [start_temp]
-    curr, sweep = start_temp, 1
-    if not multiple_anneal:
-        while sweep < total_sweeps:
-            curr *= alpha
-            temps.append(curr)
-            sweep += 1
-    else:
-        while sweep < total_sweeps:
-            temps.extend(np.linspace(curr, 0.10, 100).tolist())
-            sweep += 100
-            temps.extend(np.linspace(0.10, 0.08, 200).tolist())
-            sweep += 200
-            temps.extend(np.repeat(0.08, 200).tolist())
-            sweep += 200
-            temps.extend(np.linspace(0.08, curr, 10).tolist())
-    return temps[:total_sweeps]
+    """Temperature per sweep with the reference's argument names (``mcmc/utils/sampling.py:10-67``, without its plot /
+    csv side effects): geometric cooling, or the cyclic schedule above."""
+    if multiple_anneal:
+        return cyclic_schedule(start_temp, total_sweeps)
+    return geometric_schedule(start_temp, total_sweeps, alpha)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -206,6 +216,7 @@ class ChainEnsemble:
         self.state = ChainState(np.full((B, S), self.n_ads, np.int16), np.zeros((B, S), np.int64), np.ones(B, np.int64))
         self.step_count = 0
         self.relaxed = [None] * B           # relaxed Structure of the current state of every chain
+        self.oob = np.zeros(B, bool)        # out-of-bounds flag of the last evaluation of every chain (reference: energy_oob)
         self.n_evaluations = 0
 
     # ---- proposal: vectorised ChangeProposal.get_action ------------------------------------------------------------
@@ -309,8 +320,14 @@ class ChainEnsemble:
         if self.relax:
             fixed = None if self.fixed_indices is None else [self.fixed_indices] * len(slabs)
             out = self.calc.relax_batch(slabs, fixed_indices=fixed, relax_steps=self.relax_steps, fmax=self.fmax)
-            raw = [o[2] for o in out]
+            # The acceptance energy is the TRUE energy of the relaxed slab: the reference discards optimize_slab's clamped
+            # value (mcmc/system.py:466-469 re-evaluates surface_energy on relaxed_atoms) and uses the out-of-bounds flag
+            # only to save the offending structure (mcmc/system.py:375-378).  A 240-atom SrTiO3 slab sits near -1870 eV,
+            # far beyond the +-1000 eV guard.
+            raw = [self._final_energy(o) for o in out]
             relaxed = [o[0] for o in out]
+            for b, o in zip(idx, out):
+                self.oob[int(b)] = bool(o[3])
         else:
             out = self.calc.calculate_batch(slabs)
             raw = [float(np.ravel(o["energy"])[0]) for o in out]
@@ -318,6 +335,15 @@ class ChainEnsemble:
         self.n_evaluations += len(slabs)
         energies = np.array([self.surface_energy_fn(e, s) for e, s in zip(raw, slabs)], float)
         return energies, relaxed
+
+    @staticmethod
+    def _final_energy(relax_out) -> float:
+        """Energy of the relaxed slab from a ``relax_batch`` tuple: the results of its final evaluation when the backend
+        returns them, else the tuple's energy field."""
+        res = relax_out[4] if len(relax_out) > 4 else None
+        if isinstance(res, dict) and "energy" in res:
+            return float(np.ravel(res["energy"])[0])
+        return float(relax_out[2])
 
     def initialize(self):
         """Surface energy of the starting states (the reference evaluates the start state before the first sweep)."""

@@ -216,6 +216,31 @@ def test_relaxation_path_uses_relax_batch_and_fixed_atoms():
     assert all(r is not None for r in ens.relaxed)
 
 
+def test_acceptance_uses_the_true_energy_beyond_the_out_of_bounds_guard():
+    """Slabs with |E| > 1000 eV (any SrTiO3 slab above ~130 atoms): the reference re-evaluates the surface energy on the
+    relaxed slab and uses the clamped 1000 only as a flag (mcmc/system.py:375-378,466-469).  A backend that clamps like
+    optimize_slab (mcmc/dynamics.py:159-168) must not flatten the Metropolis energies."""
+    ens, calc = _toy(32, relax=True, seed=5)
+    shift = -1870.0
+
+    def clamping_relax(slabs, fixed_indices=None, relax_steps=20, fmax=0.01):
+        out = []
+        for s_ in slabs:
+            e = calc._energy(s_) + shift
+            oob = abs(e) > 1000.0
+            out.append((s_.copy(), None, 1000.0 if oob else e, oob, {"energy": np.array([e], np.float32)}))
+        return out
+
+    calc.relax_batch = clamping_relax
+    e0 = ens.initialize()
+    assert np.allclose(e0, shift, atol=1e-3) and ens.oob.all()
+    for _ in range(6):
+        ens.step_semigrand()
+    expected = np.array([calc._energy(ens.structure(b)) + shift for b in range(32)])
+    assert np.allclose(ens.state.energy, expected, atol=2e-3)      # float32 results, true energies
+    assert len(np.unique(np.round(ens.state.energy, 3))) > 1           # not the constant 1000
+
+
 def test_detailed_balance_on_a_two_site_lattice_gas():
     """2 sites, adsorbates {Sr, O}: 9 states with known energies -> visit frequencies follow exp(-E/kT)."""
     ens, calc = _toy(512, n_sites=2, seed=11)

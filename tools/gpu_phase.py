@@ -27,10 +27,12 @@ names = {0: "fwd: load tiles + barrier", 1: "fwd: GEMM1 (U, V)", 2: "fwd: norms 
          22: "bwd: GEMM3", 23: "bwd: qb stores (scalar loads of sbar / vbar)", 24: "bwd: barrier", 25: "bwd: GEMM W4^T + stores", 26: "bwd: barrier",
          27: "bwd: GEMM W3^T", 28: "bwd: barrier", 29: "bwd: ab stores (scalar loads of vbar)", 30: "bwd: barrier", 31: "bwd: GEMM [U|V]^T",
          32: "bwd: barrier", 33: "bwd: tile + coalesced pass"}
-for base in (0, 16):
-    tot = sum(v[k] for k in names if base <= k < base + 18)
+names.update({40: "bwd head R: loads + barrier", 41: "bwd head R: readout GEMMs", 42: "bwd head P: loads + barrier",
+              43: "bwd head P: GEMM W1, W2^T", 44: "bwd head P: barrier + v tile load", 45: "bwd head P: h1bar stores, barrier, GEMM W1^T"})
+for lo, hi in ((0, 16), (16, 64)):
+    tot = sum(v[k] for k in names if lo <= k < hi)
     for k in sorted(names):
-        if base <= k < base + 18:
-            print(f"{names[k]:52s} {100 * v[k] / tot:6.1f} %")
+        if lo <= k < hi:
+            print(f"{names[k]:52s} {100 * v[k] / max(tot, 1):6.1f} %   {v[k]:14.0f} ticks")
     print()
 eng.close()
