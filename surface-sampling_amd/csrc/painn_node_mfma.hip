@@ -147,6 +147,11 @@ __device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)
                                 part[j][t][c], 0, 0, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
+            // End of the group's MFMA block (marker for tools/check_mfma_loads.py).  The loads that follow refill fragment
+            // registers of MFMAs that have all been ISSUED (in-order issue; every round runs over >= 4 independent
+            // accumulators, so none of them waits inside the pipe with unread sources).
+            asm volatile("; gemm16_group_end");
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
@@ -780,7 +785,8 @@ size_t node_mfma_lds_bytes(int which) {
 }
 static_assert(sizeof(_Float16) * plane_halves(16, RH) + sizeof(float) * (RH / 16) * 16 <= sizeof(float) * 3 * 16 * FT,
               "readout scratch fits the vbar region");
-static int g_upd_rt = 2;   // atoms per update_bwd workgroup / 16 (VSSR_UPD_RT)
+// (RT = 1 -- 16-atom tiles, two workgroups per CU -- was measured at -5 % for this kernel without the pipelined GEMMs and
+// spills with them; only RT = 2 is instantiated.  profiles/r02/NOTES_node_kernels.md)
 
 bool readout_mfma_supported(int hidden) { return hidden == RH; }
 
@@ -793,12 +799,9 @@ int node_mfma_init(vssr_handle *h) {
                                     (int)node_mfma_lds_bytes(2)));
 #define SET_UPD(MODE)                                                                                                     \
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma<MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)node_mfma_lds_bytes(3)));                                                       \
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)node_mfma_lds_bytes(5)));
+                                    (int)node_mfma_lds_bytes(3)));
     SET_UPD(0) SET_UPD(1) SET_UPD(2)
 #undef SET_UPD
-    if (const char *e = getenv("VSSR_UPD_RT")) g_upd_rt = atoi(e) == 1 ? 1 : 2;
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_readout_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(4)));
     return VSSR_OK;
@@ -829,18 +832,13 @@ void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int v
                             const float *s_msg, const float *v_msg, const float *sbar_src, const float *vbar,
                             const float *s_next, const float *phibar, const float *e_excl, float *e_atom,
                             float *sbar_msg, float *vbar_msg) {
-    const int ta = 16 * g_upd_rt;
-    const dim3 grid((N + ta - 1) / ta, M), blk(NTHREADS);
-    const size_t lds = node_mfma_lds_bytes(g_upd_rt == 1 ? 5 : 3);
+    const dim3 grid((N + TA - 1) / TA, M), blk(NTHREADS);
+    const size_t lds = node_mfma_lds_bytes(3);
     if (mode == 1) vbar_is_zero = 1;
-#define LAUNCH_UPD(MODE, RT)                                                                                              \
-    hipLaunchKernelGGL((k_update_bwd_mfma<MODE, RT>), grid, blk, lds, st, N, l, vbar_is_zero, MW, s_msg, v_msg, sbar_src, vbar, \
+#define LAUNCH_UPD(MODE)                                                                                                    \
+    hipLaunchKernelGGL((k_update_bwd_mfma<MODE, 2>), grid, blk, lds, st, N, l, vbar_is_zero, MW, s_msg, v_msg, sbar_src, vbar, \
                        s_next, phibar, e_excl, e_atom, sbar_msg, vbar_msg)
-    if (g_upd_rt == 1) {
-        if (mode == 1) LAUNCH_UPD(1, 1); else if (mode == 2) LAUNCH_UPD(2, 1); else LAUNCH_UPD(0, 1);
-    } else {
-        if (mode == 1) LAUNCH_UPD(1, 2); else if (mode == 2) LAUNCH_UPD(2, 2); else LAUNCH_UPD(0, 2);
-    }
+    if (mode == 1) LAUNCH_UPD(1); else if (mode == 2) LAUNCH_UPD(2); else LAUNCH_UPD(0);
 #undef LAUNCH_UPD
 }
 

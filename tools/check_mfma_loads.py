@@ -2,7 +2,8 @@
 """Build-time check of the MFMA / load ordering rules (see mfma_load_fence in painn_edge_mfma.hip) on the emitted gfx950
 ISA.  Rule 1 (files with fences): no load (LDS, global, scratch, flat) may sit between the first MFMA of a step and the
 '; mfma_load_fence' marker that follows it.  Rule 2 (every file): no load inside a dense MFMA block, i.e. between two
-MFMAs that are at most DENSE_GAP instructions apart.  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
+MFMAs that are at most DENSE_GAP instructions apart; a '; gemm16_group_end' marker (painn_node_mfma.hip, pipelined GEMMs)
+closes a block: the fragment loads of the next chunk group legitimately follow it.  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
 import os, re, subprocess, sys, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -56,6 +57,8 @@ def check(hip):
         if m:
             kernel, last_mfma, pending = m.group(1), None, []
         t = l.strip()
+        if "gemm16_group_end" in t:
+            last_mfma, pending = None, []
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
             continue
         instr_idx += 1
