@@ -18,7 +18,28 @@ constexpr int NW = 8;             // waves per workgroup
 constexpr int NTHREADS = 64 * NW;
 constexpr int PADH = 8;           // row pad of the fp16 planes (halves): conflict-free ds_read_b128 of 16 rows
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// sigmoid on the hardware exp2 / rcp units (1 ulp each) instead of libdevice expf + IEEE division (~35 issue slots, and
+// the node kernels evaluate 24 .. 32 of them per lane: a fifth of their vector instructions).  The rounding error of the
+// argument product x * (-log2 e), which would grow with |x|, is recovered exactly with one fma and applied to first order,
+// so the result stays within ~2 ulp of the correctly rounded sigmoid over the whole range.
+#ifndef VSSR_FAST_SIGMOID
+#define VSSR_FAST_SIGMOID 1
+#endif
+__device__ __forceinline__ float sigm(float x) {
+#if VSSR_FAST_SIGMOID && defined(__HIP_DEVICE_COMPILE__)
+    constexpr float C_HI = -1.44269502162933349609375f;      // fp32(-log2 e)
+    constexpr float C_LO = -1.9259629911266175e-08f;         // -log2 e - C_HI
+    constexpr float LN2 = 0.693147182464599609375f;
+    x = fmaxf(x, -87.f);                                     // exp(-x) stays finite (sigmoid(-87) = 1.6e-38); NaN propagates
+    const float y = x * C_HI;
+    const float r = fmaf(x, C_LO, fmaf(x, C_HI, -y));       // exact product error + low part of the constant
+    const float e = __builtin_amdgcn_exp2f(y);               // exp(-x) up to the factor 2^r
+    const float en = fmaf(e, r * LN2, e);
+    return __builtin_amdgcn_rcpf(1.f + en);
+#else
+    return 1.f / (1.f + expf(-x));
+#endif
+}
 __device__ __forceinline__ float swish(float x) { return x * sigm(x); }
 __device__ __forceinline__ float dswish(float x) {
     float sg = sigm(x);
@@ -87,7 +108,22 @@ __device__ __forceinline__ void load_rows_split(const Planes &P, int col0, RowPt
         store_split4(P, idx >> 5, col0 + 4 * (idx & 31), v[it]);
     }
 }
-
+// same, and the fp32 values stay with the threads that loaded them (residual operands of a later output pass)
+template <int NROWS, class RowPtr>
+__device__ __forceinline__ void load_rows_split_keep(const Planes &P, int col0, RowPtr rowptr,
+                                                     float4 (&v)[NROWS * (F / 4) / NTHREADS]) {
+    constexpr int NIT = NROWS * (F / 4) / NTHREADS;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * NTHREADS;
+        v[it] = *reinterpret_cast<const float4 *>(rowptr(idx >> 5) + 4 * (idx & 31));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * NTHREADS;
+        store_split4(P, idx >> 5, col0 + 4 * (idx & 31), v[it]);
+    }
+}
 
 // ---- coalesced global I/O for data that lives in the accumulator layout --------------------------------------------------
 // In the accumulator layout a lane owns ONE column and 4 rows per tile: written or read directly, every dword access

@@ -314,12 +314,14 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
                             const int *__restrict__ counters, float rc, float excl_sigma, int excl_power,
                             float4 *__restrict__ erec, float *__restrict__ rho, float *__restrict__ drho,
                             float2 *__restrict__ dist2, uint4 *__restrict__ rho16, uint4 *__restrict__ drho16,
-                            const int *__restrict__ Z, const int *__restrict__ zmap, unsigned char *__restrict__ zslot) {
+                            const int *__restrict__ Z, const int *__restrict__ zmap, unsigned char *__restrict__ zslot,
+                            float *__restrict__ e_excl) {
     if (counters[2]) return;
     const int i = blockIdx.x;                 // centre atom
     const int a0 = cfg_start[atom_cfg[i]];
     const int e0 = row_start[i], e1 = row_start[i + 1];
     const float alpha = 3.14159265358979323846f / rc;
+    float ex = 0.f;   // excluded-volume energy of the centre: sum over its slots of (sigma / d)^p
     for (int t = threadIdx.x; t < (e1 - e0) * 4; t += blockDim.x) {
         const int slot = e0 + (t >> 2), kq = t & 3;
         const float4 ed = edge[slot];
@@ -370,10 +372,15 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
             const int zi = valid ? zmap[Z[j]] : -1;
             zslot[slot] = (unsigned char)(zi >= 0 ? zi : 255);
             erec[slot] = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, __int_as_float(valid ? j - a0 : 0));
-            dist2[slot] = valid ? make_float2(inv, -(float)excl_power * powf(excl_sigma * inv, (float)excl_power) * inv)
-                                : make_float2(-1.f, 0.f);
+            const float rep = valid ? powf(excl_sigma * inv, (float)excl_power) : 0.f;
+            ex += rep;
+            dist2[slot] = valid ? make_float2(inv, -(float)excl_power * rep * inv) : make_float2(-1.f, 0.f);
         }
     }
+    // one wave per centre (launch: 64 threads): fixed-order butterfly, so the sum does not depend on batching
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ex += __shfl_xor(ex, off, 64);
+    if (threadIdx.x == 0) e_excl[i] = ex;
 }
 
 // Work list of the MFMA edge kernels: per chain, the centres sorted by padded slot count (descending; ties by index) as
@@ -441,7 +448,8 @@ int build_neighbors(vssr_handle *h, double cutoff) {
         if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
             h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float2) * h->slot_cap) ||
             h->d_rho16.ensure(sizeof(uint4) * 8 * h->slot_cap) || h->d_drho16.ensure(sizeof(uint4) * 8 * h->slot_cap) ||
-            h->d_zslot.ensure((size_t)h->slot_cap) || h->d_bundle.ensure(sizeof(int4) * (size_t)n))
+            h->d_zslot.ensure((size_t)h->slot_cap) || h->d_bundle.ensure(sizeof(int4) * (size_t)n) ||
+            h->d_excl.ensure(sizeof(float) * (size_t)n))
             return set_err(h, VSSR_E_NOMEM, "edge geometry tables: out of device memory");
         // the last slot of the capacity is never used by the CSR (counters[2] flags slots > cap - 64): it is the
         // all-zero table entry that exhausted lanes of the edge kernels read
@@ -454,7 +462,8 @@ int build_neighbors(vssr_handle *h, double cutoff) {
                            h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,
                            h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),
                            h->d_drho.as<float>(), h->d_dist.as<float2>(), h->d_rho16.as<uint4>(),
-                           h->d_drho16.as<uint4>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_zslot.as<unsigned char>());
+                           h->d_drho16.as<uint4>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_zslot.as<unsigned char>(),
+                           h->d_excl.as<float>());
         if ((size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024)   // chains of the MFMA edge kernels (LDS slices) are far smaller
             hipLaunchKernelGGL(k_bundle_sort, dim3(h->n_cfg), dim3(256), (size_t)h->max_cfg_atoms * sizeof(int), st,
                                h->d_cfg_start.as<int>(), h->d_row_start.as<int>(), h->d_counters.as<int>(),

@@ -101,9 +101,8 @@ __global__ void __launch_bounds__(128)
 k_edge_fwd(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *__restrict__ counters,
            float rc, int excl_vol, float excl_sigma, int excl_power, const float *__restrict__ s_in,
            const float *__restrict__ v_in, const float *__restrict__ phi, float *__restrict__ s_msg,
-           float *__restrict__ v_msg, float *__restrict__ e_excl) {
+           float *__restrict__ v_msg) {
     __shared__ EdgeChunk S;
-    __shared__ float exs[ECHUNK];
     if (counters[2]) return;
     const int i = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
     const LayerW &W = MW[m].layer[l];
@@ -117,13 +116,12 @@ k_edge_fwd(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *
     wb[RB - 1] = W.bd[F + f];
     wc[RB - 1] = W.bd[2 * F + f];
 
-    float acc_s = 0.f, ax = 0.f, ay = 0.f, az = 0.f, ex = 0.f;
+    float acc_s = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
     const int e_begin = G.row_start[i], e_end = G.row_start[i + 1];
     const size_t mN = (size_t)m * N;
     for (int e0 = e_begin; e0 < e_end; e0 += ECHUNK) {
         int ne = min(ECHUNK, e_end - e0);
         stage_chunk<false>(S, G.edge, e0, ne, rc);
-        if (L0 && excl_vol && f < ne && S.j[f] >= 0) ex += powf(excl_sigma / S.u[f][3], (float)excl_power);
         for (int e = 0; e < ne; ++e) {
             int j = S.j[e];
             if (j < 0) continue;
@@ -157,13 +155,6 @@ k_edge_fwd(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *
         v_msg[(a * 3 + 0) * F + f] = ax;
         v_msg[(a * 3 + 1) * F + f] = ay;
         v_msg[(a * 3 + 2) * F + f] = az;
-        if (f < ECHUNK) exs[f] = ex;
-        __syncthreads();
-        if (f == 0) {
-            float tot = 0.f;
-            for (int k = 0; k < ECHUNK; ++k) tot += exs[k];
-            e_excl[a] = tot;
-        }
     } else {
         v_msg[(a * 3 + 0) * F + f] = v_in[(a * 3 + 0) * F + f] + ax;
         v_msg[(a * 3 + 1) * F + f] = v_in[(a * 3 + 1) * F + f] + ay;
@@ -205,7 +196,7 @@ k_readout(int N, int H, const ModelW *__restrict__ MW, const float *__restrict__
         if (atom < N) {
             float e = W.b6[0];
             for (int o = 0; o < H; ++o) e += es[o][tid];
-            if (excl_vol) e += e_excl[mN + atom];
+            if (excl_vol) e += e_excl[atom];
             e_atom[mN + atom] = e;
         }
     }
@@ -449,7 +440,7 @@ k_finalize_energy(int N, int M, const int *__restrict__ cfg_start, const int *__
 int painn_alloc_state(vssr_handle *h) {
     const size_t N = h->n_atoms, M = h->n_models, L = h->num_conv;
     const size_t nS = M * N * F, nV = 3 * nS, nP = 3 * nS;
-    size_t floats = (L + 1) * (nS + nV) + L * nP + L * (nS + nV) + 2 * M * N  // forward
+    size_t floats = (L + 1) * (nS + nV) + L * nP + L * (nS + nV) + M * N  // forward
                     + 2 * (nS + nV) + nP;                                          // reverse
     if (h->d_state.ensure(floats * sizeof(float)))
         return set_err(h, VSSR_E_NOMEM, "activation arena (%zu MB): out of device memory", floats * 4 >> 20);
@@ -464,7 +455,6 @@ int painn_alloc_state(vssr_handle *h) {
         sv.v_msg[l] = p; p += nV;
     }
     sv.e_atom = p; p += M * N;
-    sv.e_excl = p; p += M * N;
     sv.sbar = p; p += nS;
     sv.vbar = p; p += nV;
     sv.sbar_msg = p; p += nS;
@@ -488,6 +478,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
     rc = painn_alloc_state(h);
     if (rc) return rc;
     StateView &sv = h->sv;
+    sv.e_excl = h->d_excl.as<float>();
     GraphView G;
     G.n_atoms = N;
     G.n_cfg = h->n_cfg;
@@ -528,7 +519,6 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.begin(KC_L0_FWD, st);
             rc = l0_run_forward(h, G, sv.s_msg[0], sv.v_msg[0]);
             if (rc) return rc;
-            if (h->excl_vol) launch_excl_vol(st, N, M, G, counters, h->excl_sigma, h->excl_power, sv.e_excl);
             P.end(st);
             P.begin(KC_UPDATE_FWD, st);
             launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
@@ -545,11 +535,11 @@ int painn_run(vssr_handle *h, uint32_t want) {
         else if (l == 0)
             hipLaunchKernelGGL(k_edge_fwd<true>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
                                h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
-                               sv.v_msg[l], sv.e_excl);
+                               sv.v_msg[l]);
         else
             hipLaunchKernelGGL(k_edge_fwd<false>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
                                h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
-                               sv.v_msg[l], sv.e_excl);
+                               sv.v_msg[l]);
         P.end(st);
         P.begin(KC_UPDATE_FWD, st);
         launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);

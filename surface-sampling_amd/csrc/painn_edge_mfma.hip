@@ -752,28 +752,6 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     }
 }
 
-// layer-0 excluded volume: e_excl[i] = sum_e (sigma/d_e)^p  (geometry only, identical for all ensemble
-// members that share sigma/p; written per member to keep the readout kernel's indexing)
-__global__ void __launch_bounds__(256)
-k_excl_vol(int N, int M, GraphView G, const int *__restrict__ counters, float sigma, int power,
-           float *__restrict__ e_excl) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N || counters[2]) return;
-    float tot = 0.f;
-    for (int e = G.row_start[i]; e < G.row_start[i + 1]; ++e) {
-        float4 ed = G.edge[e];
-        if (__float_as_int(ed.w) < 0) continue;
-        float d = sqrtf(fmaf(ed.z, ed.z, fmaf(ed.y, ed.y, ed.x * ed.x)));
-        tot += powf(sigma / d, (float)power);
-    }
-    for (int m = 0; m < M; ++m) e_excl[(size_t)m * N + i] = tot;
-}
-
-void launch_excl_vol(hipStream_t st, int N, int M, const GraphView &G, const int *counters, float sigma, int power,
-                     float *e_excl) {
-    hipLaunchKernelGGL(k_excl_vol, dim3((N + 255) / 256), dim3(256), 0, st, N, M, G, counters, sigma, power, e_excl);
-}
-
 int edge_mfma_init(vssr_handle *h) {
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

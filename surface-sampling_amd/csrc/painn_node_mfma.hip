@@ -376,7 +376,11 @@ constexpr int CF_XS = plane_halves(3 * TA, F);                    // halves
 constexpr int CF_LDS_HALVES = CF_XS + plane_halves(TA, F);        // 34 816 halves = 69 632 B
 static_assert(2 * plane_halves(TA, F) <= CF_XS, "|Vv| and swish planes overlay the v tile");
 static_assert(4 * TA * FT * sizeof(float) <= CF_LDS_HALVES * sizeof(_Float16), "output tile overlays the planes");
-__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))   // two workgroups per CU
+// BIG = 1: one workgroup per CU with the 256-register budget instead: the fp32 input tile stays in the registers of the
+// threads that loaded it and serves as the residual of the output pass (no second read of s_msg / v_msg), and the GEMMs
+// run the software pipeline.
+template <int BIG>
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 2 : 4, BIG ? 2 : 4)))
 k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
                   const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
@@ -386,25 +390,40 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
     const size_t mN = (size_t)m * N;
     const Planes vt = make_planes(ldsh, 3 * TA, F), xs = make_planes(ldsh + CF_XS, TA, F);
     const Planes nr = make_planes(ldsh, TA, F), as_ = make_planes(ldsh + plane_halves(TA, F), TA, F);   // overlays of vt
-    load_rows_split<3 * TA>(vt, 0, [&](int row) {
-        int x = row / TA, a = min(a0 + (row % TA), N - 1);
-        return v_msg + ((mN + a) * 3 + x) * F;
-    });
-    load_rows_split<TA>(xs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
+    constexpr int PF = BIG ? 1 : 0;
+    float4 keep_v[BIG ? 3 * TA * (F / 4) / NTHREADS : 1], keep_s[BIG ? TA * (F / 4) / NTHREADS : 1];
+    PH_INIT
+    if constexpr (BIG != 0) {
+        load_rows_split_keep<3 * TA>(vt, 0, [&](int row) {
+            int x = row / TA, a = min(a0 + (row % TA), N - 1);
+            return v_msg + ((mN + a) * 3 + x) * F;
+        }, keep_v);
+        load_rows_split_keep<TA>(xs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; }, keep_s);
+    } else {
+        load_rows_split<3 * TA>(vt, 0, [&](int row) {
+            int x = row / TA, a = min(a0 + (row % TA), N - 1);
+            return v_msg + ((mN + a) * 3 + x) * F;
+        });
+        load_rows_split<TA>(xs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
+    }
     __syncthreads();
+    PH(0)
     f32x4 uv[6][2];   // [2 x + t][0] = U v_x, [..][1] = V v_x
     zero_acc(uv);
     {
         const uint4 *wp[2] = {WTILE(U, L.w, F), WTILE(V, L.w, F)};
-        gemm16<F, 6, 2>(vt, wp, uv);
+        gemm16<F, 6, 2, PF>(vt, wp, uv);
     }
+    PH(1)
     f32x4 h3[2][1];   // gate MLP, first layer: the s half of [s ; |Vv|] now, the |Vv| half after the barrier
     zero_acc(h3);
     {
         const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F)};
-        gemm16<F, 2, 1>(xs, wp, h3);
+        gemm16<F, 2, 1, PF>(xs, wp, h3);
     }
+    PH(2)
     __syncthreads();   // every wave is done with the v tile
+    PH(3)
     f32x4 inner[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -421,21 +440,24 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
             store_split(nr, L.row(t, i), L.col, sqrtf(n2));
         }
     __syncthreads();
+    PH(4)
     {
         const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F) + (F / 32) * 2 * 64};   // chunks F/32 .. 2F/32 - 1 of the same column tile
-        gemm16<F, 2, 1>(nr, wp, h3);
+        gemm16<F, 2, 1, PF>(nr, wp, h3);
         const float b = W.b3[L.col];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) store_split(as_, L.row(t, i), L.col, swish(h3[t][0][i] + b));
     }
+    PH(5)
     __syncthreads();
+    PH(6)
     f32x4 gate[2][3];   // a_vv, a_sv, a_ss
     zero_acc(gate);
     {
         const uint4 *wp[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
-        gemm16<F, 2, 3>(as_, wp, gate);
+        gemm16<F, 2, 3, PF>(as_, wp, gate);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float b = W.b4[c * F + L.col];
@@ -443,7 +465,9 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
             for (int t = 0; t < 2; ++t) gate[t][c] += (f32x4){b, b, b, b};
         }
     }
+    PH(7)
     __syncthreads();   // every wave is done with the planes: the region becomes the fp32 output tile
+    PH(8)
     // increments (rows [0, TA): s, rows TA (1 + x) + atom: v_x); the residual is added in the coalesced pass
     float *T = reinterpret_cast<float *>(ldsh);
 #pragma unroll
@@ -460,13 +484,25 @@ k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__re
         const int q = row / TA, a = min(a0 + row % TA, N - 1);
         return q == 0 ? (mN + a) * F + col : ((mN + a) * 3 + (q - 1)) * F + col;
     };
-    stage_rows_residual<4 * TA>(
-        T, [&](int row, int col) { return *reinterpret_cast<const float4 *>((row < TA ? s_msg : v_msg) + gofs(row, col)); },
-        [&](int row, int col, const float4 &d, const float4 &r) {
-            if (a0 + row % TA >= N) return;
-            *reinterpret_cast<float4 *>((row < TA ? s_out : v_out) + gofs(row, col)) =
-                make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
-        });
+    PH(9)
+    auto put = [&](int row, int col, const float4 &d, const float4 &r) {
+        if (a0 + row % TA >= N) return;
+        *reinterpret_cast<float4 *>((row < TA ? s_out : v_out) + gofs(row, col)) =
+            make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
+    };
+    if constexpr (BIG != 0) {   // the loading pass and this pass map (thread, iteration) to (row, column) identically: rows [0, TA) = s
+        constexpr int NS = TA * (F / 4) / NTHREADS, NV = 3 * TA * (F / 4) / NTHREADS;
+#pragma unroll
+        for (int it = 0; it < NS + NV; ++it) {
+            const int idx = threadIdx.x + it * NTHREADS, row = idx >> 5, c4 = idx & 31;
+            put(row, 4 * c4, *reinterpret_cast<const float4 *>(T + row * FT + 4 * c4), it < NS ? keep_s[it < NS ? it : 0] : keep_v[it < NS ? 0 : it - NS]);
+        }
+    } else {
+        stage_rows_residual<4 * TA>(
+            T, [&](int row, int col) { return *reinterpret_cast<const float4 *>((row < TA ? s_msg : v_msg) + gofs(row, col)); },
+            put);
+    }
+    PH(10)
 }
 
 // ---- readout on the matrix pipe ---------------------------------------------------------------
@@ -506,7 +542,7 @@ __device__ __forceinline__ void readout_head(const ModelW &W, const Planes &xs, 
             float e = W.b6[0];
 #pragma unroll
             for (int k = 0; k < NCW; ++k) e += red[k * TA + threadIdx.x];
-            if (e_excl) e += e_excl[mN + atom];
+            if (e_excl) e += e_excl[atom];
             e_atom[mN + atom] = e;
         }
     }
@@ -779,7 +815,7 @@ size_t node_mfma_lds_bytes(int which) {
         case 1: return sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(TA, F3));   // msg mlp bwd
         case 2: return sizeof(_Float16) * CF_LDS_HALVES;                                  // update fwd (compact layout)
         case 4: return sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(TA, RH)) + sizeof(float) * (RH / 16) * TA;   // readout
-        case 5: return sizeof(_Float16) * UpdLds<1>::HALVES + sizeof(float) * 3 * 16 * FT;  // update bwd, 16-atom tiles
+        case 6: return 96 * 1024;   // update fwd, one workgroup per CU: the LDS request keeps a second workgroup off the CU
         default: return sizeof(_Float16) * UpdLds<2>::HALVES + sizeof(float) * 3 * TA * FT;  // update bwd: planes + fp32 vbar tile
     }
 }
@@ -788,6 +824,8 @@ static_assert(sizeof(_Float16) * plane_halves(16, RH) + sizeof(float) * (RH / 16
 // (RT = 1 -- 16-atom tiles, two workgroups per CU -- was measured at -5 % for this kernel without the pipelined GEMMs and
 // spills with them; only RT = 2 is instantiated.  profiles/r02/NOTES_node_kernels.md)
 
+static bool g_updfwd_big = true;   // VSSR_UPDFWD_BIG=0 selects the two-workgroups-per-CU variant (128 registers, residual re-read)
+
 bool readout_mfma_supported(int hidden) { return hidden == RH; }
 
 int node_mfma_init(vssr_handle *h) {
@@ -795,8 +833,11 @@ int node_mfma_init(vssr_handle *h) {
                                     (int)node_mfma_lds_bytes(0)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(1)));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(2)));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(6)));
+    if (const char *e = getenv("VSSR_UPDFWD_BIG")) g_updfwd_big = atoi(e) != 0;
 #define SET_UPD(MODE)                                                                                                     \
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma<MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)node_mfma_lds_bytes(3)));
@@ -818,8 +859,12 @@ void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *
 }
 void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_msg,
                             const float *v_msg, float *s_out, float *v_out) {
-    hipLaunchKernelGGL(k_update_fwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(2), st, N, l, MW,
-                       s_msg, v_msg, s_out, v_out);
+    if (g_updfwd_big)
+        hipLaunchKernelGGL(k_update_fwd_mfma<1>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(6), st, N, l,
+                           MW, s_msg, v_msg, s_out, v_out);
+    else
+        hipLaunchKernelGGL(k_update_fwd_mfma<0>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(2), st, N, l,
+                           MW, s_msg, v_msg, s_out, v_out);
 }
 void launch_readout_mfma(hipStream_t st, int N, int M, const ModelW *MW, const float *s, const float *e_excl,
                          float *e_atom) {

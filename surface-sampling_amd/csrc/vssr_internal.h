@@ -72,7 +72,7 @@ struct StateView {  // activations of all models: index [m][atom][...]
     float *s_msg[MAX_LAYERS];     // after message block l
     float *v_msg[MAX_LAYERS];
     float *e_atom;                // [M][N]
-    float *e_excl;                // [M][N] excluded-volume part
+    const float *e_excl;          // [N] excluded-volume part (geometry only: written by k_edge_geom, nbr.hip)
     // reverse
     float *sbar;                  // [M][N][F]     adjoint of s_in[l+1] / s_in[l]
     float *vbar;                  // [M][N][3][F]
@@ -180,7 +180,7 @@ struct vssr_handle {
     std::vector<int> h_n_atoms, h_cfg_start;
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
     vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
-    vssr::DevBuf d_erec, d_rho, d_drho, d_dist, d_rho16, d_drho16, d_zslot, d_bundle;
+    vssr::DevBuf d_erec, d_rho, d_drho, d_dist, d_rho16, d_drho16, d_zslot, d_bundle, d_excl;
     vssr::DevBuf d_hits;         // neighbor search: per (centre, candidate) 64-bit hit masks of the counting pass
     // layer-0 species factorisation (painn_l0.hip)
     int l0_enabled = 1, l0_nz = 0;
@@ -247,8 +247,6 @@ int l0_mfma_init(vssr_handle *h);
 int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_msg);
 int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const float *sbar_msg, const float *vbar_msg,
                    float4 *gbar, long long gbar_stride, int n_groups);
-void launch_excl_vol(hipStream_t st, int N, int M, const GraphView &G, const int *counters, float sigma, int power,
-                     float *e_excl);
 // LDS-slice + MFMA edge stages (painn_edge_mfma.hip)
 int edge_mfma_init(vssr_handle *h);
 int edge_bwd_groups();

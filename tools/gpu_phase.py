@@ -21,8 +21,8 @@ for _ in range(3):
 eng.synchronize()
 lib.vssr_debug_phases(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
-names = {0: "fwd: load tiles + barrier", 1: "fwd: GEMM1 (U, V)", 2: "fwd: norms + plane stores", 3: "fwd: barrier", 4: "fwd: GEMM2 + stores",
-         5: "fwd: barrier", 6: "fwd: GEMM3", 7: "fwd: tile stores + barrier", 8: "fwd: coalesced pass",
+names = {0: "fwd: load tiles + barrier", 1: "fwd: GEMM1 (U, V)", 2: "fwd: GEMM2a (W3 on s)", 3: "fwd: barrier", 4: "fwd: norms + plane stores + barrier",
+         5: "fwd: GEMM2b (W3 on |Vv|) + swish stores", 6: "fwd: barrier", 7: "fwd: GEMM3 (W4)", 8: "fwd: barrier", 9: "fwd: T tile stores + barrier", 10: "fwd: coalesced residual pass",
          16: "bwd: load tiles + barrier", 17: "bwd: GEMM1", 18: "bwd: norms", 19: "bwd: barrier", 20: "bwd: GEMM2", 21: "bwd: barrier",
          22: "bwd: GEMM3", 23: "bwd: qb stores (scalar loads of sbar / vbar)", 24: "bwd: barrier", 25: "bwd: GEMM W4^T + stores", 26: "bwd: barrier",
          27: "bwd: GEMM W3^T", 28: "bwd: barrier", 29: "bwd: ab stores (scalar loads of vbar)", 30: "bwd: barrier", 31: "bwd: GEMM [U|V]^T",
