@@ -143,6 +143,19 @@ typedef struct {
 int vssr_batch_relax_fire(vssr_handle *h, const vssr_fire_params *params, const uint8_t *fixed, uint32_t want,
                           double *pos_out, int32_t *n_steps, uint8_t *converged);
 
+/* ASE BFGS (ase/optimize/bfgs.py: alpha = 70 eV/A^2, maxstep = 0.2 A) -- the optimizer of the reference's SrTiO3
+ * configuration (scripts/configs/sample_config_painn.json:26 "optimizer": "BFGS", dispatched at mcmc/dynamics.py:119-141).
+ * Same contract as vssr_batch_relax_fire.  max_steps <= 46 in this build (the per-chain Hessian is kept in factored form
+ * H = alpha I + Q B Q^T with at most 2 max_steps + 2 columns; csrc/relax.hip). */
+typedef struct {
+    int32_t max_steps; /* relax_steps (reference: 20) */
+    float fmax;        /* 0.01 eV/A */
+    float alpha;       /* initial Hessian, 70 eV/A^2 */
+    float maxstep;     /* longest atomic displacement per step, 0.2 A */
+} vssr_bfgs_params;
+int vssr_batch_relax_bfgs(vssr_handle *h, const vssr_bfgs_params *params, const uint8_t *fixed, uint32_t want,
+                          double *pos_out, int32_t *n_steps, uint8_t *converged);
+
 /* ---- introspection used by tests and bench (no effect on results) ---------------------- */
 /* Per-kernel timing with HIP events on the handle's own stream.  enable=1 starts recording;
  * vssr_profile_read synchronises and returns, for each kernel class, the number of launches and
@@ -159,6 +172,10 @@ int vssr_batch_stats(vssr_handle *h, int64_t *n_atoms, int64_t *n_edges, int64_t
  * arrays may be NULL to query the size. */
 int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, int32_t *eS,
                          float *er, int64_t *n_edges);
+/* Test hook for the capacity-regrow paths: initial neighbor capacity in slots per atom (<= 0: unchanged), tight != 0:
+ * regrow to the exact need only (every later growth of the edge count overflows again), tight < 0: unchanged;
+ * n_regrows (may be NULL) receives the number of regrows of the last relaxation. */
+int vssr_debug_capacity(vssr_handle *h, int32_t slots_per_atom, int32_t tight, int32_t *n_regrows);
 /* Copy a named device intermediate of model m (fp32) to host; for parity debugging.
  * Names: "phi<l>", "s_msg<l>", "v_msg<l>", "s_upd<l>", "v_upd<l>", "sbar_msg<l>", "vbar_msg<l>",
  * "e_atom".  Layouts: s [N][F], v [N][3][F], phi [N][3F]. */

@@ -23,7 +23,7 @@ EXPORTS = (
     "vssr_batch_upload", "vssr_batch_set_positions", "vssr_batch_run", "vssr_batch_download",
     "vssr_synchronize", "vssr_profile_enable", "vssr_profile_reset", "vssr_profile_read",
     "vssr_batch_stats", "vssr_batch_neighbors", "vssr_debug_read", "vssr_tersoff_create",
-    "vssr_tersoff_eval_batch", "vssr_batch_relax_fire",
+    "vssr_tersoff_eval_batch", "vssr_batch_relax_fire", "vssr_batch_relax_bfgs", "vssr_debug_capacity",
 )
 
 
@@ -51,6 +51,15 @@ class FireParams(C.Structure):
     @classmethod
     def default(cls, max_steps=20, fmax=0.01):
         return cls(int(max_steps), float(fmax), 0.1, 0.2, 1.0, 1.1, 0.5, 0.1, 0.99, 5)
+
+
+class BfgsParams(C.Structure):
+    """vssr_bfgs_params; defaults = ASE BFGS defaults and the reference's relax_steps / fmax."""
+    _fields_ = [("max_steps", C.c_int32), ("fmax", C.c_float), ("alpha", C.c_float), ("maxstep", C.c_float)]
+
+    @classmethod
+    def default(cls, max_steps=20, fmax=0.01):
+        return cls(int(max_steps), float(fmax), 70.0, 0.2)
 
 
 class Out(C.Structure):
@@ -113,6 +122,10 @@ def load_library():
     L.vssr_tersoff_eval_batch.argtypes = [vp, C.c_int32, ip, ip, dp, dp, u8p, C.c_uint32, C.POINTER(Out), dp, dp, dp]
     L.vssr_batch_relax_fire.restype = C.c_int
     L.vssr_batch_relax_fire.argtypes = [vp, C.POINTER(FireParams), u8p, C.c_uint32, dp, ip, u8p]
+    L.vssr_batch_relax_bfgs.restype = C.c_int
+    L.vssr_batch_relax_bfgs.argtypes = [vp, C.POINTER(BfgsParams), u8p, C.c_uint32, dp, ip, u8p]
+    L.vssr_debug_capacity.restype = C.c_int
+    L.vssr_debug_capacity.argtypes = [vp, C.c_int32, C.c_int32, ip]
     if L.vssr_abi_version() != 1:
         raise BackendError("libvssr_eval.so ABI version mismatch")
     _lib = L
@@ -210,11 +223,34 @@ class _Handle:
         return self.download(want)
 
     # -- lock-step relaxation ------------------------------------------------------------------------
+    def relax(self, optimizer="FIRE", **kw):
+        """Dispatch on the reference's optimizer names (``mcmc/dynamics.py:119-127``: a name containing "BFGS" selects
+        BFGS, everything else FIRE; BFGSLineSearch / CG / LAMMPS are not provided by this backend)."""
+        name = str(optimizer)
+        if "BFGSLineSearch" in name or "CG" in name or "LAMMPS" in name:
+            raise BackendError(f"optimizer {optimizer!r} is not available on the device (FIRE and BFGS are)")
+        return self.relax_bfgs(**kw) if "BFGS" in name else self.relax_fire(**kw)
+
+    def relax_bfgs(self, fixed=None, max_steps=20, fmax=0.01, want=WANT_ALL, params=None):
+        """BFGS-relax every chain of the resident batch on the device (ASE BFGS, the reference's SrTiO3 optimizer).
+        Same arguments and return value as :meth:`relax_fire`."""
+        p = params or BfgsParams.default(max_steps, fmax)
+        return self._relax_call(self._lib.vssr_batch_relax_bfgs, p, fixed, want)
+
     def relax_fire(self, fixed=None, max_steps=20, fmax=0.01, want=WANT_ALL, params=None):
         """FIRE-relax every chain of the resident batch on the device (reference optimize_slab with FIRE).
         ``fixed``: bool/uint8 [sum N], True = held fixed.  Returns dict(positions [sum N,3] float64,
         n_steps [B], converged [B]) — fetch energies/forces of the relaxed batch with download()."""
         p = params or FireParams.default(max_steps, fmax)
+        return self._relax_call(self._lib.vssr_batch_relax_fire, p, fixed, want)
+
+    def debug_capacity(self, slots_per_atom=0, tight=-1):
+        """Test hook (vssr_debug_capacity); returns the regrow count of the last relaxation."""
+        n = C.c_int32(0)
+        self._check(self._lib.vssr_debug_capacity(self._h, int(slots_per_atom), int(tight), C.byref(n)))
+        return n.value
+
+    def _relax_call(self, fn, p, fixed, want):
         N, B = self._n_atoms, self._n_cfg
         fx = None
         if fixed is not None:
@@ -224,9 +260,8 @@ class _Handle:
         pos = np.zeros((N, 3), np.float64)
         steps = np.zeros(B, np.int32)
         conv = np.zeros(B, np.uint8)
-        self._check(self._lib.vssr_batch_relax_fire(self._h, C.byref(p), _ptr(fx, C.c_uint8), int(want),
-                                                    _ptr(pos, C.c_double), _ptr(steps, C.c_int32),
-                                                    _ptr(conv, C.c_uint8)))
+        self._check(fn(self._h, C.byref(p), _ptr(fx, C.c_uint8), int(want), _ptr(pos, C.c_double),
+                       _ptr(steps, C.c_int32), _ptr(conv, C.c_uint8)))
         return {"positions": pos, "n_steps": steps, "converged": conv.astype(bool)}
 
     # -- introspection -----------------------------------------------------------------------------

@@ -357,10 +357,13 @@ class EnsembleNFFSurface(_Base):
     ENERGY_THRESHOLD = 1000.0
     MAX_FORCE_THRESHOLD = 1000.0
 
-    def relax_batch(self, atoms_list, fixed_indices=None, relax_steps: int = 20, fmax: float = 0.01):
-        """Relax B independent slabs at once on the device with FIRE — the batched counterpart of
-        ``optimize_slab(slab, optimizer="FIRE", relax_steps=..., save_traj=False)`` (reference
-        ``mcmc/dynamics.py:83-170``).  ``fixed_indices``: per slab, the atom indices held by FixAtoms (or None).
+    def relax_batch(self, atoms_list, fixed_indices=None, relax_steps: int = 20, fmax: float = 0.01, optimizer=None):
+        """Relax B independent slabs at once on the device — the batched counterpart of
+        ``optimize_slab(slab, optimizer=..., relax_steps=..., save_traj=False)`` (reference
+        ``mcmc/dynamics.py:83-170``).  ``optimizer``: "BFGS" (ASE BFGS, the reference's SrTiO3 setting,
+        ``scripts/configs/sample_config_painn.json:26``) or "FIRE" (the reference's default); None takes
+        ``parameters["optimizer"]`` (how ``calc_settings`` reach ``optimize_slab``), else "FIRE".
+        ``fixed_indices``: per slab, the atom indices held by FixAtoms (or None).
         Returns, per slab, the reference's tuple ``(relaxed_slab, traj=None, energy, energy_oob)`` where
         ``energy_oob`` follows the same +-1000 guard, plus the results dict of the final evaluation."""
         eng = self._get_engine()
@@ -374,7 +377,9 @@ class EnsembleNFFSurface(_Base):
                 if idx is not None and len(idx):
                     fixed[o + np.asarray(idx, dtype=np.int64)] = 1
                 o += len(p[0])
-        info = eng.relax_fire(fixed=fixed, max_steps=relax_steps, fmax=fmax)
+        if optimizer is None:
+            optimizer = self.parameters.get("optimizer", "FIRE")
+        info = eng.relax(optimizer, fixed=fixed, max_steps=relax_steps, fmax=fmax)
         res = eng.download()
         out = []
         for b, atoms in enumerate(atoms_list):

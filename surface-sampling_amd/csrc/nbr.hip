@@ -66,11 +66,16 @@ __global__ void __launch_bounds__(256)
 k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
       const int *__restrict__ cfg_start, const double *__restrict__ cell, const double *__restrict__ invcell,
       const int *__restrict__ nimg, double rc2, int *__restrict__ deg, const int *__restrict__ row_start, float4 *__restrict__ edge,
-      int *__restrict__ edge_S, long long slot_cap, unsigned long long *__restrict__ hits_buf, int hits_stride) {
+      int *__restrict__ edge_S, long long slot_cap, unsigned long long *__restrict__ hits_buf, int hits_stride,
+      const unsigned char *__restrict__ active) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     const int c = atom_cfg[i];
+    if (active && !active[c]) {   // chain switched off by the relaxation driver: an empty row (its 8 pad slots are never read)
+        if (!FILL && lane == 0) deg[i] = 0;
+        return;
+    }
     const int a0 = cfg_start[c], a1 = cfg_start[c + 1];
     const double *C = cell + 9 * c;
     const int n0 = nimg[3 * c], n1 = nimg[3 * c + 1], n2 = nimg[3 * c + 2];
@@ -237,10 +242,10 @@ k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int
 // reverse-edge slot: for slot (i -> j, S') find (j -> i, -S') in j's row.  One wave per centre, lane per slot.
 __global__ void __launch_bounds__(256)
 k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
-      const int *__restrict__ edge_S, int *__restrict__ rev, const int *__restrict__ counters) {
+      const int *__restrict__ edge_S, int *__restrict__ rev, const int *__restrict__ counters, ActiveView av) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= n || counters[2]) return;
+    if (i >= n || counters[2] || !av.atom(i)) return;
     for (int e = row_start[i] + lane; e < row_start[i + 1]; e += 64) {
         int j = __float_as_int(edge[e].w);
         int found = -1;
@@ -315,9 +320,10 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
                             float4 *__restrict__ erec, float *__restrict__ rho, float *__restrict__ drho,
                             float2 *__restrict__ dist2, uint4 *__restrict__ rho16, uint4 *__restrict__ drho16,
                             const int *__restrict__ Z, const int *__restrict__ zmap, unsigned char *__restrict__ zslot,
-                            float *__restrict__ e_excl) {
+                            float *__restrict__ e_excl, const unsigned char *__restrict__ active) {
     if (counters[2]) return;
     const int i = blockIdx.x;                 // centre atom
+    if (active && !active[atom_cfg[i]]) return;
     const int a0 = cfg_start[atom_cfg[i]];
     const int e0 = row_start[i], e1 = row_start[i + 1];
     const float alpha = 3.14159265358979323846f / rc;
@@ -389,9 +395,9 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
 // are reduced / written with all lanes active.  One workgroup per chain, O(N^2) ranking on LDS broadcasts.
 __global__ void __launch_bounds__(256)
 k_bundle_sort(const int *__restrict__ cfg_start, const int *__restrict__ row_start, const int *__restrict__ counters,
-              int4 *__restrict__ bundle) {
+              int4 *__restrict__ bundle, const unsigned char *__restrict__ active) {
     extern __shared__ int sdeg[];
-    if (counters[2]) return;
+    if (counters[2] || (active && !active[blockIdx.x])) return;
     const int b = blockIdx.x, a0 = cfg_start[b], n = cfg_start[b + 1] - a0;
     for (int c = threadIdx.x; c < n; c += blockDim.x) sdeg[c] = row_start[a0 + c + 1] - row_start[a0 + c];
     __syncthreads();
@@ -416,7 +422,7 @@ int build_neighbors(vssr_handle *h, double cutoff) {
         h->d_deg.ensure(sizeof(int) * n) || h->d_row_start.ensure(sizeof(int) * (n + 1)) ||
         h->d_counters.ensure(sizeof(int) * 4))
         return set_err(h, VSSR_E_NOMEM, "neighbor buffers: out of device memory");
-    if (h->slot_cap < (int64_t)n * 64 + 64) h->slot_cap = (int64_t)n * 64 + 64;
+    if (h->slot_cap < (int64_t)n * h->cap_per_atom + 64) h->slot_cap = (int64_t)n * h->cap_per_atom + 64;
     if (h->d_edge.ensure(sizeof(float4) * h->slot_cap) || h->d_edge_S.ensure(sizeof(int) * h->slot_cap) ||
         h->d_rev.ensure(sizeof(int) * h->slot_cap))
         return set_err(h, VSSR_E_NOMEM, "edge buffers: out of device memory");
@@ -435,15 +441,17 @@ int build_neighbors(vssr_handle *h, double cutoff) {
     hipLaunchKernelGGL(k_nbr<false>, wgrd, wblk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_nimg.as<int>(),
                        cutoff * cutoff, h->d_deg.as<int>(), (const int *)nullptr, (float4 *)nullptr,
-                       (int *)nullptr, (long long)0, hits_buf, hits_stride);
+                       (int *)nullptr, (long long)0, hits_buf, hits_stride, h->active_mask);
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, n, h->d_deg.as<int>(),
                        h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap);
     hipLaunchKernelGGL(k_nbr<true>, wgrd, wblk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_nimg.as<int>(),
                        cutoff * cutoff, h->d_deg.as<int>(), h->d_row_start.as<int>(),
-                       h->d_edge.as<float4>(), h->d_edge_S.as<int>(), (long long)h->slot_cap, hits_buf, hits_stride);
+                       h->d_edge.as<float4>(), h->d_edge_S.as<int>(), (long long)h->slot_cap, hits_buf, hits_stride,
+                       h->active_mask);
     hipLaunchKernelGGL(k_rev, wgrd, wblk, 0, st, n, h->d_row_start.as<int>(), h->d_edge.as<float4>(),
-                       h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>());
+                       h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>(),
+                       ActiveView{h->active_mask, h->d_atom_cfg.as<int>()});
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
         if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
             h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float2) * h->slot_cap) ||
@@ -463,11 +471,11 @@ int build_neighbors(vssr_handle *h, double cutoff) {
                            h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),
                            h->d_drho.as<float>(), h->d_dist.as<float2>(), h->d_rho16.as<uint4>(),
                            h->d_drho16.as<uint4>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_zslot.as<unsigned char>(),
-                           h->d_excl.as<float>());
+                           h->d_excl.as<float>(), h->active_mask);
         if ((size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024)   // chains of the MFMA edge kernels (LDS slices) are far smaller
             hipLaunchKernelGGL(k_bundle_sort, dim3(h->n_cfg), dim3(256), (size_t)h->max_cfg_atoms * sizeof(int), st,
                                h->d_cfg_start.as<int>(), h->d_row_start.as<int>(), h->d_counters.as<int>(),
-                               h->d_bundle.as<int4>());
+                               h->d_bundle.as<int4>(), h->active_mask);
     }
     h->prof.end(st);
     VSSR_HIP(h, hipMemcpyAsync(h->h_counters, h->d_counters.as<int>(), sizeof(int) * 4,

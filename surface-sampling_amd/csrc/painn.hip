@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(128) k_embed(int N, const int *__restrict__ Z,
     int i = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
     const ModelW &W = MW[m];
     size_t a = (size_t)m * N + i;
-    s0[a * F + f] = W.embed[(size_t)Z[i] * F + f];
+    s0[a * F + f] = W.embed[(size_t)Z[i] * F + f];   // (cheap: runs for switched-off chains as well)
     v0[(a * 3 + 0) * F + f] = 0.f;
     v0[(a * 3 + 1) * F + f] = 0.f;
     v0[(a * 3 + 2) * F + f] = 0.f;
@@ -103,7 +103,7 @@ k_edge_fwd(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *
            const float *__restrict__ v_in, const float *__restrict__ phi, float *__restrict__ s_msg,
            float *__restrict__ v_msg) {
     __shared__ EdgeChunk S;
-    if (counters[2]) return;
+    if (counters[2] || !G.act.atom(blockIdx.x)) return;
     const int i = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
     const LayerW &W = MW[m].layer[l];
     float wa[RB], wb[RB], wc[RB];
@@ -164,12 +164,13 @@ k_edge_fwd(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *
 
 // ---- readout (+ its own reverse): e_i = w6.swish(W5 s + b5) + b6 ; sbar = W5^T (w6 * swish'(h5)) ---------
 __global__ void __launch_bounds__(128)
-k_readout(int N, int H, const ModelW *__restrict__ MW, const float *__restrict__ s, const float *__restrict__ e_excl,
-          int excl_vol, float *__restrict__ e_atom, float *__restrict__ sbar) {
+k_readout(int N, int H, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s,
+          const float *__restrict__ e_excl, int excl_vol, float *__restrict__ e_atom, float *__restrict__ sbar) {
     __shared__ float xs[F][T];
     __shared__ float hb[F][T];
     __shared__ float es[F][T];
     const int tid = threadIdx.x, m = blockIdx.y, a0 = blockIdx.x * T;
+    if (!av.tile(min(a0, N - 1), min(a0 + T - 1, N - 1))) return;
     const ModelW &W = MW[m];
     const size_t mN = (size_t)m * N;
     for (int t = 0; t < T; ++t) {
@@ -225,7 +226,7 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
     __shared__ EdgeChunk S;
     __shared__ float red[ECHUNK][4][F + 1];
     __shared__ float tots[ECHUNK][4];
-    if (counters[2]) return;
+    if (counters[2] || !G.act.atom(blockIdx.x)) return;
     const int c = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
     const LayerW &W = MW[m].layer[l];
     float wa[RB], wb[RB], wc[RB];
@@ -358,7 +359,7 @@ k_finalize_forces(int N, int M, GraphView G, const int *__restrict__ counters,
                   float *__restrict__ forces, float *__restrict__ forces_std) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (c >= N || counters[2]) return;
+    if (c >= N || counters[2] || !G.act.atom(c)) return;
     const int e0 = G.row_start[c], e1 = G.row_start[c + 1];
     double fm[3] = {0, 0, 0}, f2[3] = {0, 0, 0};
     for (int m = 0; m < M; ++m) {
@@ -388,13 +389,14 @@ k_finalize_forces(int N, int M, GraphView G, const int *__restrict__ counters,
 }
 
 __global__ void __launch_bounds__(256)
-k_finalize_energy(int N, int M, const int *__restrict__ cfg_start, const int *__restrict__ Z,
+k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const int *__restrict__ cfg_start, const int *__restrict__ Z,
                   const float *__restrict__ e_atom, double units_per_ev, const double *__restrict__ offset_per_z,
                   double offset_const, float *__restrict__ energy, float *__restrict__ energy_std,
                   float *__restrict__ energy_models, float *__restrict__ e_atoms_mean) {
     __shared__ double red[256];
     __shared__ double em[MAX_MODELS];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (active && !active[b]) return;
     const int a0 = cfg_start[b], a1 = cfg_start[b + 1];
     double off = 0.0;
     if (offset_per_z) {
@@ -496,6 +498,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     G.drho16 = h->d_drho16.as<uint4>();
     G.zslot = h->d_zslot.as<unsigned char>();
     G.bundle = h->d_bundle.as<int4>();
+    G.act = ActiveView{h->active_mask, h->d_atom_cfg.as<int>()};
+    const ActiveView &av = G.act;
     const ModelW *MW = h->model_table.as<ModelW>();
     const int *counters = h->d_counters.as<int>();
     const int *Z = h->d_Z.as<int>();
@@ -521,12 +525,12 @@ int painn_run(vssr_handle *h, uint32_t want) {
             if (rc) return rc;
             P.end(st);
             P.begin(KC_UPDATE_FWD, st);
-            launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
+            launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
             P.end(st);
             continue;
         }
         P.begin(KC_MSG_MLP, st);
-        launch_msg_mlp_mfma(st, N, M, l, MW, sv.s_in[l], sv.phi[l]);
+        launch_msg_mlp_mfma(st, N, M, l, av, MW, sv.s_in[l], sv.phi[l]);
         P.end(st);
         P.begin(KC_EDGE_FWD, st);
         if (use_edge_mfma && l > 0)
@@ -542,7 +546,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
                                sv.v_msg[l]);
         P.end(st);
         P.begin(KC_UPDATE_FWD, st);
-        launch_update_fwd_mfma(st, N, M, l, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
+        launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
         P.end(st);
     }
     // Readout.  With forces wanted (and the compiled readout width) it runs as the head of the last layer's reverse kernel;
@@ -552,9 +556,9 @@ int painn_run(vssr_handle *h, uint32_t want) {
     const float *e_excl = h->excl_vol ? sv.e_excl : (const float *)nullptr;
     if (!(fused && want_forces)) {
         P.begin(KC_READOUT, st);
-        if (fused) launch_readout_mfma(st, N, M, MW, sv.s_in[L], e_excl, sv.e_atom);
+        if (fused) launch_readout_mfma(st, N, M, av, MW, sv.s_in[L], e_excl, sv.e_atom);
         else
-            hipLaunchKernelGGL(k_readout, g_tile, blk, 0, st, N, H, MW, sv.s_in[L], sv.e_excl, h->excl_vol, sv.e_atom,
+            hipLaunchKernelGGL(k_readout, g_tile, blk, 0, st, N, H, av, MW, sv.s_in[L], sv.e_excl, h->excl_vol, sv.e_atom,
                                sv.sbar);
         P.end(st);
     }
@@ -569,13 +573,13 @@ int painn_run(vssr_handle *h, uint32_t want) {
             const float *sbar_msg_up = sb_buf[(L - l) & 1];   // adjoint of s_msg[l + 1] (fused path, l < L - 1)
             P.begin(KC_UPDATE_BWD, st);
             if (!fused)
-                launch_update_bwd_mfma(st, N, M, l, 0, (int)(l == L - 1), MW, sv.s_msg[l], sv.v_msg[l], sv.sbar, sv.vbar,
+                launch_update_bwd_mfma(st, N, M, l, 0, (int)(l == L - 1), av, MW, sv.s_msg[l], sv.v_msg[l], sv.sbar, sv.vbar,
                                        nullptr, nullptr, nullptr, nullptr, sbar_msg_l, sv.vbar_msg);
             else if (l == L - 1)
-                launch_update_bwd_mfma(st, N, M, l, 1, 1, MW, sv.s_msg[l], sv.v_msg[l], nullptr, sv.vbar, sv.s_in[L], nullptr,
+                launch_update_bwd_mfma(st, N, M, l, 1, 1, av, MW, sv.s_msg[l], sv.v_msg[l], nullptr, sv.vbar, sv.s_in[L], nullptr,
                                        e_excl, sv.e_atom, sbar_msg_l, sv.vbar_msg);
             else
-                launch_update_bwd_mfma(st, N, M, l, 2, 0, MW, sv.s_msg[l], sv.v_msg[l], sbar_msg_up, sv.vbar, sv.s_in[l + 1],
+                launch_update_bwd_mfma(st, N, M, l, 2, 0, av, MW, sv.s_msg[l], sv.v_msg[l], sbar_msg_up, sv.vbar, sv.s_in[l + 1],
                                        sv.phibar, nullptr, nullptr, sbar_msg_l, sv.vbar_msg);
             P.end(st);
             sv.sbar_msg_l0 = sbar_msg_l;
@@ -601,7 +605,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.end(st);
             if (l > 0 && !fused) {
                 P.begin(KC_MSG_MLP_BWD, st);
-                launch_msg_mlp_bwd_mfma(st, N, M, l, MW, sv.s_in[l], sv.phibar, sv.sbar_msg, sv.sbar);
+                launch_msg_mlp_bwd_mfma(st, N, M, l, av, MW, sv.s_in[l], sv.phibar, sv.sbar_msg, sv.sbar);
                 P.end(st);
             }
         }
@@ -615,7 +619,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
                            (long long)h->slot_cap * n_groups, h->units_per_ev, h->d_forces.as<float>(),
                            h->d_forces_std.as<float>());
     }
-    hipLaunchKernelGGL(k_finalize_energy, dim3(h->n_cfg), dim3(256), 0, st, N, M, G.cfg_start, Z, sv.e_atom,
+    hipLaunchKernelGGL(k_finalize_energy, dim3(h->n_cfg), dim3(256), 0, st, N, M, h->active_mask, G.cfg_start, Z, sv.e_atom,
                        h->units_per_ev, h->has_offset ? h->offset_per_z.as<double>() : (const double *)nullptr,
                        h->offset_const, h->d_energy.as<float>(), h->d_energy_std.as<float>(),
                        h->d_energy_models.as<float>(), h->d_e_atoms.as<float>());

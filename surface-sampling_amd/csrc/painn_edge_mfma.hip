@@ -284,7 +284,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int wg = blockIdx.x, xcd = wg & 7, rest = wg >> 3;
     const int per_chain = NSLICE * n_models;
     const int t = rest % per_chain, b = (rest / per_chain) * 8 + xcd;
-    if (b >= G.n_cfg) return;
+    if (b >= G.n_cfg || !G.act.chain(b)) return;
     const int fs = t % NSLICE, m = t / NSLICE;
     const int a0 = G.cfg_start[b], Nc = G.cfg_start[b + 1] - a0;
     const size_t mN = (size_t)m * N;
@@ -490,7 +490,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     const int wg = blockIdx.x, xcd = wg & 7, rest = wg >> 3;
     const int per_chain = NSG * n_models;
     const int t = rest % per_chain, b = (rest / per_chain) * 8 + xcd;
-    if (b >= G.n_cfg) return;
+    if (b >= G.n_cfg || !G.act.chain(b)) return;
     const int fs = t % NSG, m = t / NSG;   // feature slice = partial-gradient group
     const int a0 = G.cfg_start[b], Nc = G.cfg_start[b + 1] - a0;
     const size_t mN = (size_t)m * N;

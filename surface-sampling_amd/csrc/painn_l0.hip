@@ -25,7 +25,7 @@ template <int NZ>   // number of species of the batch (the per-slot select runs 
 __global__ void __launch_bounds__(96)
 k_l0_accum(GraphView G, const int *__restrict__ counters, float *__restrict__ T) {
     constexpr int nz = NZ;
-    if (counters[2]) return;
+    if (counters[2] || !G.act.atom(blockIdx.x)) return;
     const int i = blockIdx.x, comp = threadIdx.x / KP, kap = threadIdx.x % KP;
     float acc[NZ];
 #pragma unroll
@@ -84,12 +84,13 @@ constexpr int L0_TILE_U4 = 1024;   // uint4 per (model, species, section) in eit
 // forward: s_msg0 = Emb[Z] + T[:, 0] . Ab ,  v_msg0[x] = T[:, 1 + x] . Ac  for every model; workgroup = 32 atoms (the T
 // planes are model independent and are reused for all M models), wave w = features 16 w .. 16 w + 15
 __global__ void __launch_bounds__(NTHREADS)
-k_l0_fwd16(int N, int M, int nz, const int *__restrict__ counters, const int *__restrict__ Z,
+k_l0_fwd16(int N, int M, int nz, ActiveView av, const int *__restrict__ counters, const int *__restrict__ Z,
            const int *__restrict__ zlist, const ModelW *__restrict__ MW, const uint4 *__restrict__ A16, int n_embed,
            const float *__restrict__ T, float *__restrict__ s_msg, float *__restrict__ v_msg) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     if (counters[2]) return;
     const int K = 32 * nz, a0 = blockIdx.x * TA;
+    if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;
     const Planes Ts = make_planes(ldsh, TA, K), Tv = make_planes(ldsh + plane_halves(TA, K), 3 * TA, K);
     const LaneGeo L;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -146,12 +147,13 @@ k_l0_fwd16(int N, int M, int nz, const int *__restrict__ counters, const int *__
 // reverse, per atom: Q_n,z[comp][kappa] = sum_f A_z[f][kappa] X_comp[f], X = [sbar; vbar_x; vbar_y; vbar_z].  Workgroup =
 // (32 atoms, model); the 2 nz column tiles (species x kappa half) are spread over the 8 waves.
 __global__ void __launch_bounds__(NTHREADS)
-k_l0_q16(int N, int nz, const int *__restrict__ counters, const int *__restrict__ zlist, const uint4 *__restrict__ At16,
+k_l0_q16(int N, int nz, ActiveView av, const int *__restrict__ counters, const int *__restrict__ zlist, const uint4 *__restrict__ At16,
          int n_embed, const float *__restrict__ sbar_msg, const float *__restrict__ vbar_msg,
          float *__restrict__ Q /*[M][N][nz][4][24]*/) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     if (counters[2]) return;
     const int a0 = blockIdx.x * TA, m = blockIdx.y;
+    if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;
     const size_t mN = (size_t)m * N;
     const Planes Xs = make_planes(ldsh, TA, F), Xv = make_planes(ldsh + plane_halves(TA, F), 3 * TA, F);
     load_rows_split<TA>(Xs, 0, [&](int row) { return sbar_msg + (mN + min(a0 + row, N - 1)) * F; });
@@ -216,7 +218,7 @@ k_l0_bwd(int N, int M, int nz, int first_write, int excl_vol, GraphView G, const
     extern __shared__ __attribute__((aligned(16))) float qs_all[];   // [wave][m][species][4][24]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane >> 2, kq = lane & 3;
     const int n = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (n >= N || counters[2]) return;
+    if (n >= N || counters[2] || !G.act.atom(n)) return;
     const int per_model = nz * TBLK;
     float *qs = qs_all + (size_t)wave * M * per_model;
     for (int m = 0; m < M; ++m) {
@@ -372,7 +374,7 @@ int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_ms
         }
     }
     const size_t lds_fwd = sizeof(_Float16) * (plane_halves(TA, 32 * nz) + plane_halves(3 * TA, 32 * nz));
-    hipLaunchKernelGGL(k_l0_fwd16, dim3((N + TA - 1) / TA), dim3(NTHREADS), lds_fwd, st, N, M, nz, h->d_counters.as<int>(),
+    hipLaunchKernelGGL(k_l0_fwd16, dim3((N + TA - 1) / TA), dim3(NTHREADS), lds_fwd, st, N, M, nz, G.act, h->d_counters.as<int>(),
                        h->d_Z.as<int>(), h->d_zlist.as<int>(), h->model_table.as<ModelW>(), h->d_l0A.as<uint4>(), h->n_embed,
                        h->d_l0T.as<float>(), s_msg, v_msg);
     return VSSR_OK;
@@ -383,7 +385,7 @@ int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const fl
     const int N = h->n_atoms, M = h->n_models, nz = h->l0_nz;
     hipStream_t st = h->stream;
     const size_t lds_q = sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(3 * TA, F));
-    hipLaunchKernelGGL(k_l0_q16, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), lds_q, st, N, nz, h->d_counters.as<int>(),
+    hipLaunchKernelGGL(k_l0_q16, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), lds_q, st, N, nz, G.act, h->d_counters.as<int>(),
                        h->d_zlist.as<int>(), h->d_l0At.as<uint4>(), h->n_embed, sbar_msg, vbar_msg, h->d_l0Q.as<float>());
     if (sizeof(float) * 4 * M * nz * TBLK > 48 * 1024)   // (3 models x 3 species: 13.8 KB)
         VSSR_HIP(h, hipFuncSetAttribute((const void *)k_l0_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -180,11 +180,12 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRT][NCT]) {
 
 // ---- message MLP forward: phi = W2 swish(W1 s + b1) + b2 ---------------------------------------------------
 __global__ void __launch_bounds__(NTHREADS)
-k_msg_mlp_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
+k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
                float *__restrict__ phi) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     const Planes xs = make_planes(ldsh, TA, F), hs = make_planes(ldsh + plane_halves(TA, F), TA, F);
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
@@ -221,12 +222,13 @@ k_msg_mlp_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restr
 
 // ---- message MLP reverse: sbar_in = sbar_msg + W1^T[(W2^T phibar) * swish'(W1 s + b1)] ------------------------------
 __global__ void __launch_bounds__(NTHREADS)
-k_msg_mlp_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
+k_msg_mlp_bwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
                    const float *__restrict__ phibar, const float *__restrict__ sbar_msg, float *__restrict__ sbar_in) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     const Planes xs = make_planes(ldsh, TA, F);                          // s tile, later h1bar
     const Planes pb = make_planes(ldsh + plane_halves(TA, F), TA, F3);   // phibar tile
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
@@ -381,10 +383,11 @@ static_assert(4 * TA * FT * sizeof(float) <= CF_LDS_HALVES * sizeof(_Float16), "
 // run the software pipeline.
 template <int BIG>
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 2 : 4, BIG ? 2 : 4)))
-k_update_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
+k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
                   const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
@@ -558,10 +561,11 @@ __device__ __forceinline__ void readout_head(const ModelW &W, const Planes &xs, 
 
 // energy-only evaluations: readout of the final scalar features
 __global__ void __launch_bounds__(NTHREADS)
-k_readout_mfma(int N, const ModelW *__restrict__ MW, const float *__restrict__ s, const float *__restrict__ e_excl,
+k_readout_mfma(int N, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s, const float *__restrict__ e_excl,
                float *__restrict__ e_atom) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
     const size_t mN = (size_t)m * N;
     const Planes xs = make_planes(ldsh, TA, F), hp = make_planes(ldsh + plane_halves(TA, F), TA, RH);
@@ -588,13 +592,14 @@ k_readout_mfma(int N, const ModelW *__restrict__ MW, const float *__restrict__ s
 // buffer than the sbar_msg this launch writes).
 template <int MODE, int RT>
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(RT == 1 ? 4 : 2, RT == 1 ? 4 : 2)))
-k_update_bwd_mfma(int N, int l, int vbar_is_zero, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
+k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
                   const float *__restrict__ v_msg, const float *__restrict__ sbar_src, const float *__restrict__ vbar,
                   const float *__restrict__ s_next, const float *__restrict__ phibar, const float *__restrict__ e_excl,
                   float *__restrict__ e_atom, float *__restrict__ sbar_msg, float *__restrict__ vbar_msg) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     constexpr int TA = 16 * RT, OFF_VT = UpdLds<RT>::OFF_VT, OFF_AS = UpdLds<RT>::OFF_AS, UPD_LDS_HALVES = UpdLds<RT>::HALVES;
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
+    if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
@@ -848,32 +853,33 @@ int node_mfma_init(vssr_handle *h) {
     return VSSR_OK;
 }
 
-void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in, float *phi) {
-    hipLaunchKernelGGL(k_msg_mlp_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(0), st, N, l, MW,
+void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
+                         float *phi) {
+    hipLaunchKernelGGL(k_msg_mlp_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(0), st, N, l, av, MW,
                        s_in, phi);
 }
-void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in,
+void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
                              const float *phibar, const float *sbar_msg, float *sbar_in) {
-    hipLaunchKernelGGL(k_msg_mlp_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(1), st, N, l, MW,
+    hipLaunchKernelGGL(k_msg_mlp_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(1), st, N, l, av, MW,
                        s_in, phibar, sbar_msg, sbar_in);
 }
-void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_msg,
+void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_msg,
                             const float *v_msg, float *s_out, float *v_out) {
     if (g_updfwd_big)
         hipLaunchKernelGGL(k_update_fwd_mfma<1>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(6), st, N, l,
-                           MW, s_msg, v_msg, s_out, v_out);
+                           av, MW, s_msg, v_msg, s_out, v_out);
     else
         hipLaunchKernelGGL(k_update_fwd_mfma<0>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(2), st, N, l,
-                           MW, s_msg, v_msg, s_out, v_out);
+                           av, MW, s_msg, v_msg, s_out, v_out);
 }
-void launch_readout_mfma(hipStream_t st, int N, int M, const ModelW *MW, const float *s, const float *e_excl,
-                         float *e_atom) {
-    hipLaunchKernelGGL(k_readout_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(4), st, N, MW, s,
+void launch_readout_mfma(hipStream_t st, int N, int M, const ActiveView &av, const ModelW *MW, const float *s,
+                         const float *e_excl, float *e_atom) {
+    hipLaunchKernelGGL(k_readout_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(4), st, N, av, MW, s,
                        e_excl, e_atom);
 }
 // mode 0: sbar_src = sbar ; mode 1: s_next = final s, e_excl (or null), e_atom ; mode 2: s_next = s_in(l+1), phibar,
 // sbar_src = sbar_msg(l+1)
-void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int vbar_is_zero, const ModelW *MW,
+void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int vbar_is_zero, const ActiveView &av, const ModelW *MW,
                             const float *s_msg, const float *v_msg, const float *sbar_src, const float *vbar,
                             const float *s_next, const float *phibar, const float *e_excl, float *e_atom,
                             float *sbar_msg, float *vbar_msg) {
@@ -881,7 +887,7 @@ void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int v
     const size_t lds = node_mfma_lds_bytes(3);
     if (mode == 1) vbar_is_zero = 1;
 #define LAUNCH_UPD(MODE)                                                                                                    \
-    hipLaunchKernelGGL((k_update_bwd_mfma<MODE, 2>), grid, blk, lds, st, N, l, vbar_is_zero, MW, s_msg, v_msg, sbar_src, vbar, \
+    hipLaunchKernelGGL((k_update_bwd_mfma<MODE, 2>), grid, blk, lds, st, N, l, vbar_is_zero, av, MW, s_msg, v_msg, sbar_src, vbar, \
                        s_next, phibar, e_excl, e_atom, sbar_msg, vbar_msg)
     if (mode == 1) LAUNCH_UPD(1); else if (mode == 2) LAUNCH_UPD(2); else LAUNCH_UPD(0);
 #undef LAUNCH_UPD

@@ -1,31 +1,34 @@
-// relax.hip — lock-step FIRE relaxation of all resident chains on the device.
+// relax.hip — lock-step relaxation of all resident chains on the device: FIRE and BFGS.
 //
-// Counterpart of optimize_slab (reference mcmc/dynamics.py:83-170) with optimizer="FIRE" (its default):
-//   dyn = FIRE(slab); dyn.run(steps=relax_steps, fmax=0.01)
-// ASE's FIRE (ase/optimize/fire.py; defaults dt=0.1, maxstep=0.2, dtmax=1.0, Nmin=5, finc=1.1, fdec=0.5,
-// astart=0.1, fa=0.99) restated per chain; FixAtoms (reference mcmc/system.py:288-294) enters as a per-atom mask
-// that zeroes the force.  The reference drives one structure from Python; here every chain carries its own
-// (velocity, dt, a, Nsteps) state on the device and all chains step together: one energy+force evaluation of the
-// whole batch per iteration, positions and forces never leave HBM.  A chain whose max |F_i| drops below fmax
-// freezes (ASE's convergence test, evaluated before each step).
+// Counterpart of optimize_slab (reference mcmc/dynamics.py:83-170):
+//   dyn = Optimizer(slab); dyn.run(steps=relax_steps, fmax=0.01)
+// with Optimizer = ase.optimize.BFGS for the reference's SrTiO3 configuration (scripts/configs/sample_config_painn.json:26,
+// dispatch mcmc/dynamics.py:119-127) and ase.optimize.FIRE as the default.  FixAtoms (reference mcmc/system.py:288-294)
+// enters as a per-atom mask that zeroes the force.  The reference drives one structure from Python; here every chain
+// carries its own optimizer state on the device and all chains step together: one energy+force evaluation of the batch
+// per iteration, positions and forces never leave HBM.  A chain whose max |F_i| drops below fmax freezes (ASE's
+// convergence test, evaluated before each step) and is marked inactive: the evaluation kernels skip inactive chains, so an
+// iteration costs what its unconverged chains cost.
+//
+// FIRE (ase/optimize/fire.py; defaults dt=0.1, maxstep=0.2, dtmax=1.0, Nmin=5, finc=1.1, fdec=0.5, astart=0.1, fa=0.99)
+// is restated per chain with (velocity, dt, a, Nsteps) state.
+//
+// BFGS (ase/optimize/bfgs.py; alpha = 70, maxstep = 0.2): H0 = alpha I; per step the rank-2 update
+//   H <- H - df df^T / (dr.df) - (H dr)(H dr)^T / (dr.H dr)        (skipped when max|dr| < 1e-7)
+// and the step dr = V |W|^-1 V^T f from the eigen-decomposition H = V W V^T, rescaled so that the longest atomic
+// displacement is at most maxstep.  ASE holds the dense 3N x 3N matrix; here the SAME matrix is held in factored form.
+// After k updates H = alpha I + Q B Q^T exactly, where the m <= 2k orthonormal columns of Q span the update vectors
+// (df_i, H_i dr_i) and B is m x m: H dr costs O(N m), the eigen-decomposition is that of the m x m matrix alpha I + B
+// (every direction outside span(Q) keeps the eigenvalue alpha), and
+//   |H|^-1 f = (f - Q Q^T f) / alpha + Q Y |L|^-1 Y^T Q^T f ,   alpha I + B = Y L Y^T.
+// No 3N x 3N storage and no large eigensolve for any number of free atoms; the m x m problem (m <= 2 relax_steps) is
+// solved by cyclic Jacobi rotations in LDS, fp64.  Pinned against the reference's stored BFGS traces through
+// tests/bfgs_oracle.py (dense restatement of ASE's algorithm) -- tests/test_bfgs.py.
 #include "vssr_internal.h"
 
 namespace vssr {
 
-struct FireState {   // per chain
-    double dt, a;
-    int nsteps_pos;  // steps since the last power <= 0 (ASE's Nsteps)
-    int has_v;       // 0 until the first step (ASE: self.v is None)
-    int steps;       // optimizer steps taken
-    int converged;
-};
-
-__global__ void k_fire_init(int B, double dt0, double astart, FireState *__restrict__ st) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    st[b].dt = dt0; st[b].a = astart; st[b].nsteps_pos = 0; st[b].has_v = 0; st[b].steps = 0; st[b].converged = 0;
-}
-
+// ---- shared block reductions (fp64) ---------------------------------------------------------------------------------------
 __device__ inline double block_sum(double v, double *red) {
     const int tid = threadIdx.x;
     red[tid] = v;
@@ -51,13 +54,39 @@ __device__ inline double block_max(double v, double *red) {
     return r;
 }
 
-// One workgroup per chain: convergence test on the forces of the CURRENT positions, then one FIRE step.
+// chain b has converged: freeze it and take it out of the evaluation
+__device__ inline void mark_converged(int b, int *converged, unsigned char *active) {
+    *converged = 1;
+    active[b] = 0;
+}
+
+// ---- FIRE ---------------------------------------------------------------------------------------------------------------
+struct FireState {   // per chain
+    double dt, a;
+    int nsteps_pos;  // steps since the last power <= 0 (ASE's Nsteps)
+    int has_v;       // 0 until the first step (ASE: self.v is None)
+    int steps;       // optimizer steps taken
+    int converged;
+};
+
+__global__ void k_fire_init(int B, double dt0, double astart, FireState *__restrict__ st, unsigned char *__restrict__ active) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    st[b].dt = dt0; st[b].a = astart; st[b].nsteps_pos = 0; st[b].has_v = 0; st[b].steps = 0; st[b].converged = 0;
+    active[b] = 1;
+}
+
+// One workgroup per chain: convergence test on the forces of the CURRENT positions, then one FIRE step.  Nothing moves
+// when the neighbor capacity overflowed in the evaluation that produced `forces` (counters[2]): the host regrows the
+// buffers, repeats the evaluation and launches this kernel again.
 __global__ void __launch_bounds__(256)
-k_fire_step(const int *__restrict__ cfg_start, const float *__restrict__ forces, const uint8_t *__restrict__ fixed,
-            double fmax_tol, double maxstep, double dtmax, double finc, double fdec, double astart, double fa, int nmin,
-            double *__restrict__ pos, double *__restrict__ vel, FireState *__restrict__ st, int *__restrict__ n_active) {
+k_fire_step(const int *__restrict__ cfg_start, const int *__restrict__ counters, const float *__restrict__ forces,
+            const uint8_t *__restrict__ fixed, double fmax_tol, double maxstep, double dtmax, double finc, double fdec,
+            double astart, double fa, int nmin, int max_steps, double *__restrict__ pos, double *__restrict__ vel,
+            FireState *__restrict__ st, unsigned char *__restrict__ active, int *__restrict__ n_active) {
     __shared__ double red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (counters[2]) return;
     const int a0 = cfg_start[b], a1 = cfg_start[b + 1];
     FireState S = st[b];
     if (S.converged) return;
@@ -70,9 +99,10 @@ k_fire_step(const int *__restrict__ cfg_start, const float *__restrict__ forces,
     }
     fm2 = block_max(fm2, red);
     if (!(fm2 >= fmax_tol * fmax_tol)) {   // converged (a NaN force also stops the chain: nothing sane to follow)
-        if (tid == 0) st[b].converged = 1;
+        if (tid == 0) mark_converged(b, &st[b].converged, active);
         return;
     }
+    if (S.steps >= max_steps) return;   // (iterations repeated after a capacity regrow never exceed relax_steps)
     double vf = 0.0, ff = 0.0, vv = 0.0;
     for (int i = a0 + tid; i < a1; i += blockDim.x) {
         const bool fx_ = fixed && fixed[i];
@@ -123,56 +153,373 @@ k_fire_step(const int *__restrict__ cfg_start, const float *__restrict__ forces,
     }
 }
 
+// ---- BFGS ---------------------------------------------------------------------------------------------------------------
+struct BfgsState {   // per chain
+    int m;           // columns of Q
+    int has_prev;    // r0 / f0 hold the previous step's positions / forces
+    int steps;
+    int converged;
+};
+
+__global__ void k_bfgs_init(int B, BfgsState *__restrict__ st, unsigned char *__restrict__ active) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    st[b].m = 0; st[b].has_prev = 0; st[b].steps = 0; st[b].converged = 0;
+    active[b] = 1;
+}
+
+// Eigen-decomposition of the symmetric m x m matrix A (LDS, row stride ld): cyclic Jacobi with the round-robin parallel
+// ordering -- m / 2 disjoint rotations per round, m - 1 rounds per sweep.  On return diag(A) = eigenvalues and the columns
+// of Y the eigenvectors (A_in = Y diag Y^T).  cs: 2 * (m / 2 + 1) doubles of scratch.  All threads of the block take part.
+__device__ void jacobi_eigh(double *A, double *Y, int m, int ld, double *cs, double *red) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int t = tid; t < m * m; t += nt) Y[(t / m) * ld + t % m] = (t / m == t % m) ? 1.0 : 0.0;
+    __syncthreads();
+    if (m < 2) return;
+    const int me = m + (m & 1);          // players of the tournament (a dummy player when m is odd)
+    const int half = me / 2;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        // off-diagonal weight against the diagonal
+        double off = 0.0, dg = 0.0;
+        for (int t = tid; t < m * m; t += nt) {
+            const int p = t / m, q = t % m;
+            const double v = A[p * ld + q];
+            if (p == q) dg += v * v; else off += v * v;
+        }
+        off = block_sum(off, red);
+        dg = block_sum(dg, red);
+        if (off <= 1e-30 * dg || off == 0.0) break;
+        for (int r = 0; r < me - 1; ++r) {
+            // rotation angles of this round's pairs
+            if (tid < half) {
+                int p = tid == 0 ? me - 1 : (r + tid) % (me - 1);
+                int q = tid == 0 ? r : (r - tid + (me - 1)) % (me - 1);
+                if (p > q) { const int t2 = p; p = q; q = t2; }
+                double c = 1.0, s = 0.0;
+                if (q < m) {
+                    const double apq = A[p * ld + q];
+                    if (apq != 0.0) {
+                        const double tau = (A[q * ld + q] - A[p * ld + p]) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        s = t * c;
+                    }
+                }
+                cs[2 * tid] = c; cs[2 * tid + 1] = s;
+            }
+            __syncthreads();
+            // columns p, q of A and of Y:  (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q) for every row
+            for (int t = tid; t < half * m; t += nt) {
+                const int i = t / m, k = t % m;
+                int p = i == 0 ? me - 1 : (r + i) % (me - 1);
+                int q = i == 0 ? r : (r - i + (me - 1)) % (me - 1);
+                if (p > q) { const int t2 = p; p = q; q = t2; }
+                if (q >= m) continue;
+                const double c = cs[2 * i], s = cs[2 * i + 1];
+                const double ap = A[k * ld + p], aq = A[k * ld + q];
+                A[k * ld + p] = c * ap - s * aq; A[k * ld + q] = s * ap + c * aq;
+                const double yp = Y[k * ld + p], yq = Y[k * ld + q];
+                Y[k * ld + p] = c * yp - s * yq; Y[k * ld + q] = s * yp + c * yq;
+            }
+            __syncthreads();
+            // rows p, q of A
+            for (int t = tid; t < half * m; t += nt) {
+                const int i = t / m, k = t % m;
+                int p = i == 0 ? me - 1 : (r + i) % (me - 1);
+                int q = i == 0 ? r : (r - i + (me - 1)) % (me - 1);
+                if (p > q) { const int t2 = p; p = q; q = t2; }
+                if (q >= m) continue;
+                const double c = cs[2 * i], s = cs[2 * i + 1];
+                const double ap = A[p * ld + k], aq = A[q * ld + k];
+                A[p * ld + k] = c * ap - s * aq; A[q * ld + k] = s * ap + c * aq;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// One workgroup per chain.  Vectors are over ALL 3 N_b coordinates of the chain with the entries of held atoms zero (their
+// force is zeroed and they never move), which is exactly ASE's block structure.  Q: [mmax][3 N_b] rows (basis vectors),
+// Bm: [mmax][mmax] (row stride mmax).
+__global__ void __launch_bounds__(256)
+k_bfgs_step(const int *__restrict__ cfg_start, const int *__restrict__ counters, const float *__restrict__ forces,
+            const uint8_t *__restrict__ fixed, double fmax_tol, double alpha, double maxstep, int mmax, int max_steps,
+            double *__restrict__ pos, double *__restrict__ r0, double *__restrict__ f0, double *__restrict__ Qall,
+            double *__restrict__ Ball, double *__restrict__ work /*[3 sum N] step vector*/, BfgsState *__restrict__ st,
+            unsigned char *__restrict__ active, int *__restrict__ n_active) {
+    extern __shared__ double lds[];
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (counters[2]) return;
+    const int a0 = cfg_start[b], a1 = cfg_start[b + 1];
+    const int n = 3 * (a1 - a0);
+    BfgsState S = st[b];
+    if (S.converged) return;
+    double *Q = Qall + (size_t)3 * a0 * mmax;          // rows of length n
+    double *Bm = Ball + (size_t)b * mmax * mmax;
+    double *x = pos + 3 * (size_t)a0, *xr0 = r0 + 3 * (size_t)a0, *xf0 = f0 + 3 * (size_t)a0, *w = work + 3 * (size_t)a0;
+    const float *fg = forces + 3 * (size_t)a0;
+    const uint8_t *fx = fixed ? fixed + a0 : nullptr;
+    auto F = [&](int k) -> double { return (fx && fx[k / 3]) ? 0.0 : (double)fg[k]; };
+    // LDS carve-up
+    const int ld = mmax | 1;                             // odd row stride: no bank conflicts on column walks
+    double *A = lds, *Y = A + (size_t)mmax * ld, *c1 = Y + (size_t)mmax * ld, *c2 = c1 + mmax, *cf = c2 + mmax,
+           *tv = cf + mmax, *cs = tv + mmax;             // cs: mmax + 2
+
+    // ---- convergence: max_i |F_i|^2 < fmax^2 (ase/optimize/optimize.py converged()) ----------------------------------------
+    double fm2 = 0.0;
+    for (int i = tid; i < a1 - a0; i += nt) {
+        const double f0_ = F(3 * i), f1_ = F(3 * i + 1), f2_ = F(3 * i + 2);
+        fm2 = fmax(fm2, f0_ * f0_ + f1_ * f1_ + f2_ * f2_);
+    }
+    fm2 = block_max(fm2, red);
+    if (!(fm2 >= fmax_tol * fmax_tol)) {
+        if (tid == 0) mark_converged(b, &st[b].converged, active);
+        return;
+    }
+    if (S.steps >= max_steps) return;
+    int m = S.m;
+    // ---- update of H from the previous step (ase/optimize/bfgs.py update()) -------------------------------------------------
+    if (S.has_prev) {
+        double mx = 0.0;
+        for (int k = tid; k < n; k += nt) mx = fmax(mx, fabs(x[k] - xr0[k]));
+        mx = block_max(mx, red);
+        if (mx >= 1e-7 && m + 2 <= mmax) {
+            // a = dr.df ; c1 = Q^T dr
+            double a = 0.0;
+            for (int k = tid; k < n; k += nt) a += (x[k] - xr0[k]) * (F(k) - xf0[k]);
+            a = block_sum(a, red);
+            for (int j = 0; j < m; ++j) {
+                double d = 0.0;
+                for (int k = tid; k < n; k += nt) d += Q[(size_t)j * n + k] * (x[k] - xr0[k]);
+                d = block_sum(d, red);
+                if (tid == 0) c1[j] = d;
+            }
+            __syncthreads();
+            // tv = B c1 ; dg = alpha dr + Q tv -> w ; b = dr.dg
+            for (int j = tid; j < m; j += nt) {
+                double d = 0.0;
+                for (int i = 0; i < m; ++i) d += Bm[(size_t)j * mmax + i] * c1[i];
+                tv[j] = d;
+            }
+            __syncthreads();
+            double bb = 0.0;
+            for (int k = tid; k < n; k += nt) {
+                const double dr = x[k] - xr0[k];
+                double g = alpha * dr;
+                for (int j = 0; j < m; ++j) g += Q[(size_t)j * n + k] * tv[j];
+                w[k] = g;
+                bb += dr * g;
+            }
+            bb = block_sum(bb, red);
+            // append the two update vectors to the basis: coefficients c1 (df), c2 (dg) in the extended basis.
+            // Two Gram-Schmidt passes ("twice is enough"); a vector already inside span(Q) adds no column.
+            for (int which = 0; which < 2; ++which) {
+                double *cc = which == 0 ? c1 : c2;
+                double *qn = Q + (size_t)m * n;            // candidate column
+                double nrm0 = 0.0;
+                for (int k = tid; k < n; k += nt) {
+                    const double v = which == 0 ? F(k) - xf0[k] : w[k];
+                    qn[k] = v;
+                    nrm0 += v * v;
+                }
+                nrm0 = block_sum(nrm0, red);
+                for (int j = tid; j < mmax; j += nt) cc[j] = 0.0;
+                __syncthreads();
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int j = 0; j < m; ++j) {
+                        double d = 0.0;
+                        for (int k = tid; k < n; k += nt) d += Q[(size_t)j * n + k] * qn[k];
+                        d = block_sum(d, red);
+                        for (int k = tid; k < n; k += nt) qn[k] -= d * Q[(size_t)j * n + k];
+                        if (tid == 0) cc[j] += d;
+                        __syncthreads();
+                    }
+                double nrm = 0.0;
+                for (int k = tid; k < n; k += nt) nrm += qn[k] * qn[k];
+                nrm = block_sum(nrm, red);
+                if (nrm > 1e-24 * nrm0 && nrm > 0.0) {
+                    const double inv = 1.0 / sqrt(nrm);
+                    for (int k = tid; k < n; k += nt) qn[k] *= inv;
+                    if (tid == 0) cc[m] = sqrt(nrm);
+                    // new row / column of B (zeros)
+                    for (int j = tid; j <= m; j += nt) { Bm[(size_t)m * mmax + j] = 0.0; Bm[(size_t)j * mmax + m] = 0.0; }
+                    ++m;
+                }
+                __syncthreads();
+            }
+            // B -= c1 c1^T / a + c2 c2^T / b
+            for (int t = tid; t < m * m; t += nt) {
+                const int i = t / m, j = t % m;
+                Bm[(size_t)i * mmax + j] -= c1[i] * c1[j] / a + c2[i] * c2[j] / bb;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- step: dr = |H|^-1 f -------------------------------------------------------------------------------------------------
+    for (int t = tid; t < m * m; t += nt) {
+        const int i = t / m, j = t % m;
+        A[i * ld + j] = Bm[(size_t)i * mmax + j] + (i == j ? alpha : 0.0);
+    }
+    __syncthreads();
+    jacobi_eigh(A, Y, m, ld, cs, red);
+    for (int j = 0; j < m; ++j) {   // cf = Q^T f
+        double d = 0.0;
+        for (int k = tid; k < n; k += nt) d += Q[(size_t)j * n + k] * F(k);
+        d = block_sum(d, red);
+        if (tid == 0) cf[j] = d;
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += nt) {   // tv = |L|^-1 Y^T cf
+        double d = 0.0;
+        for (int i = 0; i < m; ++i) d += Y[i * ld + j] * cf[i];
+        tv[j] = d / fabs(A[j * ld + j]);
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += nt) {   // c1 = Y tv - cf / alpha   (coefficients of Q in the step)
+        double d = 0.0;
+        for (int j = 0; j < m; ++j) d += Y[i * ld + j] * tv[j];
+        c1[i] = d - cf[i] / alpha;
+    }
+    __syncthreads();
+    double mx2 = 0.0;
+    for (int i = tid; i < a1 - a0; i += nt) {
+        double s2 = 0.0;
+        for (int xk = 0; xk < 3; ++xk) {
+            const int k = 3 * i + xk;
+            double d = F(k) / alpha;
+            for (int j = 0; j < m; ++j) d += Q[(size_t)j * n + k] * c1[j];
+            w[k] = d;
+            s2 += d * d;
+        }
+        mx2 = fmax(mx2, s2);
+    }
+    mx2 = block_max(mx2, red);
+    const double longest = sqrt(mx2);
+    const double scale = longest >= maxstep ? maxstep / longest : 1.0;
+    for (int k = tid; k < n; k += nt) {
+        xr0[k] = x[k];
+        xf0[k] = F(k);
+        x[k] += scale * w[k];
+    }
+    if (tid == 0) {
+        S.m = m;
+        S.has_prev = 1;
+        S.steps += 1;
+        st[b] = S;
+        atomicAdd(n_active, 1);
+    }
+}
+
 __global__ void k_narrow_forces(int n3, const double *__restrict__ f64, float *__restrict__ f32) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n3) f32[i] = (float)f64[i];
 }
 
-__global__ void k_fire_report(int B, const FireState *__restrict__ st, int *__restrict__ steps, uint8_t *__restrict__ conv) {
+template <class State>
+__global__ void k_relax_report(int B, const State *__restrict__ st, int *__restrict__ steps, uint8_t *__restrict__ conv) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     steps[b] = st[b].steps;
     conv[b] = (uint8_t)st[b].converged;
 }
 
-int relax_fire(vssr_handle *h, const vssr_fire_params *fp, const uint8_t *fixed_host, uint32_t want) {
+// ---- host driver ----------------------------------------------------------------------------------------------------------
+// Iteration i: evaluate energies / forces of the chains still active, then (device side) test convergence and step.  The host
+// only enqueues; every POLL iterations it reads the number of chains that took a step and the neighbor-capacity flag.  If
+// the capacity overflowed, the step kernels of the affected iterations did nothing (they test the flag): the buffers are
+// regrown and the loop continues from the same positions.  Iterations enqueued after every chain has converged find no
+// active chain and cost only their (empty) launches.
+static size_t bfgs_lds_bytes(int mmax) { return sizeof(double) * ((size_t)2 * mmax * (mmax | 1) + 5 * (size_t)mmax + 8); }
+
+int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr_bfgs_params *bp,
+              const uint8_t *fixed_host, uint32_t want) {
     const int B = h->n_cfg, N = h->n_atoms;
     hipStream_t st = h->stream;
-    if (h->d_vel.ensure(sizeof(double) * 3 * N) || h->d_fire.ensure(sizeof(FireState) * B) ||
-        h->d_fixed.ensure((size_t)N) || h->d_relax_steps.ensure(sizeof(int) * B) || h->d_relax_conv.ensure((size_t)B) ||
-        h->d_counters.ensure(sizeof(int) * 4))
+    const int max_steps = method == 1 ? bp->max_steps : fp->max_steps;
+    const double fmax_tol = method == 1 ? bp->fmax : fp->fmax;
+    int mmax = 0;
+    if (h->d_fixed.ensure((size_t)N) || h->d_relax_steps.ensure(sizeof(int) * B) || h->d_relax_conv.ensure((size_t)B) ||
+        h->d_active.ensure((size_t)B) || h->d_counters.ensure(sizeof(int) * 4))
         return set_err(h, VSSR_E_NOMEM, "relaxation state: out of device memory");
+    if (method == 0) {
+        if (h->d_vel.ensure(sizeof(double) * 3 * N) || h->d_fire.ensure(sizeof(FireState) * B))
+            return set_err(h, VSSR_E_NOMEM, "FIRE state: out of device memory");
+    } else {
+        mmax = 2 * max_steps + 2;
+        if (bfgs_lds_bytes(mmax) > 160 * 1024 - 4096)   // (the kernel also holds 2 KB of static reduction scratch)
+            return set_err(h, VSSR_E_BADARG, "BFGS: relax_steps %d exceeds the on-chip limit of this build (46)", max_steps);
+        if (h->d_fire.ensure(sizeof(BfgsState) * B) || h->d_vel.ensure(sizeof(double) * 3 * N * 3) ||
+            h->d_bfgs_q.ensure(sizeof(double) * 3 * (size_t)N * mmax) || h->d_bfgs_b.ensure(sizeof(double) * (size_t)B * mmax * mmax))
+            return set_err(h, VSSR_E_NOMEM, "BFGS state: out of device memory");
+        VSSR_HIP(h, hipFuncSetAttribute((const void *)k_bfgs_step, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bfgs_lds_bytes(mmax)));
+    }
     const uint8_t *fixed = nullptr;
     if (fixed_host) {
         VSSR_HIP(h, hipMemcpyAsync(h->d_fixed.p, fixed_host, (size_t)N, hipMemcpyHostToDevice, st));
         fixed = h->d_fixed.as<uint8_t>();
     }
-    hipLaunchKernelGGL(k_fire_init, dim3((B + 127) / 128), dim3(128), 0, st, B, (double)fp->dt, (double)fp->astart,
-                       h->d_fire.as<FireState>());
+    unsigned char *active = h->d_active.as<unsigned char>();
+    if (method == 0)
+        hipLaunchKernelGGL(k_fire_init, dim3((B + 127) / 128), dim3(128), 0, st, B, (double)fp->dt, (double)fp->astart,
+                           h->d_fire.as<FireState>(), active);
+    else
+        hipLaunchKernelGGL(k_bfgs_init, dim3((B + 127) / 128), dim3(128), 0, st, B, h->d_fire.as<BfgsState>(), active);
+    h->active_mask = active;   // the evaluation kernels skip chains whose entry is 0
     int *n_active_d = h->d_counters.as<int>() + 3;   // counters[3] is free for this purpose
-    for (int it = 0; it <= fp->max_steps; ++it) {
-        int rc = h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : painn_run(h, want | VSSR_WANT_FORCES);
-        if (rc) return rc;
-        if (it == fp->max_steps) break;
-        VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
-        if (h->kind == 2) {   // Tersoff forces are fp64 on the device: the optimizer state works on an fp32 copy
-            if (h->d_forces.ensure(sizeof(float) * 3 * N)) return set_err(h, VSSR_E_NOMEM, "force buffer");
-            hipLaunchKernelGGL(k_narrow_forces, dim3((3 * N + 255) / 256), dim3(256), 0, st, 3 * N,
-                               h->d_ters_f.as<double>(), h->d_forces.as<float>());
+    const int POLL = 4;
+    int rc = VSSR_OK;
+    auto evaluate = [&]() { return h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : painn_run(h, want | VSSR_WANT_FORCES); };
+    for (int it = 0; it <= max_steps && !rc; ++it) {
+        rc = evaluate();
+        if (rc) break;
+        const bool last = it == max_steps;
+        {   // (last iteration: every unconverged chain has taken relax_steps steps -- the kernel only tests convergence, like the
+            // final check of ASE's run loop)
+            VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
+            if (h->kind == 2) {   // Tersoff forces are fp64 on the device: the optimizer state works on an fp32 copy
+                if (h->d_forces.ensure(sizeof(float) * 3 * N)) { rc = set_err(h, VSSR_E_NOMEM, "force buffer"); break; }
+                hipLaunchKernelGGL(k_narrow_forces, dim3((3 * N + 255) / 256), dim3(256), 0, st, 3 * N,
+                                   h->d_ters_f.as<double>(), h->d_forces.as<float>());
+            }
+            const float *forces = h->d_forces.as<float>();
+            if (method == 0)
+                hipLaunchKernelGGL(k_fire_step, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
+                                   forces, fixed, fmax_tol, (double)fp->maxstep, (double)fp->dtmax, (double)fp->finc,
+                                   (double)fp->fdec, (double)fp->astart, (double)fp->fa, fp->nmin, max_steps, h->d_pos.as<double>(),
+                                   h->d_vel.as<double>(), h->d_fire.as<FireState>(), active, n_active_d);
+            else
+                hipLaunchKernelGGL(k_bfgs_step, dim3(B), dim3(256), bfgs_lds_bytes(mmax), st, h->d_cfg_start.as<int>(),
+                                   h->d_counters.as<int>(), forces, fixed, fmax_tol, (double)bp->alpha, (double)bp->maxstep, mmax, max_steps,
+                                   h->d_pos.as<double>(), h->d_vel.as<double>(), h->d_vel.as<double>() + 3 * (size_t)N,
+                                   h->d_bfgs_q.as<double>(), h->d_bfgs_b.as<double>(),
+                                   h->d_vel.as<double>() + 6 * (size_t)N, h->d_fire.as<BfgsState>(), active, n_active_d);
+            VSSR_HIP(h, hipMemcpyAsync(h->h_counters + 3, n_active_d, sizeof(int), hipMemcpyDeviceToHost, st));
         }
-        const float *forces = h->d_forces.as<float>();
-        hipLaunchKernelGGL(k_fire_step, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), forces, fixed,
-                           (double)fp->fmax, (double)fp->maxstep, (double)fp->dtmax, (double)fp->finc, (double)fp->fdec,
-                           (double)fp->astart, (double)fp->fa, fp->nmin, h->d_pos.as<double>(), h->d_vel.as<double>(),
-                           h->d_fire.as<FireState>(), n_active_d);
-        VSSR_HIP(h, hipMemcpyAsync(h->h_counters + 3, n_active_d, sizeof(int), hipMemcpyDeviceToHost, st));
-        VSSR_HIP(h, hipStreamSynchronize(st));
-        if (h->h_counters[2])   // neighbor capacity overflow: grow and redo this iteration's evaluation
-            return set_err(h, VSSR_E_CAPACITY, "neighbor capacity exceeded during relaxation (re-upload and retry)");
-        if (h->h_counters[3] == 0) break;   // every chain converged: positions did not move, results are final
+        if (last || (it + 1) % POLL == 0) {
+            VSSR_HIP(h, hipStreamSynchronize(st));
+            if (h->h_counters[2]) {   // neighbor capacity overflow in one of the enqueued evaluations: grow, redo
+                if (h->h_counters[0] <= 0) { rc = set_err(h, VSSR_E_CAPACITY, "neighbor list exceeds 2^31 slots"); break; }
+                h->slot_cap = (int64_t)h->h_counters[0] + (h->cap_tight ? 0 : (int64_t)h->h_counters[0] / 8) + 64;
+                // the step kernels behind the overflowed evaluations did not move anything and did not count steps: go back
+                // by one polling window (chains that did step in it are held to relax_steps by their own step counters)
+                it -= POLL;
+                if (it < -1) it = -1;
+                if (++h->relax_regrows > (h->cap_tight ? 64 : 8)) { rc = set_err(h, VSSR_E_CAPACITY, "neighbor capacity could not be satisfied"); break; }
+                continue;
+            }
+            if (!last && h->h_counters[3] == 0) break;   // no chain stepped in the last iteration: all converged, results final
+        }
     }
-    hipLaunchKernelGGL(k_fire_report, dim3((B + 127) / 128), dim3(128), 0, st, B, h->d_fire.as<FireState>(),
-                       h->d_relax_steps.as<int>(), h->d_relax_conv.as<uint8_t>());
+    h->active_mask = nullptr;
+    if (rc) return rc;
+    if (method == 0)
+        hipLaunchKernelGGL(k_relax_report<FireState>, dim3((B + 127) / 128), dim3(128), 0, st, B, h->d_fire.as<FireState>(),
+                           h->d_relax_steps.as<int>(), h->d_relax_conv.as<uint8_t>());
+    else
+        hipLaunchKernelGGL(k_relax_report<BfgsState>, dim3((B + 127) / 128), dim3(128), 0, st, B, h->d_fire.as<BfgsState>(),
+                           h->d_relax_steps.as<int>(), h->d_relax_conv.as<uint8_t>());
     VSSR_HIP(h, hipGetLastError());
     h->ran = true;
     return VSSR_OK;

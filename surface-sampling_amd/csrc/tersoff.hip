@@ -71,9 +71,9 @@ __global__ void k_tersoff_site(int N, int nt, const TersP *__restrict__ P, const
                                const double *__restrict__ wpos, const int *__restrict__ row_start,
                                const float4 *__restrict__ edge, const int *__restrict__ edge_S,
                                const int *__restrict__ counters, double *__restrict__ eps /*[slots]*/,
-                               double *__restrict__ gslot /*[slots][3]*/) {
+                               double *__restrict__ gslot /*[slots][3]*/, ActiveView av) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N || counters[2]) return;
+    if (i >= N || counters[2] || !av.atom(i)) return;
     const double *C = cell + 9 * atom_cfg[i];
     const int ti = type[i];
     const int e0 = row_start[i], e1 = row_start[i + 1];
@@ -144,9 +144,9 @@ __global__ void k_tersoff_site(int N, int nt, const TersP *__restrict__ P, const
 __global__ void k_tersoff_gather(int N, const int *__restrict__ row_start, const int *__restrict__ rev,
                                  const int *__restrict__ counters, const double *__restrict__ eps,
                                  const double *__restrict__ gslot, double *__restrict__ e_atom,
-                                 double *__restrict__ forces) {
+                                 double *__restrict__ forces, ActiveView av) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N || counters[2]) return;
+    if (c >= N || counters[2] || !av.atom(c)) return;
     double ea = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0;
     for (int e = row_start[c]; e < row_start[c + 1]; ++e) {
         int r = rev[e];
@@ -161,9 +161,11 @@ __global__ void k_tersoff_gather(int N, const int *__restrict__ row_start, const
 }
 
 __global__ void __launch_bounds__(256)
-k_tersoff_energy(const int *__restrict__ cfg_start, const double *__restrict__ e_atom, double *__restrict__ energy) {
+k_tersoff_energy(const int *__restrict__ cfg_start, const double *__restrict__ e_atom, double *__restrict__ energy,
+                 const unsigned char *__restrict__ active) {
     __shared__ double red[256];
     int b = blockIdx.x, tid = threadIdx.x;
+    if (active && !active[b]) return;
     double acc = 0.0;
     for (int i = cfg_start[b] + tid; i < cfg_start[b + 1]; i += blockDim.x) acc += e_atom[i];
     red[tid] = acc;
@@ -188,14 +190,15 @@ int tersoff_run(vssr_handle *h, uint32_t want) {
     double *gslot = eps + h->slot_cap;
     h->prof.begin(KC_TERSOFF, st);
     dim3 blk(64), grd((N + 63) / 64);
+    const ActiveView av{h->active_mask, h->d_atom_cfg.as<int>()};
     hipLaunchKernelGGL(k_tersoff_site, grd, blk, 0, st, N, h->n_types, h->ters_params.as<TersP>(), h->d_Z.as<int>(),
                        h->d_atom_cfg.as<int>(), h->d_cell.as<double>(), h->d_wpos.as<double>(),
                        h->d_row_start.as<int>(), h->d_edge.as<float4>(), h->d_edge_S.as<int>(),
-                       h->d_counters.as<int>(), eps, gslot);
+                       h->d_counters.as<int>(), eps, gslot, av);
     hipLaunchKernelGGL(k_tersoff_gather, grd, blk, 0, st, N, h->d_row_start.as<int>(), h->d_rev.as<int>(),
-                       h->d_counters.as<int>(), eps, gslot, h->d_ters_ea.as<double>(), h->d_ters_f.as<double>());
+                       h->d_counters.as<int>(), eps, gslot, h->d_ters_ea.as<double>(), h->d_ters_f.as<double>(), av);
     hipLaunchKernelGGL(k_tersoff_energy, dim3(h->n_cfg), dim3(256), 0, st, h->d_cfg_start.as<int>(),
-                       h->d_ters_ea.as<double>(), h->d_ters_e.as<double>());
+                       h->d_ters_ea.as<double>(), h->d_ters_e.as<double>(), h->active_mask);
     h->prof.end(st);
     VSSR_HIP(h, hipGetLastError());
     return VSSR_OK;

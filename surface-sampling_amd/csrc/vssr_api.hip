@@ -249,18 +249,20 @@ static void cell_host_setup(const double *cell, const uint8_t *pbc, double cutof
 static double handle_cutoff(const vssr_handle *h) { return h->kind == 2 ? h->ters_cutmax : (double)h->cutoff; }
 
 static int run_any(vssr_handle *h, uint32_t want) {
+    h->last_want = want;
     return h->kind == 2 ? tersoff_run(h, want) : painn_run(h, want);
 }
 
 // synchronise; if the neighbor capacity overflowed, grow and rerun
-static int sync_and_check(vssr_handle *h, uint32_t want) {
+static int sync_and_check(vssr_handle *h) {
+    const uint32_t want = h->last_want;   // a rerun after a capacity overflow produces what the original run was asked for
     for (int attempt = 0; attempt < 4; ++attempt) {
         VSSR_HIP(h, hipStreamSynchronize(h->stream));
         h->prof.collect();
         if (!h->ran || !h->h_counters[2]) return VSSR_OK;
         if (h->h_counters[0] <= 0)
             return set_err(h, VSSR_E_CAPACITY, "neighbor list exceeds 2^31 slots");
-        h->slot_cap = (int64_t)h->h_counters[0] + (int64_t)h->h_counters[0] / 8 + 64;
+        h->slot_cap = (int64_t)h->h_counters[0] + (h->cap_tight ? 0 : (int64_t)h->h_counters[0] / 8) + 64;
         int rc = run_any(h, want);
         if (rc) return rc;
     }
@@ -362,7 +364,7 @@ void vssr_destroy(vssr_handle *h) {
     h->prof.destroy();
     DevBuf *bufs[] = {&h->weights, &h->model_table, &h->offset_per_z, &h->ters_params, &h->d_pos, &h->d_wpos,
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
-                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->d_zslot, &h->d_bundle, &h->d_excl, &h->d_hits, &h->wd16, &h->node16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv,
+                      &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->d_zslot, &h->d_bundle, &h->d_excl, &h->d_hits, &h->wd16, &h->node16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv, &h->d_active, &h->d_bfgs_q, &h->d_bfgs_b,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
                       &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f};
     for (DevBuf *b : bufs) b->release();
@@ -448,6 +450,7 @@ int vssr_batch_set_positions(vssr_handle *h, const double *pos) {
     VSSR_HIP(h, hipSetDevice(h->device));
     VSSR_HIP(h, hipStreamSynchronize(h->stream));
     VSSR_HIP(h, hipMemcpy(h->d_pos.p, pos, sizeof(double) * 3 * h->n_atoms, hipMemcpyHostToDevice));
+    h->ran = false;   // results on the device belong to the old positions
     return VSSR_OK;
 }
 
@@ -464,7 +467,7 @@ int vssr_batch_run(vssr_handle *h, uint32_t want) {
 int vssr_synchronize(vssr_handle *h) {
     if (!h) return VSSR_E_BADARG;
     VSSR_HIP(h, hipSetDevice(h->device));
-    return sync_and_check(h, VSSR_WANT_ENERGY | VSSR_WANT_FORCES);
+    return sync_and_check(h);
 }
 
 int vssr_batch_download(vssr_handle *h, uint32_t want, vssr_out *out) {
@@ -472,7 +475,9 @@ int vssr_batch_download(vssr_handle *h, uint32_t want, vssr_out *out) {
     if (!h->ran) return set_err(h, VSSR_E_STATE, "vssr_batch_download before vssr_batch_run");
     if (!out) return set_err(h, VSSR_E_BADARG, "null output");
     VSSR_HIP(h, hipSetDevice(h->device));
-    int rc = sync_and_check(h, want);
+    if ((want & VSSR_WANT_FORCES) && !(h->last_want & VSSR_WANT_FORCES))
+        return set_err(h, VSSR_E_STATE, "forces requested, but the last run was asked for energies only");
+    int rc = sync_and_check(h);
     if (rc) return rc;
     const size_t B = h->n_cfg, N = h->n_atoms, M = h->n_models;
     if (h->kind == 2) {
@@ -535,6 +540,22 @@ int vssr_tersoff_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atom
     return VSSR_OK;
 }
 
+static int relax_finish(vssr_handle *h, double *pos_out, int32_t *n_steps, uint8_t *converged);
+
+int vssr_batch_relax_bfgs(vssr_handle *h, const vssr_bfgs_params *params, const uint8_t *fixed, uint32_t want,
+                          double *pos_out, int32_t *n_steps, uint8_t *converged) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->batch_valid) return set_err(h, VSSR_E_STATE, "vssr_batch_relax_bfgs before vssr_batch_upload");
+    if (!params || params->max_steps < 0 || !(params->fmax > 0) || !(params->alpha > 0) || !(params->maxstep > 0))
+        return set_err(h, VSSR_E_BADARG, "bad BFGS parameters");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    h->relax_regrows = 0;
+    h->last_want = want | VSSR_WANT_FORCES;
+    int rc = relax_run(h, 1, nullptr, params, fixed, want);
+    if (rc) return rc;
+    return relax_finish(h, pos_out, n_steps, converged);
+}
+
 int vssr_batch_relax_fire(vssr_handle *h, const vssr_fire_params *params, const uint8_t *fixed, uint32_t want,
                           double *pos_out, int32_t *n_steps, uint8_t *converged) {
     if (!h) return VSSR_E_BADARG;
@@ -542,8 +563,14 @@ int vssr_batch_relax_fire(vssr_handle *h, const vssr_fire_params *params, const 
     if (!params || params->max_steps < 0 || !(params->fmax > 0) || !(params->dt > 0) || !(params->maxstep > 0))
         return set_err(h, VSSR_E_BADARG, "bad FIRE parameters");
     VSSR_HIP(h, hipSetDevice(h->device));
-    int rc = relax_fire(h, params, fixed, want);
+    h->relax_regrows = 0;
+    h->last_want = want | VSSR_WANT_FORCES;
+    int rc = relax_run(h, 0, params, nullptr, fixed, want);
     if (rc) return rc;
+    return relax_finish(h, pos_out, n_steps, converged);
+}
+
+static int relax_finish(vssr_handle *h, double *pos_out, int32_t *n_steps, uint8_t *converged) {
     VSSR_HIP(h, hipStreamSynchronize(h->stream));
     h->prof.collect();
     if (pos_out) VSSR_HIP(h, hipMemcpy(pos_out, h->d_pos.p, sizeof(double) * 3 * h->n_atoms, hipMemcpyDeviceToHost));
@@ -585,7 +612,7 @@ int vssr_profile_read(vssr_handle *h, int32_t cap, const char **names, int64_t *
 int vssr_batch_stats(vssr_handle *h, int64_t *n_atoms, int64_t *n_edges, int64_t *n_slots) {
     if (!h) return VSSR_E_BADARG;
     if (!h->ran) return set_err(h, VSSR_E_STATE, "no completed run");
-    int rc = sync_and_check(h, VSSR_WANT_ENERGY | VSSR_WANT_FORCES);
+    int rc = sync_and_check(h);
     if (rc) return rc;
     if (n_atoms) *n_atoms = h->n_atoms;
     if (n_edges) *n_edges = h->h_counters[1];
@@ -597,7 +624,7 @@ int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, 
                          int64_t *n_edges) {
     if (!h || !n_edges) return VSSR_E_BADARG;
     if (!h->ran) return set_err(h, VSSR_E_STATE, "no completed run");
-    int rc = sync_and_check(h, VSSR_WANT_ENERGY | VSSR_WANT_FORCES);
+    int rc = sync_and_check(h);
     if (rc) return rc;
     const int N = h->n_atoms;
     const int64_t slots = h->h_counters[0];
@@ -628,11 +655,22 @@ int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, 
     return VSSR_OK;
 }
 
+int vssr_debug_capacity(vssr_handle *h, int32_t slots_per_atom, int32_t tight, int32_t *n_regrows) {
+    if (!h) return VSSR_E_BADARG;
+    if (slots_per_atom > 0) {
+        h->cap_per_atom = slots_per_atom;
+        h->slot_cap = 0;   // re-derived at the next neighbor build
+    }
+    if (tight >= 0) h->cap_tight = tight != 0;
+    if (n_regrows) *n_regrows = h->relax_regrows;
+    return VSSR_OK;
+}
+
 int vssr_debug_read(vssr_handle *h, const char *name, int32_t model, float *dst, int64_t cap, int64_t *n_out) {
     if (!h || !name || !n_out) return VSSR_E_BADARG;
     if (!h->ran || h->kind != 1) return set_err(h, VSSR_E_STATE, "no completed PaiNN run");
     if (model < 0 || model >= h->n_models) return set_err(h, VSSR_E_BADARG, "model index out of range");
-    int rc = sync_and_check(h, VSSR_WANT_ENERGY | VSSR_WANT_FORCES);
+    int rc = sync_and_check(h);
     if (rc) return rc;
     const size_t N = h->n_atoms;
     const StateView &sv = h->sv;

@@ -42,6 +42,23 @@ struct ModelW {
     const uint4 *qW5, *qW5t;               // readout matrices as fp16 pieces in MFMA fragment order (painn_node_mfma.hip)
 };
 
+// Chains that take part in an evaluation.  During a lock-step relaxation converged chains are switched off: every kernel
+// tests its chain (or the chains of its atom tile) and leaves at once, so an iteration costs what the unconverged chains cost;
+// the results of a switched-off chain stay those of its last evaluation.  mask == nullptr: all chains.
+struct ActiveView {
+    const unsigned char *mask;   // [n_cfg] 1 = evaluate
+    const int *atom_cfg;         // [n_atoms]
+    __device__ __forceinline__ bool chain(int c) const { return !mask || mask[c]; }
+    __device__ __forceinline__ bool atom(int i) const { return !mask || mask[atom_cfg[i]]; }
+    // any active chain among atoms [a0, a1]?  (chains are contiguous atom ranges)
+    __device__ __forceinline__ bool tile(int a0, int a1) const {
+        if (!mask) return true;
+        for (int c = atom_cfg[a0], c1 = atom_cfg[a1]; c <= c1; ++c)
+            if (mask[c]) return true;
+        return false;
+    }
+};
+
 struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by centre)
     int n_atoms;             // total atoms in the batch
     int n_cfg;
@@ -60,6 +77,7 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const unsigned char *zslot;   // [slots] species index (zmap) of the neighbor, 255 for pads / unmapped
     const float2 *dist2;     // [slots] {1 / edge length (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
     const int4 *bundle;      // [n_atoms] per chain: centres sorted by padded degree (descending): {centre (chain-local), first slot, padded slot count, 0}
+    ActiveView act;          // chains switched off by the relaxation driver
 };
 
 struct StateView {  // activations of all models: index [m][atom][...]
@@ -189,7 +207,12 @@ struct vssr_handle {
     vssr::DevBuf d_zmap, d_zlist;        // species index of Z (or -1), distinct Z of the resident batch
     vssr::DevBuf d_l0T, d_l0Q;
     // lock-step relaxation (relax.hip)
-    vssr::DevBuf d_vel, d_fire, d_fixed, d_relax_steps, d_relax_conv;
+    vssr::DevBuf d_vel, d_fire, d_fixed, d_relax_steps, d_relax_conv, d_active, d_bfgs_q, d_bfgs_b;
+    const unsigned char *active_mask = nullptr;   // set by relax_run for the duration of a relaxation
+    int relax_regrows = 0;
+    int cap_per_atom = 64;        // initial neighbor capacity (slots per atom); vssr_debug_capacity
+    bool cap_tight = false;       // regrow to the exact need only (tests: forces repeated overflows)
+    uint32_t last_want = 0;                       // outputs produced by the last run
     int64_t slot_cap = 0;
     int *h_counters = nullptr;   // pinned: [0] total slots, [1] total real edges, [2] overflow flag
 
@@ -221,18 +244,21 @@ int painn_run(vssr_handle *h, uint32_t want);
 // Tersoff (tersoff.hip)
 int tersoff_run(vssr_handle *h, uint32_t want);
 // lock-step FIRE relaxation (relax.hip)
-int relax_fire(vssr_handle *h, const vssr_fire_params *fp, const uint8_t *fixed_host, uint32_t want);
+// method 0: FIRE (fp), 1: BFGS (bp)
+int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr_bfgs_params *bp,
+              const uint8_t *fixed_host, uint32_t want);
 // MFMA node stages (painn_node_mfma.hip)
 int node_mfma_init(vssr_handle *h);
-void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in, float *phi);
-void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_in,
+void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
+                         float *phi);
+void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
                              const float *phibar, const float *sbar_msg, float *sbar_in);
-void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ModelW *MW, const float *s_msg,
+void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_msg,
                             const float *v_msg, float *s_out, float *v_out);
 bool readout_mfma_supported(int hidden);
-void launch_readout_mfma(hipStream_t st, int N, int M, const ModelW *MW, const float *s, const float *e_excl,
+void launch_readout_mfma(hipStream_t st, int N, int M, const ActiveView &av, const ModelW *MW, const float *s, const float *e_excl,
                          float *e_atom);
-void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int vbar_is_zero, const ModelW *MW,
+void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int vbar_is_zero, const ActiveView &av, const ModelW *MW,
                             const float *s_msg, const float *v_msg, const float *sbar_src, const float *vbar,
                             const float *s_next, const float *phibar, const float *e_excl, float *e_atom,
                             float *sbar_msg, float *vbar_msg);

@@ -199,7 +199,7 @@ class ChainEnsemble:
 
     def __init__(self, base, ads_coords, adsorbates, n_chains: int, calc, *, seed: int = 0, first_chain: int = 0,
                  relax: bool = True, relax_steps: int = 20, fmax: float = 0.01, fixed_indices=None,
-                 surface_energy_fn=None, temperature: float = 1.0):
+                 surface_energy_fn=None, temperature: float = 1.0, optimizer: str = "BFGS"):
         self.base = base
         self.ads_coords = np.asarray(ads_coords, float).reshape(-1, 3)
         self.adsorbates = list(adsorbates)
@@ -208,6 +208,7 @@ class ChainEnsemble:
         self.calc = calc
         self.seed, self.first_chain = int(seed), int(first_chain)
         self.relax, self.relax_steps, self.fmax = bool(relax), int(relax_steps), float(fmax)
+        self.optimizer = optimizer   # reference SrTiO3 configuration: BFGS (scripts/configs/sample_config_painn.json:26)
         self.fixed_indices = None if fixed_indices is None else np.asarray(fixed_indices, np.int64)
         self.temp = float(temperature)
         self.surface_energy_fn = surface_energy_fn or self._default_surface_energy
@@ -319,7 +320,7 @@ class ChainEnsemble:
         slabs = [self.structure(int(b), state) for b in idx]
         if self.relax:
             fixed = None if self.fixed_indices is None else [self.fixed_indices] * len(slabs)
-            out = self.calc.relax_batch(slabs, fixed_indices=fixed, relax_steps=self.relax_steps, fmax=self.fmax)
+            out = self._relax_batch(slabs, fixed)
             # The acceptance energy is the TRUE energy of the relaxed slab: the reference discards optimize_slab's clamped
             # value (mcmc/system.py:466-469 re-evaluates surface_energy on relaxed_atoms) and uses the out-of-bounds flag
             # only to save the offending structure (mcmc/system.py:375-378).  A 240-atom SrTiO3 slab sits near -1870 eV,
@@ -335,6 +336,18 @@ class ChainEnsemble:
         self.n_evaluations += len(slabs)
         energies = np.array([self.surface_energy_fn(e, s) for e, s in zip(raw, slabs)], float)
         return energies, relaxed
+
+    def _relax_batch(self, slabs, fixed):
+        """``calc.relax_batch`` with this ensemble's optimizer (backends without the keyword use their own)."""
+        import inspect
+
+        kw = dict(fixed_indices=fixed, relax_steps=self.relax_steps, fmax=self.fmax)
+        try:
+            if "optimizer" in inspect.signature(self.calc.relax_batch).parameters:
+                kw["optimizer"] = self.optimizer
+        except (TypeError, ValueError):
+            pass
+        return self.calc.relax_batch(slabs, **kw)
 
     @staticmethod
     def _final_energy(relax_out) -> float:

@@ -31,13 +31,13 @@ def _free_fixed(golden, case):
     return s, free, np.setdiff1d(np.arange(len(s)), free)
 
 
-def check_trace(trace, ref, name):
+def check_trace(trace, ref, name, f_tol_early=F_TOL_EARLY):
     """Same length (the optimizer stops at the same step) and point-wise agreement."""
     assert len(trace) == len(ref), (name, len(trace), len(ref))
     for k, ((e, f), (er, fr)) in enumerate(zip(trace, ref)):
         late = k >= 6
         assert abs(e - er) <= (E_TOL_LATE if late else E_TOL), (name, k, e, er)
-        assert abs(f - fr) <= (F_TOL_LATE if late else F_TOL_EARLY), (name, k, f, fr)
+        assert abs(f - fr) <= (F_TOL_LATE if late else f_tol_early), (name, k, f, fr)
 
 
 def test_bfgs_restatement_reproduces_reference_traces(golden, oracle_mod):
@@ -75,3 +75,125 @@ def test_bfgs_restatement_on_a_quadratic():
     assert conv and steps < 40 and np.abs(pos).max() < 1e-6
     e = [t[0] for t in trace]
     assert all(b <= a + 1e-15 for a, b in zip(e, e[1:]))
+
+
+def test_bfgs_params_struct_layout():
+    import ctypes
+
+    from surface_sampling_amd import backend
+
+    p = backend.BfgsParams.default(20, 0.01)
+    assert ctypes.sizeof(backend.BfgsParams) == 16 and p.max_steps == 20
+    assert (p.alpha, p.maxstep) == (pytest.approx(70.0), pytest.approx(0.2))
+
+
+def _mask(slabs, fixed_idx):
+    mask = np.zeros(sum(len(s) for s in slabs), np.uint8)
+    o = 0
+    for s, idx in zip(slabs, fixed_idx):
+        mask[o + np.asarray(idx, dtype=np.int64)] = 1
+        o += len(s)
+    return mask
+
+
+@pytest.mark.gpu
+def test_bfgs_gpu_reproduces_reference_traces(golden, oracle_mod):
+    """Device BFGS (vssr_batch_relax_bfgs) against the (E, fmax) traces stored by the reference: point k of a trace is
+    the state after k optimizer steps, so a lock-step batch relaxed with relax_steps = k must print it.  All four cases
+    are relaxed together (ragged batch, chains converge at different steps and drop out of the evaluation)."""
+    from surface_sampling_amd import backend
+
+    T = _traces()
+    table, const = golden.offset_table()
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    cases = [(c,) + _free_fixed(golden, c) for c in T["cases"]]
+    slabs = [s for _, s, _, _ in cases]
+    packs = [(s.numbers, s.positions, s.cell, s.pbc) for s in slabs]
+    mask = _mask(slabs, [fx for _, _, _, fx in cases])
+    longest = max(len(c["trace"]) for c in T["cases"])
+    got = [[] for _ in cases]
+    for k in range(longest):
+        eng.upload(packs)
+        info = eng.relax_bfgs(fixed=mask, max_steps=k, fmax=T["fmax"])
+        res = eng.download()
+        cs = res["cfg_start"]
+        for b, (c, s, free, fixed) in enumerate(cases):
+            n_ref = len(c["trace"])
+            kk = min(k, n_ref - 1)                      # a converged chain stays at its last point
+            assert info["n_steps"][b] == kk, (c["structure"], k, info["n_steps"][b])
+            assert bool(info["converged"][b]) == (k >= n_ref - 1), (c["structure"], k)
+            f = res["forces"][cs[b]:cs[b + 1]].astype(np.float64)[free]
+            if k < n_ref:
+                got[b].append((float(res["energy"][b]), float(np.sqrt((f ** 2).sum(axis=1).max()))))
+            p = info["positions"][cs[b]:cs[b + 1]]
+            assert np.array_equal(p[fixed], s.positions[fixed])          # FixAtoms respected exactly
+    for b, (c, s, free, fixed) in enumerate(cases):
+        # Against the reference's prints.  The device follows exact arithmetic more closely than the reference's fp32 does:
+        # where fp32 rounding moves a printed fmax (pristine slab, point 2: fp64 oracle 0.079271, print 0.079328), the device
+        # (0.079265) sits with fp64 -- hence 1e-4 here and the tighter fp64 comparison below.
+        check_trace(got[b], c["trace"], c["structure"], f_tol_early=1e-4)
+
+        def fn(pos, s=s):
+            r = oracle_mod.ensemble(golden.blobs, s.numbers, pos, s.cell, s.pbc, 64, table, const)
+            return r["energy"], r["forces"]
+
+        _, t64, _, _ = bfgs_relax(fn, s.positions, fixed=fixed, max_steps=T["relax_steps"], fmax=T["fmax"])
+        assert len(t64) == len(got[b])
+        for k, ((e, f), (e64, f64)) in enumerate(zip(got[b], t64)):
+            assert abs(e - e64) <= (1e-4 if k < 6 else 3e-4), (c["structure"], k, e, e64)
+            assert abs(f - f64) <= (2e-5 + 5e-5 * f64 if k < 6 else 3e-3), (c["structure"], k, f, f64)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_bfgs_gpu_matches_dense_restatement_without_fixatoms(golden, oracle_mod):
+    """No FixAtoms: ASE's Hessian would be 180 x 180; the factored device form must follow the dense restatement (driven
+    by the fp64 oracle) step for step.  Positions after 10 steps agree to the fp32-force noise."""
+    from surface_sampling_amd import backend, structures
+
+    table, const = golden.offset_table()
+    s = structures.synth_chain(golden.structure("SrTiO3_2x2_pristine"), 5, grid=(4, 4))
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    eng.upload([(s.numbers, s.positions, s.cell, s.pbc)])
+    info = eng.relax_bfgs(max_steps=10, fmax=0.01)
+    res = eng.download()
+
+    def fn(pos):
+        r = oracle_mod.ensemble(golden.blobs, s.numbers, pos, s.cell, s.pbc, 64, table, const)
+        return r["energy"], r["forces"]
+
+    pref, trace, steps, conv = bfgs_relax(fn, s.positions, max_steps=10)
+    assert info["n_steps"][0] == steps == 10
+    assert np.abs(info["positions"] - pref).max() < 5e-3
+    assert abs(float(res["energy"][0]) - trace[-1][0]) < 1e-3
+    assert trace[-1][0] < trace[0][0] - 0.05                              # it did relax
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optimizer", ["BFGS", "FIRE"])
+def test_relaxation_survives_neighbor_capacity_overflows(golden, optimizer):
+    """A capacity that is too small from the start and regrows to the exact need only: the relaxation overflows at the
+    first evaluation and again whenever the edge count grows.  The driver regrows in place and the result is identical
+    to the run with ample capacity (the step kernels do not move anything behind an overflowed evaluation)."""
+    from surface_sampling_amd import backend, structures
+
+    table, const = golden.offset_table()
+    base = golden.structure("SrTiO3_2x2_pristine")
+    slabs = [structures.synth_chain(base, c, grid=(4, 4)) for c in range(6)]
+    packs = [(s.numbers, s.positions, s.cell, s.pbc) for s in slabs]
+    mask = _mask(slabs, [np.arange(40)] * len(slabs))
+    out = []
+    for tight in (False, True):
+        eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+        if tight:
+            eng.debug_capacity(slots_per_atom=8, tight=1)
+        eng.upload(packs)
+        info = eng.relax(optimizer, fixed=mask, max_steps=12, fmax=0.01)
+        res = eng.download()
+        out.append((info, res, eng.debug_capacity()))
+        eng.close()
+    (i0, r0, g0), (i1, r1, g1) = out
+    assert g0 == 0 and g1 >= 1
+    assert np.array_equal(i0["n_steps"], i1["n_steps"]) and np.array_equal(i0["positions"], i1["positions"])
+    assert np.array_equal(r0["energy"], r1["energy"]) and np.array_equal(r0["forces"], r1["forces"])
