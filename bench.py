@@ -8,7 +8,15 @@ One "step" = one lock-step energy+force evaluation of every resident chain: neig
 mcmc/calculators/calculators.py:484).  Workload at N=1: BASELINE configs[3] — 256 independent chains of
 the SrTiO3(001) 2x2 slab tiled 2x2 in-plane (240 atoms) plus 8..32 seeded adsorbates,
 inputs resident in HBM before the timed region.  N > 1: every rank owns 256 more chains (weak scaling,
-BASELINE configs[4]); the only collective is the RCCL all_gather of per-chain energies.
+BASELINE configs[4]: rank r owns global chains [256 r, 256 r + 256)); the only collective is the RCCL all_gather of
+per-chain (E, sigma_E), read in place from the engine's device buffers (surface_sampling_amd.sharding).
+
+The ONE JSON line carries, besides the contract fields:
+  roofline      dominant kernel = reverse neighbor pass; `achieved` = SURVEY §8(d) flops (2 x 17 408 per real directed edge
+                and model) / HIP-event launch time; `views` gives the same launch against three yardsticks (fp32 vector /
+                matrix peak, the fp16 matrix pipe it executes on, HBM) and names the binding resource;
+  pcie_inclusive  the same evaluations with new host positions uploaded and energies + forces downloaded every step;
+  cpu_baseline  CPU ports of the same evaluation timed on this host (the reference's own CPU path is not installable).
 """
 
 import argparse
@@ -23,9 +31,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CHAINS_PER_GPU = 256
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak (no xf32 on gfx950)
-F = 128
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0            # HBM3E 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3         # fp32 vector = fp32-input MFMA peak (no xf32 on gfx950)
+F16_MFMA_PEAK_TFLOPS = 2500.0    # dense fp16 / bf16 matrix peak
+F, R = 128, 20
+FLOP_PER_EDGE_FWD = 2 * R * 3 * F + 16 * F     # = 17 408, SURVEY.md §8(d): radial filter 2 R 3F + message arithmetic 16 F
+MFMA_FLOP = 16 * 16 * 32 * 2                   # one v_mfma_f32_16x16x32_f16
+MFMA_PER_STEP = {"fwd": 11, "bwd": 20}         # matrix instructions per 16-slot step of the edge kernels (static count)
+DTYPE = "f32 via fp16x2-split MFMA (3 products), fp32 accumulate; neighbor decisions f64"
 
 
 def load_golden():
@@ -46,75 +60,136 @@ def build_chains(S, first, count):
     return [structures.synth_chain(big, c) for c in range(first, first + count)]
 
 
+def shard_plan(world, chains_per_gpu=CHAINS_PER_GPU):
+    """(first chain, count) of every rank: weak scaling, rank r owns [r B, r B + B) of the world B global chains."""
+    from surface_sampling_amd.sharding import all_ranges
+
+    return all_ranges(world * chains_per_gpu, world)
+
+
+def make_step(sharded, want):
+    """The timed unit, for every world size: one lock-step evaluation + (N > 1) the per-chain result gather."""
+    return lambda: sharded.step(want)
+
+
+# ---- algorithmic work of the edge kernels (SURVEY.md §8(d)) -----------------------------------------------------------------
 def neighbor_sum_bytes(n_atoms, n_edges, n_models):
-    """Algorithmic HBM bytes of ONE forward neighbor-sum launch (layer >= 1), SURVEY.md §8(d):
-    read phi [N,3F], v [N,3,F], s [N,F] + 16 B per edge; write s' [N,F], v' [N,3,F]."""
-    per_atom = (3 * F + 3 * F + F + F + 3 * F) * 4
-    return n_models * (per_atom * n_atoms + 16 * n_edges)
+    """Algorithmic HBM bytes of ONE forward neighbor-sum launch (one layer): read phi [N,3F], v [N,3,F], s [N,F] + 16 B per
+    edge; write s' [N,F], v' [N,3,F]  ->  5632 N + 16 E per model."""
+    return n_models * ((3 * F + 3 * F + F + F + 3 * F) * 4 * n_atoms + 16 * n_edges)
 
 
-def neighbor_sum_flops(n_slots, n_models):
-    """fp32 FLOPs of ONE forward neighbor-sum launch: per slot and model the radial filter (3F x 21 GEMV, bias column
-    included) plus the message arithmetic of painn_edge_mfma.hip (18 flops per feature: 3 products, 7 fma)."""
-    return n_models * n_slots * (3 * F * 21 * 2 + F * 18)
+def neighbor_sum_flops(n_edges, n_models):
+    return n_models * n_edges * FLOP_PER_EDGE_FWD
 
 
 def reverse_pass_bytes(n_atoms, n_edges, n_models):
-    """Algorithmic HBM bytes of ONE reverse neighbor-pass launch: read sbar, vbar [N,4F], phi [N,3F], v [N,3,F];
-    write phibar [N,3F], vbar_in [N,3,F]; per edge 16 B geometry in, 16 B edge gradient out."""
-    return n_models * ((4 * F + 3 * F + 3 * F + 3 * F + 3 * F) * 4 * n_atoms + 32 * n_edges)
+    """the reverse pass re-reads the forward's operands and writes gradients, 1.5 x the forward bytes."""
+    return 1.5 * neighbor_sum_bytes(n_atoms, n_edges, n_models)
 
 
-def reverse_pass_flops(n_slots, n_models):
-    """fp32 FLOPs of ONE reverse neighbor-pass launch: the filter AND its radial derivative (2 x 3F x 21 GEMV) plus
-    the per-feature adjoint arithmetic (36 flops per feature, `feature()` in k_edge_bwd_mfma).  These are the
-    fp32-precision flops the algorithm needs; the kernel executes each GEMV as six bf16 partial products."""
-    return n_models * n_slots * (2 * 3 * F * 21 * 2 + F * 36)
+def reverse_pass_flops(n_edges, n_models):
+    """reverse = 2 x forward."""
+    return 2 * neighbor_sum_flops(n_edges, n_models)
+
+
+def executed_mfma_flops(which, n_slots, n_models):
+    """Matrix-pipe flops the kernel executes per launch: 8 feature slices x slots / 16 steps x MFMAs per step."""
+    return n_models * 8 * (n_slots / 16.0) * MFMA_PER_STEP[which] * MFMA_FLOP
 
 
 def measured_traffic(kernel):
     """HBM bytes per launch from committed PMC passes (profiles/: FETCH_SIZE, WRITE_SIZE in KB, separate passes;
     FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM for 16-B/lane streams).  None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_edge_kernels_v10.json")
-    if not os.path.exists(path):
-        return None
-    raw = json.load(open(path))
-    tot, n = 0.0, 0
-    for name, d in raw.items():
-        if kernel in name and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-            k = d["FETCH_SIZE"]["n"]
-            tot += k * (2.0 * d["FETCH_SIZE"]["mean_raw"] + d["WRITE_SIZE"]["mean_raw"]) * 1024.0
-            n += k
-    return tot / n if n else None
+    for rel in (("profiles", "r02", "pmc_traffic_edge_kernels.json"), ("profiles", "r01", "pmc_traffic_edge_kernels_v10.json")):
+        path = os.path.join(ROOT, *rel)
+        if not os.path.exists(path):
+            continue
+        raw = json.load(open(path))
+        tot, n = 0.0, 0
+        for name, d in raw.items():
+            if kernel in name and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                k = d["FETCH_SIZE"]["n"]
+                tot += k * (2.0 * d["FETCH_SIZE"]["mean_raw"] + d["WRITE_SIZE"]["mean_raw"]) * 1024.0
+                n += k
+        if n:
+            return tot / n
+    return None
 
 
-def cpu_baseline(blobs, chains, table, const, budget_s=20.0):
-    """Time the CPU oracle (a port: the reference's CPU path is not installable) on a bounded
-    sample of the same workload.  The oracle is only the reported baseline / checker, never the product."""
+def cpu_baseline(blobs, chains, table, const, budget_s=12.0):
+    """CPU ports of the same evaluation on a bounded sample of the same workload (the reference's own CPU path -- ase + nff +
+    torch_scatter -- is not installable): the OpenMP C oracle (fp32 mode) and the torch-CPU restatement
+    (forward + autograd, the way nff computes it).  Checker code, timed only here; never the product."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
 
     oracle.build()
-    n, t0 = 0, time.perf_counter()
-    threads = oracle.set_threads(min(os.cpu_count() or 1, 32))
-    s = chains[0]
-    oracle.ensemble(blobs, s.numbers, s.positions, s.cell, s.pbc, 32, table, const)  # warm-up (page-in, threads)
-    t0 = time.perf_counter()
-    while n < len(chains) and (time.perf_counter() - t0 < budget_s or n < 4):
-        s = chains[n]
-        oracle.ensemble(blobs, s.numbers, s.positions, s.cell, s.pbc, 32, table, const)
-        n += 1
-    dt = time.perf_counter() - t0
-    cores = threads
-    return {"value": n / dt, "unit": "evaluations/s", "cores": cores, "kind": "port",
-            "sample": f"{n} chains of the same workload (fp32 oracle, OpenMP, {dt:.1f} s)"}
+    cores = min(os.cpu_count() or 1, 32)
+    threads = oracle.set_threads(cores)
+
+    def timed(fn):
+        fn(chains[0])   # warm-up (page-in, thread pools)
+        n, t0 = 0, time.perf_counter()
+        while n < len(chains) and (time.perf_counter() - t0 < budget_s or n < 3):
+            fn(chains[n])
+            n += 1
+        return n, time.perf_counter() - t0
+
+    n_c, dt_c = timed(lambda s: oracle.ensemble(blobs, s.numbers, s.positions, s.cell, s.pbc, 32, table, const))
+    out = {"value": n_c / dt_c, "unit": "evaluations/s", "cores": threads, "kind": "port",
+           "sample": f"{n_c} chains of the same workload, one at a time (C oracle, fp32, OpenMP, {dt_c:.1f} s)"}
+    try:
+        import torch
+
+        import torch_port
+
+        torch.set_num_threads(cores)
+        te = torch_port.TorchEnsemble(blobs, torch.float32)
+        n_t, dt_t = timed(lambda s: te.evaluate(s.numbers, s.positions, s.cell, s.pbc, table, const))
+        alt = {"value": n_t / dt_t, "unit": "evaluations/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{n_t} chains of the same workload, one at a time (torch-CPU fp32 forward + autograd, {dt_t:.1f} s)"}
+        if alt["value"] > out["value"]:
+            out, alt = alt, out
+        out["other_port"] = alt
+    except Exception as exc:   # torch CPU threading problems must not cost the bench line
+        out["other_port"] = {"error": str(exc)}
+    return out
+
+
+class EngineGroup:
+    """--streams S: this rank's block split over S engines (own HIP streams) that run concurrently; engine interface of
+    ShardedEnsemble (host result path)."""
+
+    def __init__(self, engines):
+        self.engines = engines
+        self.bounds = None
+
+    def upload(self, structs):
+        n, s = len(structs), len(self.engines)
+        self.bounds = [((k * n) // s, ((k + 1) * n) // s) for k in range(s)]
+        for e, (lo, hi) in zip(self.engines, self.bounds):
+            e.upload(structs[lo:hi])
+
+    def run(self, want):
+        for e in self.engines:
+            e.run(want)
+
+    def synchronize(self):
+        for e in self.engines:
+            e.synchronize()
+
+    def download(self, want):
+        parts = [e.download(want) for e in self.engines]
+        out = {k: np.concatenate([p[k] for p in parts]) for k in ("energy", "energy_std", "forces", "forces_std")}
+        return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)     # SURVEY §8(d): 200 timed lock-step evaluations ...
+    ap.add_argument("--warmup", type=int, default=20)     # ... after 20 warm-up
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
@@ -134,7 +209,7 @@ def main():
 
     from surface_sampling_amd import backend
     from surface_sampling_amd.calculators import stoich_offset_table
-    from surface_sampling_amd.sharding import chain_range
+    from surface_sampling_amd.sharding import ShardedEnsemble
 
     dist = None
     if world > 1:
@@ -147,31 +222,22 @@ def main():
     blobs, S, offset_data = load_golden()
     table, const = stoich_offset_table(offset_data)
     B = args.chains_per_gpu
-    first, count = chain_range(world * B, world, rank)   # block partition of the global chain list
+    first, count = shard_plan(world, B)[rank]            # block partition of the global chain list
     chains = build_chains(S, first, count)
+    packs = [(s.numbers, s.positions, s.cell, s.pbc) for s in chains]
 
     n_str = max(1, min(args.streams, count))
-    engs = []
-    for k in range(n_str):   # block partition of this rank's chains over its engines
-        lo, hi = (k * count) // n_str, ((k + 1) * count) // n_str
-        e = backend.PainnEngine(blobs, device=local_rank, offset_per_z=table, offset_const=const)
-        e.upload([(s.numbers, s.positions, s.cell, s.pbc) for s in chains[lo:hi]])   # inputs resident in HBM
-        engs.append(e)
-    want = backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD
+    engs = [backend.PainnEngine(blobs, device=local_rank, offset_per_z=table, offset_const=const) for _ in range(n_str)]
+    engine = engs[0] if n_str == 1 else EngineGroup(engs)
     dev = torch.device("cuda", local_rank)
-    gathered = torch.empty(world * count * 2, dtype=torch.float32, device=dev) if world > 1 else None
-
-    def step():
-        for e in engs:
-            e.run(want)
-        if world > 1:   # the path's only exchange: per-chain (E_mean, E_std) to every rank
-            parts = [e.download(backend.WANT_ENERGY | backend.WANT_STD) for e in engs]
-            mine = torch.from_numpy(np.concatenate([p["energy"] for p in parts] + [p["energy_std"] for p in parts])).to(dev)
-            dist.all_gather_into_tensor(gathered, mine)
+    sharded = ShardedEnsemble(engine, world * B, dist, dev)
+    assert (sharded.first, sharded.count) == (first, count)
+    sharded.upload(local_chains=packs)                    # inputs resident in HBM
+    want = backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD
+    step = make_step(sharded, want)
 
     def fence():
-        for e in engs:
-            e.synchronize()
+        engine.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -203,61 +269,88 @@ def main():
     for e in engs:
         for k, v in e.stats().items():
             stats[k] += v
-        res = e.download(want)
-        if not (np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()):
-            raise SystemExit("non-finite results in the timed region")
+    res = engine.download(want)
+    if not (np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()):
+        raise SystemExit("non-finite results in the timed region")
+
+    # ---- the same evaluations with the host round trip the reference's calculate() makes: positions up, E + F down ---------
+    pcie = None
+    if world == 1 and n_str == 1:
+        pos_host = np.concatenate([s.positions for s in chains])
+        k2 = max(5, min(args.steps, 50))
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            engine.set_positions(pos_host)
+            engine.run(want)
+            engine.download(want)
+        dt2 = time.perf_counter() - t1
+        pcie = {"value": count * k2 / dt2, "unit": "evaluations/s", "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
+                "per_step": "vssr_batch_set_positions (66.5 k x 24 B up) + run + vssr_batch_download (E, sigma_E, F, sigma_F down)"}
 
     if rank == 0:
         total_evals = world * count * args.steps
         value = total_evals / elapsed
         M = len(blobs)
-        # Dominant kernel: the reverse neighbor pass (k_edge_bwd_mfma, layers 2 and 1; layer 0 runs through the species
-        # factorisation and has its own profiler class).  Launch durations are HIP-event times on the handle's stream.
-        def kernel_view(cls, flops, nbytes):
+
+        def launch_ms(cls):
             k = prof.get(cls, {"launches": 0, "total_ms": 0.0})
-            ms = k["total_ms"] / max(1, k["launches"])
-            return {"avg_launch_ms": ms, "launches": k["launches"], "algorithmic_flops_per_launch": flops,
-                    "achieved_TFLOPs": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                    "algorithmic_bytes_per_launch": nbytes,
-                    "achieved_GBps": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+            return (k["total_ms"] / k["launches"] if k["launches"] else 0.0), k["launches"]
+
+        def view(flops, nbytes, mfma_flops, ms):
+            t = ms * 1e-3
+            if t <= 0:
+                return {}
+            return {"fp32_yardstick": {"achieved_TFLOPs": flops / t / 1e12, "peak_TFLOPs": FP32_PEAK_TFLOPS,
+                                       "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
+                    "executed_matrix_pipe": {"achieved_TFLOPs": mfma_flops / t / 1e12, "peak_TFLOPs": F16_MFMA_PEAK_TFLOPS,
+                                             "frac": mfma_flops / t / 1e12 / F16_MFMA_PEAK_TFLOPS},
+                    "hbm": {"achieved_GBps": nbytes / t / 1e9, "peak_GBps": HBM_PEAK_GBS, "frac": nbytes / t / 1e9 / HBM_PEAK_GBS}}
 
         # (per launch = per engine: with --streams S a launch covers 1/S of this GPU's chains and overlaps the other engines)
-        bwd = kernel_view("edge_message_bwd", reverse_pass_flops(stats["slots"], M) / n_str,
-                          reverse_pass_bytes(stats["atoms"], stats["edges"], M) / n_str)
-        fwd = kernel_view("edge_message_fwd", neighbor_sum_flops(stats["slots"], M) / n_str,
-                          neighbor_sum_bytes(stats["atoms"], stats["edges"], M) / n_str)
+        E, N, SL = stats["edges"] / n_str, stats["atoms"] / n_str, stats["slots"] / n_str
+        bwd_ms, bwd_n = launch_ms("edge_message_bwd")
+        fwd_ms, fwd_n = launch_ms("edge_message_fwd")
+        bwd_flops, bwd_bytes = reverse_pass_flops(E, M), reverse_pass_bytes(N, E, M)
+        fwd_flops, fwd_bytes = neighbor_sum_flops(E, M), neighbor_sum_bytes(N, E, M)
+        bwd_views = view(bwd_flops, bwd_bytes, executed_mfma_flops("bwd", SL, M), bwd_ms)
+        fwd_views = view(fwd_flops, fwd_bytes, executed_mfma_flops("fwd", SL, M), fwd_ms)
+        achieved = bwd_flops / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
         step_ms = sum(v["total_ms"] for v in prof.values()) / args.steps
         line = {
             "metric": "MC energy-evaluations/sec (SrTiO3(001) ~250-atom slabs, 3-model PaiNN ensemble E+F incl. neighbor list)",
             "value": value, "unit": "evaluations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": f"SrTiO3(001) PaiNN x3, {count} batched independent chains per GPU "
                                    f"(BASELINE configs[{3 if world == 1 else 4}]), 248-272 atoms/chain",
                        "chains_per_gpu": count, "atoms_per_gpu": stats["atoms"], "edges_per_gpu": stats["edges"],
-                       "streams_per_gpu": n_str,
-                       "parallelism": f"chains sharded x{world}, RCCL all_gather of per-chain energies"},
-            # The reverse neighbor pass is instruction / matrix-pipe bound, not HBM bound (its HBM view is given beside
-            # it): `achieved` = fp32-precision algorithmic TFLOP/s (filter GEMVs + adjoint arithmetic, formulas above)
-            # against the fp32 peak of MI355X_MICROARCH.md; the filter runs as 3 fp16 partial products per GEMV on
-            # the 16-bit MFMA pipe (2-way split, fp32-level accuracy), the rest on the fp32 VALU.
+                       "slots_per_gpu": stats["slots"], "models": M, "streams_per_gpu": n_str,
+                       "parallelism": ("one GPU, no collective" if world == 1 else
+                                       f"chains sharded x{world} (rank r owns chains [{count} r, {count} r + {count})), "
+                                       "RCCL all_gather of per-chain (E, sigma_E) from device buffers")},
+            # Dominant kernel: the reverse neighbor pass (k_edge_bwd_mfma, layers 2 and 1; layer 0 is factorised by species and
+            # has its own profiler class).  achieved = algorithmic flops of SURVEY §8(d) (reverse = 2 x 17 408 per real
+            # directed edge and model) / avg_launch_ms, launch times = HIP events on the handle's stream.
             "roofline": {"bound": "mfma", "kernel": "edge_message_bwd (reverse neighbor pass, k_edge_bwd_mfma)",
-                         "achieved": bwd["achieved_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": bwd["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": measured_traffic("k_edge_bwd_mfma"),
-                         "algorithmic_flops_per_launch": bwd["algorithmic_flops_per_launch"],
-                         "avg_launch_ms": bwd["avg_launch_ms"], "launches": bwd["launches"],
-                         "hbm_view": {"algorithmic_bytes_per_launch": bwd["algorithmic_bytes_per_launch"],
-                                      "achieved_GBps": bwd["achieved_GBps"], "peak_GBps": HBM_PEAK_GBS,
-                                      "frac": bwd["achieved_GBps"] / HBM_PEAK_GBS},
+                         "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": measured_traffic("k_edge_bwd_mfma"),
+                         "formula": "achieved = models x edges_per_gpu x 2 x 17408 / avg_launch_ms ; peak = fp32 vector/matrix "
+                                    "peak (a yardstick: the filter GEMVs execute as 3 fp16 products on the 2.5 PF matrix pipe)",
+                         "avg_launch_ms": bwd_ms, "launches": bwd_n, "algorithmic_flops_per_launch": bwd_flops,
+                         "algorithmic_bytes_per_launch": bwd_bytes, "views": bwd_views,
+                         "binding_resource": "SIMD instruction issue: per 16-slot step ~130 vector + 20 matrix instructions whose "
+                                             "issue times add up (130 x 4 + 20 x 17 cycles + LDS/VMEM/SALU = the measured ~1010 "
+                                             "cycles; interleaving them across steps did not overlap them: "
+                                             "profiles/r02/NOTES_node_kernels.md); TA 85-93 % busy (profiles/r01/pmc_ta_all_kernels_v9.txt)",
                          "second_kernel": {"kernel": "edge_message_fwd (neighbor-sum, k_edge_fwd_mfma)",
-                                           "achieved": fwd["achieved_TFLOPs"],
-                                           "frac": fwd["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS,
-                                           "avg_launch_ms": fwd["avg_launch_ms"],
-                                           "traffic": measured_traffic("k_edge_fwd_mfma"),
-                                           "algorithmic_bytes_per_launch": fwd["algorithmic_bytes_per_launch"]}},
+                                           "avg_launch_ms": fwd_ms, "launches": fwd_n,
+                                           "algorithmic_flops_per_launch": fwd_flops,
+                                           "algorithmic_bytes_per_launch": fwd_bytes,
+                                           "traffic": measured_traffic("k_edge_fwd_mfma"), "views": fwd_views}},
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]},
             "device_ms_per_step": step_ms,
+            "pcie_inclusive": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blobs, chains, table, const)

@@ -172,6 +172,10 @@ int vssr_batch_stats(vssr_handle *h, int64_t *n_atoms, int64_t *n_edges, int64_t
  * arrays may be NULL to query the size. */
 int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, int32_t *eS,
                          float *er, int64_t *n_edges);
+/* Device addresses of the per-chain results of the resident batch (energy [B], energy_std [B], fp32, valid after a
+ * synchronised run): lets the multi-GPU result gather (RCCL all_gather of per-chain scalars) read
+ * them in place instead of through the host.  The pointers stay valid until the next vssr_batch_upload. */
+int vssr_batch_device_results(vssr_handle *h, const float **energy, const float **energy_std);
 /* Test hook for the capacity-regrow paths: initial neighbor capacity in slots per atom (<= 0: unchanged), tight != 0:
  * regrow to the exact need only (every later growth of the edge count overflows again), tight < 0: unchanged;
  * n_regrows (may be NULL) receives the number of regrows of the last relaxation. */

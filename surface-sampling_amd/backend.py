@@ -24,6 +24,7 @@ EXPORTS = (
     "vssr_synchronize", "vssr_profile_enable", "vssr_profile_reset", "vssr_profile_read",
     "vssr_batch_stats", "vssr_batch_neighbors", "vssr_debug_read", "vssr_tersoff_create",
     "vssr_tersoff_eval_batch", "vssr_batch_relax_fire", "vssr_batch_relax_bfgs", "vssr_debug_capacity",
+    "vssr_batch_device_results",
 )
 
 
@@ -124,6 +125,8 @@ def load_library():
     L.vssr_batch_relax_fire.argtypes = [vp, C.POINTER(FireParams), u8p, C.c_uint32, dp, ip, u8p]
     L.vssr_batch_relax_bfgs.restype = C.c_int
     L.vssr_batch_relax_bfgs.argtypes = [vp, C.POINTER(BfgsParams), u8p, C.c_uint32, dp, ip, u8p]
+    L.vssr_batch_device_results.restype = C.c_int
+    L.vssr_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.vssr_debug_capacity.restype = C.c_int
     L.vssr_debug_capacity.argtypes = [vp, C.c_int32, C.c_int32, ip]
     if L.vssr_abi_version() != 1:
@@ -144,6 +147,14 @@ def pack_batch(structs):
     cell = np.ascontiguousarray(np.stack([np.asarray(s[2], dtype=np.float64).reshape(9) for s in structs]))
     pbc = np.ascontiguousarray(np.stack([np.asarray(s[3]).astype(np.uint8).reshape(3) for s in structs]))
     return n_atoms, Z, pos, cell, pbc
+
+
+class _DeviceArray:
+    """A float32 vector in device memory owned by an engine (``__cuda_array_interface__`` v2)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), True), "version": 2,
+                                         "strides": None}
 
 
 class _Handle:
@@ -216,6 +227,13 @@ class _Handle:
         self._check(self._lib.vssr_batch_download(self._h, int(want), C.byref(out)))
         res["cfg_start"] = self._cfg_start
         return res
+
+    def device_results(self):
+        """``(energy, energy_std)`` of the resident batch as zero-copy device arrays (objects with
+        ``__cuda_array_interface__``: ``torch.as_tensor(x, device="cuda")`` wraps them).  Valid after a synchronised run."""
+        e, s = C.c_void_p(None), C.c_void_p(None)
+        self._check(self._lib.vssr_batch_device_results(self._h, C.byref(e), C.byref(s)))
+        return _DeviceArray(e.value, self._n_cfg), _DeviceArray(s.value, self._n_cfg)
 
     def evaluate(self, structs, want=WANT_ALL):
         self.upload(structs)

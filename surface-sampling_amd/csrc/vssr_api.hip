@@ -655,6 +655,14 @@ int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, 
     return VSSR_OK;
 }
 
+int vssr_batch_device_results(vssr_handle *h, const float **energy, const float **energy_std) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->ran || h->kind != 1) return set_err(h, VSSR_E_STATE, "no completed PaiNN run");
+    if (energy) *energy = h->d_energy.as<float>();
+    if (energy_std) *energy_std = h->d_energy_std.as<float>();
+    return VSSR_OK;
+}
+
 int vssr_debug_capacity(vssr_handle *h, int32_t slots_per_atom, int32_t tight, int32_t *n_regrows) {
     if (!h) return VSSR_E_BADARG;
     if (slots_per_atom > 0) {

@@ -4,6 +4,9 @@ Chains never interact: GPU g owns the contiguous block ``chain_range(B, G, g)`` 
 list, weights are replicated, and the only exchange is a gather of per-chain scalars (energies,
 flags) — one process per GPU, ``torch.distributed`` with the ``nccl`` (= RCCL over xGMI) backend on
 the GPU box, ``gloo`` in CPU tests.  Forces stay on the owning GPU.
+
+``ShardedEnsemble`` is the one code path for N = 1 and N > 1: ``bench.py`` times its ``step()``, the
+world-size-2 gloo test runs the same ``step()`` with a stand-in engine.
 """
 
 from __future__ import annotations
@@ -24,44 +27,100 @@ def all_ranges(n_chains: int, world: int) -> list[tuple[int, int]]:
     return [chain_range(n_chains, world, r) for r in range(world)]
 
 
-def gather_chain_scalars(local: np.ndarray, n_chains: int, dist=None, device=None) -> np.ndarray:
+def _world(dist):
+    return dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+
+
+def gather_chain_scalars(local, n_chains: int, dist=None, device=None, keep_on_device: bool = False):
     """All ranks receive the per-chain array of every rank, in global chain order.
 
-    ``local``: float32 [count, k] (or [count]) for this rank's block.  Uneven blocks are padded to the
-    largest block for the collective and trimmed afterwards."""
+    ``local``: float32 ``[count, k]`` (or ``[count]``) for this rank's block — a numpy array, or a torch tensor that may
+    already live on the GPU (then nothing passes through the host before the collective).  Uneven blocks are padded to the
+    largest block for the collective and trimmed afterwards.  Returns a numpy array, or with ``keep_on_device`` the
+    gathered torch tensor ``[n_chains, k]``."""
     import torch
 
-    local = np.ascontiguousarray(local, dtype=np.float32)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local.copy()
-    world, rank = dist.get_world_size(), dist.get_rank()
+    is_tensor = isinstance(local, torch.Tensor)
+    world = _world(dist)
+    if world == 1:
+        if is_tensor:
+            return local.clone() if keep_on_device else local.detach().cpu().numpy().copy()
+        return np.ascontiguousarray(local, dtype=np.float32).copy()
+    rank = dist.get_rank()
     ranges = all_ranges(n_chains, world)
-    if local.shape[0] != ranges[rank][1]:
+    shape_tail = tuple(local.shape[1:])
+    if int(local.shape[0]) != ranges[rank][1]:
         raise ValueError("local block does not match this rank's chain range")
-    width = int(np.prod(local.shape[1:])) if local.ndim > 1 else 1
+    width = int(np.prod(shape_tail)) if shape_tail else 1
     cmax = max(c for _, c in ranges)
-    buf = torch.zeros(cmax * width, dtype=torch.float32, device=device)
-    buf[: local.size] = torch.from_numpy(local.reshape(-1)).to(buf.device)
-    out = torch.empty(world * cmax * width, dtype=torch.float32, device=device)
+    if is_tensor:
+        flat = local.to(dtype=torch.float32).reshape(-1)
+        dev = flat.device if device is None else device
+    else:
+        flat = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32).reshape(-1))
+        dev = device
+    buf = torch.zeros(cmax * width, dtype=torch.float32, device=dev)
+    buf[: flat.numel()] = flat.to(buf.device)
+    out = torch.empty(world * cmax * width, dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(out, buf)
-    out = out.cpu().numpy().reshape(world, cmax, width)
-    parts = [out[r, :c] for r, (_, c) in enumerate(ranges)]
-    full = np.concatenate(parts, axis=0)
-    return full.reshape((n_chains,) + local.shape[1:])
+    out = out.reshape(world, cmax, width)
+    full = torch.cat([out[r, :c] for r, (_, c) in enumerate(ranges)], dim=0).reshape((n_chains,) + shape_tail)
+    return full if keep_on_device else full.cpu().numpy()
 
 
 class ShardedEnsemble:
-    """Runs one engine per rank on that rank's block of chains and gathers per-chain energies."""
+    """One engine per rank on that rank's block of chains; per-chain energies gathered to every rank.
+
+    The engine needs ``upload(structs)``, ``run(want)``, ``synchronize()``, ``download(want)`` and either
+    ``device_results()`` (zero-copy device arrays: the collective reads the energies where the kernels wrote them) or only
+    ``download`` (host path; the CPU stand-in of the tests)."""
 
     def __init__(self, engine, n_chains: int, dist=None, device=None):
         self.engine, self.n_chains, self.dist, self.device = engine, n_chains, dist, device
-        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.world = _world(dist)
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.first, self.count = chain_range(n_chains, self.world, self.rank)
+        self.gathered = None
 
     def local_slice(self, chains: list) -> list:
         return chains[self.first:self.first + self.count]
 
+    # ---- resident batch: upload once, then lock-step evaluations ------------------------------------------
+    def upload(self, all_chains: list | None = None, local_chains: list | None = None):
+        """Make this rank's block resident (pass the global list or the block itself)."""
+        block = local_chains if local_chains is not None else self.local_slice(all_chains)
+        if len(block) != self.count:
+            raise ValueError("block does not match this rank's chain range")
+        self.engine.upload(block)
+
+    def _local_scalars(self, want_energy_flags):
+        """This rank's per-chain (E, sigma_E) as ``[count, 2]``: device tensor when the engine exposes its buffers."""
+        if hasattr(self.engine, "device_results"):
+            import torch
+
+            self.engine.synchronize()   # the engine runs on its own stream
+            e, s = self.engine.device_results()
+            dev = self.device if self.device is not None else "cuda"
+            return torch.stack([torch.as_tensor(e, device=dev), torch.as_tensor(s, device=dev)], dim=1)
+        res = self.engine.download(want_energy_flags)
+        return np.stack([res["energy"], res["energy_std"]], axis=1)
+
+    def step(self, want, gather: bool | None = None):
+        """One lock-step evaluation of the resident block (asynchronous on one GPU) and, when the chains are sharded, the
+        path's only exchange: per-chain (E, sigma_E) to every rank.  Returns the gathered ``[n_chains, 2]`` (tensor or array)
+        or None when nothing was gathered."""
+        self.engine.run(want)
+        if gather is None:
+            gather = self.world > 1
+        if not gather:
+            return None
+        from . import backend
+
+        scal = self._local_scalars(backend.WANT_ENERGY | backend.WANT_STD)
+        self.gathered = gather_chain_scalars(scal, self.n_chains, self.dist, self.device, keep_on_device=True)
+        return self.gathered
+
+    # ---- one-shot form -------------------------------------------------------------------------------------
     def evaluate(self, all_chains: list) -> dict:
         """``all_chains``: the global list (every rank passes the same list; only its block is evaluated).
         Returns global per-chain ``energy`` / ``energy_std`` on every rank and this rank's ``forces``."""

@@ -125,3 +125,23 @@ def test_neighbors_against_bruteforce(golden, oracle_mod, pbc):
                     ref.add((int(i), int(j), a, b, c))
     got = {(int(i), int(j), *map(int, S)) for i, j, S in zip(ei, ej, eS)}
     assert got == ref
+
+
+def test_torch_port_matches_oracle(golden, oracle_mod):
+    """The torch restatement (oracle/torch_port.py: forward + torch.autograd.grad, the way the reference computes forces)
+    and the C oracle (hand-derived reverse pass) are independent derivations of the same model: fp64 results agree to
+    rounding.  The torch port is bench.py's second CPU baseline."""
+    import torch
+
+    import torch_port
+
+    table, const = golden.offset_table()
+    te = torch_port.TorchEnsemble(golden.blobs, torch.float64)
+    for name in ("SrTiO3_2x2_pristine", "O40Sr16Ti12"):
+        s = golden.structure(name)
+        r = te.evaluate(s.numbers, s.positions, s.cell, s.pbc, table, const)
+        o = oracle_mod.ensemble(golden.blobs, s.numbers, s.positions, s.cell, s.pbc, 64, table, const)
+        assert abs(r["energy"] - o["energy"]) < 1e-10
+        assert np.abs(r["forces"] - o["forces"]).max() < 1e-10
+        assert np.abs(r["energy_models"] - o["energy_models"]).max() < 1e-10
+        assert np.abs(r["forces_std"] - o["forces_std"]).max() < 1e-10

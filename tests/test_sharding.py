@@ -55,6 +55,82 @@ def _worker(rank, world, port, n_chains, out_dir):
     dist.destroy_process_group()
 
 
+class _FakeResidentEngine:
+    """Resident-batch interface of the GPU engine (upload / run / synchronize / download), energies = f(chain content)."""
+
+    def __init__(self):
+        self.structs, self.runs = None, 0
+
+    def upload(self, structs):
+        self.structs = list(structs)
+
+    def run(self, want):
+        self.runs += 1
+
+    def synchronize(self):
+        pass
+
+    def download(self, want):
+        e = np.array([float(np.sum(s[1])) + self.runs for s in self.structs], dtype=np.float32)
+        return {"energy": e, "energy_std": 0.25 * e}
+
+
+def _bench_worker(rank, world, port, per_gpu, out_dir):
+    """bench.py's timed unit (make_step over ShardedEnsemble.step) with a stand-in engine: the rank / offset arithmetic of
+    BASELINE configs[4] (rank r owns global chains [B r, B r + B)) and the gather, on gloo."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import bench
+    from surface_sampling_amd import backend
+    from surface_sampling_amd.sharding import ShardedEnsemble
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = bench.shard_plan(world, per_gpu)[rank]
+    rng = np.random.default_rng(0)
+    chains = [(np.ones(3 + c % 4, np.int32), rng.normal(size=(3 + c % 4, 3)), np.eye(3), [1, 1, 1])
+              for c in range(world * per_gpu)]
+    eng = _FakeResidentEngine()
+    sh = ShardedEnsemble(eng, world * per_gpu, dist)
+    ok = (sh.first, sh.count) == (first, count) == (rank * per_gpu, per_gpu)
+    sh.upload(local_chains=chains[first:first + count])
+    step = bench.make_step(sh, backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD)
+    for k in range(3):
+        g = step()
+        g = g.cpu().numpy() if hasattr(g, "cpu") else np.asarray(g)
+        want = np.array([float(np.sum(c[1])) + (k + 1) for c in chains], dtype=np.float32)
+        ok = ok and g.shape == (world * per_gpu, 2) and np.array_equal(g[:, 0], want) and np.array_equal(g[:, 1], 0.25 * want)
+    np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_function_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    import bench
+
+    plan = bench.shard_plan(8)     # BASELINE configs[4]: 2048 chains on 8 GPUs
+    assert plan == [(256 * r, 256) for r in range(8)]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_bench_worker, args=(2, port, 256, str(tmp_path)), nprocs=2, join=True)
+    assert all(np.load(tmp_path / f"ok{r}.npy")[0] == 1 for r in (0, 1))
+
+
+def test_single_rank_step_has_no_collective():
+    import bench
+    from surface_sampling_amd.sharding import ShardedEnsemble
+
+    eng = _FakeResidentEngine()
+    sh = ShardedEnsemble(eng, 4, None)
+    sh.upload(local_chains=[(np.ones(2, np.int32), np.zeros((2, 3)), np.eye(3), [1, 1, 1])] * 4)
+    assert bench.make_step(sh, 7)() is None and eng.runs == 1
+
+
 @pytest.mark.parametrize("n_chains", [8, 7])
 def test_gather_world_size_2_gloo(tmp_path, n_chains):
     import torch.multiprocessing as mp
