@@ -127,8 +127,18 @@ def _materialise(t, unpickler) -> np.ndarray:
     kind, storage, offset, size, stride = t
     assert kind == "tensor"
     base = unpickler.storage(storage)
+    # the pickle is untrusted: the strided view must stay inside its storage
+    size, stride = tuple(int(x) for x in size), tuple(int(x) for x in stride)
+    offset = int(offset)
+    if len(size) != len(stride) or offset < 0 or any(n < 0 for n in size) or any(st < 0 for st in stride):
+        raise ValueError("checkpoint tensor with a negative offset, size or stride")
+    last = offset + sum((n - 1) * st for n, st in zip(size, stride)) if all(n > 0 for n in size) else offset
+    if last >= base.size and (len(size) == 0 or all(n > 0 for n in size)):
+        raise ValueError(f"checkpoint tensor reaches element {last} of a storage with {base.size}")
     if len(size) == 0:
         return np.array(base[offset], dtype=np.float32)
+    if any(n == 0 for n in size):
+        return np.zeros(size, dtype=np.float32)
     view = np.lib.stride_tricks.as_strided(
         base[offset:], shape=size, strides=tuple(s * 4 for s in stride), writeable=False
     )
@@ -274,10 +284,42 @@ def blob_to_fields(blob: np.ndarray, hp: dict | None = None) -> "OrderedDict[str
     return out
 
 
+# pickled module attribute -> hyper-parameter of this backend
+_ATTR_TO_HPARAM = (("excl_vol", "excl_vol"), ("power", "V_ex_power"), ("sigma", "V_ex_sigma"), ("cutoff", "cutoff"))
+
+
+def check_model_against_hparams(path: str, sd: dict, hp: dict | None = None) -> None:
+    """A checkpoint whose stored hyper-parameters differ from the ones the engine will be created with would load and give
+    wrong energies silently: compare the pickled module attributes (excluded volume on/off, power, sigma, cutoff) and the
+    radial-basis frequencies (a learnable ``n`` that is no longer 1..n_rbf) with ``hp`` and raise on any difference."""
+    hp = {**DEFAULT_HPARAMS, **(hp or {})}
+    attrs = read_model_attrs(path)
+    for attr, key in _ATTR_TO_HPARAM:
+        if attr in attrs and key in hp and attrs[attr] is not None:
+            a, b = attrs[attr], hp[key]
+            same = (bool(a) == bool(b)) if isinstance(a, bool) or isinstance(b, bool) else abs(float(a) - float(b)) < 1e-9
+            if not same:
+                raise ValueError(f"{path}: checkpoint has {attr}={a!r} but the backend is configured with {key}={b!r}")
+    n_ref = np.arange(1, hp["n_rbf"] + 1, dtype=np.float64)
+    consumed = {key for _, key in painn_blob_order(hp["num_conv"])}
+    for key, arr in sd.items():
+        if key in consumed:
+            continue
+        if key.endswith("dist_embed.block.0.n"):
+            if arr.shape != n_ref.shape or np.abs(np.asarray(arr, np.float64) - n_ref).max() > 1e-6:
+                raise ValueError(f"{path}: learnable radial frequencies {key} differ from 1..{hp['n_rbf']}")
+        elif key.endswith(("means", "stddevs")) and arr.size:
+            raise ValueError(f"{path}: non-empty ScaleShift parameter {key} is not supported")
+        else:
+            raise ValueError(f"{path}: parameter {key} {tuple(arr.shape)} is not part of the supported PaiNN layout")
+
+
 def load_painn_blob(path: str, hp: dict | None = None) -> np.ndarray:
     """``best_model`` (torch zip) or ``.f32`` raw blob -> canonical fp32 blob."""
     if zipfile.is_zipfile(path):
-        return state_dict_to_blob(read_state_dict(path), hp)
+        sd = read_state_dict(path)
+        check_model_against_hparams(path, sd, hp)
+        return state_dict_to_blob(sd, hp)
     blob = np.fromfile(path, dtype="<f4")
     blob_to_fields(blob, hp)  # validates the size
     return blob

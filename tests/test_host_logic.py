@@ -193,3 +193,41 @@ def test_pourbaix_calculator_surface_without_gpu(golden):
     want = calcs.pourbaix_potential_from_energy(-467.5, s.get_chemical_symbols(), pa, 0.03, 0.5, 3.0, {})
     assert calc.surface_energy_of(np.array([-467.5]), s) == pytest.approx(want)
     assert calc.get_delta_G2(s) == pytest.approx(sum(calc.get_delta_G2_individual(x) for x in s.get_chemical_symbols()))
+
+
+def test_checkpoint_tensor_views_are_bounds_checked():
+    """The pickle inside a checkpoint is untrusted: (offset, size, stride) of every tensor must stay inside its storage."""
+    from surface_sampling_amd import checkpoint
+
+    class _U:
+        def storage(self, ref):
+            return np.arange(12, dtype="<f4")
+
+    ok = checkpoint._materialise(("tensor", None, 2, (2, 3), (3, 1)), _U())
+    assert ok.shape == (2, 3) and ok[1, 2] == 7.0
+    assert checkpoint._materialise(("tensor", None, 11, (), ()), _U()) == 11.0
+    for bad in [("tensor", None, 8, (2, 3), (3, 1)),      # last element = 8 + 3 + 2 = 13 > 11
+                ("tensor", None, -1, (2,), (1,)), ("tensor", None, 0, (2,), (-1,)), ("tensor", None, 12, (), ()),
+                ("tensor", None, 0, (4, 4), (4, 1)), ("tensor", None, 0, (2, 2), (1,))]:
+        with pytest.raises(ValueError):
+            checkpoint._materialise(bad, _U())
+
+
+def test_checkpoint_hyper_parameters_must_match_the_engine(monkeypatch):
+    """A checkpoint trained with another excluded-volume setting / cutoff, or with extra learnable tensors, must not load
+    silently (the engine takes these numbers from hparams, not from the file)."""
+    from surface_sampling_amd import checkpoint
+
+    attrs = {"excl_vol": True, "power": 12, "sigma": 1.5, "cutoff": 5.0}
+    monkeypatch.setattr(checkpoint, "read_model_attrs", lambda path: dict(attrs))
+    sd = {key: np.zeros(1, np.float32) for _, key in checkpoint.painn_blob_order(3)}
+    checkpoint.check_model_against_hparams("x", sd)                                    # defaults agree
+    for hp in ({"V_ex_sigma": 2.0}, {"V_ex_power": 6}, {"excl_vol": False}, {"cutoff": 6.0}):
+        with pytest.raises(ValueError):
+            checkpoint.check_model_against_hparams("x", sd, hp)
+    n_key = "message_blocks.0.inv_message.dist_embed.block.0.n"
+    checkpoint.check_model_against_hparams("x", {**sd, n_key: np.arange(1, 21, dtype=np.float32)})
+    with pytest.raises(ValueError):
+        checkpoint.check_model_against_hparams("x", {**sd, n_key: np.arange(1, 21, dtype=np.float32) * 1.01})
+    with pytest.raises(ValueError):
+        checkpoint.check_model_against_hparams("x", {**sd, "extra.weight": np.zeros((3, 3), np.float32)})
