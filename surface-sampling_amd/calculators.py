@@ -320,6 +320,9 @@ class EnsembleNFFSurface(_Base):
             "forces": res["forces"][a0:a1].copy(),
             "forces_std": res["forces_std"][a0:a1].copy(),
             "energy_models": res["energy_models"][b].copy(),
+            # ensemble-mean per-atom energies in eV (the stoichiometric offset is not distributed over atoms); what the
+            # reference's Boltzmann-weighted switch proposal reads from results["per_atom_energies"] (mcmc/slab.py:92)
+            "per_atom_energies": res["energy_atoms"][a0:a1].copy(),
         }
 
     def calculate(self, atoms=None, properties=implemented_properties, system_changes=all_changes):

@@ -13,11 +13,16 @@ how chains are batched or sharded over GPUs, and the B proposed slabs are relaxe
 Canonical sampling (``MCMC.step_canonical`` ``mcmc/mcmc.py:190-231``: ``SwitchProposal`` ``mcmc/events/proposal.py:154-197``
 -> ``get_complementary_idx`` ``mcmc/slab.py:168-232`` with uniform weights, ``Exchange`` ``mcmc/events/event.py:138-156``) is
 the same array arithmetic: two different "types" present on the lattice (a species or "None" for empty sites), one site of
-each, adsorbates exchanged.  The per-atom-energy (Boltzmann) and distance-decay site weights of the reference's proposal are
-not covered.
+each, adsorbates exchanged.  Site weights: uniform, Boltzmann in the per-atom energies (``compute_boltzmann_weights``,
+``mcmc/slab.py:73-113``) and / or distance decay around the first site (``get_complementary_idx_distance_decay``
+``mcmc/slab.py:116-165``, matrix ``compute_distance_weight_matrix`` ``mcmc/utils/misc.py:170-190``).  With
+``reference_groupby=True`` the candidate sites of a species are those of the reference's ``get_adsorbate_indices``
+(``mcmc/slab.py:36-57``): ``itertools.groupby`` over the filled sites in site order keyed by the symbol of the adsorbate's
+first atom, a dict that keeps only the LAST consecutive run of every key -- reproduced here run for run; the default
+(all sites of a species) is what the reference's docstring describes.
 
-Single-atom adsorbates only (the SrTiO3 / GaN configurations of BASELINE.json); the reference's multi-atom
-``ATOM_GROUPS`` are not covered.
+Adsorbates are single atoms or the reference's multi-atom ``ATOM_GROUPS`` ("HO", "H2O"; ``mcmc/slab.py:22-33``, added /
+removed as in ``add_atom_group`` / ``remove_atom_group`` ``:313-346,398-436``).
 """
 from __future__ import annotations
 
@@ -93,31 +98,69 @@ class SiteState:
         return [structures.SYMBOLS[int(z)] for z in self.numbers]
 
 
+# multi-atom adsorbates of the reference (mcmc/slab.py:22-33): symbols and positions relative to the site coordinate
+ATOM_GROUPS = {
+    "HO": (("O", "H"), ((0.0, 0.0, 0.0), (1.0, 0.0, 0.0))),
+    "H2O": (("O", "H", "H"), ((0.0, 0.0, 0.0), (0.5, -np.sqrt(3.0) / 2.0, 0.0), (0.5, np.sqrt(3.0) / 2.0, 0.0))),
+}
+
+
+def adsorbate_atoms(name: str):
+    """``(atomic numbers [k], offsets [k, 3])`` of an adsorbate: an element symbol or an ``ATOM_GROUPS`` name."""
+    if name in ATOM_GROUPS:
+        syms, offs = ATOM_GROUPS[name]
+        return np.array([structures.ATOMIC_NUMBERS[x] for x in syms], np.int32), np.array(offs, float)
+    return np.array([structures.ATOMIC_NUMBERS[name]], np.int32), np.zeros((1, 3))
+
+
 def change_site(state: SiteState, site_idx: int, end_ads: str) -> SiteState:
-    """``change_site`` of the reference (``mcmc/slab.py:235-274``) for single-atom adsorbates: remove what sits on the
-    site (later atom indices and ``occ`` / ``ads_group`` entries shift down, ``mcmc/slab.py:347-390``), then append the
-    new adsorbate at the site coordinate with ``occ[site] = ads_group[-1] =`` its atom index (``:291-309``)."""
+    """``change_site`` of the reference (``mcmc/slab.py:235-274``): remove what sits on the site -- one atom or a whole group,
+    i.e. every atom whose ``ads_group`` equals the site's ``occ`` entry; later atom indices and ``occ`` / ``ads_group``
+    entries shift down by the number of atoms removed (``:347-395``) -- then append the new adsorbate (atom or
+    ``ATOM_GROUPS`` member, ``:291-346``) at the site coordinate with ``occ[site] = ads_group =`` the index of its first atom."""
     if site_idx >= len(state.occ) or site_idx < 0:
         raise IndexError("site index out of range")
     s = state.copy()
     idx = int(s.occ[site_idx])
     if idx != 0:
         assert np.count_nonzero(s.occ == idx) == 1, "adsorbate index must belong to exactly one site"
-        s.numbers = np.delete(s.numbers, idx)
-        s.positions = np.delete(s.positions, idx, axis=0)
-        s.ads_group = np.delete(s.ads_group, idx)
-        s.occ = np.where(s.occ >= idx, s.occ - 1, s.occ)
-        s.ads_group = np.where(s.ads_group >= idx, s.ads_group - 1, s.ads_group)
+        members = np.flatnonzero(s.ads_group == idx)
+        k = len(members)
+        assert k >= 1 and np.array_equal(members, np.arange(idx, idx + k)), "an adsorbate's atoms are contiguous"
+        s.numbers = np.delete(s.numbers, members)
+        s.positions = np.delete(s.positions, members, axis=0)
+        s.ads_group = np.delete(s.ads_group, members)
+        s.occ = np.where(s.occ >= idx, s.occ - k, s.occ)
+        s.ads_group = np.where(s.ads_group >= idx, s.ads_group - k, s.ads_group)
         s.occ = np.where(s.occ < 0, 0, s.occ)
         s.ads_group = np.where(s.ads_group < 0, 0, s.ads_group)
         s.occ[site_idx] = 0
     if end_ads != "None":
         new_idx = len(s.numbers)
-        s.numbers = np.append(s.numbers, structures.ATOMIC_NUMBERS[end_ads]).astype(state.numbers.dtype)
-        s.positions = np.vstack([s.positions, np.asarray(s.ads_coords[site_idx], float)[None]])
-        s.ads_group = np.append(s.ads_group, new_idx)
+        z, offs = adsorbate_atoms(end_ads)
+        s.numbers = np.concatenate([s.numbers, z]).astype(state.numbers.dtype)
+        s.positions = np.vstack([s.positions, np.asarray(s.ads_coords[site_idx], float)[None] + offs])
+        s.ads_group = np.concatenate([s.ads_group, np.full(len(z), new_idx, s.ads_group.dtype)])
         s.occ[site_idx] = new_idx
     return s
+
+
+def compute_distance_weight_matrix(ads_coords, distance_decay_factor: float) -> np.ndarray:
+    """Row-wise softmax of ``-distance / decay`` between adsorption sites (``mcmc/utils/misc.py:170-190``)."""
+    x = np.asarray(ads_coords, float)
+    d = np.sqrt(((x[:, None, :] - x[None, :, :]) ** 2).sum(axis=2))
+    z = -d / float(distance_decay_factor)
+    z -= z.max(axis=1, keepdims=True)
+    w = np.exp(z)
+    return w / w.sum(axis=1, keepdims=True)
+
+
+def boltzmann_atom_weights(per_atom_energies, temperature: float) -> np.ndarray:
+    """``softmax(per_atom_energies / T)`` over the atoms of one slab (``compute_boltzmann_weights``, ``mcmc/slab.py:104``)."""
+    z = np.asarray(per_atom_energies, float) / float(temperature)
+    z = z - z.max()
+    w = np.exp(z)
+    return w / w.sum()
 
 
 def metropolis_accept(prev_energy, curr_energy, temperature: float, u) -> np.ndarray:
@@ -188,7 +231,8 @@ class ChainEnsemble:
     Args:
         base: the pristine slab (``structures.Structure``; slab atoms only).
         ads_coords: ``[S, 3]`` adsorption-site coordinates (``SurfaceSystem.ads_coords``).
-        adsorbates: adsorbate symbols, e.g. ``("Sr", "O")`` (``ChangeProposal`` default, ``proposal.py:55``).
+        adsorbates: adsorbate names, e.g. ``("Sr", "O")`` (``ChangeProposal`` default, ``proposal.py:55``); element symbols or
+            ``ATOM_GROUPS`` names ("HO", "H2O").
         n_chains: chains owned by this process; ``first_chain`` = global id of the first one (sharding).
         calc: energy backend with ``relax_batch(atoms_list, fixed_indices, relax_steps, fmax)`` (relax=True) or
             ``calculate_batch(atoms_list)`` (relax=False), e.g. ``calculators.EnsembleNFFSurface``.
@@ -199,12 +243,24 @@ class ChainEnsemble:
 
     def __init__(self, base, ads_coords, adsorbates, n_chains: int, calc, *, seed: int = 0, first_chain: int = 0,
                  relax: bool = True, relax_steps: int = 20, fmax: float = 0.01, fixed_indices=None,
-                 surface_energy_fn=None, temperature: float = 1.0, optimizer: str = "BFGS"):
+                 surface_energy_fn=None, temperature: float = 1.0, optimizer: str = "BFGS",
+                 reference_groupby: bool = False, require_per_atom_energies: bool = False,
+                 require_distance_decay: bool = False, distance_decay_factor: float = 1.0):
         self.base = base
         self.ads_coords = np.asarray(ads_coords, float).reshape(-1, 3)
         self.adsorbates = list(adsorbates)
         self.n_ads = len(self.adsorbates)
-        self.ads_numbers = np.array([structures.ATOMIC_NUMBERS[a] for a in self.adsorbates], np.int32)
+        self.ads_atoms = [adsorbate_atoms(a) for a in self.adsorbates]          # (numbers [k], offsets [k, 3]) per adsorbate
+        self.ads_sizes = np.array([len(z) for z, _ in self.ads_atoms] + [0], np.int64)   # (+ the "None" code)
+        # switch-proposal options of the reference's SwitchProposal (mcmc/events/proposal.py:112-160)
+        self.reference_groupby = bool(reference_groupby)
+        self.require_per_atom_energies = bool(require_per_atom_energies)
+        self.require_distance_decay = bool(require_distance_decay)
+        self.distance_weight_matrix = (compute_distance_weight_matrix(self.ads_coords, distance_decay_factor)
+                                       if require_distance_decay else None)
+        # key of an adsorbate in the reference's grouping = symbol of its FIRST atom ("HO" and "O" share the key "O")
+        first = [int(z[0]) for z, _ in self.ads_atoms]
+        self.group_key = np.array([first.index(f) for f in first] + [self.n_ads], np.int64)
         self.calc = calc
         self.seed, self.first_chain = int(seed), int(first_chain)
         self.relax, self.relax_steps, self.fmax = bool(relax), int(relax_steps), float(fmax)
@@ -218,6 +274,7 @@ class ChainEnsemble:
         self.step_count = 0
         self.relaxed = [None] * B           # relaxed Structure of the current state of every chain
         self.oob = np.zeros(B, bool)        # out-of-bounds flag of the last evaluation of every chain (reference: energy_oob)
+        self.per_atom_energies = [None] * B  # of the current state (filled when the backend returns them)
         self.n_evaluations = 0
 
     # ---- proposal: vectorised ChangeProposal.get_action ------------------------------------------------------------
@@ -235,19 +292,64 @@ class ChainEnsemble:
         return site, end, start, u[:, 2]
 
     # ---- proposal: vectorised SwitchProposal.get_action (uniform weights) -------------------------------------------
+    def switch_candidates(self, state: ChainState | None = None) -> np.ndarray:
+        """``[B, n_types, S]`` bool: candidate sites of every type code (the last code = empty sites).  Default: all sites
+        that carry the type.  ``reference_groupby``: the reference's ``get_adsorbate_indices`` (``mcmc/slab.py:36-57``) --
+        filled sites in site order, grouped by CONSECUTIVE equal key (symbol of the adsorbate's first atom) with
+        ``itertools.groupby``, collected in a dict, so a later run of a key replaces the earlier ones: the candidates of a
+        key are the sites of its last run (types that share a first-atom symbol share one entry)."""
+        st = state or self.state
+        B, S = st.species.shape
+        filled = st.species != self.n_ads
+        cand = np.zeros((B, self.n_ads + 1, S), bool)
+        cand[:, self.n_ads] = ~filled
+        if not self.reference_groupby:
+            for c in range(self.n_ads):
+                cand[:, c] = st.species == c
+            return cand
+        key = self.group_key[st.species]                              # [B, S]; n_ads for empty sites
+        # key of the previous FILLED site (empty sites do not interrupt a run: groupby only sees the filled ones)
+        idx = np.where(filled, np.arange(S)[None, :], -1)
+        last_filled = np.maximum.accumulate(idx, axis=1)
+        prev = np.concatenate([np.full((B, 1), -1), last_filled[:, :-1]], axis=1)
+        prev_key = np.where(prev >= 0, np.take_along_axis(key, np.maximum(prev, 0), axis=1), -1)
+        run_start = filled & (key != prev_key)
+        run_id = np.cumsum(run_start, axis=1)                         # run number of every filled site (1-based)
+        for c in sorted(set(self.group_key[: self.n_ads].tolist())):
+            m = filled & (key == c)
+            last_run = np.where(m, run_id, 0).max(axis=1)
+            cand[:, c] = m & (run_id == last_run[:, None])
+        return cand
+
+    def _site_weights(self, cand: np.ndarray, state: ChainState) -> np.ndarray:
+        """Per-site selection weights ``[B, S]``: 1, or the Boltzmann weight of the adsorbate's first atom
+        (``compute_boltzmann_weights``: softmax of per-atom energies / T over the slab's atoms; empty sites weigh 1)."""
+        B, S = state.species.shape
+        if not self.require_per_atom_energies:
+            return np.ones((B, S))
+        occ = self.occ(state)
+        w = np.ones((B, S))
+        for b in range(B):
+            pae = self.per_atom_energies[b]
+            if pae is None:
+                raise ValueError("require_per_atom_energies is True, but no per_atom_energies were provided")
+            bw = boltzmann_atom_weights(pae, self.temp)
+            f = state.species[b] != self.n_ads
+            w[b, f] = bw[occ[b, f]]
+        return w
+
     def propose_switch(self, step: int, state: ChainState | None = None):
-        """Per chain: an ordered pair of DIFFERENT types present on the lattice (species codes, ``n_ads`` = "None" for
-        empty sites; ``random.sample(types, 2)``, ``mcmc/slab.py:60-71``), then a uniformly random site of each type
-        (``mcmc/slab.py:217-222``).  Returns ``(site1 [B], site2 [B], type1 [B], type2 [B], valid [B], u_acc [B])``;
-        ``valid`` is False for chains with fewer than two types on the lattice (the reference cannot propose there).
-        The reference collects the sites of a species with ``itertools.groupby`` over the site order, which keeps only
-        the last consecutive run of a species; ALL sites of the species are candidates here."""
+        """Per chain: an ordered pair of DIFFERENT types present on the lattice (``random.sample(types, 2)``,
+        ``mcmc/slab.py:60-71``), then one site of each type (``mcmc/slab.py:200-222``): uniformly, or with Boltzmann weights
+        (``require_per_atom_energies``), the second site additionally weighted by the distance-decay row of the first
+        (``require_distance_decay``, ``mcmc/slab.py:116-165``).  Returns ``(site1 [B], site2 [B], type1 [B], type2 [B],
+        valid [B], u_acc [B])``; ``valid`` is False for chains with fewer than two types on the lattice (the reference cannot
+        propose there).  Candidate sites: :meth:`switch_candidates`."""
         st = state or self.state
         u = chain_uniforms(self.seed, self.chain_ids, step)
         B, S = st.species.shape
-        codes = np.arange(self.n_ads + 1)
-        counts = (st.species[:, :, None] == codes[None, None, :]).sum(axis=1)          # [B, n_ads + 1]
-        present = counts > 0
+        cand = self.switch_candidates(st)                                                # [B, T, S]
+        present = cand.any(axis=2)
         T = present.sum(axis=1)
         valid = T >= 2
         Tm = np.maximum(T, 2)
@@ -257,14 +359,26 @@ class ChainEnsemble:
         rank = np.cumsum(present, axis=1) - 1                                           # index among the present types
         type1 = np.argmax(present & (rank == i1[:, None]), axis=1)
         type2 = np.argmax(present & (rank == i2[:, None]), axis=1)
+        w = self._site_weights(cand, st)
+        rows = np.arange(B)
 
-        def pick(type_code, uu):
-            mask = st.species == type_code[:, None]
-            n = np.maximum(mask.sum(axis=1), 1)
-            j = np.minimum((uu * n).astype(np.int64), n - 1)
-            return np.argmax(mask & ((np.cumsum(mask, axis=1) - 1) == j[:, None]), axis=1)
+        def pick(mask, weights, uu):
+            ww = np.where(mask, weights, 0.0)
+            cum = np.cumsum(ww, axis=1)
+            tot = np.maximum(cum[:, -1], 1e-300)
+            j = (cum <= (uu * tot)[:, None]).sum(axis=1)           # first site whose cumulative weight exceeds u * total
+            j = np.minimum(j, S - 1)
+            # guard against round-off landing on a zero-weight site: move to the last candidate at or before j, else the first
+            ok = mask[rows, j]
+            first = np.argmax(mask, axis=1)
+            lastc = S - 1 - np.argmax(mask[:, ::-1], axis=1)
+            return np.where(ok, j, np.where(j > lastc, lastc, first))
 
-        site1, site2 = pick(type1, u[:, 1]), pick(type2, u[:, 3])
+        site1 = pick(cand[rows, type1], w, u[:, 1])
+        w2 = w
+        if self.require_distance_decay:
+            w2 = w * self.distance_weight_matrix[site1]
+        site2 = pick(cand[rows, type2], w2, u[:, 3])
         return site1, site2, type1, type2, valid, u[:, 2]
 
     # ---- vectorised change_site ------------------------------------------------------------------------------------
@@ -284,12 +398,20 @@ class ChainEnsemble:
         st = state or self.state
         filled = st.species != self.n_ads
         key = np.where(filled, st.order, np.iinfo(np.int64).max)
-        rank = np.argsort(np.argsort(key, axis=1, kind="stable"), axis=1, kind="stable")
-        return np.where(filled, len(self.base) + rank, 0)
+        order = np.argsort(key, axis=1, kind="stable")                       # sites in adsorption order
+        sizes = np.take_along_axis(np.where(filled, self.ads_sizes[st.species], 0), order, axis=1)
+        first = np.cumsum(sizes, axis=1) - sizes                             # atoms of earlier adsorbates
+        start = np.empty_like(first)
+        np.put_along_axis(start, order, first, axis=1)
+        return np.where(filled, len(self.base) + start, 0)
 
     def num_adsorbates(self, state: ChainState | None = None) -> np.ndarray:
         st = state or self.state
         return (st.species != self.n_ads).sum(axis=1)
+
+    def num_adsorbate_atoms(self, state: ChainState | None = None) -> np.ndarray:
+        st = state or self.state
+        return self.ads_sizes[st.species].sum(axis=1)
 
     def structure(self, b: int, state: ChainState | None = None):
         """Unrelaxed slab of chain b: slab atoms, then adsorbates at their site coordinates in adsorption order
@@ -297,9 +419,12 @@ class ChainEnsemble:
         st = state or self.state
         sites = np.flatnonzero(st.species[b] != self.n_ads)
         sites = sites[np.argsort(st.order[b, sites], kind="stable")]
-        numbers = np.concatenate([self.base.numbers, self.ads_numbers[st.species[b, sites]]]).astype(np.int32)
-        positions = np.vstack([self.base.positions, self.ads_coords[sites]]) if len(sites) else self.base.positions.copy()
-        return structures.Structure(numbers, positions, self.base.cell, self.base.pbc)
+        zs, xs = [self.base.numbers], [self.base.positions]
+        for site in sites:
+            z, offs = self.ads_atoms[int(st.species[b, site])]
+            zs.append(z)
+            xs.append(self.ads_coords[site][None] + offs)
+        return structures.Structure(np.concatenate(zs).astype(np.int32), np.vstack(xs), self.base.cell, self.base.pbc)
 
     # ---- energies --------------------------------------------------------------------------------------------------
     def _default_surface_energy(self, energy, struct):
@@ -329,10 +454,12 @@ class ChainEnsemble:
             relaxed = [o[0] for o in out]
             for b, o in zip(idx, out):
                 self.oob[int(b)] = bool(o[3])
+            self._last_pae = [o[4].get("per_atom_energies") if len(o) > 4 and isinstance(o[4], dict) else None for o in out]
         else:
             out = self.calc.calculate_batch(slabs)
             raw = [float(np.ravel(o["energy"])[0]) for o in out]
             relaxed = slabs
+            self._last_pae = [o.get("per_atom_energies") for o in out]
         self.n_evaluations += len(slabs)
         energies = np.array([self.surface_energy_fn(e, s) for e, s in zip(raw, slabs)], float)
         return energies, relaxed
@@ -361,6 +488,7 @@ class ChainEnsemble:
     def initialize(self):
         """Surface energy of the starting states (the reference evaluates the start state before the first sweep)."""
         self.state.energy, self.relaxed = self.evaluate(self.state)
+        self.per_atom_energies = list(self._last_pae)
         return self.state.energy
 
     # ---- one Change event + Metropolis for every chain --------------------------------------------------------------
@@ -374,6 +502,7 @@ class ChainEnsemble:
         site, end, _, u_acc = self.propose(self.step_count, before)
         after = self.apply(before, site, end)                 # change_site + save_state("after")
         after.energy, relaxed_after = self.evaluate(after)    # get_surface_energy(recalculate=True)
+        pae_after = list(self._last_pae)
         accept = metropolis_accept(before.energy, after.energy, temp, u_acc)
         # accepted chains keep "after", the others are restored to "before" (Event.backward)
         a2 = accept[:, None]
@@ -381,6 +510,7 @@ class ChainEnsemble:
                                 np.where(accept, after.counter, before.counter),
                                 np.where(accept, after.energy, before.energy))
         self.relaxed = [ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, self.relaxed)]
+        self.per_atom_energies = [pa if acc else pb for acc, pa, pb in zip(accept, pae_after, self.per_atom_energies)]
         return accept
 
     # ---- one Exchange event + Metropolis for every chain ------------------------------------------------------------
@@ -398,17 +528,20 @@ class ChainEnsemble:
         moved = np.flatnonzero(valid)
         after.energy = before.energy.copy()
         relaxed_after = list(self.relaxed)
+        pae_after = list(self.per_atom_energies)
         if len(moved):
             e, r = self.evaluate(after, moved)
             after.energy[moved] = e
-            for b, rb in zip(moved, r):
+            for b, rb, pb in zip(moved, r, self._last_pae):
                 relaxed_after[int(b)] = rb
+                pae_after[int(b)] = pb
         accept = metropolis_accept(before.energy, after.energy, temp, u_acc) & valid
         a2 = accept[:, None]
         self.state = ChainState(np.where(a2, after.species, before.species), np.where(a2, after.order, before.order),
                                 np.where(accept, after.counter, before.counter),
                                 np.where(accept, after.energy, before.energy))
         self.relaxed = [ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, self.relaxed)]
+        self.per_atom_energies = [pa if acc else pb for acc, pa, pb in zip(accept, pae_after, self.per_atom_energies)]
         return accept
 
     def sweep(self, i: int = 0, sweep_size: int = 20, temperature: float | None = None, canonical: bool = False) -> dict:

@@ -345,3 +345,152 @@ def test_canonical_trajectories_do_not_depend_on_batching():
     part.run(total_sweeps=2, sweep_size=5, perform_annealing=False, canonical=True)
     assert np.array_equal(whole.state.species[8:], part.state.species)
     assert np.allclose(whole.state.energy[8:], part.state.energy)
+
+
+# ---- multi-atom adsorbates: mirrors the reference's tests/test_slab_groups.py:41-87 (same fixture, same expected arrays) ----
+def _group_fixture():
+    Z = structures.ATOMIC_NUMBERS
+    return mc.SiteState(np.array([Z["Ga"], Z["As"], Z["Ga"], Z["As"]]),
+                        np.array([[0, 0, 0], [0, 0, 3], [1, 1, 1], [1, 1, 4]], float), np.array([0, 1, 2, 0]),
+                        np.array([1, 2, 0]), np.array([(0, 0, 3), (1, 1, 1), (2, 2, 5)], float))
+
+
+def test_change_site_groups_follow_the_reference_sequence():
+    s0 = _group_fixture()
+    a = mc.change_site(s0, 0, "HO")                       # existing adsorbate -> group
+    assert len(a) == 5 and np.array_equal(a.occ, [3, 1, 0]) and a.symbols[3:] == ["O", "H"]
+    assert np.array_equal(a.ads_group, [0, 1, 0, 3, 3])
+    assert np.allclose(a.positions[3], [0, 0, 3]) and np.allclose(a.positions[4], [1, 0, 3])   # group offsets at the site
+    b = mc.change_site(a, 2, "Ir")                        # empty site -> atom, behind the group
+    assert len(b) == 6 and np.array_equal(b.occ, [3, 1, 5]) and b.symbols[5] == "Ir"
+    assert np.array_equal(b.ads_group, [0, 1, 0, 3, 3, 5])
+    c = mc.change_site(b, 0, "None")                      # remove the group: two atoms leave, later indices drop by 2
+    assert len(c) == 4 and np.array_equal(c.occ, [0, 1, 3]) and c.symbols[3] == "Ir"
+    assert np.array_equal(c.ads_group, [0, 1, 0, 3])
+    d = mc.change_site(c, 1, "None")                      # remove a single atom
+    assert len(d) == 3 and np.array_equal(d.occ, [0, 0, 2]) and d.symbols[2] == "Ir"
+    assert np.array_equal(d.ads_group, [0, 0, 2])
+    w = mc.change_site(s0, 2, "H2O")
+    assert w.symbols[4:] == ["O", "H", "H"] and np.array_equal(w.ads_group[4:], [4, 4, 4]) and w.occ[2] == 4
+    assert np.allclose(np.linalg.norm(w.positions[5:] - w.positions[4], axis=1), 1.0)
+
+
+def _group_ensemble(n_chains=40, **kw):
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[1.5 * s, 0.0, 2.0] for s in range(7)], float)
+    calc = LatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02, Z["H"]: 0.01}, J=0.0)
+    return mc.ChainEnsemble(base, coords, ("Sr", "O", "HO", "H2O"), n_chains, calc, seed=9, relax=False, temperature=0.05,
+                            **kw), calc
+
+
+def test_batched_groups_equal_reference_bookkeeping():
+    """Random sequences of changes with atoms and groups: the batched state reproduces, chain by chain, the atom order,
+    positions, ``occ`` and the group membership of the reference-style single-chain bookkeeping."""
+    ens, _ = _group_ensemble()
+    B, S = ens.state.species.shape
+    refs = [mc.SiteState(ens.base.numbers.copy(), ens.base.positions.copy(), np.zeros(len(ens.base), np.int64),
+                         np.zeros(S, np.int64), ens.ads_coords) for _ in range(B)]
+    names = ens.adsorbates + ["None"]
+    state = ens.state
+    for step in range(1, 30):
+        site, end, _, _ = ens.propose(step, state)
+        state = ens.apply(state, site, end)
+        refs = [mc.change_site(r, int(si), names[int(e)]) for r, si, e in zip(refs, site, end)]
+    occ = ens.occ(state)
+    assert (ens.num_adsorbate_atoms(state) > ens.num_adsorbates(state)).any()          # groups are present
+    for b in range(B):
+        st = ens.structure(b, state)
+        assert np.array_equal(st.numbers, refs[b].numbers) and np.allclose(st.positions, refs[b].positions)
+        assert np.array_equal(occ[b], refs[b].occ)
+        assert len(st) == len(ens.base) + ens.num_adsorbate_atoms(state)[b]
+
+
+# ---- switch proposals: the reference's candidate sets and weights --------------------------------------------------------
+def test_reference_groupby_keeps_the_last_consecutive_run_of_a_species():
+    """``get_adsorbate_indices`` (mcmc/slab.py:36-57): groupby over the filled sites in site order, later runs of a key
+    replace earlier ones.  Sites: Sr . O Sr Sr . O  ->  reference candidates Sr: {3, 4}, O: {6}, None: {1, 5}; the default mode
+    offers every site of the species."""
+    ens, _ = _toy(1, n_sites=7)
+    SR, O, E = 0, 1, ens.n_ads
+    sp = np.array([[SR, E, O, SR, SR, E, O]], np.int16)
+    order = np.where(sp != E, np.cumsum(sp != E, axis=1), 0)
+    st = mc.ChainState(sp, order.astype(np.int64), np.array([order.max() + 1]))
+    cand = ens.switch_candidates(st)[0]
+    assert [np.flatnonzero(c).tolist() for c in cand] == [[0, 3, 4], [2, 6], [1, 5]]
+    ens.reference_groupby = True
+    cand = ens.switch_candidates(st)[0]
+    assert [np.flatnonzero(c).tolist() for c in cand] == [[3, 4], [6], [1, 5]]
+    # the reference's own fixture (tests/test_slab.py:84-87): occ [1, 2, 0] -> {"As": [0], "Ga": [1], "None": [2]}
+    sp2 = np.array([[O, SR, E]], np.int16)
+    st2 = mc.ChainState(sp2, np.array([[1, 2, 0]]), np.array([3]))
+    ens2, _ = _toy(1, n_sites=3)
+    ens2.reference_groupby = True
+    assert [np.flatnonzero(c).tolist() for c in ens2.switch_candidates(st2)[0]] == [[1], [0], [2]]
+    # proposals in reference mode only ever use the reference's candidates
+    ens.chain_ids = np.arange(500)
+    big = mc.ChainState(np.repeat(sp, 500, 0), np.repeat(order, 500, 0).astype(np.int64), np.full(500, order.max() + 1))
+    s1, s2, t1, t2, valid, _ = ens.propose_switch(3, big)
+    allowed = {SR: {3, 4}, O: {6}, E: {1, 5}}
+    assert valid.all() and all(int(a) in allowed[int(t)] for a, t in zip(s1, t1))
+    assert all(int(a) in allowed[int(t)] for a, t in zip(s2, t2)) and (t1 != t2).all()
+    assert {int(x) for x in s1} | {int(x) for x in s2} == {1, 3, 4, 5, 6}
+
+
+def test_group_and_atom_share_the_first_atom_key_in_reference_mode():
+    """The reference keys adsorbates by the symbol of their first atom: an "HO" group next to an "O" atom extends the O run."""
+    ens, _ = _group_ensemble(1, reference_groupby=True)
+    SR, O, HO, H2O, E = 0, 1, 2, 3, ens.n_ads
+    sp = np.array([[O, HO, SR, H2O, E, E, E]], np.int16)
+    order = np.where(sp != E, np.cumsum(sp != E, axis=1), 0)
+    cand = ens.switch_candidates(mc.ChainState(sp, order.astype(np.int64), np.array([5])))[0]
+    assert np.flatnonzero(cand[O]).tolist() == [3]          # runs of key "O": [0, 1] then [3]: the last one survives
+    assert np.flatnonzero(cand[SR]).tolist() == [2] and not cand[HO].any() and not cand[H2O].any()
+
+
+def test_boltzmann_and_distance_decay_weights_match_the_reference_numbers():
+    """``compute_boltzmann_weights`` on the reference's fixture (tests/test_slab.py:90-113): per-atom energies
+    [1.0, 0.5, 1.0, 0.6], T = 1 -> As 0.1850956, Ga 0.30517106, empty 1; ``compute_distance_weight_matrix``
+    (mcmc/utils/misc.py:170-190): rows sum to 1 and decay with distance."""
+    bw = mc.boltzmann_atom_weights([1.0, 0.5, 1.0, 0.6], 1.0)
+    assert np.allclose(bw[[1, 2]], [0.1850956, 0.30517106])
+    D = mc.compute_distance_weight_matrix([(0, 0, 3), (1, 1, 1), (2, 2, 5)], 1.0)
+    assert np.allclose(D.sum(axis=1), 1.0) and D[0, 0] > D[0, 1] > D[0, 2]
+    # site weights inside the ensemble: filled sites carry the weight of their adsorbate's first atom, empty sites 1
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ga"]], np.int32), np.zeros((1, 3)), np.diag([20.0] * 3), np.array([True] * 3))
+    ens = mc.ChainEnsemble(base, [(0, 0, 3), (1, 1, 1), (2, 2, 5)], ("As", "Ga"), 1, LatticeGasCalc(1, {}), relax=False,
+                           temperature=1.0, require_per_atom_energies=True)
+    st = mc.ChainState(np.array([[0, 1, 2]], np.int16), np.array([[1, 2, 0]]), np.array([3]))
+    ens.per_atom_energies = [np.array([1.0, 0.5, 1.0])]     # slab atom, As, Ga
+    w = ens._site_weights(ens.switch_candidates(st), st)[0]
+    ref = mc.boltzmann_atom_weights([1.0, 0.5, 1.0], 1.0)
+    assert np.allclose(w, [ref[1], ref[2], 1.0])
+    ens.per_atom_energies = [None]
+    with pytest.raises(ValueError):
+        ens._site_weights(ens.switch_candidates(st), st)
+
+
+def test_weighted_switch_proposals_follow_their_weights():
+    """Two candidate sites of a species with Boltzmann weights 3 : 1 are proposed 3 : 1; with distance decay the partner
+    site concentrates near the first site."""
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"]], np.int32), np.zeros((1, 3)), np.diag([30.0] * 3), np.array([True] * 3))
+    coords = [(0.0, 0, 2), (1.0, 0, 2), (2.0, 0, 2), (9.0, 0, 2)]
+    n = 6000
+    ens = mc.ChainEnsemble(base, coords, ("Sr",), n, LatticeGasCalc(1, {}), relax=False, temperature=1.0, seed=4,
+                           require_per_atom_energies=True, require_distance_decay=True, distance_decay_factor=1.0)
+    sp = np.tile(np.array([[0, 1, 1, 0]], np.int16), (n, 1))          # Sr on sites 0 and 3, sites 1 and 2 empty
+    st = mc.ChainState(sp, np.tile(np.array([[1, 0, 0, 2]]), (n, 1)), np.full(n, 3))
+    e = np.array([0.0, np.log(3.0), 0.0])                               # atoms: slab, Sr@0 (weight 3), Sr@3 (weight 1)
+    ens.per_atom_energies = [e] * n
+    s1, s2, t1, t2, valid, _ = ens.propose_switch(1, st)
+    assert valid.all()
+    sr_first = t1 == 0
+    frac0 = (s1[sr_first] == 0).mean()
+    assert abs(frac0 - 0.75) < 0.03                                      # Boltzmann 3 : 1 between the two Sr sites
+    # empty partner of Sr@0: sites 1 (distance 1) and 2 (distance 2): exp(-1) : exp(-2)
+    part = s2[sr_first & (s1 == 0)]
+    assert set(part.tolist()) <= {1, 2}
+    assert abs((part == 1).mean() - np.exp(-1) / (np.exp(-1) + np.exp(-2))) < 0.04
