@@ -186,6 +186,22 @@ int vssr_debug_capacity(vssr_handle *h, int32_t slots_per_atom, int32_t tight, i
 int vssr_debug_read(vssr_handle *h, const char *name, int32_t model, float *dst, int64_t cap,
                     int64_t *n_out);
 
+/* ---- EAM (Cu(100) toy config, BASELINE configs[0]) ------------------------------------------------------ */
+/* One-element funcfl tables of LAMMPS `pair_style eam` (reference: LAMMPSRunSurfCalc + mcmc/potentials/Cu_u3.eam,
+ * mcmc/calculators/calculators.py:755-811, tests/test_Cu.py:41): frho[nrho] embedding energy F(rho) in eV on the grid
+ * rho = k drho; zr[nr] effective charge Z(r) and rhor[nr] density rho(r) on r = k dr; pair term
+ * phi(r) = 27.2 * 0.529 * Z(r)^2 / r.  Evaluate with vssr_tersoff_eval_batch / vssr_eam_eval_batch (all types 0). */
+typedef struct {
+    int32_t nrho, nr;
+    double drho, dr, cutoff;
+} vssr_eam_grid;
+int vssr_eam_create(int32_t device, const vssr_eam_grid *grid, const double *frho, const double *zr, const double *rhor,
+                    vssr_handle **out);
+/* same signature and meaning as vssr_tersoff_eval_batch (fp64 energies / per-atom energies / forces) */
+int vssr_eam_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, const int32_t *type, const double *pos,
+                        const double *cell, const uint8_t *pbc, uint32_t want, vssr_out *out, double *energy_f64,
+                        double *energy_atoms_f64, double *forces_f64);
+
 /* ---- Tersoff (GaN config) ---------------------------------------------------------------- */
 /* params: n_types^3 entries ordered [i][j][k], 14 doubles each, LAMMPS column order
  * (m gamma lambda3 c d costheta0 n beta lambda2 B R D lambda1 A). */

@@ -24,7 +24,7 @@ EXPORTS = (
     "vssr_synchronize", "vssr_profile_enable", "vssr_profile_reset", "vssr_profile_read",
     "vssr_batch_stats", "vssr_batch_neighbors", "vssr_debug_read", "vssr_tersoff_create",
     "vssr_tersoff_eval_batch", "vssr_batch_relax_fire", "vssr_batch_relax_bfgs", "vssr_debug_capacity",
-    "vssr_batch_device_results",
+    "vssr_batch_device_results", "vssr_eam_create", "vssr_eam_eval_batch",
 )
 
 
@@ -52,6 +52,10 @@ class FireParams(C.Structure):
     @classmethod
     def default(cls, max_steps=20, fmax=0.01):
         return cls(int(max_steps), float(fmax), 0.1, 0.2, 1.0, 1.1, 0.5, 0.1, 0.99, 5)
+
+
+class EamGrid(C.Structure):
+    _fields_ = [("nrho", C.c_int32), ("nr", C.c_int32), ("drho", C.c_double), ("dr", C.c_double), ("cutoff", C.c_double)]
 
 
 class BfgsParams(C.Structure):
@@ -121,6 +125,10 @@ def load_library():
     L.vssr_tersoff_create.argtypes = [C.c_int32, C.c_int32, dp, C.POINTER(vp)]
     L.vssr_tersoff_eval_batch.restype = C.c_int
     L.vssr_tersoff_eval_batch.argtypes = [vp, C.c_int32, ip, ip, dp, dp, u8p, C.c_uint32, C.POINTER(Out), dp, dp, dp]
+    L.vssr_eam_create.restype = C.c_int
+    L.vssr_eam_create.argtypes = [C.c_int32, C.POINTER(EamGrid), dp, dp, dp, C.POINTER(vp)]
+    L.vssr_eam_eval_batch.restype = C.c_int
+    L.vssr_eam_eval_batch.argtypes = L.vssr_tersoff_eval_batch.argtypes
     L.vssr_batch_relax_fire.restype = C.c_int
     L.vssr_batch_relax_fire.argtypes = [vp, C.POINTER(FireParams), u8p, C.c_uint32, dp, ip, u8p]
     L.vssr_batch_relax_bfgs.restype = C.c_int
@@ -356,19 +364,8 @@ class PainnEngine(_Handle):
         self.cutoff = float(cutoff)
 
 
-class TersoffEngine(_Handle):
-    """Tersoff evaluator (fp64 on device)."""
-
-    def __init__(self, params, device=0):
-        super().__init__()
-        params = np.ascontiguousarray(params, dtype=np.float64)
-        if params.ndim != 4 or params.shape[3] != 14 or not (params.shape[0] == params.shape[1] == params.shape[2]):
-            raise ValueError("params must be [nt, nt, nt, 14]")
-        self.n_types = params.shape[0]
-        rc = self._lib.vssr_tersoff_create(int(device), self.n_types, _ptr(params, C.c_double), C.byref(self._h))
-        if rc != 0:
-            msg = self._lib.vssr_last_error(None)
-            raise BackendError(f"vssr_tersoff_create failed ({rc}): {msg.decode() if msg else '?'}")
+class _AnalyticEngine(_Handle):
+    """Shared fp64 interface of the analytic potentials (Tersoff, EAM): types instead of atomic numbers."""
 
     def relax_f64(self, structs, fixed=None, max_steps=100, fmax=0.01):
         """FIRE-relax (types, positions, cell, pbc) structures; returns (energy [B], e_atom [N], forces [N,3],
@@ -397,3 +394,35 @@ class TersoffEngine(_Handle):
         self._n_cfg, self._n_atoms = B, N
         self._cfg_start = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
         return e, ea, f
+
+
+class TersoffEngine(_AnalyticEngine):
+    """Tersoff evaluator (fp64 on device)."""
+
+    def __init__(self, params, device=0):
+        super().__init__()
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        if params.ndim != 4 or params.shape[3] != 14 or not (params.shape[0] == params.shape[1] == params.shape[2]):
+            raise ValueError("params must be [nt, nt, nt, 14]")
+        self.n_types = params.shape[0]
+        rc = self._lib.vssr_tersoff_create(int(device), self.n_types, _ptr(params, C.c_double), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.vssr_last_error(None)
+            raise BackendError(f"vssr_tersoff_create failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+class EAMEngine(_AnalyticEngine):
+    """One-element EAM (LAMMPS funcfl tables) evaluator, fp64 on device; every atom has type 0."""
+
+    def __init__(self, funcfl, device=0):
+        super().__init__()
+        grid = EamGrid(int(funcfl.nrho), int(funcfl.nr), float(funcfl.drho), float(funcfl.dr), float(funcfl.cutoff))
+        frho, zr, rhor = (np.ascontiguousarray(a, dtype=np.float64) for a in (funcfl.frho, funcfl.zr, funcfl.rhor))
+        if frho.size != funcfl.nrho or zr.size != funcfl.nr or rhor.size != funcfl.nr:
+            raise ValueError("EAM tables do not match their grid")
+        self.n_types = 1
+        rc = self._lib.vssr_eam_create(int(device), C.byref(grid), _ptr(frho, C.c_double), _ptr(zr, C.c_double),
+                                       _ptr(rhor, C.c_double), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.vssr_last_error(None)
+            raise BackendError(f"vssr_eam_create failed ({rc}): {msg.decode() if msg else '?'}")

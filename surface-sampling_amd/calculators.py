@@ -502,45 +502,35 @@ class NFFPourbaix(EnsembleNFFSurface):
                 "surface_energy", self.surface_energy_of(self.results["energy"], self.atoms if atoms is None else atoms))
 
 
-class TersoffSurfCalc(_Base):
-    """Tersoff energy / per-atom energies / forces on MI355X (drop-in for ``LAMMPSSurfCalc`` with
-    ``pair_style tersoff``, reference ``calculators.py:492-752``): ``energy`` is the static energy,
-    ``per_atom_energies`` is LAMMPS' ``pe/atom``; periodic in all directions like the reference's
-    ``boundary p p p`` template."""
+class _AnalyticSurfCalc(_Base):
+    """Shared front end of the analytic potentials that the reference evaluates through LAMMPS (Tersoff, EAM): fp64
+    ``energy`` / ``per_atom_energies`` / ``forces`` from the device, ``surface_energy`` = potential energy
+    (reference ``calculators.py:707-719,766-777``), batched evaluation and lock-step relaxation for ``mc.ChainEnsemble``."""
 
     implemented_properties = ("energy", "relaxed_energy", "forces", "per_atom_energies", "surface_energy")
-    name = "tersoff_mi355x"
+    species: list = []
 
-    def __init__(self, potential, species, device="cuda", all_periodic=True, logger=None, **kwargs):
-        """potential: path or text of a LAMMPS tersoff file, or a params array [nt,nt,nt,14];
-        species: symbols in LAMMPS type order (e.g. ["Ga", "N"])."""
-        if isinstance(potential, np.ndarray):
-            self.params = np.ascontiguousarray(potential, dtype=np.float64)
-        else:
-            text = potential
-            if "\n" not in str(potential):
-                with open(potential) as fh:
-                    text = fh.read()
-            self.params = tersoff_io.parse_tersoff(text, list(species))
-        self.species = list(species)
+    def _init_common(self, device, all_periodic, logger):
         self.device = device
         self.all_periodic = bool(all_periodic)
         self.run_dir = None
         self.relax_steps = 100
         self.logger = logger or logging.getLogger(__name__)
         self._engine = None
-        super().__init__(**kwargs)
+
+    def _make_engine(self):
+        raise NotImplementedError
 
     def _get_engine(self):
         if self._engine is None:
-            self._engine = backend.TersoffEngine(self.params, device=_device_index(self.device))
+            self._engine = self._make_engine()
         return self._engine
 
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            setattr(new, k, None if k == "_engine" else (v if k in ("params", "logger") else copy.deepcopy(v, memo)))
+            setattr(new, k, None if k == "_engine" else (v if k in ("params", "funcfl", "logger") else copy.deepcopy(v, memo)))
         return new
 
     def set(self, **kwargs) -> dict:
@@ -608,3 +598,66 @@ class TersoffSurfCalc(_Base):
             out.append({"energy": float(e[b]), "per_atom_energies": ea[o:o + n].copy(), "forces": f[o:o + n].copy()})
             o += n
         return out
+
+
+class TersoffSurfCalc(_AnalyticSurfCalc):
+    """Tersoff energy / per-atom energies / forces on MI355X (drop-in for ``LAMMPSSurfCalc`` with
+    ``pair_style tersoff``, reference ``calculators.py:492-752``): ``energy`` is the static energy,
+    ``per_atom_energies`` is LAMMPS' ``pe/atom``; periodic in all directions like the reference's
+    ``boundary p p p`` template."""
+
+    name = "tersoff_mi355x"
+
+    def __init__(self, potential, species, device="cuda", all_periodic=True, logger=None, **kwargs):
+        """potential: path or text of a LAMMPS tersoff file, or a params array [nt,nt,nt,14];
+        species: symbols in LAMMPS type order (e.g. ["Ga", "N"])."""
+        if isinstance(potential, np.ndarray):
+            self.params = np.ascontiguousarray(potential, dtype=np.float64)
+        else:
+            text = potential
+            if "\n" not in str(potential):
+                with open(potential) as fh:
+                    text = fh.read()
+            self.params = tersoff_io.parse_tersoff(text, list(species))
+        self.species = list(species)
+        self._init_common(device, all_periodic, logger)
+        super().__init__(**kwargs)
+
+    def _make_engine(self):
+        return backend.TersoffEngine(self.params, device=_device_index(self.device))
+
+
+class EAMSurfCalc(_AnalyticSurfCalc):
+    """One-element EAM on MI355X: drop-in for ``LAMMPSRunSurfCalc`` (reference ``calculators.py:755-811``, a modified ASE
+    ``lammpsrun`` that pipes ``pair_style eam`` / ``pair_coeff * * Cu_u3.eam`` to an ``lmp`` subprocess; used by
+    ``tests/test_Cu.py`` and ``tutorials/example.ipynb``).  Constructor keeps the reference's keywords: ``files=[potential
+    file]`` (funcfl), ``keep_tmp_files`` / ``keep_alive`` / ``tmp_dir`` are accepted and unused (nothing is written to
+    disk); ``set(pair_style="eam", pair_coeff=[...])`` is recorded in ``parameters``.  Boundary conditions follow the
+    atoms' ``pbc`` (ASE lammpsrun derives ``boundary`` from it)."""
+
+    name = "eam_mi355x"
+
+    def __init__(self, files=None, potential=None, device="cuda", all_periodic=False, logger=None, keep_tmp_files=False,
+                 keep_alive=False, tmp_dir=None, **kwargs):
+        from . import eam as eam_io
+
+        src = potential if potential is not None else (list(files)[0] if files else None)
+        if src is None:
+            raise ValueError("EAMSurfCalc needs files=[<funcfl potential file>]")
+        self.funcfl = src if isinstance(src, eam_io.Funcfl) else (
+            eam_io.parse_funcfl(src) if "\n" in str(src) else eam_io.read_funcfl(src))
+        self.species = [structures.SYMBOLS[self.funcfl.atomic_number]]
+        self._init_common(device, all_periodic, logger)
+        super().__init__(**kwargs)
+
+    def set(self, **kwargs) -> dict:
+        style = kwargs.get("pair_style")
+        if style is not None and str(style).split()[0] != "eam":
+            raise ValueError(f"pair_style {style!r}: this calculator evaluates `pair_style eam` (funcfl) only")
+        return super().set(**kwargs)
+
+    def _make_engine(self):
+        return backend.EAMEngine(self.funcfl, device=_device_index(self.device))
+
+
+LAMMPSRunSurfCalc = EAMSurfCalc   # the reference's class name for this role

@@ -470,7 +470,10 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
     int *n_active_d = h->d_counters.as<int>() + 3;   // counters[3] is free for this purpose
     const int POLL = 4;
     int rc = VSSR_OK;
-    auto evaluate = [&]() { return h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : painn_run(h, want | VSSR_WANT_FORCES); };
+    auto evaluate = [&]() {
+        return h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES)
+                            : h->kind == 3 ? eam_run(h, want | VSSR_WANT_FORCES) : painn_run(h, want | VSSR_WANT_FORCES);
+    };
     for (int it = 0; it <= max_steps && !rc; ++it) {
         rc = evaluate();
         if (rc) break;
@@ -478,7 +481,7 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
         {   // (last iteration: every unconverged chain has taken relax_steps steps -- the kernel only tests convergence, like the
             // final check of ASE's run loop)
             VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
-            if (h->kind == 2) {   // Tersoff forces are fp64 on the device: the optimizer state works on an fp32 copy
+            if (h->kind == 2 || h->kind == 3) {   // Tersoff / EAM forces are fp64 on the device: the optimizer state works on an fp32 copy
                 if (h->d_forces.ensure(sizeof(float) * 3 * N)) { rc = set_err(h, VSSR_E_NOMEM, "force buffer"); break; }
                 hipLaunchKernelGGL(k_narrow_forces, dim3((3 * N + 255) / 256), dim3(256), 0, st, 3 * N,
                                    h->d_ters_f.as<double>(), h->d_forces.as<float>());

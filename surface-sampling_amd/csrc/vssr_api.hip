@@ -246,11 +246,13 @@ static void cell_host_setup(const double *cell, const uint8_t *pbc, double cutof
         if (pbc[k]) nimg[k] = (int)std::floor(cutoff / hgt[k]) + 1;
 }
 
-static double handle_cutoff(const vssr_handle *h) { return h->kind == 2 ? h->ters_cutmax : (double)h->cutoff; }
+static double handle_cutoff(const vssr_handle *h) {
+    return h->kind == 2 ? h->ters_cutmax : h->kind == 3 ? h->eam_grid.cutoff : (double)h->cutoff;
+}
 
 static int run_any(vssr_handle *h, uint32_t want) {
     h->last_want = want;
-    return h->kind == 2 ? tersoff_run(h, want) : painn_run(h, want);
+    return h->kind == 2 ? tersoff_run(h, want) : h->kind == 3 ? eam_run(h, want) : painn_run(h, want);
 }
 
 // synchronise; if the neighbor capacity overflowed, grow and rerun
@@ -348,6 +350,45 @@ int vssr_tersoff_create(int32_t device, int32_t n_types, const double *params, v
     if (!rc && h->ters_params.ensure(sizeof(double) * 14 * np)) rc = set_err(h, VSSR_E_NOMEM, "tersoff params");
     if (!rc && hipMemcpy(h->ters_params.p, params, sizeof(double) * 14 * np, hipMemcpyHostToDevice) != hipSuccess)
         rc = set_err(h, VSSR_E_DEVICE, "tersoff params upload failed");
+    if (rc) {
+        g_create_error = h->err;
+        vssr_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return VSSR_OK;
+}
+
+int vssr_eam_create(int32_t device, const vssr_eam_grid *grid, const double *frho, const double *zr, const double *rhor,
+                    vssr_handle **out) {
+    if (!grid || !frho || !zr || !rhor || !out) return set_err(nullptr, VSSR_E_BADARG, "null EAM argument");
+    *out = nullptr;
+    if (grid->nrho < 5 || grid->nr < 5 || !(grid->drho > 0) || !(grid->dr > 0) || !(grid->cutoff > 0))
+        return set_err(nullptr, VSSR_E_BADARG, "bad EAM grid");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_err(nullptr, VSSR_E_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_err(nullptr, VSSR_E_BADARG, "device %d out of range", device);
+    for (int k = 0; k < grid->nrho; ++k)
+        if (!std::isfinite(frho[k])) return set_err(nullptr, VSSR_E_BADARG, "non-finite EAM table entry");
+    for (int k = 0; k < grid->nr; ++k)
+        if (!std::isfinite(zr[k]) || !std::isfinite(rhor[k])) return set_err(nullptr, VSSR_E_BADARG, "non-finite EAM table entry");
+    vssr_handle *h = new vssr_handle();
+    h->kind = 3;
+    h->n_types = 1;
+    h->n_embed = 1;
+    h->eam_grid = *grid;
+    int rc = common_init(h, device);
+    // spline tables: frho [nrho + 1][7] | rhor [nr + 1][7] | z2r [nr + 1][7]   (LAMMPS file2array + array2spline for one file)
+    const size_t nF = 7 * (size_t)(grid->nrho + 1), nR = 7 * (size_t)(grid->nr + 1);
+    std::vector<double> tab(nF + 2 * nR), z2r(grid->nr);
+    for (int k = 0; k < grid->nr; ++k) z2r[k] = 27.2 * 0.529 * zr[k] * zr[k];
+    eam_build_spline(frho, grid->nrho, grid->drho, tab.data());
+    eam_build_spline(rhor, grid->nr, grid->dr, tab.data() + nF);
+    eam_build_spline(z2r.data(), grid->nr, grid->dr, tab.data() + nF + nR);
+    if (!rc && h->ters_params.ensure(sizeof(double) * tab.size())) rc = set_err(h, VSSR_E_NOMEM, "EAM tables");
+    if (!rc && hipMemcpy(h->ters_params.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice) != hipSuccess)
+        rc = set_err(h, VSSR_E_DEVICE, "EAM table upload failed");
     if (rc) {
         g_create_error = h->err;
         vssr_destroy(h);
@@ -480,7 +521,7 @@ int vssr_batch_download(vssr_handle *h, uint32_t want, vssr_out *out) {
     int rc = sync_and_check(h);
     if (rc) return rc;
     const size_t B = h->n_cfg, N = h->n_atoms, M = h->n_models;
-    if (h->kind == 2) {
+    if (h->kind == 2 || h->kind == 3) {
         std::vector<double> e(B), ea(N), f(3 * N);
         VSSR_HIP(h, hipMemcpy(e.data(), h->d_ters_e.p, sizeof(double) * B, hipMemcpyDeviceToHost));
         if (out->energy) for (size_t b = 0; b < B; ++b) out->energy[b] = (float)e[b];
@@ -527,7 +568,7 @@ int vssr_tersoff_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atom
                             const double *pos, const double *cell, const uint8_t *pbc, uint32_t want, vssr_out *out,
                             double *energy_f64, double *energy_atoms_f64, double *forces_f64) {
     if (!h) return VSSR_E_BADARG;
-    if (h->kind != 2) return set_err(h, VSSR_E_STATE, "not a Tersoff handle");
+    if (h->kind != 2 && h->kind != 3) return set_err(h, VSSR_E_STATE, "not a Tersoff / EAM handle");
     vssr_out dummy;
     memset(&dummy, 0, sizeof dummy);
     int rc = vssr_eval_batch(h, n_cfg, n_atoms, type, pos, cell, pbc, want, out ? out : &dummy);
@@ -541,6 +582,13 @@ int vssr_tersoff_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atom
 }
 
 static int relax_finish(vssr_handle *h, double *pos_out, int32_t *n_steps, uint8_t *converged);
+
+int vssr_eam_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, const int32_t *type, const double *pos,
+                        const double *cell, const uint8_t *pbc, uint32_t want, vssr_out *out, double *energy_f64,
+                        double *energy_atoms_f64, double *forces_f64) {
+    return vssr_tersoff_eval_batch(h, n_cfg, n_atoms, type, pos, cell, pbc, want, out, energy_f64, energy_atoms_f64,
+                                   forces_f64);
+}
 
 int vssr_batch_relax_bfgs(vssr_handle *h, const vssr_bfgs_params *params, const uint8_t *fixed, uint32_t want,
                           double *pos_out, int32_t *n_steps, uint8_t *converged) {

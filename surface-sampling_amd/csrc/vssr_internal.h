@@ -160,7 +160,8 @@ struct Profiler {
 }  // namespace vssr
 
 struct vssr_handle {
-    int kind = 0;  // 1 = PaiNN ensemble, 2 = Tersoff
+    int kind = 0;  // 1 = PaiNN ensemble, 2 = Tersoff, 3 = EAM (funcfl)
+    vssr_eam_grid eam_grid = {0, 0, 0.0, 0.0, 0.0};   // EAM: grids; spline tables live in ters_params
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -243,6 +244,9 @@ int painn_alloc_state(vssr_handle *h);
 int painn_run(vssr_handle *h, uint32_t want);
 // Tersoff (tersoff.hip)
 int tersoff_run(vssr_handle *h, uint32_t want);
+// EAM (eam.hip)
+int eam_run(vssr_handle *h, uint32_t want);
+void eam_build_spline(const double *f, int n, double delta, double *spl /*[n + 1][7]*/);
 // lock-step FIRE relaxation (relax.hip)
 // method 0: FIRE (fp), 1: BFGS (bp)
 int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr_bfgs_params *bp,

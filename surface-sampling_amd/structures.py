@@ -265,3 +265,85 @@ def synth_chain(base: Structure, chain: int, species=(38, 22, 8), grid=(8, 8),
     positions = np.concatenate([base.positions, np.array(ads_pos).reshape(-1, 3)])
     positions = positions + rng.normal(0.0, sigma, size=positions.shape)
     return Structure(numbers, positions, base.cell.copy(), base.pbc.copy())
+
+
+# ---- LAMMPS data files (atom_style atomic) ----------------------------------------------------------------------------------
+def _lammps_prism(cell):
+    """LAMMPS' restricted triclinic box of a general cell: a along x, b in the xy plane (ASE ``Prism``): returns
+    ``(lx, ly, lz, xy, xz, yz)`` and the matrix that rotates Cartesian vectors into that frame."""
+    cell = np.asarray(cell, float).reshape(3, 3)
+    a, b, c = cell
+    lx = np.linalg.norm(a)
+    ah = a / lx
+    xy = float(np.dot(b, ah))
+    ly = float(np.sqrt(max(np.dot(b, b) - xy * xy, 0.0)))
+    xz = float(np.dot(c, ah))
+    yz = float((np.dot(b, c) - xy * xz) / ly)
+    lz = float(np.sqrt(max(np.dot(c, c) - xz * xz - yz * yz, 0.0)))
+    new = np.array([[lx, 0.0, 0.0], [xy, ly, 0.0], [xz, yz, lz]])
+    rot = np.linalg.solve(cell, new)          # x_lammps = x_cart @ rot   (fractional coordinates are preserved)
+    return (float(lx), ly, lz, xy, xz, yz), rot
+
+
+def write_lammps_data(path, atoms, specorder=None, name="lammps.data") -> list:
+    """Write ``atoms`` as a LAMMPS data file, ``atom_style atomic`` -- what the reference's LAMMPS calculators produce
+    with ``slab.write(lammps_data_file, format="lammps-data", atom_style="atomic")`` before every LAMMPS call (reference
+    ``mcmc/calculators/calculators.py:548``; ``mcmc/calculators/lammpsrun.py:356-366``).  Atom types are numbered by
+    ``specorder`` (symbols; default: the species present, sorted alphabetically like ASE).  Returns the species order.
+    ``path`` may be a file name or an open text file."""
+    Z, pos, cell, _ = as_arrays(atoms)
+    symbols = [SYMBOLS[int(z)] for z in Z]
+    species = list(specorder) if specorder is not None else sorted(set(symbols))
+    missing = set(symbols) - set(species)
+    if missing:
+        raise ValueError(f"specorder lacks {sorted(missing)}")
+    (lx, ly, lz, xy, xz, yz), rot = _lammps_prism(cell)
+    x = np.asarray(pos, float) @ rot
+    out = [f"{name} (written by surface_sampling_amd, ASE lammps-data layout)", "", f"{len(Z)} atoms",
+           f"{len(species)} atom types", "", f"0.0 {lx:23.17g}  xlo xhi", f"0.0 {ly:23.17g}  ylo yhi",
+           f"0.0 {lz:23.17g}  zlo zhi"]
+    if max(abs(xy), abs(xz), abs(yz)) > 1e-12:
+        out.append(f"{xy:23.17g} {xz:23.17g} {yz:23.17g}  xy xz yz")
+    out += ["", "Atoms # atomic", ""]
+    for i, (s, p) in enumerate(zip(symbols, x)):
+        out.append(f"{i + 1:>6} {species.index(s) + 1:>3} {p[0]:23.17g} {p[1]:23.17g} {p[2]:23.17g}")
+    text = "\n".join(out) + "\n"
+    if hasattr(path, "write"):
+        path.write(text)
+    else:
+        with open(path, "w") as fh:
+            fh.write(text)
+    return species
+
+
+def read_lammps_data(path, species, pbc=(True, True, True)) -> Structure:
+    """Read an ``atom_style atomic`` data file (the reference reads LAMMPS' ``write_data`` output back after a
+    minimisation, ``mcmc/calculators/calculators.py:586``).  ``species``: symbol of type 1, 2, ..."""
+    text = path.read() if hasattr(path, "read") else open(path).read()
+    lines = [l.split("#")[0].strip() for l in text.splitlines()]
+    n = lx = ly = lz = None
+    xy = xz = yz = 0.0
+    start = None
+    for k, l in enumerate(lines):
+        t = l.split()
+        if len(t) == 2 and t[1] == "atoms":
+            n = int(t[0])
+        elif len(t) == 4 and t[2:] == ["xlo", "xhi"]:
+            x0, lx = float(t[0]), float(t[1]) - float(t[0])
+        elif len(t) == 4 and t[2:] == ["ylo", "yhi"]:
+            y0, ly = float(t[0]), float(t[1]) - float(t[0])
+        elif len(t) == 4 and t[2:] == ["zlo", "zhi"]:
+            z0, lz = float(t[0]), float(t[1]) - float(t[0])
+        elif len(t) == 6 and t[3:] == ["xy", "xz", "yz"]:
+            xy, xz, yz = (float(v) for v in t[:3])
+        elif t[:1] == ["Atoms"]:
+            start = k + 1
+            break
+    if None in (n, lx, ly, lz, start):
+        raise ValueError("not a LAMMPS data file with an Atoms section")
+    rows = [l.split() for l in lines[start:] if l][:n]
+    rows.sort(key=lambda r: int(r[0]))
+    Z = np.array([ATOMIC_NUMBERS[species[int(r[1]) - 1]] for r in rows], np.int32)
+    pos = np.array([[float(v) for v in r[2:5]] for r in rows]) - np.array([x0, y0, z0])
+    cell = np.array([[lx, 0, 0], [xy, ly, 0], [xz, yz, lz]], float)
+    return Structure(Z, pos, cell, np.array(pbc, bool))

@@ -66,16 +66,49 @@ def write_bfgs_traces(R, out):
     print("bfgs traces:", [(c["structure"], len(c["trace"])) for c in cases])
 
 
+def write_eam_fixtures(R, out):
+    """BASELINE configs[0] (Cu(100) toy): the funcfl potential file (data), the 8-atom slab and its 16 adsorption sites, the
+    reference's numbers.  catkit / pymatgen are not installable here, so the slab is written down from the reference's
+    own log (tutorials/example.ipynb cell 7 output: fcc Cu a = 3.6147, (100) 2 x 2 x 2, vacuum 15: 8 atoms, site
+    coordinates at z_top + 1.5 = 18.307 on the on-top / bridge / hollow positions of the 5.112 A cell, e.g. [0, 5.112, 18.307],
+    [2.556, 0, 18.307], [2.556, 3.834, 18.307])."""
+    import shutil
+
+    shutil.copyfile(os.path.join(R, "mcmc/potentials/Cu_u3.eam"), os.path.join(out, "Cu_u3.eam"))
+    a = 3.6147
+    b = a / np.sqrt(2.0)
+    bottom = [[(i + 0.5) * b, (j + 0.5) * b, 15.0] for i in range(2) for j in range(2)]
+    top = [[i * b, j * b, 15.0 + a / 2] for i in range(2) for j in range(2)]
+    zs = 15.0 + a / 2 + 1.5
+    ontop = [[i * b, j * b, zs] for i in range(2) for j in range(2)]
+    bridge = [[(i + 0.5) * b, j * b, zs] for i in range(2) for j in range(2)] + [[i * b, (j + 0.5) * b, zs] for i in range(2) for j in range(2)]
+    hollow = [[(i + 0.5) * b, (j + 0.5) * b, zs] for i in range(2) for j in range(2)]
+    np.savez(os.path.join(out, "cu100.npz"), numbers=np.full(8, 29, np.int32), positions=np.array(bottom + top),
+             cell=np.diag([2 * b, 2 * b, a / 2 + 30.0]), pbc=np.array([True, True, False]),
+             ads_coords=np.array(ontop + bridge + hollow), site_kind=np.array([0] * 4 + [1] * 8 + [2] * 4))
+    with open(os.path.join(out, "eam_kat.json"), "w") as fh:
+        json.dump({"potential": "mcmc/potentials/Cu_u3.eam (Foiles, Baskes, Daw, PRB 33, 7983 (1986); funcfl)",
+                   "min_energy_one_bridge_adatom": {"value": -25.2893, "source": "tests/test_Cu.py:19 (np.allclose)"},
+                   "tutorial_energies": {"values": [-24.740, -24.355, -28.050, -28.190],
+                                         "source": "tutorials/example.ipynb cell 9 output (surface energies of visited states)"},
+                   "site_height_above_top_layer": 1.5,
+                   "site_log": {"values": [[0.0, 5.112, 18.307], [2.556, 0.0, 18.307], [0.0, 2.556, 18.307],
+                                           [2.556, 2.556, 18.307], [2.556, 3.834, 18.307]],
+                                "source": "tutorials/example.ipynb cell 7 output"}}, fh, indent=1)
+    print("eam fixtures written")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
-    ap.add_argument("--only", default="", help="'traces': rewrite only tests/golden/bfgs_traces.json")
+    ap.add_argument("--only", default="", help="'traces' / 'eam': rewrite only the small trace and EAM fixtures")
     args = ap.parse_args()
     R = args.reference
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(os.path.join(out, "weights"), exist_ok=True)
     write_bfgs_traces(R, out)
-    if args.only == "traces":
+    write_eam_fixtures(R, out)
+    if args.only in ("traces", "eam"):
         return
 
     # --- PaiNN ensemble weights -> canonical blobs (include/vssr_eval.h layout) -------------
