@@ -206,6 +206,12 @@ int vssr_eam_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, c
 /* params: n_types^3 entries ordered [i][j][k], 14 doubles each, LAMMPS column order
  * (m gamma lambda3 c d costheta0 n beta lambda2 B R D lambda1 A). */
 int vssr_tersoff_create(int32_t device, int32_t n_types, const double *params, vssr_handle **out);
+/* The same from the text of a LAMMPS tersoff potential file and the species in LAMMPS type order -- what the reference
+ * passes to LAMMPS as `pair_coeff * * <file> Ga N` (mcmc/calculators/calculators.py:559-568).
+ * Entries `e1 e2 e3 m gamma lambda3 c d costheta0 n beta lambda2 B R D lambda1 A` may span lines, `#` starts a comment;
+ * every triplet of the given species must be present. */
+int vssr_tersoff_create_from_text(int32_t device, const char *param_text, int32_t n_species, const char *const *species,
+                                  vssr_handle **out);
 /* type[i] in [0,n_types).  Fills out->energy (total, eV), out->energy_atoms (WANT_PER_ATOM),
  * out->forces (WANT_FORCES).  fp64 arithmetic on the device; results narrowed to fp32 in
  * vssr_out, and returned exactly through the optional double arrays. */

@@ -25,6 +25,7 @@ EXPORTS = (
     "vssr_batch_stats", "vssr_batch_neighbors", "vssr_debug_read", "vssr_tersoff_create",
     "vssr_tersoff_eval_batch", "vssr_batch_relax_fire", "vssr_batch_relax_bfgs", "vssr_debug_capacity",
     "vssr_batch_device_results", "vssr_eam_create", "vssr_eam_eval_batch",
+    "vssr_tersoff_create_from_text",
 )
 
 
@@ -125,6 +126,8 @@ def load_library():
     L.vssr_tersoff_create.argtypes = [C.c_int32, C.c_int32, dp, C.POINTER(vp)]
     L.vssr_tersoff_eval_batch.restype = C.c_int
     L.vssr_tersoff_eval_batch.argtypes = [vp, C.c_int32, ip, ip, dp, dp, u8p, C.c_uint32, C.POINTER(Out), dp, dp, dp]
+    L.vssr_tersoff_create_from_text.restype = C.c_int
+    L.vssr_tersoff_create_from_text.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(vp)]
     L.vssr_eam_create.restype = C.c_int
     L.vssr_eam_create.argtypes = [C.c_int32, C.POINTER(EamGrid), dp, dp, dp, C.POINTER(vp)]
     L.vssr_eam_eval_batch.restype = C.c_int
@@ -399,8 +402,21 @@ class _AnalyticEngine(_Handle):
 class TersoffEngine(_AnalyticEngine):
     """Tersoff evaluator (fp64 on device)."""
 
-    def __init__(self, params, device=0):
+    def __init__(self, params, device=0, species=None):
+        """``params``: array [nt, nt, nt, 14], or the TEXT of a LAMMPS tersoff file together with ``species`` (LAMMPS type
+        order) -- then the file is parsed by the library (vssr_tersoff_create_from_text)."""
         super().__init__()
+        if isinstance(params, (str, bytes)):
+            if not species:
+                raise ValueError("species (LAMMPS type order) are required with a potential text")
+            text = params if isinstance(params, bytes) else params.encode()
+            arr = (C.c_char_p * len(species))(*[s.encode() for s in species])
+            self.n_types = len(species)
+            rc = self._lib.vssr_tersoff_create_from_text(int(device), text, len(species), arr, C.byref(self._h))
+            if rc != 0:
+                msg = self._lib.vssr_last_error(None)
+                raise BackendError(f"vssr_tersoff_create_from_text failed ({rc}): {msg.decode() if msg else '?'}")
+            return
         params = np.ascontiguousarray(params, dtype=np.float64)
         if params.ndim != 4 or params.shape[3] != 14 or not (params.shape[0] == params.shape[1] == params.shape[2]):
             raise ValueError("params must be [nt, nt, nt, 14]")

@@ -224,8 +224,22 @@ class EnsembleNFFSurface(_Base):
 
     @staticmethod
     def _load_model(m, hparams):
+        """A model may be a checkpoint path (nff ``best_model`` or canonical ``.f32``), a float32 blob in the canonical
+        layout, or -- what ``scripts/sample_surface.py:164-174`` passes -- an nff ``Painn`` module (anything with
+        ``state_dict()``): its tensors are taken over, its excluded-volume / cutoff attributes are checked against
+        ``hparams`` like those of a checkpoint file."""
         if isinstance(m, (str, bytes)) or hasattr(m, "__fspath__"):
             return checkpoint.load_painn_blob(str(m), hparams)
+        if hasattr(m, "state_dict") and callable(m.state_dict):
+            sd = {}
+            for k, v in m.state_dict().items():
+                for attr in ("detach", "cpu", "numpy"):
+                    if hasattr(v, attr):
+                        v = getattr(v, attr)()
+                sd[k] = np.asarray(v, dtype=np.float32)
+            attrs = {a: getattr(m, a) for a in ("excl_vol", "power", "sigma", "cutoff") if hasattr(m, a)}
+            checkpoint.check_model_against_hparams(type(m).__name__, sd, hparams, attrs=attrs)
+            return checkpoint.state_dict_to_blob(sd, hparams)
         blob = np.ascontiguousarray(m, dtype=np.float32).reshape(-1)
         checkpoint.blob_to_fields(blob, hparams)
         return blob

@@ -288,12 +288,13 @@ def blob_to_fields(blob: np.ndarray, hp: dict | None = None) -> "OrderedDict[str
 _ATTR_TO_HPARAM = (("excl_vol", "excl_vol"), ("power", "V_ex_power"), ("sigma", "V_ex_sigma"), ("cutoff", "cutoff"))
 
 
-def check_model_against_hparams(path: str, sd: dict, hp: dict | None = None) -> None:
+def check_model_against_hparams(path: str, sd: dict, hp: dict | None = None, attrs: dict | None = None) -> None:
     """A checkpoint whose stored hyper-parameters differ from the ones the engine will be created with would load and give
     wrong energies silently: compare the pickled module attributes (excluded volume on/off, power, sigma, cutoff) and the
     radial-basis frequencies (a learnable ``n`` that is no longer 1..n_rbf) with ``hp`` and raise on any difference."""
     hp = {**DEFAULT_HPARAMS, **(hp or {})}
-    attrs = read_model_attrs(path)
+    if attrs is None:
+        attrs = read_model_attrs(path)
     for attr, key in _ATTR_TO_HPARAM:
         if attr in attrs and key in hp and attrs[attr] is not None:
             a, b = attrs[attr], hp[key]

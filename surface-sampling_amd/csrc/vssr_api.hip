@@ -359,6 +359,57 @@ int vssr_tersoff_create(int32_t device, int32_t n_types, const double *params, v
     return VSSR_OK;
 }
 
+int vssr_tersoff_create_from_text(int32_t device, const char *param_text, int32_t n_species, const char *const *species,
+                                  vssr_handle **out) {
+    if (!param_text || !species || !out || n_species < 1 || n_species > 8)
+        return set_err(nullptr, VSSR_E_BADARG, "bad tersoff arguments");
+    *out = nullptr;
+    std::vector<std::string> tok;
+    {
+        std::string line, text(param_text);
+        size_t pos = 0;
+        while (pos <= text.size()) {
+            size_t nl = text.find('\n', pos);
+            if (nl == std::string::npos) nl = text.size();
+            line = text.substr(pos, nl - pos);
+            pos = nl + 1;
+            const size_t hash = line.find('#');
+            if (hash != std::string::npos) line.erase(hash);
+            size_t i = 0;
+            while (i < line.size()) {
+                while (i < line.size() && isspace((unsigned char)line[i])) ++i;
+                size_t j = i;
+                while (j < line.size() && !isspace((unsigned char)line[j])) ++j;
+                if (j > i) tok.push_back(line.substr(i, j - i));
+                i = j;
+            }
+        }
+    }
+    if (tok.empty() || tok.size() % 17) return set_err(nullptr, VSSR_E_BADARG, "tersoff file: token count is not a multiple of 17");
+    auto index_of = [&](const std::string &s) {
+        for (int t = 0; t < n_species; ++t)
+            if (species[t] && s == species[t]) return t;
+        return -1;
+    };
+    const size_t np = (size_t)n_species * n_species * n_species;
+    std::vector<double> params(14 * np, 0.0);
+    std::vector<char> seen(np, 0);
+    for (size_t o = 0; o < tok.size(); o += 17) {
+        const int a = index_of(tok[o]), b = index_of(tok[o + 1]), c = index_of(tok[o + 2]);
+        if (a < 0 || b < 0 || c < 0) continue;   // entry of another element
+        const size_t e = ((size_t)a * n_species + b) * n_species + c;
+        for (int k = 0; k < 14; ++k) {
+            char *end = nullptr;
+            params[14 * e + k] = strtod(tok[o + 3 + k].c_str(), &end);
+            if (!end || *end) return set_err(nullptr, VSSR_E_BADARG, "tersoff file: bad number '%s'", tok[o + 3 + k].c_str());
+        }
+        seen[e] = 1;
+    }
+    for (size_t e = 0; e < np; ++e)
+        if (!seen[e]) return set_err(nullptr, VSSR_E_BADARG, "tersoff file lacks entries for some species triplets");
+    return vssr_tersoff_create(device, n_species, params.data(), out);
+}
+
 int vssr_eam_create(int32_t device, const vssr_eam_grid *grid, const double *frho, const double *zr, const double *rhor,
                     vssr_handle **out) {
     if (!grid || !frho || !zr || !rhor || !out) return set_err(nullptr, VSSR_E_BADARG, "null EAM argument");

@@ -1,0 +1,108 @@
+"""The ASE-derived branch of the calculators (``_Base = ase.calculators.calculator.Calculator``) runs in a subprocess with
+the stand-in package tests/fake_ase on sys.path (real ASE is not installable here)."""
+
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, os.path.join(ROOT, "tests", "fake_ase"))
+sys.path.insert(0, ROOT)
+import numpy as np
+from ase.calculators.calculator import Calculator
+from surface_sampling_amd import backend, calculators, structures
+
+assert calculators.HAVE_ASE and issubclass(calculators.EnsembleNFFSurface, Calculator)
+assert issubclass(calculators.TersoffSurfCalc, Calculator) and issubclass(calculators.LAMMPSRunSurfCalc, Calculator)
+
+
+class FakeEngine:          # stands in for the HIP engine: the branch under test is host logic
+    calls = 0
+
+    def __init__(self, blobs, **kw):
+        self.n_models = len(blobs)
+
+    def evaluate(self, structs, want=None):
+        FakeEngine.calls += 1
+        n = [len(s[0]) for s in structs]
+        cs = np.concatenate([[0], np.cumsum(n)])
+        e = np.array([float(np.sum(s[1])) for s in structs], np.float32)
+        return {"energy": e, "energy_std": 0 * e, "forces": np.ones((cs[-1], 3), np.float32), "forces_std": np.zeros((cs[-1], 3), np.float32),
+                "energy_models": np.tile(e[:, None], (1, self.n_models)), "energy_atoms": np.zeros(cs[-1], np.float32), "cfg_start": cs}
+
+    def close(self):
+        pass
+
+
+backend.PainnEngine = FakeEngine
+S = np.load(os.path.join(ROOT, "tests", "golden", "structures.npz"))
+k = "O36Sr12Ti12"
+atoms = structures.Structure(S[f"{k}.numbers"], S[f"{k}.positions"], S[f"{k}.cell"], S[f"{k}.pbc"])
+blob = np.fromfile(os.path.join(ROOT, "tests", "golden", "weights", "SrTiO3_painn_model01.f32"), dtype="<f4")
+with open(os.path.join(ROOT, "tests", "golden", "offset_data.json")) as fh:
+    offset_data = json.load(fh)
+calc = calculators.EnsembleNFFSurface([blob, blob, blob], device="cuda:0")
+changed = calc.set(chem_pots={"Sr": -2, "Ti": 0, "O": 0}, offset_data=offset_data, offset=True, relax_steps=20, optimizer="BFGS")
+assert set(changed) == {"chem_pots", "offset_data", "offset", "relax_steps", "optimizer"} and calc.parameters["optimizer"] == "BFGS"
+assert calc.chem_pots["Sr"] == -2 and len(calc.models) == 3
+e = calc.get_potential_energy(atoms)                       # ASE path: get_property -> check_state -> calculate
+assert FakeEngine.calls == 1 and e.shape == (1,) and calc.results["forces"].shape == (len(atoms), 3)
+calc.get_forces(atoms)                                     # cached: unchanged atoms
+assert FakeEngine.calls == 1
+moved = atoms.copy(); moved.set_positions(atoms.positions + 0.01)
+calc.get_potential_energy(moved)
+assert FakeEngine.calls == 2 and calc.check_state(moved) == [] and calc.check_state(atoms) == ["positions"]
+se = calc.get_property("surface_energy", moved)
+assert FakeEngine.calls == 3 or FakeEngine.calls == 2     # recalculated (results were reset) or served with the same evaluation
+ref = calculators.surface_energy_from_energy(calc.results["energy"], moved.get_chemical_symbols(), calc.chem_pots, offset_data)
+assert abs(float(np.ravel(se)[0]) - float(np.ravel(ref)[0])) < 1e-9
+import copy
+c2 = copy.deepcopy(calc)
+assert c2._engine is None and c2.parameters["relax_steps"] == 20 and c2.models[0] is calc.models[0]
+try:
+    calc.get_property("stresses", atoms)
+except NotImplementedError:
+    pass
+else:
+    raise AssertionError("unknown property must raise")
+print(json.dumps({"ok": True, "base": calculators._Base.__module__}))
+"""
+
+
+def test_ase_derived_branch_runs_against_the_stand_in():
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + SCRIPT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out == {"ok": True, "base": "ase.calculators.calculator"}
+
+
+def test_models_may_be_modules_with_a_state_dict(golden):
+    """scripts/sample_surface.py:164-174 hands nff Painn modules to EnsembleNFFSurface: anything with state_dict() is taken
+    over tensor by tensor (names of the nff module tree), hyper-parameter attributes are checked."""
+    import numpy as np
+    import pytest
+
+    from surface_sampling_amd import checkpoint
+    from surface_sampling_amd.calculators import EnsembleNFFSurface
+
+    fields = checkpoint.blob_to_fields(golden.blobs[0])
+    sd = {key: fields[field].copy() for field, key in checkpoint.painn_blob_order(3)}
+
+    class Painn:
+        excl_vol, power, sigma, cutoff = True, 12, 1.5, 5.0
+
+        def state_dict(self):
+            return sd
+
+    calc = EnsembleNFFSurface([Painn(), golden.blobs[1]], device="cuda:0")
+    assert np.array_equal(calc.models[0], golden.blobs[0]) and len(calc.models) == 2
+
+    class Other(Painn):
+        sigma = 2.0
+
+    with pytest.raises(ValueError):
+        EnsembleNFFSurface([Other()], device="cuda:0")

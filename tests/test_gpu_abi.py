@@ -97,3 +97,44 @@ def test_resident_batch_set_positions_and_profiler(golden):
         assert eng.stats()["atoms"] == len(s0) + len(s1)
     finally:
         eng.close()
+
+
+def test_tersoff_create_from_text_and_state_errors(golden, oracle_mod):
+    """vssr_tersoff_create_from_text (potential text + species, parsed by the library) gives the same
+    energies as the array form; call-sequence errors of the resident-batch API are reported, not served from stale buffers."""
+    from surface_sampling_amd import backend
+
+    sp = golden.tersoff["species"]
+    P = golden.tersoff_params
+    lines = ["# GaN test potential, entries rebuilt from the golden parameter table", ""]
+    for i, a in enumerate(sp):
+        for j, b in enumerate(sp):
+            for k, c in enumerate(sp):
+                v = ["%.17g" % x for x in P[i, j, k]]
+                lines += [f"{a} {b} {c}  " + " ".join(v[:7]) + "   # three-body part", "        " + " ".join(v[7:]), ""]
+    lines.append("Si Si Si 3.0 1.0 0.0 100390 16.217 -0.59825 0.78734 1.1e-6 1.7322 471.18 2.85 0.15 2.4799 1830.8")
+    text = "\n".join(lines)
+    g = golden.structure("GaN_3x3_pristine")
+    types = np.array([0 if z == 31 else 1 for z in g.numbers], np.int32)
+    pack = [(types, g.positions, g.cell, np.ones(3, np.uint8))]
+    e_text = backend.TersoffEngine(text, device=0, species=sp)
+    e_arr = backend.TersoffEngine(P, device=0)
+    a, b = e_text.evaluate_f64(pack), e_arr.evaluate_f64(pack)
+    assert a[0][0] == b[0][0] and np.array_equal(a[2], b[2]) and abs(a[0][0] - (-144.059)) < 1e-3
+    with pytest.raises(backend.BackendError):
+        backend.TersoffEngine(text, device=0, species=["Ga", "As"])        # triplets with As are missing
+    with pytest.raises(backend.BackendError):
+        backend.TersoffEngine("Ga Ga Ga 1.0 2.0", device=0, species=["Ga"])
+    e_text.close(); e_arr.close()
+    table, const = golden.offset_table()
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    s = golden.structure("SrTiO3_2x2_pristine")
+    eng.upload([(s.numbers, s.positions, s.cell, s.pbc)])
+    eng.run(backend.WANT_ENERGY)
+    with pytest.raises(backend.BackendError):
+        eng.download(backend.WANT_ENERGY | backend.WANT_FORCES)             # forces were not produced by that run
+    assert np.isfinite(eng.download(backend.WANT_ENERGY)["energy"]).all()
+    eng.set_positions(s.positions + 0.01)
+    with pytest.raises(backend.BackendError):
+        eng.download(backend.WANT_ENERGY)                                   # results belong to the old positions
+    eng.close()
