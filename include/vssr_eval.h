@@ -156,6 +156,22 @@ typedef struct {
 int vssr_batch_relax_bfgs(vssr_handle *h, const vssr_bfgs_params *params, const uint8_t *fixed, uint32_t want,
                           double *pos_out, int32_t *n_steps, uint8_t *converged);
 
+/* LAMMPS `min_style cg` + `minimize etol ftol maxiter maxeval` for the analytic (fp64) potentials -- the reference relaxes
+ * GaN with it ("optimizer": "LAMMPS": mcmc/dynamics.py:107-116 -> LAMMMPSCalc.run_lammps_opt, mcmc/calculators/calculators.py:600-619,
+ * template tutorials/data/GaN_0001/GaN_0001_lammps_opt_template.txt: `fix 2 bulk setforce 0 0 0`, `min_style cg`,
+ * `minimize 1e-5 1e-5 {relax_steps} 10000`).  Polak-Ribiere conjugate gradients with LAMMPS' quadratic line search
+ * (dmax 0.1 A per coordinate and line search), restated from LAMMPS min_cg.cpp / min_linesearch.cpp; Tersoff and EAM
+ * handles only (fp64 energies drive the line search).  stop_reason [B] (may be NULL): 1 energy tolerance, 2 force tolerance,
+ * 3 maxiter, 4 maxeval, 5 search direction not downhill, 6 zero force, 7 zero quadratic step, 8 zero alpha. */
+typedef struct {
+    int32_t max_iter;  /* relax_steps (reference GaN: 100) */
+    int32_t max_eval;  /* 10000 */
+    double etol, ftol; /* 1e-5, 1e-5 */
+    double dmax;       /* 0.1 */
+} vssr_cg_params;
+int vssr_batch_relax_cg(vssr_handle *h, const vssr_cg_params *params, const uint8_t *fixed, uint32_t want,
+                        double *pos_out, int32_t *n_iter, int32_t *n_eval, int32_t *stop_reason);
+
 /* ---- introspection used by tests and bench (no effect on results) ---------------------- */
 /* Per-kernel timing with HIP events on the handle's own stream.  enable=1 starts recording;
  * vssr_profile_read synchronises and returns, for each kernel class, the number of launches and

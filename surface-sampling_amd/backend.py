@@ -25,7 +25,7 @@ EXPORTS = (
     "vssr_batch_stats", "vssr_batch_neighbors", "vssr_debug_read", "vssr_tersoff_create",
     "vssr_tersoff_eval_batch", "vssr_batch_relax_fire", "vssr_batch_relax_bfgs", "vssr_debug_capacity",
     "vssr_batch_device_results", "vssr_eam_create", "vssr_eam_eval_batch",
-    "vssr_tersoff_create_from_text",
+    "vssr_tersoff_create_from_text", "vssr_batch_relax_cg",
 )
 
 
@@ -57,6 +57,20 @@ class FireParams(C.Structure):
 
 class EamGrid(C.Structure):
     _fields_ = [("nrho", C.c_int32), ("nr", C.c_int32), ("drho", C.c_double), ("dr", C.c_double), ("cutoff", C.c_double)]
+
+
+class CgParams(C.Structure):
+    """vssr_cg_params; defaults = the reference's LAMMPS template (minimize 1e-5 1e-5 {relax_steps} 10000, dmax 0.1)."""
+    _fields_ = [("max_iter", C.c_int32), ("max_eval", C.c_int32), ("etol", C.c_double), ("ftol", C.c_double), ("dmax", C.c_double)]
+
+    @classmethod
+    def default(cls, max_iter=100, max_eval=10000, etol=1e-5, ftol=1e-5):
+        return cls(int(max_iter), int(max_eval), float(etol), float(ftol), 0.1)
+
+
+CG_STOP_REASONS = {1: "energy tolerance", 2: "force tolerance", 3: "max iterations", 4: "max force evaluations",
+                   5: "search direction is not downhill", 6: "forces are zero", 7: "linesearch: zero quadratic step",
+                   8: "linesearch alpha is zero"}
 
 
 class BfgsParams(C.Structure):
@@ -128,6 +142,8 @@ def load_library():
     L.vssr_tersoff_eval_batch.argtypes = [vp, C.c_int32, ip, ip, dp, dp, u8p, C.c_uint32, C.POINTER(Out), dp, dp, dp]
     L.vssr_tersoff_create_from_text.restype = C.c_int
     L.vssr_tersoff_create_from_text.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(vp)]
+    L.vssr_batch_relax_cg.restype = C.c_int
+    L.vssr_batch_relax_cg.argtypes = [vp, C.POINTER(CgParams), u8p, C.c_uint32, dp, ip, ip, ip]
     L.vssr_eam_create.restype = C.c_int
     L.vssr_eam_create.argtypes = [C.c_int32, C.POINTER(EamGrid), dp, dp, dp, C.POINTER(vp)]
     L.vssr_eam_eval_batch.restype = C.c_int
@@ -370,12 +386,12 @@ class PainnEngine(_Handle):
 class _AnalyticEngine(_Handle):
     """Shared fp64 interface of the analytic potentials (Tersoff, EAM): types instead of atomic numbers."""
 
-    def relax_f64(self, structs, fixed=None, max_steps=100, fmax=0.01):
-        """FIRE-relax (types, positions, cell, pbc) structures; returns (energy [B], e_atom [N], forces [N,3],
+    def relax_f64(self, structs, fixed=None, max_steps=100, fmax=0.01, optimizer="FIRE"):
+        """Relax (types, positions, cell, pbc) structures with FIRE / BFGS; returns (energy [B], e_atom [N], forces [N,3],
         positions [N,3], n_steps [B], converged [B]) with fp64 energies/forces of the relaxed structures."""
         self.upload(structs)
-        info = self.relax_fire(fixed=fixed, max_steps=max_steps, fmax=fmax,
-                               want=WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM)
+        info = self.relax(optimizer, fixed=fixed, max_steps=max_steps, fmax=fmax,
+                          want=WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM)
         packs = []
         o = 0
         for t, p, c, b in structs:
@@ -384,6 +400,30 @@ class _AnalyticEngine(_Handle):
             o += n
         e, ea, f = self.evaluate_f64(packs)
         return e, ea, f, info["positions"], info["n_steps"], info["converged"]
+
+    def relax_cg_f64(self, structs, fixed=None, max_iter=100, max_eval=10000, etol=1e-5, ftol=1e-5):
+        """LAMMPS ``min_style cg`` / ``minimize etol ftol max_iter max_eval`` on the device (vssr_batch_relax_cg).  Returns
+        (energy [B], e_atom [N], forces [N,3], positions [N,3], n_iter [B], n_eval [B], stop_reason [B])."""
+        self.upload(structs)
+        N, B = self._n_atoms, self._n_cfg
+        fx = None
+        if fixed is not None:
+            fx = np.ascontiguousarray(fixed, dtype=np.uint8)
+            if fx.size != N:
+                raise ValueError("fixed mask does not match the resident batch")
+        p = CgParams.default(max_iter, max_eval, etol, ftol)
+        pos = np.zeros((N, 3), np.float64)
+        it, ev, why = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+        self._check(self._lib.vssr_batch_relax_cg(self._h, C.byref(p), _ptr(fx, C.c_uint8),
+                                                  WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM, _ptr(pos, C.c_double),
+                                                  _ptr(it, C.c_int32), _ptr(ev, C.c_int32), _ptr(why, C.c_int32)))
+        packs, o = [], 0
+        for t, _, c, b in structs:
+            n = len(t)
+            packs.append((t, pos[o:o + n], c, b))
+            o += n
+        e, ea, f = self.evaluate_f64(packs)
+        return e, ea, f, pos, it, ev, why
 
     def evaluate_f64(self, structs, want=WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM):
         """structs: list of (types, positions, cell, pbc). Returns fp64 energy [B], e_atom [N], forces [N,3]."""

@@ -587,17 +587,30 @@ class _AnalyticSurfCalc(_Base):
         if "surface_energy" in properties:
             self.results["surface_energy"] = self.results["energy"]
 
-    def run_lammps_opt(self, slab, run_dir=None, fixed_indices=None, **kwargs):
-        """Relaxation counterpart of ``LAMMMPSCalc.run_lammps_opt`` (reference ``calculators.py:600-619``; the
-        reference minimises with LAMMPS CG for ``relax_steps`` iterations): here FIRE on the device.  Returns the
-        reference's tuple ``(relaxed_slab, energy, per_atom_energies)``."""
+    def run_lammps_opt(self, slab, run_dir=None, fixed_indices=None, optimizer="CG", **kwargs):
+        """Relaxation counterpart of ``LAMMMPSCalc.run_lammps_opt`` (reference ``calculators.py:600-619``: LAMMPS
+        ``min_style cg``, ``minimize 1e-5 1e-5 {relax_steps} 10000``, bulk atoms with ``setforce 0``): the same minimiser on
+        the device (``vssr_batch_relax_cg``; ``etol`` / ``ftol`` keywords override 1e-5).  ``optimizer="FIRE"`` / ``"BFGS"``
+        select the ASE-style optimizers with ``fmax`` (default 0.01) instead.  Returns the reference's tuple
+        ``(relaxed_slab, energy, per_atom_energies)``; ``self.last_opt`` holds iteration / evaluation counts and the stop
+        reason."""
         types, pos, cell, pbc = self._pack(slab)
         fixed = None
         if fixed_indices is not None and len(fixed_indices):
             fixed = np.zeros(len(types), np.uint8)
             fixed[np.asarray(fixed_indices, dtype=np.int64)] = 1
-        e, ea, f, new_pos, steps, conv = self._get_engine().relax_f64(
-            [(types, pos, cell, pbc)], fixed=fixed, max_steps=int(self.relax_steps), fmax=kwargs.get("fmax", 0.01))
+        eng = self._get_engine()
+        if str(optimizer).upper() in ("CG", "LAMMPS"):
+            e, ea, f, new_pos, it, ev, why = eng.relax_cg_f64(
+                [(types, pos, cell, pbc)], fixed=fixed, max_iter=int(self.relax_steps), etol=kwargs.get("etol", 1e-5),
+                ftol=kwargs.get("ftol", 1e-5))
+            self.last_opt = {"optimizer": "CG", "iterations": int(it[0]), "evaluations": int(ev[0]),
+                             "stop": backend.CG_STOP_REASONS.get(int(why[0]), str(int(why[0])))}
+        else:
+            e, ea, f, new_pos, steps, conv = eng.relax_f64(
+                [(types, pos, cell, pbc)], fixed=fixed, max_steps=int(self.relax_steps), fmax=kwargs.get("fmax", 0.01),
+                optimizer=optimizer)
+            self.last_opt = {"optimizer": str(optimizer), "iterations": int(steps[0]), "converged": bool(conv[0])}
         relaxed = slab.copy()
         relaxed.set_positions(new_pos)
         relaxed.calc = getattr(slab, "calc", None)

@@ -528,4 +528,207 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
     return VSSR_OK;
 }
 
+// ---- LAMMPS min_style cg (Polak-Ribiere + quadratic line search) as a per-chain state machine ------------------------------
+// One evaluation of the batch per driver iteration; every chain consumes it according to its own phase:
+//   PH_START   forces at the current CG point are known: set up the line search (or the very first direction), move to the
+//              first trial point x0 + alphamax h;
+//   PH_TRIAL   energy / forces at x0 + alpha h: secant ("quadratic") projection -> PH_PROJ, or accept, or halve alpha;
+//   PH_PROJ    energy at the projected x0 + alpha0 h: accept if it is below the start, else fall through to the backtrack test
+//              of LAMMPS' loop (which, like LAMMPS, then compares the PROJECTED point's energy with the ideal decrease at alpha);
+//   PH_RESET   the chain went back to x0 after a failed line search: this evaluation restores consistent results, then stop.
+// Constants of min_linesearch.cpp: ALPHA_MAX 1, ALPHA_REDUCE 0.5, BACKTRACK_SLOPE 0.4, QUADRATIC_TOL 0.1, EMACH 1e-8,
+// EPS_QUAD 1e-28; of min_cg.cpp: EPS_ENERGY 1e-8.  thermo normalisation off (forces / energies extensive).
+enum { PH_START = 0, PH_TRIAL = 1, PH_PROJ = 2, PH_RESET = 3 };
+struct CgState {
+    int phase, started, niter, neval, reason, pending;   // reason != 0: finished; pending: reason to report after PH_RESET
+    double gg, eprevious, eoriginal, alpha, alphaprev, alphamax, fhprev, engprev, fdothall, fh_trial;
+};
+
+__global__ void k_cg_init(int B, CgState *__restrict__ st, unsigned char *__restrict__ active) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    CgState S = {};
+    S.phase = PH_START;
+    st[b] = S;
+    active[b] = 1;
+}
+
+__global__ void __launch_bounds__(256)
+k_cg_step(const int *__restrict__ cfg_start, const int *__restrict__ counters, const double *__restrict__ energy,
+          const double *__restrict__ forces, const uint8_t *__restrict__ fixed, int max_iter, int max_eval, double etol,
+          double ftol, double dmax, double *__restrict__ pos, double *__restrict__ x0all, double *__restrict__ hall,
+          double *__restrict__ gall, CgState *__restrict__ st, unsigned char *__restrict__ active, int *__restrict__ n_active) {
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (counters[2]) return;
+    CgState S = st[b];
+    if (S.reason) return;
+    const int a0 = cfg_start[b], n = 3 * (cfg_start[b + 1] - a0);
+    double *x = pos + 3 * (size_t)a0, *x0 = x0all + 3 * (size_t)a0, *h = hall + 3 * (size_t)a0, *g = gall + 3 * (size_t)a0;
+    const double *fg = forces + 3 * (size_t)a0;
+    const uint8_t *fx = fixed ? fixed + a0 : nullptr;
+    auto F = [&](int k) -> double { return (fx && fx[k / 3]) ? 0.0 : fg[k]; };
+    const double ecur = energy[b];
+    S.neval += 1;
+    // every exit stores the state; `stop` also switches the chain off
+    auto stop = [&](int reason) {
+        if (tid == 0) { S.reason = reason; st[b] = S; active[b] = 0; }
+    };
+    auto keep_going = [&]() {
+        if (tid == 0) { st[b] = S; atomicAdd(n_active, 1); }
+    };
+    auto move_to = [&](double alpha) {
+        for (int k = tid; k < n; k += nt) x[k] = x0[k] + alpha * h[k];
+    };
+    auto reset_to_start = [&](int pending) {   // alpha_step(0.0, 0): back to x0, one more evaluation, then report `pending`
+        move_to(0.0);
+        S.phase = PH_RESET; S.pending = pending;
+        keep_going();
+    };
+    // a new iteration of min_cg.cpp: line search along h from the current point (forces of this evaluation)
+    auto start_linesearch = [&]() {
+        S.niter += 1;
+        S.eprevious = ecur;
+        double c = 0.0;
+        for (int k = tid; k < n; k += nt) c += F(k) * h[k];
+        const double fh = block_sum(c, red);
+        S.fdothall = fh;
+        if (fh <= 0.0) { stop(5); return; }
+        double hm = 0.0;
+        for (int k = tid; k < n; k += nt) hm = fmax(hm, fabs(h[k]));
+        hm = block_max(hm, red);
+        if (hm == 0.0) { stop(6); return; }
+        S.alphamax = fmin(1.0, dmax / hm);
+        for (int k = tid; k < n; k += nt) x0[k] = x[k];
+        __syncthreads();
+        S.eoriginal = ecur; S.alpha = S.alphamax; S.alphaprev = 0.0; S.fhprev = fh; S.engprev = ecur;
+        S.phase = PH_TRIAL;
+        if (S.neval >= max_eval) { stop(4); return; }
+        move_to(S.alpha);
+        keep_going();
+    };
+
+    if (S.phase == PH_RESET) { stop(S.pending); return; }
+    if (S.phase == PH_START) {   // min_cg.cpp setup: h = g = f, gg = f.f
+        double a = 0.0;
+        for (int k = tid; k < n; k += nt) { const double f = F(k); g[k] = f; h[k] = f; a += f * f; }
+        S.gg = block_sum(a, red);
+        if (max_iter <= 0) { stop(3); return; }
+        start_linesearch();
+        return;
+    }
+    bool line_done = false;
+    double e_test = ecur, fh_test = S.fh_trial;
+    if (S.phase == PH_TRIAL) {
+        double c = 0.0;
+        for (int k = tid; k < n; k += nt) c += F(k) * h[k];
+        const double fh = block_sum(c, red);
+        const double delfh = fh - S.fhprev;
+        if (fabs(fh) < 1e-28 || fabs(delfh) < 1e-28) { reset_to_start(7); return; }
+        const double relerr = fabs(1.0 - (0.5 * (S.alpha - S.alphaprev) * (fh + S.fhprev) + ecur) / S.engprev);
+        const double alpha0 = S.alpha - (S.alpha - S.alphaprev) * fh / delfh;
+        if (relerr <= 0.1 && alpha0 > 0.0 && alpha0 < S.alphamax) {   // secant projection: evaluate x0 + alpha0 h next
+            S.fh_trial = fh;
+            S.phase = PH_PROJ;
+            if (S.neval >= max_eval) { stop(4); return; }
+            move_to(alpha0);
+            keep_going();
+            return;
+        }
+        fh_test = fh;
+    } else {   // PH_PROJ
+        if (ecur - S.eoriginal < 1e-8) line_done = true;
+    }
+    if (!line_done) {   // backtracking test of the loop, on the energy of the last evaluated point
+        const double de_ideal = -0.4 * S.alpha * S.fdothall;
+        const double de = e_test - S.eoriginal;
+        if (de <= de_ideal) line_done = true;
+        else {
+            S.fhprev = fh_test; S.engprev = e_test; S.alphaprev = S.alpha;
+            S.alpha *= 0.5;
+            if (S.alpha <= 0.0 || de_ideal >= -1e-8) { reset_to_start(8); return; }
+            S.phase = PH_TRIAL;
+            if (S.neval >= max_eval) { stop(4); return; }
+            move_to(S.alpha);
+            keep_going();
+            return;
+        }
+    }
+    // ---- line search succeeded: tolerances and the next direction (min_cg.cpp iterate) ----
+    if (fabs(ecur - S.eprevious) < etol * 0.5 * (fabs(ecur) + fabs(S.eprevious) + 1e-8)) { stop(1); return; }
+    double d0 = 0.0, d1 = 0.0;
+    for (int k = tid; k < n; k += nt) { const double f = F(k); d0 += f * f; d1 += f * g[k]; }
+    d0 = block_sum(d0, red);
+    d1 = block_sum(d1, red);
+    if (d0 < ftol * ftol) { stop(2); return; }
+    double beta = fmax(0.0, (d0 - d1) / S.gg);
+    if ((S.niter + 1) % max(n, 1) == 0) beta = 0.0;   // restart every ndof iterations
+    S.gg = d0;
+    double gh = 0.0;
+    for (int k = tid; k < n; k += nt) { const double f = F(k); g[k] = f; h[k] = f + beta * h[k]; gh += f * h[k]; }
+    gh = block_sum(gh, red);
+    if (gh <= 0.0)
+        for (int k = tid; k < n; k += nt) h[k] = g[k];
+    __syncthreads();
+    if (S.niter >= max_iter) { stop(3); return; }
+    start_linesearch();
+}
+
+__global__ void k_cg_report(int B, const CgState *__restrict__ st, int *__restrict__ out /*[B][3]*/) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    out[3 * b] = st[b].niter; out[3 * b + 1] = st[b].neval; out[3 * b + 2] = st[b].reason;
+}
+
+int relax_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host, uint32_t want) {
+    const int B = h->n_cfg, N = h->n_atoms;
+    hipStream_t st = h->stream;
+    if (h->kind != 2 && h->kind != 3)
+        return set_err(h, VSSR_E_STATE, "conjugate gradients need an fp64 potential (Tersoff / EAM handle); use BFGS or FIRE");
+    if (h->d_fixed.ensure((size_t)N) || h->d_relax_steps.ensure(sizeof(int) * 3 * B) || h->d_active.ensure((size_t)B) ||
+        h->d_counters.ensure(sizeof(int) * 4) || h->d_fire.ensure(sizeof(CgState) * B) || h->d_vel.ensure(sizeof(double) * 9 * N))
+        return set_err(h, VSSR_E_NOMEM, "CG state: out of device memory");
+    const uint8_t *fixed = nullptr;
+    if (fixed_host) {
+        VSSR_HIP(h, hipMemcpyAsync(h->d_fixed.p, fixed_host, (size_t)N, hipMemcpyHostToDevice, st));
+        fixed = h->d_fixed.as<uint8_t>();
+    }
+    unsigned char *active = h->d_active.as<unsigned char>();
+    hipLaunchKernelGGL(k_cg_init, dim3((B + 127) / 128), dim3(128), 0, st, B, h->d_fire.as<CgState>(), active);
+    h->active_mask = active;
+    int *n_active_d = h->d_counters.as<int>() + 3;
+    const int POLL = 8;
+    int rc = VSSR_OK;
+    const long long max_launch = (long long)cp->max_eval + 2;
+    for (long long it = 0; it < max_launch && !rc; ++it) {
+        rc = h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : eam_run(h, want | VSSR_WANT_FORCES);
+        if (rc) break;
+        VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_cg_step, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
+                           h->d_ters_e.as<double>(), h->d_ters_f.as<double>(), fixed, cp->max_iter, cp->max_eval, cp->etol,
+                           cp->ftol, cp->dmax, h->d_pos.as<double>(), h->d_vel.as<double>(), h->d_vel.as<double>() + 3 * (size_t)N,
+                           h->d_vel.as<double>() + 6 * (size_t)N, h->d_fire.as<CgState>(), active, n_active_d);
+        VSSR_HIP(h, hipMemcpyAsync(h->h_counters + 3, n_active_d, sizeof(int), hipMemcpyDeviceToHost, st));
+        if ((it + 1) % POLL == 0) {
+            VSSR_HIP(h, hipStreamSynchronize(st));
+            if (h->h_counters[2]) {
+                if (h->h_counters[0] <= 0) { rc = set_err(h, VSSR_E_CAPACITY, "neighbor list exceeds 2^31 slots"); break; }
+                h->slot_cap = (int64_t)h->h_counters[0] + (h->cap_tight ? 0 : (int64_t)h->h_counters[0] / 8) + 64;
+                if (++h->relax_regrows > 64) { rc = set_err(h, VSSR_E_CAPACITY, "neighbor capacity could not be satisfied"); break; }
+                continue;   // the step kernels behind the overflow did nothing: the state machines resume where they were
+            }
+            if (h->h_counters[3] == 0) break;   // every chain has finished
+        }
+    }
+    h->active_mask = nullptr;
+    if (rc) return rc;
+    // results of the final positions for every chain (finished chains were switched off at different times)
+    rc = h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : eam_run(h, want | VSSR_WANT_FORCES);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cg_report, dim3((B + 127) / 128), dim3(128), 0, st, B, h->d_fire.as<CgState>(), h->d_relax_steps.as<int>());
+    VSSR_HIP(h, hipGetLastError());
+    h->ran = true;
+    return VSSR_OK;
+}
+
 }  // namespace vssr

@@ -634,6 +634,30 @@ int vssr_tersoff_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atom
 
 static int relax_finish(vssr_handle *h, double *pos_out, int32_t *n_steps, uint8_t *converged);
 
+int vssr_batch_relax_cg(vssr_handle *h, const vssr_cg_params *params, const uint8_t *fixed, uint32_t want, double *pos_out,
+                        int32_t *n_iter, int32_t *n_eval, int32_t *stop_reason) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->batch_valid) return set_err(h, VSSR_E_STATE, "vssr_batch_relax_cg before vssr_batch_upload");
+    if (!params || params->max_iter < 0 || params->max_eval < 1 || !(params->etol >= 0) || !(params->ftol >= 0) || !(params->dmax > 0))
+        return set_err(h, VSSR_E_BADARG, "bad CG parameters");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    h->relax_regrows = 0;
+    h->last_want = want | VSSR_WANT_FORCES;
+    int rc = relax_cg(h, params, fixed, want);
+    if (rc) return rc;
+    VSSR_HIP(h, hipStreamSynchronize(h->stream));
+    h->prof.collect();
+    if (pos_out) VSSR_HIP(h, hipMemcpy(pos_out, h->d_pos.p, sizeof(double) * 3 * h->n_atoms, hipMemcpyDeviceToHost));
+    std::vector<int> rep((size_t)3 * h->n_cfg);
+    VSSR_HIP(h, hipMemcpy(rep.data(), h->d_relax_steps.p, sizeof(int) * rep.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->n_cfg; ++b) {
+        if (n_iter) n_iter[b] = rep[3 * b];
+        if (n_eval) n_eval[b] = rep[3 * b + 1];
+        if (stop_reason) stop_reason[b] = rep[3 * b + 2];
+    }
+    return VSSR_OK;
+}
+
 int vssr_eam_eval_batch(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, const int32_t *type, const double *pos,
                         const double *cell, const uint8_t *pbc, uint32_t want, vssr_out *out, double *energy_f64,
                         double *energy_atoms_f64, double *forces_f64) {

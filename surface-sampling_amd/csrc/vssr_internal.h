@@ -251,6 +251,8 @@ void eam_build_spline(const double *f, int n, double delta, double *spl /*[n + 1
 // method 0: FIRE (fp), 1: BFGS (bp)
 int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr_bfgs_params *bp,
               const uint8_t *fixed_host, uint32_t want);
+// LAMMPS-style conjugate gradients for the fp64 potentials (relax.hip); results in d_relax_steps [B][3] = {iterations, evaluations, stop reason}
+int relax_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host, uint32_t want);
 // MFMA node stages (painn_node_mfma.hip)
 int node_mfma_init(vssr_handle *h);
 void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,

@@ -1,0 +1,121 @@
+"""LAMMPS-style conjugate-gradient minimisation (reference ``optimizer: "LAMMPS"`` for GaN, ``min_style cg``):
+the numpy restatement on CPU, the device state machine against it on the GPU."""
+
+import os
+
+import numpy as np
+import pytest
+
+from cg_oracle import cg_minimize
+from conftest import GOLDEN
+
+
+def _gan(golden, sigma=0.05, seed=4):
+    from surface_sampling_amd.structures import Structure
+
+    g = golden.structure("GaN_3x3_pristine")
+    rng = np.random.default_rng(seed)
+    types = np.array([0 if z == 31 else 1 for z in g.numbers], np.int32)
+    return Structure(g.numbers, g.positions + rng.normal(0, sigma, g.positions.shape), g.cell, g.pbc), types
+
+
+def test_cg_restatement_minimises_tersoff(golden, oracle_mod):
+    """Invariants of the restatement on the rattled GaN slab (bulk atoms held like the reference's `fix 2 bulk setforce 0`):
+    accepted energies decrease monotonically, it stops on the energy tolerance within the reference's 100 iterations, held
+    atoms do not move, and the minimum agrees with a long BFGS relaxation of the same start."""
+    from bfgs_oracle import bfgs_relax
+
+    s, types = _gan(golden)
+    fixed = np.arange(12, 36)
+
+    def fn(pos):
+        E, _, F = oracle_mod.tersoff(golden.tersoff_params, types, pos, s.cell, [1, 1, 1])
+        return E, F
+
+    pos, e, niter, neval, why, trace = cg_minimize(fn, s.positions, fixed=fixed, max_iter=100)
+    assert why == 1 and 2 <= niter <= 100 and neval >= niter
+    assert all(b <= a + 1e-12 for a, b in zip(trace, trace[1:])) and trace[-1] < trace[0] - 0.1
+    assert np.array_equal(pos[fixed], s.positions[fixed])
+    pos2, tr2, _, _ = bfgs_relax(fn, s.positions, fixed=fixed, max_steps=200, fmax=1e-4)
+    assert 0.0 <= e - tr2[-1][0] < 2e-2      # etol 1e-5 relative of ~143 eV: stops when an iteration gains < 1.4 meV, ~8 meV above the minimum
+    # tight tolerances reach the same minimum to 1e-7 eV
+    _, e_tight, _, _, why_t, _ = cg_minimize(fn, s.positions, fixed=fixed, max_iter=2000, etol=0.0, ftol=1e-6)
+    assert why_t == 2 and abs(e_tight - tr2[-1][0]) < 1e-6
+
+
+def test_cg_restatement_stop_conditions():
+    K = np.diag([1.0, 4.0, 9.0, 1.0, 2.0, 3.0])
+
+    def fn(pos):
+        x = pos.reshape(-1)
+        return 0.5 * x @ K @ x, -(K @ x).reshape(-1, 3)
+
+    x0 = np.array([[0.3, -0.2, 0.1], [0.05, 0.4, -0.3]])
+    pos, e, niter, neval, why, _ = cg_minimize(fn, x0, etol=0.0, ftol=1e-10, max_iter=200)
+    assert why == 2 and np.abs(pos).max() < 1e-9
+    assert cg_minimize(fn, x0, max_iter=1)[4] == 3
+    assert cg_minimize(fn, x0, max_eval=3, etol=0.0, ftol=0.0)[4] == 4
+    assert cg_minimize(fn, np.zeros((2, 3)))[4] in (5, 6)      # zero force: nothing to follow
+
+
+@pytest.mark.gpu
+def test_cg_gpu_follows_the_restatement(golden, oracle_mod):
+    """Device CG (vssr_batch_relax_cg) on a batch of three chains -- two rattled GaN slabs (different starts, different
+    iteration counts) on Tersoff and the Cu(100) slab with two adatoms on EAM in a second handle -- against the restatement
+    driven by the fp64 oracles: same iteration / evaluation counts and stop reasons, energies to 1e-9 eV."""
+    import eam_oracle
+    from surface_sampling_amd import backend, eam, structures
+
+    fixed = np.arange(12, 36)
+    cases = [_gan(golden, 0.05, 4), _gan(golden, 0.02, 9)]
+    packs = [(t, s.positions, s.cell, np.ones(3, np.uint8)) for s, t in cases]
+    mask = np.zeros(72, np.uint8)
+    mask[fixed] = 1
+    mask[36 + fixed] = 1
+    eng = backend.TersoffEngine(golden.tersoff_params, device=0)
+    e, ea, f, pos, it, ev, why = eng.relax_cg_f64(packs, fixed=mask, max_iter=100)
+    for b, (s, types) in enumerate(cases):
+        def fn(p, types=types, s=s):
+            E, _, F = oracle_mod.tersoff(golden.tersoff_params, types, p, s.cell, [1, 1, 1])
+            return E, F
+
+        pref, eref, niter, neval, reason, _ = cg_minimize(fn, s.positions, fixed=fixed, max_iter=100)
+        assert (it[b], ev[b], why[b]) == (niter, neval, reason), (b, it[b], ev[b], why[b], niter, neval, reason)
+        assert abs(e[b] - eref) < 1e-9 and np.abs(pos[36 * b:36 * b + 36] - pref).max() < 1e-9
+        assert np.array_equal(pos[36 * b:36 * b + 36][fixed], s.positions[fixed])
+    assert it[0] != it[1]                                         # the chains really ran different numbers of iterations
+    eng.close()
+    # EAM: Cu(100) + two adatoms, bottom layer held
+    d = np.load(os.path.join(GOLDEN, "cu100.npz"))
+    fl = eam.read_funcfl(os.path.join(GOLDEN, "Cu_u3.eam"))
+    pos0 = np.vstack([d["positions"], d["ads_coords"][[5, 12]]])
+    e2 = backend.EAMEngine(fl, device=0)
+    out = e2.relax_cg_f64([(np.zeros(10, np.int32), pos0, d["cell"], d["pbc"].astype(np.uint8))], fixed=np.array([1] * 4 + [0] * 6, np.uint8),
+                          max_iter=60)
+
+    def fn2(p):
+        E, _, F = eam_oracle.eam(fl, p, d["cell"], d["pbc"])
+        return E, F
+
+    pref, eref, niter, neval, reason, _ = cg_minimize(fn2, pos0, fixed=np.arange(4), max_iter=60)
+    assert (out[4][0], out[5][0], out[6][0]) == (niter, neval, reason)
+    assert abs(out[0][0] - eref) < 1e-9 and eref < eam_oracle.eam(fl, pos0, d["cell"], d["pbc"])[0] - 0.5
+    e2.close()
+
+
+@pytest.mark.gpu
+def test_cg_is_refused_for_the_fp32_painn_path(golden):
+    """The line search compares energies at the 1e-8 level: only the fp64 potentials offer it (the reference uses the
+    LAMMPS minimiser with LAMMPS calculators only)."""
+    import ctypes as C
+
+    from surface_sampling_amd import backend
+
+    table, const = golden.offset_table()
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    s = golden.structure("SrTiO3_2x2_pristine")
+    eng.upload([(s.numbers, s.positions, s.cell, s.pbc)])
+    p = backend.CgParams.default()
+    rc = eng._lib.vssr_batch_relax_cg(eng._h, C.byref(p), None, 3, None, None, None, None)
+    assert rc == -5 and b"fp64" in eng._lib.vssr_last_error(eng._h)
+    eng.close()
