@@ -89,6 +89,10 @@ __device__ __forceinline__ void store_split4(const Planes &P, int row, int col, 
     *reinterpret_cast<u32x2 *>(P.l + row * P.ld + col) = (u32x2){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
 }
 
+__device__ __forceinline__ void store_split4(const Planes &P, int row, int col, f32x4 v) {
+    store_split4(P, row, col, make_float4(v[0], v[1], v[2], v[3]));
+}
+
 // Cooperative tile load: NROWS rows of F floats from global, split, into plane columns [col0, col0 + F).  rowptr(row)
 // must always return a readable row (tail rows are clamped to the last atom; their results are never stored), so that
 // all loads are unconditional and issued back-to-back before the first LDS store.
@@ -164,18 +168,31 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// lane geometry shared by all kernels: wave w owns columns 16 w .. 16 w + 15; accumulator element (t, i) of a lane is
-// atom row 16 t + 4 (lane >> 4) + i and column 16 w + (lane & 15)
+// lane geometry shared by all kernels: wave w owns columns 16 w .. 16 w + 15.  The WEIGHTS are the A operand of the MFMA
+// and the activations the B operand (gemm16), so the 16 x 16 result tile comes out as D[feature][atom]: accumulator
+// element (t, i) of a lane is atom row 16 t + (lane & 15) and column 16 w + 4 (lane >> 4) + i -- FOUR CONSECUTIVE FEATURES
+// of one atom.  Everything a lane stores or fetches in this layout is a 16-byte (fp32) or 8-byte (fp16 piece) vector:
+// plane stores are ds_write_b64 with packed conversions, staging-tile and bias accesses are b128.  (With the operands the
+// other way round a lane owned one feature of four atoms: 2-byte plane stores, dword tile accesses.)
 struct LaneGeo {
-    int w, col, rbase;
+    int w, col0, r;
     __device__ __forceinline__ LaneGeo() {
         const int lane = threadIdx.x & 63;
         w = threadIdx.x >> 6;
-        col = 16 * w + (lane & 15);
-        rbase = 4 * (lane >> 4);
+        col0 = 16 * w + 4 * (lane >> 4);
+        r = lane & 15;
     }
-    __device__ __forceinline__ int row(int t, int i) const { return 16 * t + rbase + i; }
+    __device__ __forceinline__ int row(int t) const { return 16 * t + r; }
 };
+// four consecutive floats (16-byte aligned) through the global address space (see gload4u)
+__device__ __forceinline__ f32x4 gload4f(const float *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const f32x4 __attribute__((address_space(1))) *gptr;
+    return *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
+#else
+    return *reinterpret_cast<const f32x4 *>(p);
+#endif
+}
 
 }  // namespace vssr
 #endif

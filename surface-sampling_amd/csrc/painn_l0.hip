@@ -126,21 +126,19 @@ k_l0_fwd16(int N, int M, int nz, ActiveView av, const int *__restrict__ counters
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    acc[t] = mfma16(a[t][k == 1 ? 1 : 0], b[t < 2 ? 0 : 1][k == 0 ? 1 : 0], acc[t]);   // a_h w_l, a_l w_h, a_h w_h
+                    acc[t] = mfma16(b[t < 2 ? 0 : 1][k == 0 ? 1 : 0], a[t][k == 1 ? 1 : 0], acc[t]);   // w_l a_h, w_h a_l, w_h a_h: D[feature][atom] (LaneGeo)
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            const int a_ = a0 + L.row(t);
+            if (a_ >= N) continue;
+            const size_t gI = (size_t)m * N + a_;
+            *reinterpret_cast<f32x4 *>(s_msg + gI * F + L.col0) = gload4f(MW[m].embed + (size_t)Z[a_] * F + L.col0) + acc[t];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int a_ = a0 + L.row(t, i);
-                if (a_ >= N) continue;
-                const size_t gI = (size_t)m * N + a_;
-                s_msg[gI * F + L.col] = MW[m].embed[(size_t)Z[a_] * F + L.col] + acc[t][i];
-#pragma unroll
-                for (int x = 0; x < 3; ++x) v_msg[(gI * 3 + x) * F + L.col] = acc[2 + 2 * x + t][i];
-            }
+            for (int x = 0; x < 3; ++x) *reinterpret_cast<f32x4 *>(v_msg + (gI * 3 + x) * F + L.col0) = acc[2 + 2 * x + t];
+        }
     }
 }
 

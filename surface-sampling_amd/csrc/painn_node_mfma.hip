@@ -42,9 +42,10 @@ extern "C" int vssr_debug_phases(unsigned long long *out, int reset) {
 namespace vssr {
 
 // ---- GEMM on the planes ------------------------------------------------------------------------------------------------
-// acc[t][c] += A(rows 16 t .. 16 t + 15, K) . W(column tile c)^T.  A fragment of lane (r = lane & 15, g = lane >> 4) for
-// chunk q: row 16 t + r, k = 32 q + 8 g .. + 7 -> one ds_read_b128 per piece.  wq[c]: pieces of a 16-column tile,
-// [K/32][2][64 lanes] uint4 (pack_mfma_tiles16).  D: lane holds column r, rows 4 g .. 4 g + 3 of the 16 x 16 tile.
+// acc[t][c] += A(rows 16 t .. 16 t + 15, K) . W(column tile c)^T.  Activation fragment of lane (r = lane & 15, g = lane >> 4)
+// for chunk q: row 16 t + r, k = 32 q + 8 g .. + 7 -> one ds_read_b128 per piece.  wq[c]: pieces of a 16-column tile,
+// [K/32][2][64 lanes] uint4 (pack_mfma_tiles16).  The weight pieces are the MFMA's A operand, the activation pieces its B
+// operand: D[feature][atom], lane (r, g) holds atom row r, columns 4 g .. 4 g + 3 of the tile (LaneGeo, mfma16.h).
 // gemm16<K, NRT, NCT, PF>.  PF = 0: chunk groups one after the other (load, wait, multiply) in a rolled loop -- the
 // smallest register footprint (update_fwd runs two workgroups per CU inside 128 registers).
 // PF = 1: software pipeline.  Measured per-phase timings (profiles/r02/NOTES_node_kernels.md): a chunk group cost ~0.65 us
@@ -98,7 +99,7 @@ __device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)
 #pragma unroll
                         for (int c = 0; c < NCT; ++c) {
                             part[j][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                __builtin_bit_cast(f16x8, a[j][t][wi[k]]), __builtin_bit_cast(f16x8, b[j][c][ri[k]]),
+                                __builtin_bit_cast(f16x8, b[j][c][ri[k]]), __builtin_bit_cast(f16x8, a[j][t][wi[k]]),
                                 part[j][t][c], 0, 0, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -143,7 +144,7 @@ __device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)
 #pragma unroll
                         for (int c = 0; c < NCT; ++c) {
                             part[j][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                __builtin_bit_cast(f16x8, a[ca][j][t][wi[k]]), __builtin_bit_cast(f16x8, b[cur][j][c][ri[k]]),
+                                __builtin_bit_cast(f16x8, b[cur][j][c][ri[k]]), __builtin_bit_cast(f16x8, a[ca][j][t][wi[k]]),
                                 part[j][t][c], 0, 0, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -196,11 +197,14 @@ k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const
         zero_acc(acc);
         const uint4 *wp[1] = {WTILE(W1, L.w, F)};
         gemm16<F, 2, 1>(xs, wp, acc);
-        const float b = W.b1[L.col];
+        const f32x4 b = gload4f(W.b1 + L.col0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            f32x4 hv = acc[t][0] + b;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) store_split(hs, L.row(t, i), L.col, swish(acc[t][0][i] + b));
+            for (int i = 0; i < 4; ++i) hv[i] = swish(hv[i]);
+            store_split4(hs, L.row(t), L.col0, hv);
+        }
     }
     __syncthreads();
     f32x4 acc[2][3];
@@ -209,14 +213,12 @@ k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const
     gemm16<F, 2, 3>(hs, wp, acc);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float b = W.b2[c * F + L.col];
+        const f32x4 b = gload4f(W.b2 + c * F + L.col0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int a = a0 + L.row(t, i);
-                if (a < N) phi[(mN + a) * F3 + c * F + L.col] = acc[t][c][i] + b;
-            }
+        for (int t = 0; t < 2; ++t) {
+            const int a = a0 + L.row(t);
+            if (a < N) *reinterpret_cast<f32x4 *>(phi + (mN + a) * F3 + c * F + L.col0) = acc[t][c] + b;
+        }
     }
 }
 
@@ -248,11 +250,14 @@ k_msg_mlp_bwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, c
     }
     __syncthreads();  // everyone is done reading xs
     {
-        const float b = W.b1[L.col];
+        const f32x4 b = gload4f(W.b1 + L.col0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            f32x4 hv;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) store_split(xs, L.row(t, i), L.col, a1[t][0][i] * dswish(h1[t][0][i] + b));
+            for (int i = 0; i < 4; ++i) hv[i] = a1[t][0][i] * dswish(h1[t][0][i] + b[i]);
+            store_split4(xs, L.row(t), L.col0, hv);
+        }
     }
     __syncthreads();
     f32x4 acc[2][1];
@@ -260,12 +265,11 @@ k_msg_mlp_bwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, c
     const uint4 *wp[1] = {WTILE(W1t, L.w, F)};
     gemm16<F, 2, 1>(xs, wp, acc);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int a = a0 + L.row(t, i);
-            if (a < N) sbar_in[(mN + a) * F + L.col] = sbar_msg[(mN + a) * F + L.col] + acc[t][0][i];
-        }
+    for (int t = 0; t < 2; ++t) {
+        const int a = a0 + L.row(t);
+        if (a < N)
+            *reinterpret_cast<f32x4 *>(sbar_in + (mN + a) * F + L.col0) = gload4f(sbar_msg + (mN + a) * F + L.col0) + acc[t][0];
+    }
 }
 
 // ---- update block -----------------------------------------------------------------------------------------------
@@ -286,7 +290,7 @@ struct UpdLds {
 
 template <int RT>
 struct UpdRegs {
-    f32x4 uv[3 * RT][2];   // [RT x + t][0] = U v_x, [..][1] = V v_x for column `col`, atom rows 16 t + 4 g + i
+    f32x4 uv[3 * RT][2];   // [RT x + t][0] = U v_x, [..][1] = V v_x for atom row 16 t + r, columns col0 .. col0 + 3
     f32x4 h3[RT];          // pre-activation of the gate MLP
     f32x4 gate[RT][3];     // a_vv, a_sv, a_ss
     f32x4 nrm[RT], inner[RT];
@@ -306,7 +310,7 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
     }
     PH(PHB + 1)
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+    for (int t = 0; t < RT; ++t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float n2 = 0.f, in = 0.f;
@@ -318,8 +322,9 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
             }
             R.nrm[t][i] = sqrtf(n2);
             R.inner[t][i] = in;
-            store_split(hs, L.row(t, i), F + L.col, R.nrm[t][i]);
         }
+        store_split4(hs, L.row(t), F + L.col0, R.nrm[t]);
+    }
     PH(PHB + 2)
     __syncthreads();
     PH(PHB + 3)
@@ -328,14 +333,15 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
         zero_acc(acc);
         const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F)};
         gemm16<2 * F, RT, 1, UPD_PF>(hs, wp, acc);
-        const float b = W.b3[L.col];
+        const f32x4 b = gload4f(W.b3 + L.col0);
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
+        for (int t = 0; t < RT; ++t) {
+            R.h3[t] = acc[t][0] + b;
+            f32x4 sw;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                R.h3[t][i] = acc[t][0][i] + b;
-                store_split(as_, L.row(t, i), L.col, swish(R.h3[t][i]));
-            }
+            for (int i = 0; i < 4; ++i) sw[i] = swish(R.h3[t][i]);
+            store_split4(as_, L.row(t), L.col0, sw);
+        }
     }
     PH(PHB + 4)
     __syncthreads();
@@ -346,9 +352,9 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
         gemm16<F, RT, 3, UPD_PF>(as_, wp, R.gate);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float b = W.b4[c * F + L.col];
+            const f32x4 b = gload4f(W.b4 + c * F + L.col0);
 #pragma unroll
-            for (int t = 0; t < RT; ++t) R.gate[t][c] += (f32x4){b, b, b, b};
+            for (int t = 0; t < RT; ++t) R.gate[t][c] += b;
         }
     }
     PH(PHB + 6)
@@ -429,7 +435,8 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     PH(3)
     f32x4 inner[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+        f32x4 nv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float n2 = 0.f, in = 0.f;
@@ -440,18 +447,23 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
                 in = fmaf(uv[2 * x + t][0][i], vv, in);
             }
             inner[t][i] = in;
-            store_split(nr, L.row(t, i), L.col, sqrtf(n2));
+            nv[i] = sqrtf(n2);
         }
+        store_split4(nr, L.row(t), L.col0, nv);
+    }
     __syncthreads();
     PH(4)
     {
         const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F) + (F / 32) * 2 * 64};   // chunks F/32 .. 2F/32 - 1 of the same column tile
         gemm16<F, 2, 1, PF>(nr, wp, h3);
-        const float b = W.b3[L.col];
+        const f32x4 b = gload4f(W.b3 + L.col0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            f32x4 sw = h3[t][0] + b;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) store_split(as_, L.row(t, i), L.col, swish(h3[t][0][i] + b));
+            for (int i = 0; i < 4; ++i) sw[i] = swish(sw[i]);
+            store_split4(as_, L.row(t), L.col0, sw);
+        }
     }
     PH(5)
     __syncthreads();
@@ -463,9 +475,9 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
         gemm16<F, 2, 3, PF>(as_, wp, gate);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float b = W.b4[c * F + L.col];
+            const f32x4 b = gload4f(W.b4 + c * F + L.col0);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) gate[t][c] += (f32x4){b, b, b, b};
+            for (int t = 0; t < 2; ++t) gate[t][c] += b;
         }
     }
     PH(7)
@@ -474,14 +486,15 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     // increments (rows [0, TA): s, rows TA (1 + x) + atom: v_x); the residual is added in the coalesced pass
     float *T = reinterpret_cast<float *>(ldsh);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+        const int row = L.row(t);
+        f32x4 ds;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = L.row(t, i);
-            T[row * FT + L.col] = fmaf(gate[t][1][i], inner[t][i], gate[t][2][i]);
+        for (int i = 0; i < 4; ++i) ds[i] = fmaf(gate[t][1][i], inner[t][i], gate[t][2][i]);
+        *reinterpret_cast<f32x4 *>(T + row * FT + L.col0) = ds;
 #pragma unroll
-            for (int x = 0; x < 3; ++x) T[(TA * (1 + x) + row) * FT + L.col] = gate[t][0][i] * uv[2 * x + t][0][i];
-        }
+        for (int x = 0; x < 3; ++x) *reinterpret_cast<f32x4 *>(T + (TA * (1 + x) + row) * FT + L.col0) = gate[t][0] * uv[2 * x + t][0];
+    }
     __syncthreads();
     auto gofs = [&](int row, int col) -> size_t {   // q = row / TA: 0 = s, 1..3 = v_x, v_y, v_z (tail rows clamped to the last atom)
         const int q = row / TA, a = min(a0 + row % TA, N - 1);
@@ -525,18 +538,22 @@ __device__ __forceinline__ void readout_head(const ModelW &W, const Planes &xs, 
         zero_acc(acc);
         const uint4 *wp[1] = {W.qW5 + (size_t)L.w * 4 * F};
         gemm16<F, RT, 1>(xs, wp, acc);
-        const float b = W.b5[L.col], w6 = W.w6[L.col];
+        const f32x4 b = gload4f(W.b5 + L.col0), w6 = gload4f(W.w6 + L.col0);
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
+        for (int t = 0; t < RT; ++t) {
+            const f32x4 hval = acc[t][0] + b;
+            f32x4 hb;
+            float es = 0.f;   // the tile's 16 hidden units of atom row(t): 4 in this lane, then the 4 lane groups, fixed order
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float hval = acc[t][0][i] + b;
-                float es = w6 * swish(hval);
-                if (WANT_SBAR) store_split(hp, L.row(t, i), L.col, w6 * dswish(hval));
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) es += __shfl_xor(es, off, 16);   // the tile's 16 hidden units, fixed order
-                if ((lane & 15) == 0) red[L.w * TA + L.row(t, i)] = es;
+                es = fmaf(w6[i], swish(hval[i]), es);
+                hb[i] = w6[i] * dswish(hval[i]);
             }
+            if (WANT_SBAR) store_split4(hp, L.row(t), L.col0, hb);
+            es += __shfl_xor(es, 16, 64);
+            es += __shfl_xor(es, 32, 64);
+            if (lane < 16) red[L.w * TA + L.row(t)] = es;
+        }
     }
     __syncthreads();
     if (threadIdx.x < TA) {
@@ -607,12 +624,10 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     f32x4 sb[RT];   // sbar in the accumulator layout
     if (MODE != 1) {   // requested first, needed after the head / the forward recomputation
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sb[t][i] = sbar_src[(mN + min(a0 + L.row(t, i), N - 1)) * F + L.col];
+        for (int t = 0; t < RT; ++t) sb[t] = gload4f(sbar_src + (mN + min(a0 + L.row(t), N - 1)) * F + L.col0);
     }
     // vbar of the tile (96 rows, fp32) stays in LDS behind the planes for the whole kernel: it is needed three times in the
-    // accumulator layout (one column per lane), where direct global reads are scalar, uncoalesced and latency-exposed
+    // accumulator layout (an atom row and four columns per lane): one ds_read_b128 each instead of global round trips
     float *VB = reinterpret_cast<float *>(ldsh + UPD_LDS_HALVES);   // [x * TA + atom][FT]
     if (MODE == 1) vbar_is_zero = 1;   // (the region hosts the readout scratch)
     if (!vbar_is_zero) {
@@ -670,11 +685,14 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         load_update_v<RT>(ldsh, v_msg, mN, a0, N);   // the v tile takes the place of the phibar tile
         PH(44)
         {
-            const float b = Wn.b1[L.col];
+            const f32x4 b = gload4f(Wn.b1 + L.col0);
 #pragma unroll
-            for (int t = 0; t < RT; ++t)
+            for (int t = 0; t < RT; ++t) {
+                f32x4 hv;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) store_split(xs, L.row(t, i), L.col, a1[t][0][i] * dswish(h1[t][0][i] + b));
+                for (int i = 0; i < 4; ++i) hv[i] = a1[t][0][i] * dswish(h1[t][0][i] + b[i]);
+                store_split4(xs, L.row(t), L.col0, hv);
+            }
         }
         __syncthreads();
         f32x4 acc[RT][1];
@@ -693,19 +711,21 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     // Every wave has passed the barrier in front of GEMM3, i.e. finished GEMM1/GEMM2: vt and hs are free.
     const Planes qb = make_planes(ldsh + OFF_VT, TA, F3);    // overlays vt
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+    for (int t = 0; t < RT; ++t) {
+        const int row = L.row(t);
+        f32x4 abar_vv = {0.f, 0.f, 0.f, 0.f};
+        if (!vbar_is_zero) {   // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = L.row(t, i);
-            float abar_vv = 0.f;
-            if (!vbar_is_zero) {   // wave-uniform
+            for (int x = 0; x < 3; ++x) {
+                const f32x4 vb = *reinterpret_cast<const f32x4 *>(VB + (x * TA + row) * FT + L.col0);
 #pragma unroll
-                for (int x = 0; x < 3; ++x) abar_vv = fmaf(VB[(x * TA + row) * FT + L.col], R.uv[RT * x + t][0][i], abar_vv);
+                for (int i = 0; i < 4; ++i) abar_vv[i] = fmaf(vb[i], R.uv[RT * x + t][0][i], abar_vv[i]);
             }
-            store_split(qb, row, L.col, abar_vv);
-            store_split(qb, row, F + L.col, sb[t][i] * R.inner[t][i]);
-            store_split(qb, row, 2 * F + L.col, sb[t][i]);
         }
+        store_split4(qb, row, L.col0, abar_vv);
+        store_split4(qb, row, F + L.col0, sb[t] * R.inner[t]);
+        store_split4(qb, row, 2 * F + L.col0, sb[t]);
+    }
     PH(23)
     __syncthreads();   // qb complete; every wave is past GEMM3, so `as` may be overwritten
     PH(24)
@@ -716,14 +736,17 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         const uint4 *wp[1] = {WTILE(W4t, L.w, F3)};
         gemm16<F3, RT, 1, UPD_PF>(qb, wp, acc);
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
+        for (int t = 0; t < RT; ++t) {
+            f32x4 hv;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) store_split(hb, L.row(t, i), L.col, acc[t][0][i] * dswish(R.h3[t][i]));
+            for (int i = 0; i < 4; ++i) hv[i] = acc[t][0][i] * dswish(R.h3[t][i]);
+            store_split4(hb, L.row(t), L.col0, hv);
+        }
     }
     PH(25)
     __syncthreads();
     PH(26)
-    f32x4 hbar[RT][2];   // [t][0] = d/d s_msg part, [t][1] = d/d norm part, both for feature `col`
+    f32x4 hbar[RT][2];   // [t][0] = d/d s_msg part, [t][1] = d/d norm part, both for this lane's four features
     zero_acc(hbar);
     {
         const uint4 *wp[2] = {WTILE(W3t, L.w, F), WTILE(W3t, NW + L.w, F)};
@@ -734,21 +757,29 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     PH(28)
     const Planes ab = make_planes(ldsh, 3 * TA, 2 * F);     // cols [0,F) = Ubar, [F,2F) = Vbar
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+    for (int t = 0; t < RT; ++t) {
+        const int row = L.row(t);
+        f32x4 sc, sa;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = L.row(t, i);
-            const float avv = R.gate[t][0][i], asv = R.gate[t][1][i];
-            const float sc = hbar[t][1][i] / R.nrm[t][i];
-            const float sa = sb[t][i] * asv;
-#pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                const float vbo = vbar_is_zero ? 0.f : VB[(x * TA + row) * FT + L.col];
-                const float u = R.uv[RT * x + t][0][i], v = R.uv[RT * x + t][1][i];
-                store_split(ab, x * TA + row, L.col, fmaf(vbo, avv, sa * v));
-                store_split(ab, x * TA + row, F + L.col, fmaf(sa, u, sc * v));
-            }
+            sc[i] = hbar[t][1][i] / R.nrm[t][i];
+            sa[i] = sb[t][i] * R.gate[t][1][i];
         }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            f32x4 vbo = {0.f, 0.f, 0.f, 0.f};
+            if (!vbar_is_zero) vbo = *reinterpret_cast<const f32x4 *>(VB + (x * TA + row) * FT + L.col0);
+            f32x4 ub, vb2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float u = R.uv[RT * x + t][0][i], v = R.uv[RT * x + t][1][i];
+                ub[i] = fmaf(vbo[i], R.gate[t][0][i], sa[i] * v);
+                vb2[i] = fmaf(sa[i], u, sc[i] * v);
+            }
+            store_split4(ab, x * TA + row, L.col0, ub);
+            store_split4(ab, x * TA + row, F + L.col0, vb2);
+        }
+    }
     PH(29)
     __syncthreads();
     PH(30)
@@ -763,14 +794,12 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     PH(32)
     float *T = reinterpret_cast<float *>(ldsh);   // rows [0, TA): sbar_msg, rows TA (1 + x) + atom: increment of vbar_msg_x
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+    for (int t = 0; t < RT; ++t) {
+        const int row = L.row(t);
+        *reinterpret_cast<f32x4 *>(T + row * FT + L.col0) = sb[t] + hbar[t][0];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = L.row(t, i);
-            T[row * FT + L.col] = sb[t][i] + hbar[t][0][i];
-#pragma unroll
-            for (int x = 0; x < 3; ++x) T[(TA * (1 + x) + row) * FT + L.col] = out[RT * x + t][0][i];
-        }
+        for (int x = 0; x < 3; ++x) *reinterpret_cast<f32x4 *>(T + (TA * (1 + x) + row) * FT + L.col0) = out[RT * x + t][0];
+    }
     __syncthreads();
     stage_rows<4 * TA>(T, [&](int row, int col, const float4 &d) {
         const int q = row / TA, a = a0 + row % TA;
