@@ -525,13 +525,16 @@ int painn_run(vssr_handle *h, uint32_t want) {
             if (rc) return rc;
             P.end(st);
             P.begin(KC_UPDATE_FWD, st);
-            launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
+            launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1],
+                                   l + 1 < L ? sv.phi[l + 1] : nullptr);
             P.end(st);
             continue;
         }
-        P.begin(KC_MSG_MLP, st);
-        launch_msg_mlp_mfma(st, N, M, l, av, MW, sv.s_in[l], sv.phi[l]);
-        P.end(st);
+        if (l == 0) {   // (phi of layers >= 1 is the tail of the previous layer's update kernel)
+            P.begin(KC_MSG_MLP, st);
+            launch_msg_mlp_mfma(st, N, M, l, av, MW, sv.s_in[l], sv.phi[l]);
+            P.end(st);
+        }
         P.begin(KC_EDGE_FWD, st);
         if (use_edge_mfma && l > 0)
             launch_edge_fwd_mfma(st, N, h->n_cfg, M, l, h->max_cfg_atoms, MW, G, counters, (int)(h->slot_cap - 1),
@@ -546,7 +549,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
                                sv.v_msg[l]);
         P.end(st);
         P.begin(KC_UPDATE_FWD, st);
-        launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1]);
+        launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1],
+                               l + 1 < L ? sv.phi[l + 1] : nullptr);
         P.end(st);
     }
     // Readout.  With forces wanted (and the compiled readout width) it runs as the head of the last layer's reverse kernel;

@@ -376,21 +376,26 @@ __device__ __forceinline__ void load_update_s(_Float16 *ldsh, const float *__res
     load_rows_split<TA>(hs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
 }
 
-// Forward kernel with a compact LDS layout (70 KB instead of 103 KB): TWO workgroups share a CU, so the barriers and the
-// latency-bound phases of one overlap the matrix work of the other (the kernel needs 128 VGPRs: 4 waves per SIMD fit).
+// Forward kernel, compact LDS layout:
 //   [0, VT): v tile (h | l planes, 96 rows)  -- after GEMM1: |Vv| plane at 0, swish(h3) plane behind it, at the end the
 //   [VT, VT + XS): s tile (32 rows)             fp32 output tile over everything
+//   [CF_LDS_HALVES, + XS): planes of the block's scalar OUTPUT (TAIL = 1 only)
 constexpr int CF_XS = plane_halves(3 * TA, F);                    // halves
 constexpr int CF_LDS_HALVES = CF_XS + plane_halves(TA, F);        // 34 816 halves = 69 632 B
 static_assert(2 * plane_halves(TA, F) <= CF_XS, "|Vv| and swish planes overlay the v tile");
 static_assert(4 * TA * FT * sizeof(float) <= CF_LDS_HALVES * sizeof(_Float16), "output tile overlays the planes");
-// BIG = 1: one workgroup per CU with the 256-register budget instead: the fp32 input tile stays in the registers of the
-// threads that loaded it and serves as the residual of the output pass (no second read of s_msg / v_msg), and the GEMMs
-// run the software pipeline.
-template <int BIG>
-__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 2 : 4, BIG ? 2 : 4)))
+// One workgroup per CU with the 256-register budget: the fp32 input tile stays in the registers of the threads that loaded
+// it and serves as the residual of the output pass (no second read of s_msg / v_msg), and the GEMMs run the software
+// pipeline.  (A 128-register variant with two workgroups per CU re-read the residual and could not pipeline: 1.15 vs 1.09
+// ms / step, profiles/r02/NOTES_node_kernels.md.)
+// TAIL = 1: the message MLP of the NEXT layer, phi = W2 swish(W1 s_out + b1) + b2 (weights of layer l + 1), runs as the
+// kernel's tail on the scalar output tile while it is still on the chip: its planes are written by the output pass, the
+// separate k_msg_mlp_mfma launch and its read of s disappear.
+template <int TAIL>
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
-                  const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out) {
+                  const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out,
+                  float *__restrict__ phi_next) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
@@ -399,22 +404,14 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     const size_t mN = (size_t)m * N;
     const Planes vt = make_planes(ldsh, 3 * TA, F), xs = make_planes(ldsh + CF_XS, TA, F);
     const Planes nr = make_planes(ldsh, TA, F), as_ = make_planes(ldsh + plane_halves(TA, F), TA, F);   // overlays of vt
-    constexpr int PF = BIG ? 1 : 0;
-    float4 keep_v[BIG ? 3 * TA * (F / 4) / NTHREADS : 1], keep_s[BIG ? TA * (F / 4) / NTHREADS : 1];
+    constexpr int PF = 1;
+    float4 keep_v[3 * TA * (F / 4) / NTHREADS], keep_s[TA * (F / 4) / NTHREADS];
     PH_INIT
-    if constexpr (BIG != 0) {
-        load_rows_split_keep<3 * TA>(vt, 0, [&](int row) {
-            int x = row / TA, a = min(a0 + (row % TA), N - 1);
-            return v_msg + ((mN + a) * 3 + x) * F;
-        }, keep_v);
-        load_rows_split_keep<TA>(xs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; }, keep_s);
-    } else {
-        load_rows_split<3 * TA>(vt, 0, [&](int row) {
-            int x = row / TA, a = min(a0 + (row % TA), N - 1);
-            return v_msg + ((mN + a) * 3 + x) * F;
-        });
-        load_rows_split<TA>(xs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
-    }
+    load_rows_split_keep<3 * TA>(vt, 0, [&](int row) {
+        int x = row / TA, a = min(a0 + (row % TA), N - 1);
+        return v_msg + ((mN + a) * 3 + x) * F;
+    }, keep_v);
+    load_rows_split_keep<TA>(xs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; }, keep_s);
     __syncthreads();
     PH(0)
     f32x4 uv[6][2];   // [2 x + t][0] = U v_x, [..][1] = V v_x
@@ -501,24 +498,57 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
         return q == 0 ? (mN + a) * F + col : ((mN + a) * 3 + (q - 1)) * F + col;
     };
     PH(9)
+    const Planes xo = make_planes(ldsh + CF_LDS_HALVES, TA, F);   // TAIL: planes of s_out behind the output tile
     auto put = [&](int row, int col, const float4 &d, const float4 &r) {
+        const float4 o = make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
+        if (TAIL && row < TA) store_split4(xo, row, col, o);   // (rows past the last atom: clamped copies, never stored)
         if (a0 + row % TA >= N) return;
-        *reinterpret_cast<float4 *>((row < TA ? s_out : v_out) + gofs(row, col)) =
-            make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
+        *reinterpret_cast<float4 *>((row < TA ? s_out : v_out) + gofs(row, col)) = o;
     };
-    if constexpr (BIG != 0) {   // the loading pass and this pass map (thread, iteration) to (row, column) identically: rows [0, TA) = s
+    {   // the loading pass and this pass map (thread, iteration) to (row, column) identically: rows [0, TA) = s
         constexpr int NS = TA * (F / 4) / NTHREADS, NV = 3 * TA * (F / 4) / NTHREADS;
 #pragma unroll
         for (int it = 0; it < NS + NV; ++it) {
             const int idx = threadIdx.x + it * NTHREADS, row = idx >> 5, c4 = idx & 31;
             put(row, 4 * c4, *reinterpret_cast<const float4 *>(T + row * FT + 4 * c4), it < NS ? keep_s[it < NS ? it : 0] : keep_v[it < NS ? 0 : it - NS]);
         }
-    } else {
-        stage_rows_residual<4 * TA>(
-            T, [&](int row, int col) { return *reinterpret_cast<const float4 *>((row < TA ? s_msg : v_msg) + gofs(row, col)); },
-            put);
     }
     PH(10)
+    if constexpr (TAIL != 0) {
+        const LayerW &Wn = MW[m].layer[l + 1];
+        const Planes hn = make_planes(ldsh, TA, F);   // swish(W1 s + b1), over the (finished) output tile
+        __syncthreads();   // s_out planes complete; every wave is done with the output tile
+        {
+            f32x4 acc[2][1];
+            zero_acc(acc);
+            const uint4 *wp[1] = {Wn.qW1 + (size_t)L.w * 4 * F};
+            gemm16<F, 2, 1, 1>(xo, wp, acc);
+            const f32x4 b = gload4f(Wn.b1 + L.col0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 hv = acc[t][0] + b;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[i] = swish(hv[i]);
+                store_split4(hn, L.row(t), L.col0, hv);
+            }
+        }
+        __syncthreads();
+        f32x4 acc[2][3];
+        zero_acc(acc);
+        const uint4 *wp[3] = {Wn.qW2 + (size_t)L.w * 4 * F, Wn.qW2 + (size_t)(NW + L.w) * 4 * F,
+                              Wn.qW2 + (size_t)(2 * NW + L.w) * 4 * F};
+        gemm16<F, 2, 3, 1>(hn, wp, acc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x4 b = gload4f(Wn.b2 + c * F + L.col0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int a = a0 + L.row(t);
+                if (a < N) *reinterpret_cast<f32x4 *>(phi_next + (mN + a) * F3 + c * F + L.col0) = acc[t][c] + b;
+            }
+        }
+        PH(11)
+    }
 }
 
 // ---- readout on the matrix pipe ---------------------------------------------------------------
@@ -847,9 +877,8 @@ size_t node_mfma_lds_bytes(int which) {
     switch (which) {
         case 0: return sizeof(_Float16) * 2 * plane_halves(TA, F);                        // msg mlp fwd
         case 1: return sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(TA, F3));   // msg mlp bwd
-        case 2: return sizeof(_Float16) * CF_LDS_HALVES;                                  // update fwd (compact layout)
         case 4: return sizeof(_Float16) * (plane_halves(TA, F) + plane_halves(TA, RH)) + sizeof(float) * (RH / 16) * TA;   // readout
-        case 6: return 96 * 1024;   // update fwd, one workgroup per CU: the LDS request keeps a second workgroup off the CU
+        case 6: return 96 * 1024;   // update fwd: compact layout + the s_out planes of the fused tail (87 040 B), one workgroup per CU
         default: return sizeof(_Float16) * UpdLds<2>::HALVES + sizeof(float) * 3 * TA * FT;  // update bwd: planes + fp32 vbar tile
     }
 }
@@ -858,7 +887,7 @@ static_assert(sizeof(_Float16) * plane_halves(16, RH) + sizeof(float) * (RH / 16
 // (RT = 1 -- 16-atom tiles, two workgroups per CU -- was measured at -5 % for this kernel without the pipelined GEMMs and
 // spills with them; only RT = 2 is instantiated.  profiles/r02/NOTES_node_kernels.md)
 
-static bool g_updfwd_big = true;   // VSSR_UPDFWD_BIG=0 selects the two-workgroups-per-CU variant (128 registers, residual re-read)
+static_assert(sizeof(_Float16) * (CF_LDS_HALVES + plane_halves(TA, F)) <= 96 * 1024, "update fwd LDS request");
 
 bool readout_mfma_supported(int hidden) { return hidden == RH; }
 
@@ -868,10 +897,9 @@ int node_mfma_init(vssr_handle *h) {
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(1)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)node_mfma_lds_bytes(2)));
+                                    (int)node_mfma_lds_bytes(6)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(6)));
-    if (const char *e = getenv("VSSR_UPDFWD_BIG")) g_updfwd_big = atoi(e) != 0;
 #define SET_UPD(MODE)                                                                                                     \
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma<MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)node_mfma_lds_bytes(3)));
@@ -892,14 +920,15 @@ void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ActiveVi
     hipLaunchKernelGGL(k_msg_mlp_bwd_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(1), st, N, l, av, MW,
                        s_in, phibar, sbar_msg, sbar_in);
 }
+// phi_next != nullptr: also phi of layer l + 1 (the fused message MLP; layer l + 1 must exist)
 void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_msg,
-                            const float *v_msg, float *s_out, float *v_out) {
-    if (g_updfwd_big)
+                            const float *v_msg, float *s_out, float *v_out, float *phi_next) {
+    if (phi_next)
         hipLaunchKernelGGL(k_update_fwd_mfma<1>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(6), st, N, l,
-                           av, MW, s_msg, v_msg, s_out, v_out);
+                           av, MW, s_msg, v_msg, s_out, v_out, phi_next);
     else
-        hipLaunchKernelGGL(k_update_fwd_mfma<0>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(2), st, N, l,
-                           av, MW, s_msg, v_msg, s_out, v_out);
+        hipLaunchKernelGGL(k_update_fwd_mfma<0>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(6), st, N, l,
+                           av, MW, s_msg, v_msg, s_out, v_out, phi_next);
 }
 void launch_readout_mfma(hipStream_t st, int N, int M, const ActiveView &av, const ModelW *MW, const float *s,
                          const float *e_excl, float *e_atom) {

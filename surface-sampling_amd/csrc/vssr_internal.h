@@ -260,7 +260,7 @@ void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ActiveView &
 void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
                              const float *phibar, const float *sbar_msg, float *sbar_in);
 void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_msg,
-                            const float *v_msg, float *s_out, float *v_out);
+                            const float *v_msg, float *s_out, float *v_out, float *phi_next);
 bool readout_mfma_supported(int hidden);
 void launch_readout_mfma(hipStream_t st, int N, int M, const ActiveView &av, const ModelW *MW, const float *s, const float *e_excl,
                          float *e_atom);
