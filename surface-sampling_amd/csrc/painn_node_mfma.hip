@@ -55,9 +55,40 @@ namespace vssr {
 // read the A fragments (LDS) of group i + 1 ahead.  The loop is fully unrolled (K is a template parameter) so that the
 // buffer halves are static registers.  Issue rules as before: loads are issued in front of an MFMA block, never inside
 // it; the block is pinned with scheduling barriers.
-template <int K, int NRT, int NCT, int PF = 0>
-__device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)[NCT], f32x4 (&acc)[NRT][NCT]) {
+// Cross-GEMM preload: a GEMM phase of these kernels starts behind an epilogue and a barrier, and the first weight pieces
+// used to be requested after them -- one exposed L2 round trip per GEMM, 5 .. 9 per workgroup (phase timings:
+// profiles/r02/NOTES_node_kernels.md).  WPre holds the pieces of the first NPRE chunk groups; gemm16_preload() issues their
+// loads BEFORE the preceding epilogue (the ping-pong buffers of the previous GEMM are dead there, so the peak register
+// demand does not grow) and gemm16<..., NPRE> starts on them.  Plain global loads survive __syncthreads().
+template <int NRT, int NCT>
+struct GemmShape {
+    static constexpr int NT = NRT * NCT, NACC = NT >= 3 ? 1 : 2;
+};
+template <int NRT, int NCT, int NPRE>
+struct WPre {
+    u32x4 b[NPRE][GemmShape<NRT, NCT>::NACC][NCT][2];
+};
+template <int NRT, int NCT, int NPRE>
+__device__ __forceinline__ void gemm16_preload(const uint4 *const (&wq)[NCT], WPre<NRT, NCT, NPRE> &p) {
+    constexpr int NACC = GemmShape<NRT, NCT>::NACC;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int grp = 0; grp < NPRE; ++grp)
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc)
+                    p.b[grp][j][c][pc] = gload4u(wq[c] + ((size_t)((grp * NACC + j) * 2 + pc) * 64 + lane));
+    __builtin_amdgcn_sched_barrier(0);   // the requests stay in front of whatever follows
+}
+
+template <int K, int NRT, int NCT, int PF = 0, int NPRE = 0>
+__device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)[NCT], f32x4 (&acc)[NRT][NCT],
+                                       const WPre<NRT, NCT, (NPRE > 0 ? NPRE : 1)> *pre = nullptr) {
     constexpr int NT = NRT * NCT, NACC = NT >= 3 ? 1 : 2;
+    static_assert(NPRE == 0 || PF == 1, "preloaded groups need the pipelined path");
     constexpr int NQ = K / 32;
     static_assert(NQ % NACC == 0, "chunk groups");
     constexpr int NG = NQ / NACC;
@@ -105,7 +136,9 @@ __device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)
                         }
         }
     } else {
-        u32x4 b[2][NACC][NCT][2], a[PFA ? 2 : 1][NACC][NRT][2];
+        constexpr int NB = NPRE > 2 ? NPRE : 2;   // ring of weight-piece buffers
+        static_assert(NPRE <= NG, "more preloaded groups than the GEMM has");
+        u32x4 b[NB][NACC][NCT][2], a[PFA ? 2 : 1][NACC][NRT][2];
         auto load_b = [&](int buf, int grp) {
 #pragma unroll
             for (int j = 0; j < NACC; ++j)
@@ -126,13 +159,26 @@ __device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)
                 }
             }
         };
-        load_b(0, 0);
+        if constexpr (NPRE > 0) {
+#pragma unroll
+            for (int g0 = 0; g0 < NPRE; ++g0)
+#pragma unroll
+                for (int j = 0; j < NACC; ++j)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                        for (int pc = 0; pc < 2; ++pc) b[g0][j][c][pc] = pre->b[g0][j][c][pc];
+        } else {
+            load_b(0, 0);
+        }
         if (PFA) load_a(0, 0);
 #pragma unroll
         for (int grp = 0; grp < NG; ++grp) {
-            const int cur = grp & 1, ca = PFA ? cur : 0;
-            if (grp + 1 < NG) load_b(cur ^ 1, grp + 1);
-            if (PFA) { if (grp + 1 < NG) load_a(cur ^ 1, grp + 1); }
+            const int cur = grp % NB, ca = PFA ? (grp & 1) : 0;
+            // one group ahead into the other buffer; with NPRE >= 2 groups already on their way the ring is refilled NPRE
+            // groups ahead instead, into the buffer of THIS group, after its MFMA block (below)
+            if (NPRE < 2 && grp + 1 < NG) load_b(cur ^ 1, grp + 1);
+            if (PFA) { if (grp + 1 < NG) load_a((grp + 1) & 1, grp + 1); }
             else load_a(0, grp);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -153,6 +199,10 @@ __device__ __forceinline__ void gemm16(const Planes &A, const uint4 *const (&wq)
             // accumulators, so none of them waits inside the pipe with unread sources).
             asm volatile("; gemm16_group_end");
             __builtin_amdgcn_sched_barrier(0);
+            if (NPRE >= 2 && grp + NPRE < NG) {
+                load_b(cur, grp + NPRE);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 #pragma unroll
@@ -196,8 +246,9 @@ k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const
         f32x4 acc[2][1];
         zero_acc(acc);
         const uint4 *wp[1] = {WTILE(W1, L.w, F)};
-        gemm16<F, 2, 1>(xs, wp, acc);
         const f32x4 b = gload4f(W.b1 + L.col0);
+        __builtin_amdgcn_sched_barrier(0);   // the bias is requested in front of the GEMM whose epilogue adds it
+        gemm16<F, 2, 1>(xs, wp, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 hv = acc[t][0] + b;
@@ -210,10 +261,14 @@ k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const
     f32x4 acc[2][3];
     zero_acc(acc);
     const uint4 *wp[3] = {WTILE(W2, L.w, F), WTILE(W2, NW + L.w, F), WTILE(W2, 2 * NW + L.w, F)};
+    f32x4 b2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) b2[c] = gload4f(W.b2 + c * F + L.col0);
+    __builtin_amdgcn_sched_barrier(0);
     gemm16<F, 2, 3>(hs, wp, acc);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const f32x4 b = gload4f(W.b2 + c * F + L.col0);
+        const f32x4 b = b2[c];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int a = a0 + L.row(t);
@@ -242,6 +297,8 @@ k_msg_mlp_bwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, c
     f32x4 h1[2][1], a1[2][1];
     zero_acc(h1);
     zero_acc(a1);
+    const f32x4 b1v = gload4f(W.b1 + L.col0);
+    __builtin_amdgcn_sched_barrier(0);
     {
         const uint4 *wp[1] = {WTILE(W1, L.w, F)};
         gemm16<F, 2, 1>(xs, wp, h1);
@@ -250,7 +307,7 @@ k_msg_mlp_bwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, c
     }
     __syncthreads();  // everyone is done reading xs
     {
-        const f32x4 b = gload4f(W.b1 + L.col0);
+        const f32x4 b = b1v;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 hv;
@@ -332,8 +389,9 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
         f32x4 acc[RT][1];
         zero_acc(acc);
         const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F)};
-        gemm16<2 * F, RT, 1, UPD_PF>(hs, wp, acc);
         const f32x4 b = gload4f(W.b3 + L.col0);
+        __builtin_amdgcn_sched_barrier(0);   // the bias is requested in front of the GEMM whose epilogue adds it
+        gemm16<2 * F, RT, 1, UPD_PF>(hs, wp, acc);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             R.h3[t] = acc[t][0] + b;
@@ -349,10 +407,14 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
     {
         zero_acc(R.gate);
         const uint4 *wp[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
+        f32x4 b4[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b4[c] = gload4f(W.b4 + c * F + L.col0);
+        __builtin_amdgcn_sched_barrier(0);
         gemm16<F, RT, 3, UPD_PF>(as_, wp, R.gate);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const f32x4 b = gload4f(W.b4 + c * F + L.col0);
+            const f32x4 b = b4[c];
 #pragma unroll
             for (int t = 0; t < RT; ++t) R.gate[t][c] += b;
         }
@@ -407,6 +469,15 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     constexpr int PF = 1;
     float4 keep_v[3 * TA * (F / 4) / NTHREADS], keep_s[TA * (F / 4) / NTHREADS];
     PH_INIT
+    // weight pieces of every GEMM are requested one phase ahead (gemm16_preload): here those of the first two
+    const uint4 *wUV[2] = {WTILE(U, L.w, F), WTILE(V, L.w, F)};
+    const uint4 *wW3a[1] = {WTILE(W3, L.w, 2 * F)};
+    const uint4 *wW3b[1] = {WTILE(W3, L.w, 2 * F) + (F / 32) * 2 * 64};   // chunks F/32 .. 2F/32 - 1 of the same column tile
+    const uint4 *wW4[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
+    WPre<6, 2, 1> pUV;
+    WPre<2, 1, 1> pW3a;
+    gemm16_preload(wUV, pUV);
+    gemm16_preload(wW3a, pW3a);
     load_rows_split_keep<3 * TA>(vt, 0, [&](int row) {
         int x = row / TA, a = min(a0 + (row % TA), N - 1);
         return v_msg + ((mN + a) * 3 + x) * F;
@@ -416,17 +487,13 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     PH(0)
     f32x4 uv[6][2];   // [2 x + t][0] = U v_x, [..][1] = V v_x
     zero_acc(uv);
-    {
-        const uint4 *wp[2] = {WTILE(U, L.w, F), WTILE(V, L.w, F)};
-        gemm16<F, 6, 2, PF>(vt, wp, uv);
-    }
+    gemm16<F, 6, 2, PF, 1>(vt, wUV, uv, &pUV);
     PH(1)
     f32x4 h3[2][1];   // gate MLP, first layer: the s half of [s ; |Vv|] now, the |Vv| half after the barrier
     zero_acc(h3);
-    {
-        const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F)};
-        gemm16<F, 2, 1, PF>(xs, wp, h3);
-    }
+    gemm16<F, 2, 1, PF, 1>(xs, wW3a, h3, &pW3a);
+    WPre<2, 1, 2> pW3b;
+    gemm16_preload(wW3b, pW3b);
     PH(2)
     __syncthreads();   // every wave is done with the v tile
     PH(3)
@@ -450,10 +517,12 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     }
     __syncthreads();
     PH(4)
+    WPre<2, 3, 1> pW4;
     {
-        const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F) + (F / 32) * 2 * 64};   // chunks F/32 .. 2F/32 - 1 of the same column tile
-        gemm16<F, 2, 1, PF>(nr, wp, h3);
         const f32x4 b = gload4f(W.b3 + L.col0);
+        __builtin_amdgcn_sched_barrier(0);   // the bias is requested in front of the GEMM whose epilogue adds it
+        gemm16<F, 2, 1, PF, 2>(nr, wW3b, h3, &pW3b);
+        gemm16_preload(wW4, pW4);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 sw = h3[t][0] + b;
@@ -467,14 +536,25 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     PH(6)
     f32x4 gate[2][3];   // a_vv, a_sv, a_ss
     zero_acc(gate);
+    const uint4 *wW1n[1] = {nullptr}, *wW2n[3] = {nullptr, nullptr, nullptr};
+    WPre<2, 1, 2> pW1n;
     {
-        const uint4 *wp[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
-        gemm16<F, 2, 3, PF>(as_, wp, gate);
+        f32x4 b4[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b4[c] = gload4f(W.b4 + c * F + L.col0);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm16<F, 2, 3, PF, 1>(as_, wW4, gate, &pW4);
+        if constexpr (TAIL != 0) {
+            const LayerW &Wn = MW[m].layer[l + 1];
+            wW1n[0] = Wn.qW1 + (size_t)L.w * 4 * F;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wW2n[c] = Wn.qW2 + (size_t)(c * NW + L.w) * 4 * F;
+            gemm16_preload(wW1n, pW1n);
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const f32x4 b = gload4f(W.b4 + c * F + L.col0);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) gate[t][c] += b;
+            for (int t = 0; t < 2; ++t) gate[t][c] += b4[c];
         }
     }
     PH(7)
@@ -518,12 +598,14 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
         const LayerW &Wn = MW[m].layer[l + 1];
         const Planes hn = make_planes(ldsh, TA, F);   // swish(W1 s + b1), over the (finished) output tile
         __syncthreads();   // s_out planes complete; every wave is done with the output tile
+        WPre<2, 3, 1> pW2n;
         {
             f32x4 acc[2][1];
             zero_acc(acc);
-            const uint4 *wp[1] = {Wn.qW1 + (size_t)L.w * 4 * F};
-            gemm16<F, 2, 1, 1>(xo, wp, acc);
             const f32x4 b = gload4f(Wn.b1 + L.col0);
+            __builtin_amdgcn_sched_barrier(0);   // the bias is requested in front of the GEMM whose epilogue adds it
+            gemm16<F, 2, 1, 1, 2>(xo, wW1n, acc, &pW1n);
+            gemm16_preload(wW2n, pW2n);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 hv = acc[t][0] + b;
@@ -535,12 +617,14 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
         __syncthreads();
         f32x4 acc[2][3];
         zero_acc(acc);
-        const uint4 *wp[3] = {Wn.qW2 + (size_t)L.w * 4 * F, Wn.qW2 + (size_t)(NW + L.w) * 4 * F,
-                              Wn.qW2 + (size_t)(2 * NW + L.w) * 4 * F};
-        gemm16<F, 2, 3, 1>(hn, wp, acc);
+        f32x4 b2[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b2[c] = gload4f(Wn.b2 + c * F + L.col0);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm16<F, 2, 3, 1, 1>(hn, wW2n, acc, &pW2n);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const f32x4 b = gload4f(Wn.b2 + c * F + L.col0);
+            const f32x4 b = b2[c];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int a = a0 + L.row(t);
@@ -567,8 +651,9 @@ __device__ __forceinline__ void readout_head(const ModelW &W, const Planes &xs, 
         f32x4 acc[RT][1];
         zero_acc(acc);
         const uint4 *wp[1] = {W.qW5 + (size_t)L.w * 4 * F};
-        gemm16<F, RT, 1>(xs, wp, acc);
         const f32x4 b = gload4f(W.b5 + L.col0), w6 = gload4f(W.w6 + L.col0);
+        __builtin_amdgcn_sched_barrier(0);   // the bias is requested in front of the GEMM whose epilogue adds it
+        gemm16<F, RT, 1>(xs, wp, acc);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const f32x4 hval = acc[t][0] + b;
@@ -704,6 +789,8 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         f32x4 h1[RT][1], a1[RT][1];
         zero_acc(h1);
         zero_acc(a1);
+        const f32x4 b1n = gload4f(Wn.b1 + L.col0);
+        __builtin_amdgcn_sched_barrier(0);
         {
             const uint4 *wp[1] = {Wn.qW1 + (size_t)L.w * 4 * F};
             gemm16<F, RT, 1, UPD_PF>(xs, wp, h1);
@@ -715,7 +802,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         load_update_v<RT>(ldsh, v_msg, mN, a0, N);   // the v tile takes the place of the phibar tile
         PH(44)
         {
-            const f32x4 b = gload4f(Wn.b1 + L.col0);
+            const f32x4 b = b1n;
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 f32x4 hv;
