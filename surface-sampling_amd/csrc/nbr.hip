@@ -461,11 +461,19 @@ int build_neighbors(vssr_handle *h, double cutoff) {
             return set_err(h, VSSR_E_NOMEM, "edge geometry tables: out of device memory");
         // the last slot of the capacity is never used by the CSR (counters[2] flags slots > cap - 64): it is the
         // all-zero table entry that exhausted lanes of the edge kernels read
-        VSSR_HIP(h, hipMemsetAsync(h->d_rho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
-        VSSR_HIP(h, hipMemsetAsync(h->d_drho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
-        // fp16 tables: the last complete QUAD of the capacity is the all-zero entry (quad-interleaved layout, f16_unit)
-        VSSR_HIP(h, hipMemsetAsync(h->d_rho16.as<uint4>() + 32 * (size_t)((h->slot_cap >> 2) - 1), 0, 32 * sizeof(uint4), st));
-        VSSR_HIP(h, hipMemsetAsync(h->d_drho16.as<uint4>() + 32 * (size_t)((h->slot_cap >> 2) - 1), 0, 32 * sizeof(uint4), st));
+        // (nothing ever writes them: cleared once per allocation / capacity, not once per evaluation)
+        const void *tabs[4] = {h->d_rho.as<float>(), h->d_drho.as<float>(), h->d_rho16.as<uint4>(), h->d_drho16.as<uint4>()};
+        bool cleared = h->zero_entry_cap == h->slot_cap;
+        for (int k = 0; k < 4; ++k) cleared = cleared && h->zero_entry_tab[k] == tabs[k];
+        if (!cleared) {
+            VSSR_HIP(h, hipMemsetAsync(h->d_rho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
+            VSSR_HIP(h, hipMemsetAsync(h->d_drho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
+            // fp16 tables: the last complete QUAD of the capacity is the all-zero entry (quad-interleaved layout, f16_unit)
+            VSSR_HIP(h, hipMemsetAsync(h->d_rho16.as<uint4>() + 32 * (size_t)((h->slot_cap >> 2) - 1), 0, 32 * sizeof(uint4), st));
+            VSSR_HIP(h, hipMemsetAsync(h->d_drho16.as<uint4>() + 32 * (size_t)((h->slot_cap >> 2) - 1), 0, 32 * sizeof(uint4), st));
+            h->zero_entry_cap = h->slot_cap;
+            for (int k = 0; k < 4; ++k) h->zero_entry_tab[k] = tabs[k];
+        }
         hipLaunchKernelGGL(k_edge_geom, dim3(n), dim3(64), 0, st, n, h->d_row_start.as<int>(), h->d_atom_cfg.as<int>(),
                            h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,
                            h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),

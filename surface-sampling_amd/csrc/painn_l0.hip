@@ -95,25 +95,41 @@ k_l0_fwd16(int N, int M, int nz, ActiveView av, const int *__restrict__ counters
     const LaneGeo L;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     // T[(i nz + z) 96 + comp 24 + kappa] -> planes; the 8 pad entries of every species chunk are zero
-    for (int t = threadIdx.x; t < TA * nz * 4 * 32; t += NTHREADS) {
-        const int kap = t & 31, comp = (t >> 5) & 3, z = (t >> 7) % nz, a = t / (128 * nz);
-        const float val = kap < KP ? T[((size_t)min(a0 + a, N - 1) * nz + z) * TBLK + comp * KP + kap] : 0.f;
-        if (comp == 0) store_split(Ts, a, 32 * z + kap, val);
-        else store_split(Tv, (comp - 1) * TA + a, 32 * z + kap, val);
+    // (four entries per thread and pass: 16-byte loads, 8-byte plane stores; KP = 24 is a multiple of 4)
+    for (int t = threadIdx.x; t < TA * nz * 4 * 8; t += NTHREADS) {
+        const int k4 = t & 7, comp = (t >> 3) & 3, z = (t >> 5) % nz, a = t / (32 * nz);
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * k4 < KP)
+            val = *reinterpret_cast<const float4 *>(T + ((size_t)min(a0 + a, N - 1) * nz + z) * TBLK + comp * KP + 4 * k4);
+        if (comp == 0) store_split4(Ts, a, 32 * z + 4 * k4, val);
+        else store_split4(Tv, (comp - 1) * TA + a, 32 * z + 4 * k4, val);
     }
     __syncthreads();
+    // weight pieces of step (m, q + 1) are requested before the matrix instructions of step (m, q)
+    u32x4 bn[2][2];
+    auto load_w = [&](int mm, int qq) {
+        const uint4 *wb = A16 + (((size_t)mm * n_embed + zlist[qq]) * 2) * L0_TILE_U4 + (size_t)L.w * 128 + lane;
+#pragma unroll
+        for (int sec = 0; sec < 2; ++sec)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) bn[sec][pc] = gload4u(wb + sec * L0_TILE_U4 + pc * 64);
+    };
+    load_w(0, 0);
     for (int m = 0; m < M; ++m) {
         f32x4 acc[8];   // tiles 0, 1: scalar rows ; 2 + 2 x + t: component x, rows 16 t ..
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int q = 0; q < nz; ++q) {
-            const uint4 *wb = A16 + (((size_t)m * n_embed + zlist[q]) * 2) * L0_TILE_U4 + (size_t)L.w * 128 + lane;
             u32x4 b[2][2], a[8][2];
 #pragma unroll
             for (int sec = 0; sec < 2; ++sec)
 #pragma unroll
-                for (int pc = 0; pc < 2; ++pc) b[sec][pc] = gload4u(wb + sec * L0_TILE_U4 + pc * 64);
+                for (int pc = 0; pc < 2; ++pc) b[sec][pc] = bn[sec][pc];
+            {
+                const int qn = q + 1 < nz ? q + 1 : 0, mn = q + 1 < nz ? m : m + 1;
+                if (mn < M) load_w(mn, qn);   // (workgroup-uniform)
+            }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const Planes &P = t < 2 ? Ts : Tv;
@@ -167,13 +183,20 @@ k_l0_q16(int N, int nz, ActiveView av, const int *__restrict__ counters, const i
         f32x4 acc[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int c = 0; c < F / 32; ++c) {
-            u32x4 b[2][2], a[8][2];
+        // weight pieces one chunk ahead (ping-pong registers; the loop is unrolled so that the halves are static)
+        u32x4 bb[2][2][2];
+        auto load_w = [&](int buf, int c) {
 #pragma unroll
             for (int sec = 0; sec < 2; ++sec)
 #pragma unroll
-                for (int pc = 0; pc < 2; ++pc) b[sec][pc] = gload4u(wb + sec * L0_TILE_U4 + (c * 2 + pc) * 64);
+                for (int pc = 0; pc < 2; ++pc) bb[buf][sec][pc] = gload4u(wb + sec * L0_TILE_U4 + (c * 2 + pc) * 64);
+        };
+        load_w(0, 0);
+#pragma unroll
+        for (int c = 0; c < F / 32; ++c) {
+            u32x4 (&b)[2][2] = bb[c & 1];
+            u32x4 a[8][2];
+            if (c + 1 < F / 32) load_w((c + 1) & 1, c + 1);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const Planes &P = t < 2 ? Xs : Xv;
