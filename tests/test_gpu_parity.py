@@ -282,6 +282,37 @@ def test_error_paths(golden, engine):
     assert np.isfinite(lone["energy"][0]) and np.abs(lone["forces"]).max() == 0.0
 
 
+def test_other_readout_width_runs_the_unfused_reverse_path(golden, oracle_mod):
+    """A readout hidden width other than the compiled 64 takes the unfused path: stand-alone readout (painn.hip), reverse
+    update kernel reading sbar from memory (MODE 0), stand-alone reverse message MLP (k_msg_mlp_bwd_mfma).  Models: the
+    shipped ones with the readout cut to its first 32 hidden units (blob layout: include/vssr_eval.h)."""
+    from surface_sampling_amd import backend, structures
+
+    F, H, H2 = 128, 64, 32
+    tail = H * F + H + H + 1
+    cut = []
+    for b in golden.blobs:
+        head, t = b[:-tail], b[-tail:]
+        w5, b5, w6, b6 = t[:H * F].reshape(H, F), t[H * F:H * F + H], t[H * F + H:H * F + 2 * H], t[-1:]
+        cut.append(np.concatenate([head, w5[:H2].ravel(), b5[:H2], w6[:H2], b6]).astype(np.float32))
+    table, const = golden.offset_table()
+    base = golden.structure("SrTiO3_2x2_pristine")
+    chains = [structures.synth_chain(base, c, grid=(4, 4)) for c in (3, 11)]
+    eng = backend.PainnEngine(cut, device=0, offset_per_z=table, offset_const=const, hparams={"readout_hidden": H2})
+    res = eng.evaluate([_arrays(s) for s in chains])
+    e_only = eng.evaluate([_arrays(s) for s in chains], want=backend.WANT_ENERGY)
+    eng.close()
+    hp = oracle_mod.default_hparams(readout_hidden=H2)
+    for b, s in enumerate(chains):
+        ref = oracle_mod.ensemble(cut, s.numbers, s.positions, s.cell, s.pbc, 64, table, const, hp=hp)
+        a0, a1 = res["cfg_start"][b], res["cfg_start"][b + 1]
+        assert abs(float(res["energy"][b]) - ref["energy"]) <= E_TOL
+        assert np.abs(res["forces"][a0:a1] - ref["forces"]).max() <= F_TOL
+        assert abs(float(res["energy_std"][b]) - ref["energy_std"]) <= STD_TOL
+        assert float(e_only["energy"][b]) == float(res["energy"][b])   # energy-only evaluation: same readout kernel
+
+
+@pytest.mark.gpu
 def test_fallback_paths_large_chain_many_species_and_forced_gather(golden, oracle_mod):
     """Paths that the BASELINE workload does not touch: (1) a chain too large for the LDS slices (960 atoms) runs
     the gather kernels, (2) more than 8 species disables the layer-0 factorisation, (3) forcing the gather kernels
