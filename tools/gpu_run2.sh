@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of runtime knobs (env) on the same box: KNOB="VSSR_UPD_RT" VALUES="2 1"
+# A/B of runtime knobs (env) on the same box: KNOB="VSSR_L0_FACTORISE" VALUES="1 0"
 mkdir -p gpurun_out; rm -f gpurun_out/ab.log
 for v in $VALUES; do
   echo "== $KNOB=$v parity"; env $KNOB=$v timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
