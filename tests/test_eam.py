@@ -24,6 +24,45 @@ def cu():
             "funcfl": eam.read_funcfl(os.path.join(GOLDEN, "Cu_u3.eam"))}
 
 
+@pytest.fixture(scope="module")
+def au():
+    """Au(110) 2 x 2 slab and the 8 site coordinates of the reference's own regression test (tests/test_Au.py)."""
+    from surface_sampling_amd import eam, structures
+
+    d = np.load(os.path.join(GOLDEN, "au110.npz"))
+    slab = structures.Structure(d["numbers"], d["positions"], d["cell"], d["pbc"])
+    with open(os.path.join(GOLDEN, "eam_kat.json")) as fh:
+        kat = json.load(fh)["au110"]
+    return {"slab": slab, "sites": d["ads_coords"], "kat": kat, "funcfl": eam.read_funcfl(os.path.join(GOLDEN, "Au_u3.eam"))}
+
+
+def _au_states(au):
+    """All ways of placing the test's 4 + 2 Au adatoms on its 8 sites."""
+    from surface_sampling_amd import structures
+
+    slab, sites, k = au["slab"], au["sites"], au["kat"]["num_ads_atoms"]
+    out = []
+    for sub in itertools.combinations(range(len(sites)), k):
+        out.append(structures.Structure(np.concatenate([slab.numbers, np.full(k, 79, np.int32)]),
+                                        np.vstack([slab.positions, sites[list(sub)]]), slab.cell, slab.pbc))
+    return out
+
+
+def test_eam_oracle_reproduces_the_au110_minimum(au):
+    """tests/test_Au.py:19 asserts min(energy_hist) == -79.03490823689619 for canonical MC with 6 Au adatoms on the 8 given
+    sites (static energies).  The minimum over ALL 28 such states is a state-independent-of-RNG quantity: the oracle gives
+    the reference's number to 13 digits (the symmetry-equivalent state differs by 3e-6: rounded CIF coordinates)."""
+    import eam_oracle
+
+    f = au["funcfl"]
+    assert (f.atomic_number, f.lattice) == (79, "FCC")
+    e = sorted(eam_oracle.eam(f, s.positions, s.cell, s.pbc)[0] for s in _au_states(au))
+    target = au["kat"]["min_energy"]["value"]
+    assert np.allclose(e[0], target)                   # the reference's own assertion form
+    assert min(abs(x - target) for x in e[:2]) < 1e-11
+    assert e[2] - e[0] > 0.5                            # the next states are 0.8 eV up: the minimum is unambiguous
+
+
 def _with_adatoms(slab, sites, which):
     from surface_sampling_amd import structures
 
@@ -148,6 +187,24 @@ def test_eam_gpu_vs_oracle_and_reference_numbers(cu):
         assert np.abs(r["per_atom_energies"] - ea).max() <= 1e-9 and np.abs(r["forces"] - F).max() <= 1e-8
     single = calc.calculate_batch([cases[3]])[0]
     assert single["energy"] == res[3]["energy"] and np.array_equal(single["forces"], res[3]["forces"])
+
+
+@pytest.mark.gpu
+def test_au110_gpu_reproduces_the_reference_minimum(au):
+    """The same 28 states through the device EAM behind LAMMPSRunSurfCalc (fp64): the reference's -79.03490823689619."""
+    import eam_oracle
+    from surface_sampling_amd.calculators import LAMMPSRunSurfCalc
+
+    calc = LAMMPSRunSurfCalc(files=[os.path.join(GOLDEN, "Au_u3.eam")], device="cuda:0")
+    calc.set(pair_style="eam", pair_coeff=["* * Au_u3.eam"])
+    states = _au_states(au)
+    res = calc.calculate_batch(states)
+    e = np.array([r["energy"] for r in res])
+    target = au["kat"]["min_energy"]["value"]
+    assert np.allclose(e.min(), target) and np.abs(np.sort(e)[:2] - target).min() < 1e-9
+    for s, r in zip(states[:6], res[:6]):
+        E, ea, F = eam_oracle.eam(au["funcfl"], s.positions, s.cell, s.pbc)
+        assert abs(r["energy"] - E) <= 1e-9 * abs(E) and np.abs(r["forces"] - F).max() <= 1e-8
 
 
 @pytest.mark.gpu

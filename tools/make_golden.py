@@ -86,8 +86,19 @@ def write_eam_fixtures(R, out):
     np.savez(os.path.join(out, "cu100.npz"), numbers=np.full(8, 29, np.int32), positions=np.array(bottom + top),
              cell=np.diag([2 * b, 2 * b, a / 2 + 30.0]), pbc=np.array([True, True, False]),
              ads_coords=np.array(ontop + bridge + hollow), site_kind=np.array([0] * 4 + [1] * 8 + [2] * 4))
+    # Au(110) (tests/test_Au.py): the test's own slab pickle and site coordinates (the adsorbate positions of the "proper
+    # adsorbed" CIF), canonical MC with 4 + 2 Au adatoms, asserted minimum of the energy history
+    from surface_sampling_amd import structures
+
+    shutil.copyfile(os.path.join(R, "mcmc/potentials/Au_u3.eam"), os.path.join(out, "Au_u3.eam"))
+    au = structures.read_slab_pickle(os.path.join(R, "tests/data/Au_110/Au_110_2x2_pristine_slab.pkl"))
+    au_ads = structures.read_cif(os.path.join(R, "tests/data/Au_110/Au_110_2x2_proper_adsorbed_slab.cif"))
+    np.savez(os.path.join(out, "au110.npz"), numbers=au.numbers, positions=au.positions, cell=au.cell, pbc=au.pbc,
+             ads_coords=au_ads.positions[len(au):])
     with open(os.path.join(out, "eam_kat.json"), "w") as fh:
-        json.dump({"potential": "mcmc/potentials/Cu_u3.eam (Foiles, Baskes, Daw, PRB 33, 7983 (1986); funcfl)",
+        json.dump({"au110": {"potential": "mcmc/potentials/Au_u3.eam (funcfl)", "num_ads_atoms": 6,
+                             "min_energy": {"value": -79.03490823689619, "source": "tests/test_Au.py:19 (np.allclose)"}},
+                   "potential": "mcmc/potentials/Cu_u3.eam (Foiles, Baskes, Daw, PRB 33, 7983 (1986); funcfl)",
                    "min_energy_one_bridge_adatom": {"value": -25.2893, "source": "tests/test_Cu.py:19 (np.allclose)"},
                    "tutorial_energies": {"values": [-24.740, -24.355, -28.050, -28.190],
                                          "source": "tutorials/example.ipynb cell 9 output (surface energies of visited states)"},
