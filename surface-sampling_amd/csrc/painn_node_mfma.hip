@@ -9,15 +9,18 @@
 // fp32 on v_mfma_f32_16x16x32_f16.
 //
 // Structure of every kernel: one workgroup = 8 waves = a tile of 32 atoms of one ensemble member.
-//   * activations (A operand) live in LDS as two fp16 planes (h and l, same bytes as an fp32 tile): every element is
-//     split ONCE by the thread that stores it (clamped to +-65504 first; measured activations / adjoints of the SrTiO3
-//     models peak at ~160, tools/gpu_ranges.py), and an A fragment is one ds_read_b128 per piece, no arithmetic;
-//   * weights (B operand) were pre-split at vssr_create into fragment order (pack_mfma_tiles16): a wave streams the
-//     pieces of its column tiles with coalesced 1 KiB dwordx4 loads, L2-resident (all workgroups read the same ~1 MB);
+//   * activations live in LDS as two fp16 planes (h and l, same bytes as an fp32 tile): every element is split ONCE by
+//     the thread that stores it (clamped to +-65504 first; measured activations / adjoints of the SrTiO3 models peak at
+//     ~160, tools/gpu_ranges.py), and an activation fragment is one ds_read_b128 per piece, no arithmetic;
+//   * weights were pre-split at vssr_create into fragment order (pack_mfma_tiles16): a wave streams the pieces of its
+//     column tiles with coalesced 1 KiB dwordx4 loads, L2-resident (all workgroups read the same ~1 MB);
+//   * the weight pieces are the MFMA's A operand and the activation pieces its B operand: the result tile is
+//     D[feature][atom], a lane owns four consecutive features of one atom (LaneGeo, mfma16.h) and stores / fetches
+//     8- and 16-byte vectors (planes, staging tiles, biases);
 //   * wave w owns output features [16w, 16w+16) of every section for all 32 atoms (two 16-row tiles), so gates, norms and
 //     residuals that combine several GEMM outputs for the same (atom, feature) stay in one lane's registers; with half
 //     the per-wave accumulator state of a 32-column layout two waves share a SIMD and hide each other's latencies;
-//   * residual inputs (s_msg, v_msg, vbar) are re-read from global memory (L2-hot) where the fp32 value is needed.
+//   * fp32 residuals: update_fwd keeps its input tile in registers, update_bwd keeps vbar as an fp32 LDS tile.
 // MFMA issue order follows the hazard rules of painn_edge_mfma.hip: the three products of a tile are a dependent chain,
 // so products are issued in rounds over >= 3 independent accumulators (K-interleaved partial accumulators for GEMMs with
 // two tiles), pinned with scheduling barriers, and no load is issued inside the MFMA block of a chunk group.
