@@ -112,16 +112,21 @@ __device__ __forceinline__ void load_rows_split(const Planes &P, int col0, RowPt
         store_split4(P, idx >> 5, col0 + 4 * (idx & 31), v[it]);
     }
 }
-// same, and the fp32 values stay with the threads that loaded them (residual operands of a later output pass)
+// same in two halves, and the fp32 values stay with the threads that loaded them (residual operands of a later output
+// pass): rows_request() issues the loads, rows_store_split() writes the planes -- other requests (weight pieces) can be
+// queued behind the tile's loads and arrive while the tile is being split
 template <int NROWS, class RowPtr>
-__device__ __forceinline__ void load_rows_split_keep(const Planes &P, int col0, RowPtr rowptr,
-                                                     float4 (&v)[NROWS * (F / 4) / NTHREADS]) {
+__device__ __forceinline__ void rows_request(RowPtr rowptr, float4 (&v)[NROWS * (F / 4) / NTHREADS]) {
     constexpr int NIT = NROWS * (F / 4) / NTHREADS;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = threadIdx.x + it * NTHREADS;
         v[it] = *reinterpret_cast<const float4 *>(rowptr(idx >> 5) + 4 * (idx & 31));
     }
+}
+template <int NROWS>
+__device__ __forceinline__ void rows_store_split(const Planes &P, int col0, const float4 (&v)[NROWS * (F / 4) / NTHREADS]) {
+    constexpr int NIT = NROWS * (F / 4) / NTHREADS;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = threadIdx.x + it * NTHREADS;

@@ -479,13 +479,17 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     const uint4 *wW4[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
     WPre<6, 2, 1> pUV;
     WPre<2, 1, 1> pW3a;
-    gemm16_preload(wUV, pUV);
-    gemm16_preload(wW3a, pW3a);
-    load_rows_split_keep<3 * TA>(vt, 0, [&](int row) {
+    // the tile first, the weight pieces behind it (loads return in order): they arrive while the tile is being split
+    rows_request<3 * TA>([&](int row) {
         int x = row / TA, a = min(a0 + (row % TA), N - 1);
         return v_msg + ((mN + a) * 3 + x) * F;
     }, keep_v);
-    load_rows_split_keep<TA>(xs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; }, keep_s);
+    rows_request<TA>([&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; }, keep_s);
+    __builtin_amdgcn_sched_barrier(0);
+    gemm16_preload(wUV, pUV);
+    gemm16_preload(wW3a, pW3a);
+    rows_store_split<3 * TA>(vt, 0, keep_v);
+    rows_store_split<TA>(xs, 0, keep_s);
     __syncthreads();
     PH(0)
     f32x4 uv[6][2];   // [2 x + t][0] = U v_x, [..][1] = V v_x
