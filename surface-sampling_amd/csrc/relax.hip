@@ -446,9 +446,12 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
         if (h->d_vel.ensure(sizeof(double) * 3 * N) || h->d_fire.ensure(sizeof(FireState) * B))
             return set_err(h, VSSR_E_NOMEM, "FIRE state: out of device memory");
     } else {
+        // Two basis vectors per Hessian update; the rotated matrices of the eigen-decomposition (2 x mmax^2 doubles) live in
+        // LDS, which holds 46 updates.  A longer relaxation keeps stepping with the Hessian of its first 46 updates (the
+        // step kernel skips the update when the basis is full): identical to ASE up to step 46, a frozen quasi-Newton
+        // method beyond (the reference's configurations use 20 steps).
         mmax = 2 * max_steps + 2;
-        if (bfgs_lds_bytes(mmax) > 160 * 1024 - 4096)   // (the kernel also holds 2 KB of static reduction scratch)
-            return set_err(h, VSSR_E_BADARG, "BFGS: relax_steps %d exceeds the on-chip limit of this build (46)", max_steps);
+        while (bfgs_lds_bytes(mmax) > 160 * 1024 - 4096) mmax -= 2;   // (the kernel also holds 2 KB of static reduction scratch)
         if (h->d_fire.ensure(sizeof(BfgsState) * B) || h->d_vel.ensure(sizeof(double) * 3 * N * 3) ||
             h->d_bfgs_q.ensure(sizeof(double) * 3 * (size_t)N * mmax) || h->d_bfgs_b.ensure(sizeof(double) * (size_t)B * mmax * mmax))
             return set_err(h, VSSR_E_NOMEM, "BFGS state: out of device memory");

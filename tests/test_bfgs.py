@@ -171,6 +171,29 @@ def test_bfgs_gpu_matches_dense_restatement_without_fixatoms(golden, oracle_mod)
 
 
 @pytest.mark.gpu
+def test_bfgs_gpu_runs_past_the_on_chip_hessian_limit(golden):
+    """The eigen-decomposition workspace in LDS holds 46 Hessian updates.  A longer relaxation is identical up to step 46
+    (same basis capacity) and keeps stepping with that Hessian afterwards instead of being refused: no-FixAtoms chain with
+    a tolerance it cannot reach, 46 vs 70 steps."""
+    from surface_sampling_amd import backend, structures
+
+    table, const = golden.offset_table()
+    s = structures.synth_chain(golden.structure("SrTiO3_2x2_pristine"), 9, grid=(4, 4))
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    out = {}
+    for steps in (46, 47, 70):
+        eng.upload([(s.numbers, s.positions, s.cell, s.pbc)])
+        info = eng.relax_bfgs(max_steps=steps, fmax=1e-5)
+        res = eng.download()
+        assert info["n_steps"][0] == steps and not info["converged"][0]
+        out[steps] = (float(res["energy"][0]), float(np.abs(res["forces"]).max()), info["positions"].copy())
+    assert out[70][0] <= out[46][0] + 1e-4 and np.isfinite(out[70][1])     # it keeps descending (or stays put), never diverges
+    assert np.abs(out[47][2] - out[46][2]).max() <= 0.2 * np.sqrt(3) + 1e-9  # step 47 is one more bounded (maxstep 0.2) step
+    assert out[70][1] <= max(out[46][1], 0.05)
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("optimizer", ["BFGS", "FIRE"])
 def test_relaxation_survives_neighbor_capacity_overflows(golden, optimizer):
     """A capacity that is too small from the start and regrows to the exact need only: the relaxation overflows at the
