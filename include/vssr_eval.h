@@ -145,8 +145,8 @@ int vssr_batch_relax_fire(vssr_handle *h, const vssr_fire_params *params, const 
 
 /* ASE BFGS (ase/optimize/bfgs.py: alpha = 70 eV/A^2, maxstep = 0.2 A) -- the optimizer of the reference's SrTiO3
  * configuration (scripts/configs/sample_config_painn.json:26 "optimizer": "BFGS", dispatched at mcmc/dynamics.py:119-141).
- * Same contract as vssr_batch_relax_fire.  max_steps <= 46 in this build (the per-chain Hessian is kept in factored form
- * H = alpha I + Q B Q^T with at most 2 max_steps + 2 columns; csrc/relax.hip). */
+ * Same contract as vssr_batch_relax_fire.  The per-chain Hessian is kept in factored form H = alpha I + Q B Q^T; its
+ * on-chip workspace holds 46 updates: identical to ASE up to step 46, later steps keep that Hessian (csrc/relax.hip). */
 typedef struct {
     int32_t max_steps; /* relax_steps (reference: 20) */
     float fmax;        /* 0.01 eV/A */
