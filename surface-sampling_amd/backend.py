@@ -180,7 +180,8 @@ class _DeviceArray:
     """A float32 vector in device memory owned by an engine (``__cuda_array_interface__`` v2)."""
 
     def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), True), "version": 2,
+        # (read-only flag False: torch refuses read-only device arrays; consumers only read these buffers)
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2,
                                          "strides": None}
 
 

@@ -142,3 +142,49 @@ def test_gather_world_size_2_gloo(tmp_path, n_chains):
     r0, r1 = (np.load(tmp_path / f"ok{r}.npy") for r in (0, 1))
     assert r0[0] == 1 and r1[0] == 1
     assert r0[1] == 0 and r0[1] + r0[2] == r1[1] and r1[1] + r1[2] == n_chains
+
+
+@pytest.mark.gpu
+def test_device_results_reach_torch_and_rccl_without_a_host_copy():
+    """What a rank of the N > 1 bench does every lock-step, on one GPU: the engine's energy buffers are wrapped as torch
+    tensors (``vssr_batch_device_results`` -> ``__cuda_array_interface__``), stacked, and handed to an RCCL collective
+    (one-rank process group: the transport is trivial, the buffer registration and stream handling are the real ones)."""
+    import socket as _socket
+
+    import torch
+    import torch.distributed as dist
+
+    import bench
+    from surface_sampling_amd import backend, sharding
+    from surface_sampling_amd.calculators import stoich_offset_table
+
+    blobs, S, offset_data = bench.load_golden()
+    table, const = stoich_offset_table(offset_data)
+    chains = bench.build_chains(S, 300, 5)               # chains of a later rank's block (configs[4] touches them)
+    packs = [(s.numbers, s.positions, s.cell, s.pbc) for s in chains]
+    eng = backend.PainnEngine(blobs, device=0, offset_per_z=table, offset_const=const)
+    dev = torch.device("cuda", 0)
+    sh = sharding.ShardedEnsemble(eng, len(chains), None, dev)
+    sh.upload(local_chains=packs)
+    want = backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD
+    got = sh.step(want, gather=True)                     # world 1: the local block, taken from the device buffers
+    res = eng.download(want)
+    assert got.is_cuda and got.shape == (len(chains), 2)
+    assert np.array_equal(got[:, 0].cpu().numpy(), res["energy"]) and np.array_equal(got[:, 1].cpu().numpy(), res["energy_std"])
+    with _socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        local = sh._local_scalars(want).reshape(-1).contiguous()
+        out = torch.empty_like(local)
+        dist.all_gather_into_tensor(out, local)
+        tmax = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)      # the bench's max-over-ranks clock
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(out, local) and float(tmax.item()) == 1.5
+    finally:
+        dist.destroy_process_group()
+        eng.close()
