@@ -7,7 +7,9 @@ point raises.  The oracle under ``oracle/`` is test infrastructure and is never 
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -90,6 +92,29 @@ class Out(C.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel carries its own ``libamdhip64.so`` / ``libhsa-runtime64.so``; if
+    ``libvssr_eval.so`` has already brought up the system copy (``/opt/rocm``), a later ``import torch`` loads the second
+    copy and finds no devices ("No HIP GPUs are available": the sharding path, which hands the engine's buffers to
+    ``torch.distributed``, would fail whenever torch is imported after the first engine).  Loading torch's copy first --
+    without importing torch -- makes both sides resolve the same runtime whatever the import order
+    (``VSSR_SYSTEM_HIP=1`` skips this)."""
+    if os.environ.get("VSSR_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations or []) if spec else []:
+        p = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass   # (an unusable bundled copy: the system runtime serves the library)
+            return
+
+
 def load_library():
     """Load libvssr_eval.so; raise BackendError (never fall back) when it is absent."""
     global _lib
@@ -99,6 +124,7 @@ def load_library():
         raise BackendError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). This backend has no CPU fallback.")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, ip, dp, fp, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float), \
         C.POINTER(C.c_uint8)
