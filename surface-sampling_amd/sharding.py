@@ -101,7 +101,11 @@ class ShardedEnsemble:
             self.engine.synchronize()   # the engine runs on its own stream
             e, s = self.engine.device_results()
             dev = self.device if self.device is not None else "cuda"
-            return torch.stack([torch.as_tensor(e, device=dev), torch.as_tensor(s, device=dev)], dim=1)
+            out = torch.stack([torch.as_tensor(e, device=dev), torch.as_tensor(s, device=dev)], dim=1)
+            # the copy out of the engine's buffers has happened before the engine may overwrite them (its next run is
+            # enqueued on another stream); what the collective reads afterwards is torch-owned memory
+            torch.cuda.current_stream(out.device).synchronize()
+            return out
         res = self.engine.download(want_energy_flags)
         return np.stack([res["energy"], res["energy_std"]], axis=1)
 
