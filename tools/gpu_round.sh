@@ -2,7 +2,7 @@
 # End-of-milestone evidence run: GPU tests, the default bench line, rocprofv3 kernel stats of the same command, PMC traffic of
 # the edge kernels.  Everything lands in gpurun_out/ (copy what should be judged into profiles/rNN/).
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/pytest_gpu.log; tail -3 gpurun_out/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|^FAILED|^ERROR" > gpurun_out/pytest_gpu.log; tail -3 gpurun_out/pytest_gpu.log
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -2 gpurun_out/bench_default.err
 python3 - <<'PY'
 import json
