@@ -1,5 +1,5 @@
 """Secondary measurement (not the BASELINE metric): batched semigrand MC steps per second, B chains on one GPU, every
-step = propose + change + lock-step device FIRE relaxation (<= relax_steps evaluations) + Metropolis.  Prints one JSON
+step = propose + change + lock-step device relaxation (ChainEnsemble default: BFGS, <= relax_steps evaluations) + Metropolis.  Prints one JSON
 line.  Usage: python tools/bench_mc.py [--chains 256] [--steps 5] [--relax-steps 20]"""
 import argparse, json, os, sys, time
 
@@ -47,7 +47,7 @@ def main():
     for _ in range(args.steps):
         acc.append(ens.step_semigrand().mean())
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "batched semigrand MC steps/s (all chains advance one Change event incl. FIRE relaxation)",
+    print(json.dumps({"metric": "batched semigrand MC steps/s (all chains advance one Change event incl. the lock-step BFGS relaxation)",
                       "chains": args.chains, "atoms_per_chain": int(len(base) + ens.num_adsorbates().mean()),
                       "relax_steps": args.relax_steps, "mc_steps": args.steps, "s_per_lockstep": dt / args.steps,
                       "chain_steps_per_s": args.chains * args.steps / dt, "acceptance": float(np.mean(acc))}))
