@@ -314,14 +314,40 @@ __device__ __forceinline__ void write_f16_record(const float (&v)[5], float env,
     tab[f16_unit(slot, kq, 1)] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), pk(sl, 0u));
 }
 
-__global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
+// sum over the 16 lanes of a wave that share lane & 3 (the threads of one table quarter), result in all of them: two
+// rotations inside the 16-lane rows (DPP row_ror 4, 8), then the four rows (gfx950 row swaps) -- a fixed order
+__device__ __forceinline__ float quarter_class_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, true));   // row_ror:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));   // row_ror:8
+    const unsigned u = __float_as_uint(x);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float y = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+    const unsigned v = __float_as_uint(y);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+}
+
+// NZ > 0: the layer-0 species factorisation (painn_l0.hip) needs, per centre and neighbor species z, the 4 x 24 block
+// T[z][comp][kappa] = sum over the centre's slots with species z of rho[kappa] * {1, u_x, u_y, u_z}[comp].  The thread of
+// (slot, quarter) holds exactly the six rho values of its quarter, so the block is accumulated here, in registers (a
+// separate kernel re-read the fp32 table: 0.19 ms per evaluation), and reduced once per centre over the 16 threads of a
+// quarter.  NZ = 0: no accumulation (non-factorised layer 0, or more species than the register budget covers).
+template <int NZ>
+__global__ void __launch_bounds__(64) k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
                             const int *__restrict__ cfg_start, const float4 *__restrict__ edge,
                             const int *__restrict__ counters, float rc, float excl_sigma, int excl_power,
                             float4 *__restrict__ erec, float *__restrict__ rho, float *__restrict__ drho,
                             float2 *__restrict__ dist2, uint4 *__restrict__ rho16, uint4 *__restrict__ drho16,
                             const int *__restrict__ Z, const int *__restrict__ zmap, unsigned char *__restrict__ zslot,
-                            float *__restrict__ e_excl, const unsigned char *__restrict__ active) {
+                            float *__restrict__ e_excl, const unsigned char *__restrict__ active, float *__restrict__ l0T) {
     if (counters[2]) return;
+    float tacc[NZ > 0 ? NZ : 1][4][6];
+#pragma unroll
+    for (int z = 0; z < (NZ > 0 ? NZ : 1); ++z)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tacc[z][c][k] = 0.f;
     const int i = blockIdx.x;                 // centre atom
     if (active && !active[atom_cfg[i]]) return;
     const int a0 = cfg_start[atom_cfg[i]];
@@ -373,9 +399,22 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
             write_f16_record(rv, fc, rho16, (size_t)slot, kq, scal, (unsigned)min(valid ? j - a0 : 0, 0x7BFF));
             write_f16_record(dv, dfc, drho16, (size_t)slot, kq, 0.f, 0u);
         }
+        // species index of the neighbor (layer-0 factorisation, painn_l0.hip); pads / unmapped species: 255
+        const int zi = valid ? zmap[Z[j]] : -1;
+        if constexpr (NZ > 0) {
+            const float uc[4] = {1.f, ed.x * inv, ed.y * inv, ed.z * inv};
+#pragma unroll
+            for (int z = 0; z < NZ; ++z) {
+                const float mz = zi == z ? 1.f : 0.f;   // (pads: rho = 0 and no species matches)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float w = mz * uc[c];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) tacc[z][c][k] = fmaf(r[k], w, tacc[z][c][k]);
+                }
+            }
+        }
         if (kq == 0) {
-            // species index of the neighbor (layer-0 factorisation, painn_l0.hip); pads / unmapped species: 255
-            const int zi = valid ? zmap[Z[j]] : -1;
             zslot[slot] = (unsigned char)(zi >= 0 ? zi : 255);
             erec[slot] = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, __int_as_float(valid ? j - a0 : 0));
             const float rep = valid ? powf(excl_sigma * inv, (float)excl_power) : 0.f;
@@ -387,6 +426,21 @@ __global__ void k_edge_geom(int n_atoms, const int *__restrict__ row_start, cons
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ex += __shfl_xor(ex, off, 64);
     if (threadIdx.x == 0) e_excl[i] = ex;
+    if constexpr (NZ > 0) {
+        const int kq = threadIdx.x & 3;
+#pragma unroll
+        for (int z = 0; z < NZ; ++z)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v[k] = quarter_class_sum(tacc[z][c][k]);
+                if (threadIdx.x < 4) {   // lane = quarter: its six entries of T[i][z][c][24], 8-byte aligned
+                    float2 *dst = reinterpret_cast<float2 *>(l0T + ((size_t)i * NZ + z) * 96 + c * 24 + kq * 6);
+                    dst[0] = make_float2(v[0], v[1]); dst[1] = make_float2(v[2], v[3]); dst[2] = make_float2(v[4], v[5]);
+                }
+            }
+    }
 }
 
 // Work list of the MFMA edge kernels: per chain, the centres sorted by padded slot count (descending; ties by index) as
@@ -474,12 +528,26 @@ int build_neighbors(vssr_handle *h, double cutoff) {
             h->zero_entry_cap = h->slot_cap;
             for (int k = 0; k < 4; ++k) h->zero_entry_tab[k] = tabs[k];
         }
-        hipLaunchKernelGGL(k_edge_geom, dim3(n), dim3(64), 0, st, n, h->d_row_start.as<int>(), h->d_atom_cfg.as<int>(),
-                           h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,
-                           h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),
-                           h->d_drho.as<float>(), h->d_dist.as<float2>(), h->d_rho16.as<uint4>(),
-                           h->d_drho16.as<uint4>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_zslot.as<unsigned char>(),
-                           h->d_excl.as<float>(), h->active_mask);
+        // layer-0 factorisation with at most 4 species: its T blocks are accumulated by k_edge_geom (h->l0T_by_geom)
+        const int nzf = (h->l0_enabled && h->l0_nz >= 1 && h->l0_nz <= 4) ? h->l0_nz : 0;
+        if (nzf && h->d_l0T.ensure(sizeof(float) * (size_t)n * nzf * 96))
+            return set_err(h, VSSR_E_NOMEM, "layer-0 factorisation buffers: out of device memory");
+        h->l0T_by_geom = nzf > 0;
+#define LAUNCH_GEOM(NZ)                                                                                                          \
+        hipLaunchKernelGGL(k_edge_geom<NZ>, dim3(n), dim3(64), 0, st, n, h->d_row_start.as<int>(), h->d_atom_cfg.as<int>(),      \
+                           h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,               \
+                           h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),                         \
+                           h->d_drho.as<float>(), h->d_dist.as<float2>(), h->d_rho16.as<uint4>(),                              \
+                           h->d_drho16.as<uint4>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_zslot.as<unsigned char>(),     \
+                           h->d_excl.as<float>(), h->active_mask, nzf ? h->d_l0T.as<float>() : (float *)nullptr)
+        switch (nzf) {
+            case 1: LAUNCH_GEOM(1); break;
+            case 2: LAUNCH_GEOM(2); break;
+            case 3: LAUNCH_GEOM(3); break;
+            case 4: LAUNCH_GEOM(4); break;
+            default: LAUNCH_GEOM(0); break;
+        }
+#undef LAUNCH_GEOM
         if ((size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024)   // chains of the MFMA edge kernels (LDS slices) are far smaller
             hipLaunchKernelGGL(k_bundle_sort, dim3(h->n_cfg), dim3(256), (size_t)h->max_cfg_atoms * sizeof(int), st,
                                h->d_cfg_start.as<int>(), h->d_row_start.as<int>(), h->d_counters.as<int>(),

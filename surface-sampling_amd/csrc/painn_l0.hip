@@ -380,7 +380,7 @@ int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_ms
     if (h->d_l0T.ensure(sizeof(float) * (size_t)N * nz * TBLK) ||
         h->d_l0Q.ensure(sizeof(float) * (size_t)M * N * nz * TBLK))
         return set_err(h, VSSR_E_NOMEM, "layer-0 factorisation buffers: out of device memory");
-    {
+    if (!h->l0T_by_geom) {   // (at most 4 species: k_edge_geom has already accumulated T, nbr.hip)
         const int *cnt = h->d_counters.as<int>();
         float *T = h->d_l0T.as<float>();
         switch (nz) {

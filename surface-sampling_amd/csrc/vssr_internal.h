@@ -211,6 +211,7 @@ struct vssr_handle {
     vssr::DevBuf d_vel, d_fire, d_fixed, d_relax_steps, d_relax_conv, d_active, d_bfgs_q, d_bfgs_b;
     const unsigned char *active_mask = nullptr;   // set by relax_run for the duration of a relaxation
     int relax_regrows = 0;
+    bool l0T_by_geom = false;     // this evaluation's layer-0 T blocks were written by k_edge_geom (<= 4 species)
     int64_t zero_entry_cap = -1;  // capacity / table addresses for which the all-zero table entries were last cleared
     const void *zero_entry_tab[4] = {nullptr, nullptr, nullptr, nullptr};
     int cap_per_atom = 64;        // initial neighbor capacity (slots per atom); vssr_debug_capacity

@@ -347,6 +347,19 @@ def test_fallback_paths_large_chain_many_species_and_forced_gather(golden, oracl
     ref6 = _oracle(golden, oracle_mod, six)
     a0, a1 = r6["cfg_start"][0], r6["cfg_start"][1]
     assert abs(float(r6["energy"][0]) - ref6["energy"]) <= 3e-4 and np.abs(r6["forces"][a0:a1] - ref6["forces"]).max() <= 5e-4
+    # (2c) four and two species: the layer-0 T blocks are accumulated inside k_edge_geom<NZ> (nbr.hip; NZ = 1 .. 4), one
+    # batch with a single species count and one that mixes a 2-species chain with the 3-species slab (batch species = 3)
+    four = small.copy()
+    four.numbers[:2] = np.array([1, 1], np.int32)
+    two = small.copy()
+    two.numbers[two.numbers == 22] = 38
+    for batch in ([four], [two], [two, small]):
+        rb = eng.evaluate([_arrays(x) for x in batch])
+        for b, x in enumerate(batch):
+            refx = _oracle(golden, oracle_mod, x)
+            a0, a1 = rb["cfg_start"][b], rb["cfg_start"][b + 1]
+            assert abs(float(rb["energy"][b]) - refx["energy"]) <= 3e-4, (len(batch), b)
+            assert np.abs(rb["forces"][a0:a1] - refx["forces"]).max() <= 5e-4, (len(batch), b)
     assert eng.profile_read is not None
     ref_small = eng.evaluate([_arrays(small)])
     assert float(ref_small["energy"][0]) == float(r6["energy"][1])   # neighbors in the batch do not change a chain
