@@ -342,7 +342,9 @@ def main():
                          "binding_resource": "SIMD instruction issue: per 16-slot step ~130 vector + 20 matrix instructions whose "
                                              "issue times add up (130 x 4 + 20 x 17 cycles + LDS/VMEM/SALU = the measured ~1010 "
                                              "cycles; interleaving them across steps did not overlap them: "
-                                             "profiles/r02/NOTES_node_kernels.md); TA 85-93 % busy (profiles/r01/pmc_ta_all_kernels_v9.txt)",
+                                             "profiles/r02/NOTES_node_kernels.md); PMC of this build: matrix pipe 34 % + vector issue 38 % of the SIMD cycles, which do not overlap "
+                                             "for this MFMA shape (profiles/r02/pmc_sq_heavy_kernels.txt, micro_mfma_interleave.txt); TA 85-93 % busy "
+                                             "(profiles/r01/pmc_ta_all_kernels_v9.txt)",
                          "second_kernel": {"kernel": "edge_message_fwd (neighbor-sum, k_edge_fwd_mfma)",
                                            "avg_launch_ms": fwd_ms, "launches": fwd_n,
                                            "algorithmic_flops_per_launch": fwd_flops,
