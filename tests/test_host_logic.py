@@ -3,6 +3,7 @@ reference, the surface-energy wrapper KATs, and that the C-ABI library loads and
 symbol include/vssr_eval.h declares (no compute calls without a GPU)."""
 
 import copy
+import json
 import ctypes
 import os
 import re
@@ -177,6 +178,32 @@ def test_pourbaix_potential_arithmetic():
     b = calcs.pourbaix_potential_from_energy(-39.0, symbols, atoms, kT, 0.0, 7.0)
     assert b - a == pytest.approx(1.0, abs=1e-12)
     assert calcs._formula_counts("H2O") == {"H": 2, "O": 1} and calcs._formula_counts("OH") == {"O": 1, "H": 1}
+
+
+def test_pourbaix_potential_matches_reference_generated_vectors():
+    """SURVEY.md section 8(f) row 3, pinned: per-element data = the PourbaixAtom fields the reference's own test asserts
+    (tests/pourbaix/test_pourbaix_atoms.py:41-152), expected dG1 / dG2 / potential = outputs of the reference's
+    ``NFFPourbaix`` method bodies executed by tools/make_golden.py (``tests/golden/pourbaix_kat.json``)."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pourbaix_kat.json")) as fh:
+        kat = json.load(fh)
+    assert len(kat["atom_sets"]) == 2 and len(kat["cases"]) == 48
+    # the reference-held numbers themselves (a changed fixture would silently re-pin the test)
+    sr, ir = kat["atom_sets"][0]["atoms"]["Sr"], kat["atom_sets"][0]["atoms"]["Ir"]
+    assert (sr["num_e"], sr["species_conc"], sr["atom_std_state_energy"], sr["delta_G2_std"]) == (2, 1e-6, -1.68949, -5.79807)
+    assert (ir["dominant_species"], ir["num_e"], ir["num_H"], ir["delta_G2_std"]) == ("IrO2", 4, 4, 1.76738)
+    assert kat["atom_sets"][1]["atoms"]["Ir"]["dominant_species"] == "Ir"
+    for case in kat["cases"]:
+        aset = kat["atom_sets"][case["atom_set"]]
+        atoms = {k: calcs.PourbaixAtom(**v) for k, v in aset["atoms"].items()}
+        symbols = [s for s, n in case["formula"].items() for _ in range(n)]
+        got = calcs.pourbaix_potential_from_energy(case["energy"], symbols, atoms, case["temperature"], aset["phi"],
+                                                   aset["pH"], case["adsorbate_corrections"])
+        assert got == pytest.approx(case["pourbaix_potential"], abs=1e-10), case
+        assert -(case["delta_G1"] + case["delta_G2"]) == pytest.approx(case["pourbaix_potential"], abs=1e-10)
+        # the calculator's own dG2 (reference get_delta_G2) on the same data
+        calc = calcs.NFFPourbaix.__new__(calcs.NFFPourbaix)
+        calc.temp, calc.phi, calc.pH, calc.pourbaix_atoms = case["temperature"], aset["phi"], aset["pH"], atoms
+        assert sum(calc.get_delta_G2_individual(s) for s in symbols) == pytest.approx(case["delta_G2"], abs=1e-10)
 
 
 def test_pourbaix_calculator_surface_without_gpu(golden):

@@ -109,17 +109,146 @@ def write_eam_fixtures(R, out):
     print("eam fixtures written")
 
 
+def reference_pourbaix_atoms(R):
+    """The PourbaixAtom fields the reference's own test asserts (tests/pourbaix/test_pourbaix_atoms.py:41-152): one set per
+    test function, i.e. per (phi, pH) the atoms were generated for."""
+    import ast
+    import re
+
+    path = os.path.join(R, "tests/pourbaix/test_pourbaix_atoms.py")
+    src = open(path).read()
+    pat = re.compile(r"assert (\w+)_pourbaix_atom\.(\w+) == (?:approx\()?([^,\n\)]+)")
+    sets = []
+    for fn in ast.parse(src).body:
+        if not (isinstance(fn, ast.FunctionDef) and fn.name.startswith("test_generate_pourbaix_atoms")):
+            continue
+        seg = ast.get_source_segment(src, fn)
+        cond = {k: float(re.search(rf"\b{k} = ([-0-9.e]+)", seg).group(1)) for k in ("phi", "pH")}
+        atoms = {}
+        for who, field, val in pat.findall(seg):
+            atoms.setdefault(who, {})[field] = ast.literal_eval(val.strip())
+        sets.append({"phi": cond["phi"], "pH": cond["pH"], "source": f"tests/pourbaix/test_pourbaix_atoms.py:{fn.lineno}",
+                     "atoms": {a["symbol"]: a for a in atoms.values()}})
+    return sets
+
+
+class _GeneratorFormula:
+    """Stand-in for ``ase.formula.Formula`` (ASE is not installable here), used ONLY while the reference's
+    ``NFFPourbaix.get_delta_G1`` is executed by this generator: count(), item access, multiplication by an integer,
+    from_dict() and divmod(formula, "XY") = how many times the other formula fits (ASE's documented semantics)."""
+
+    def __init__(self, text="", _counts=None):
+        import re
+
+        self._c = dict(_counts) if _counts is not None else {}
+        if _counts is None:
+            for sym, num in re.findall(r"([A-Z][a-z]?)(\d*)", text):
+                self._c[sym] = self._c.get(sym, 0) + (int(num) if num else 1)
+
+    def count(self):
+        return dict(self._c)
+
+    def __getitem__(self, k):
+        return self._c.get(k, 0)
+
+    def __mul__(self, n):
+        return _GeneratorFormula(_counts={k: v * n for k, v in self._c.items()})
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(_counts={k: v for k, v in d.items() if v})
+
+    def __divmod__(self, other):
+        o = other if isinstance(other, _GeneratorFormula) else _GeneratorFormula(other)
+        n = min(self._c.get(k, 0) // v for k, v in o._c.items())
+        return n, _GeneratorFormula(_counts={k: v - n * o._c.get(k, 0) for k, v in self._c.items()})
+
+    def __str__(self):
+        return "".join(f"{k}{v}" for k, v in self._c.items())
+
+
+def write_pourbaix_fixtures(R, out):
+    """Known answers for the Pourbaix wrapper.  The per-element data are the numbers the
+    reference's test holds; the expected potentials are produced by EXECUTING the reference's own method bodies
+    (``NFFPourbaix.get_delta_G2_individual / get_delta_G2 / get_delta_G1 / get_pourbaix_potential``,
+    mcmc/calculators/calculators.py:197-305), extracted with ``ast`` from the read-only tree at generation time and bound
+    to a plain object that supplies ``temp / phi / pH / pourbaix_atoms / adsorbate_corrections`` and a fixed potential
+    energy.  Nothing of the reference's source is written to the repository; the fixture is inputs + outputs."""
+    import ast
+    import logging
+    import types
+    from collections import Counter
+
+    path = os.path.join(R, "mcmc/calculators/calculators.py")
+    src = open(path).read()
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "NFFPourbaix")
+    wanted = ("get_delta_G2_individual", "get_delta_G2", "get_delta_G1", "get_pourbaix_potential")
+    ns = {"np": np, "Counter": Counter, "Formula": _GeneratorFormula, "logger": logging.getLogger("make_golden"),
+          "ase": types.SimpleNamespace(Atoms=object), "PourbaixAtom": types.SimpleNamespace}
+    lines = {}
+    for fn in cls.body:
+        if isinstance(fn, ast.FunctionDef) and fn.name in wanted:
+            fn.returns = None
+            for a in fn.args.args:
+                a.annotation = None
+            exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+            lines[fn.name] = fn.lineno
+
+    class Slab:
+        def __init__(self, formula):
+            self.symbols = [s for s, n in formula.items() for _ in range(n)]
+
+        def get_chemical_symbols(self):
+            return list(self.symbols)
+
+        def get_chemical_formula(self):
+            return "".join(f"{s}{n}" for s, n in sorted(Counter(self.symbols).items()))
+
+    class Calc:
+        pass
+
+    for name in wanted:
+        setattr(Calc, name, ns[name])
+    sets = reference_pourbaix_atoms(R)
+    cases = []
+    formulas = [({"Sr": 8, "Ir": 8, "O": 24}, -250.0), ({"Sr": 8, "Ir": 8, "O": 26, "H": 2}, -270.125),
+                ({"Sr": 6, "Ir": 8, "O": 30, "H": 8}, -301.5), ({"Sr": 4, "Ir": 4, "O": 12}, -123.456789)]
+    for si, aset in enumerate(sets):
+        for temp in (0.0257, 0.03):
+            for fi, (formula, energy) in enumerate(formulas):
+                for corr in ({}, {"OH": 0.23}, {"OH": 0.23, "O": -0.05}):
+                    c = Calc()
+                    c.temp, c.phi, c.pH = temp, aset["phi"], aset["pH"]
+                    c.pourbaix_atoms = {k: types.SimpleNamespace(**v) for k, v in aset["atoms"].items()}
+                    c.adsorbate_corrections = dict(corr)
+                    c.get_potential_energy = lambda atoms=None, e=energy: e
+                    slab = Slab(formula)
+                    c.atoms = slab
+                    cases.append({"atom_set": si, "temperature": temp, "formula": formula, "energy": energy,
+                                  "adsorbate_corrections": corr,
+                                  "delta_G1": float(c.get_delta_G1(atoms=slab)), "delta_G2": float(c.get_delta_G2(atoms=slab)),
+                                  "pourbaix_potential": float(c.get_pourbaix_potential(atoms=slab))})
+    with open(os.path.join(out, "pourbaix_kat.json"), "w") as fh:
+        json.dump({"atom_sets": sets,
+                   "generated_by": {k: f"mcmc/calculators/calculators.py:{v}" for k, v in lines.items()},
+                   "note": "cases with adsorbate_corrections ran with a generator-side stand-in for ase.formula.Formula; "
+                           "the others execute reference code and numpy only",
+                   "cases": cases}, fh, indent=1)
+    print("pourbaix:", len(sets), "atom sets,", len(cases), "cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
-    ap.add_argument("--only", default="", help="'traces' / 'eam': rewrite only the small trace and EAM fixtures")
+    ap.add_argument("--only", default="", help="'traces' / 'eam' / 'pourbaix': rewrite only the small trace, EAM and Pourbaix fixtures")
     args = ap.parse_args()
     R = args.reference
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(os.path.join(out, "weights"), exist_ok=True)
     write_bfgs_traces(R, out)
     write_eam_fixtures(R, out)
-    if args.only in ("traces", "eam"):
+    write_pourbaix_fixtures(R, out)
+    if args.only in ("traces", "eam", "pourbaix"):
         return
 
     # --- PaiNN ensemble weights -> canonical blobs (include/vssr_eval.h layout) -------------
