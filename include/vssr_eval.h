@@ -156,6 +156,17 @@ typedef struct {
 int vssr_batch_relax_bfgs(vssr_handle *h, const vssr_bfgs_params *params, const uint8_t *fixed, uint32_t want,
                           double *pos_out, int32_t *n_steps, uint8_t *converged);
 
+/* Trajectory recording during vssr_batch_relax_fire / _bfgs -- the reference's TrajectoryObserver attached with
+ * `dyn.attach(obs, interval=record_interval)` (mcmc/dynamics.py:20-80,131-151; optimize_slab(save_traj=True, record_interval=5)).
+ * record_interval > 0 arms it for the following relaxations of this handle (0 = off, the default): every chain records its
+ * positions, forces (FixAtoms applied) and energy after 0, k, 2k, ... optimizer steps, like ASE calls the observer.
+ * vssr_batch_traj_read: max_records (may be NULL) = relax_steps / k + 1 of the last relaxation; with buffers of
+ * cap_records >= max_records: n_records [B] = valid records of every chain, pos [R][sum N][3], forces [R][sum N][3],
+ * energy [R][B] (record-major; entries of a chain beyond its n_records are undefined).  Any pointer may be NULL. */
+int vssr_batch_traj_configure(vssr_handle *h, int32_t record_interval);
+int vssr_batch_traj_read(vssr_handle *h, int32_t cap_records, int32_t *n_records, double *pos, float *forces, double *energy,
+                         int32_t *max_records);
+
 /* LAMMPS `min_style cg` + `minimize etol ftol maxiter maxeval` for the analytic (fp64) potentials -- the reference relaxes
  * GaN with it ("optimizer": "LAMMPS": mcmc/dynamics.py:107-116 -> LAMMMPSCalc.run_lammps_opt, mcmc/calculators/calculators.py:600-619,
  * template tutorials/data/GaN_0001/GaN_0001_lammps_opt_template.txt: `fix 2 bulk setforce 0 0 0`, `min_style cg`,
@@ -181,7 +192,9 @@ int vssr_profile_reset(vssr_handle *h);
 int vssr_profile_read(vssr_handle *h, int32_t cap, const char **names, int64_t *launches,
                       double *total_ms, int32_t *n_out);
 /* Workload counters of the resident batch after a run: atoms, directed edges (unpadded),
- * padded edge slots. */
+ * padded edge slots.  After vssr_batch_relax_fire / _bfgs the resident graph and activations cover only the chains that
+ * were still running in the last iteration: vssr_batch_stats, vssr_batch_neighbors and vssr_debug_read then return
+ * VSSR_E_STATE until the batch has been run once more (vssr_batch_run); results (download) are complete at all times. */
 int vssr_batch_stats(vssr_handle *h, int64_t *n_atoms, int64_t *n_edges, int64_t *n_slots);
 /* Neighbor multigraph of the resident batch (after a run): for every directed edge its centre i,
  * neighbor j (global atom indices) and image shift S.  Returns the edge count through n_edges;
@@ -192,6 +205,24 @@ int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, 
  * synchronised run): lets the multi-GPU result gather (RCCL all_gather of per-chain scalars) read
  * them in place instead of through the host.  The pointers stay valid until the next vssr_batch_upload. */
 int vssr_batch_device_results(vssr_handle *h, const float **energy, const float **energy_std);
+/* Latent-space embedding: the per-atom scalar features after the last update block, [sum N][feat_dim] fp32 per model --
+ * what nff's Painn returns as results["embedding"] with requires_embedding=True and the reference's clustering /
+ * uncertainty helpers read (get_embeddings_single, mcmc/calculators/calculators.py:67-93; scripts/clustering.py:239).
+ * model >= 0: that ensemble member; model = -1: all members, model-major [M][sum N][feat_dim].  Valid after a run of the
+ * resident batch; dst may be NULL to query the size through n_out. */
+int vssr_batch_embedding(vssr_handle *h, int32_t model, float *dst, int64_t cap, int64_t *n_out);
+/* Range guard of the PaiNN path.  The dense contractions run as exact 2-way fp16 splits: an
+ * activation or adjoint beyond +-65504 cannot be represented and is clamped -- the results stay finite but are no longer
+ * the model's (seen with weights scaled far outside the trained regime).  The kernels track the largest magnitude they
+ * split; flags [B] (may be NULL) receives 1 for every chain whose LAST evaluation clamped a value or produced a non-finite
+ * energy, n_flagged (may be NULL) their count.  The reference has no counterpart (fp32 torch arithmetic overflows at 3e38);
+ * callers treat a flagged chain like the out-of-bounds energies of mcmc/dynamics.py:159-168.  Tersoff / EAM: always 0. */
+int vssr_batch_saturated(vssr_handle *h, uint8_t *flags, int32_t *n_flagged);
+/* The handle's HIP device ordinal, its stream (hipStream_t: every kernel of the handle is enqueued there) and the device
+ * address of the neighbor-capacity overflow flag of the last run (int32, non-zero = the run's results are void and
+ * vssr_synchronize will repeat it with grown buffers; NULL before the first run).  For consumers that order their own device
+ * work behind an evaluation with events instead of a host synchronisation (the multi-GPU result gather, sharding.py). */
+int vssr_device_context(vssr_handle *h, int32_t *device, void **stream, const int32_t **overflow_flag);
 /* Test hook for the capacity-regrow paths: initial neighbor capacity in slots per atom (<= 0: unchanged), tight != 0:
  * regrow to the exact need only (every later growth of the edge count overflows again), tight < 0: unchanged;
  * n_regrows (may be NULL) receives the number of regrows of the last relaxation. */

@@ -27,7 +27,9 @@ EXPORTS = (
     "vssr_batch_stats", "vssr_batch_neighbors", "vssr_debug_read", "vssr_tersoff_create",
     "vssr_tersoff_eval_batch", "vssr_batch_relax_fire", "vssr_batch_relax_bfgs", "vssr_debug_capacity",
     "vssr_batch_device_results", "vssr_eam_create", "vssr_eam_eval_batch",
-    "vssr_tersoff_create_from_text", "vssr_batch_relax_cg",
+    "vssr_tersoff_create_from_text", "vssr_batch_relax_cg", "vssr_batch_saturated",
+    "vssr_batch_embedding", "vssr_batch_traj_configure", "vssr_batch_traj_read",
+    "vssr_device_context",
 )
 
 
@@ -180,6 +182,16 @@ def load_library():
     L.vssr_batch_relax_bfgs.argtypes = [vp, C.POINTER(BfgsParams), u8p, C.c_uint32, dp, ip, u8p]
     L.vssr_batch_device_results.restype = C.c_int
     L.vssr_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.vssr_batch_traj_configure.restype = C.c_int
+    L.vssr_batch_traj_configure.argtypes = [vp, C.c_int32]
+    L.vssr_batch_traj_read.restype = C.c_int
+    L.vssr_batch_traj_read.argtypes = [vp, C.c_int32, ip, dp, fp, dp, ip]
+    L.vssr_batch_embedding.restype = C.c_int
+    L.vssr_batch_embedding.argtypes = [vp, C.c_int32, fp, C.c_int64, i64p]
+    L.vssr_batch_saturated.restype = C.c_int
+    L.vssr_batch_saturated.argtypes = [vp, u8p, ip]
+    L.vssr_device_context.restype = C.c_int
+    L.vssr_device_context.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(vp)]
     L.vssr_debug_capacity.restype = C.c_int
     L.vssr_debug_capacity.argtypes = [vp, C.c_int32, C.c_int32, ip]
     if L.vssr_abi_version() != 1:
@@ -203,11 +215,11 @@ def pack_batch(structs):
 
 
 class _DeviceArray:
-    """A float32 vector in device memory owned by an engine (``__cuda_array_interface__`` v2)."""
+    """A float32 (or int32) vector in device memory owned by an engine (``__cuda_array_interface__`` v2)."""
 
-    def __init__(self, ptr, n):
+    def __init__(self, ptr, n, typestr="<f4"):
         # (read-only flag False: torch refuses read-only device arrays; consumers only read these buffers)
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2,
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2,
                                          "strides": None}
 
 
@@ -280,7 +292,26 @@ class _Handle:
                     ("energy", "energy_std", "forces", "forces_std", "energy_models", "energy_atoms")])
         self._check(self._lib.vssr_batch_download(self._h, int(want), C.byref(out)))
         res["cfg_start"] = self._cfg_start
+        res["saturated"] = self.saturated()
         return res
+
+    def embedding(self, model=None):
+        """Per-atom latent features (final scalar state, the readout's input) of the resident batch after a run:
+        ``[M, sum N, F]`` for ``model=None``, ``[sum N, F]`` for one ensemble member (vssr_batch_embedding)."""
+        n = C.c_int64(0)
+        m = -1 if model is None else int(model)
+        self._check(self._lib.vssr_batch_embedding(self._h, m, None, 0, C.byref(n)))
+        buf = np.zeros(n.value, np.float32)
+        self._check(self._lib.vssr_batch_embedding(self._h, m, _ptr(buf, C.c_float), n.value, C.byref(n)))
+        return buf.reshape((self.n_models, self._n_atoms, -1) if model is None else (self._n_atoms, -1))
+
+    def saturated(self):
+        """bool [B]: chains whose last evaluation left the range of the fp16-split arithmetic (a value beyond +-65504 was
+        clamped) or produced a non-finite energy -- their results are finite but not the model's (vssr_batch_saturated)."""
+        flags = np.zeros(self._n_cfg, np.uint8)
+        n = C.c_int32(0)
+        self._check(self._lib.vssr_batch_saturated(self._h, _ptr(flags, C.c_uint8), C.byref(n)))
+        return flags.astype(bool)
 
     def device_results(self):
         """``(energy, energy_std)`` of the resident batch as zero-copy device arrays (objects with
@@ -288,6 +319,13 @@ class _Handle:
         e, s = C.c_void_p(None), C.c_void_p(None)
         self._check(self._lib.vssr_batch_device_results(self._h, C.byref(e), C.byref(s)))
         return _DeviceArray(e.value, self._n_cfg), _DeviceArray(s.value, self._n_cfg)
+
+    def device_context(self):
+        """``(device ordinal, hipStream_t of the engine as int, device address of the overflow flag or None)``
+        (vssr_device_context)."""
+        d, st, fl = C.c_int32(0), C.c_void_p(None), C.c_void_p(None)
+        self._check(self._lib.vssr_device_context(self._h, C.byref(d), C.byref(st), C.byref(fl)))
+        return d.value, st.value or 0, fl.value
 
     def evaluate(self, structs, want=WANT_ALL):
         self.upload(structs)
@@ -303,18 +341,21 @@ class _Handle:
             raise BackendError(f"optimizer {optimizer!r} is not available on the device (FIRE and BFGS are)")
         return self.relax_bfgs(**kw) if "BFGS" in name else self.relax_fire(**kw)
 
-    def relax_bfgs(self, fixed=None, max_steps=20, fmax=0.01, want=WANT_ALL, params=None):
+    def relax_bfgs(self, fixed=None, max_steps=20, fmax=0.01, want=WANT_ALL, params=None, record_interval=0):
         """BFGS-relax every chain of the resident batch on the device (ASE BFGS, the reference's SrTiO3 optimizer).
         Same arguments and return value as :meth:`relax_fire`."""
         p = params or BfgsParams.default(max_steps, fmax)
-        return self._relax_call(self._lib.vssr_batch_relax_bfgs, p, fixed, want)
+        return self._relax_call(self._lib.vssr_batch_relax_bfgs, p, fixed, want, record_interval)
 
-    def relax_fire(self, fixed=None, max_steps=20, fmax=0.01, want=WANT_ALL, params=None):
+    def relax_fire(self, fixed=None, max_steps=20, fmax=0.01, want=WANT_ALL, params=None, record_interval=0):
         """FIRE-relax every chain of the resident batch on the device (reference optimize_slab with FIRE).
         ``fixed``: bool/uint8 [sum N], True = held fixed.  Returns dict(positions [sum N,3] float64,
-        n_steps [B], converged [B]) — fetch energies/forces of the relaxed batch with download()."""
+        n_steps [B], converged [B]) — fetch energies/forces of the relaxed batch with download().
+        ``record_interval`` k > 0 also records every chain after 0, k, 2k, ... optimizer steps (the reference's
+        TrajectoryObserver, ``mcmc/dynamics.py:131-151``): key ``"traj"`` = dict(n_records [B], positions [R, sum N, 3],
+        forces [R, sum N, 3] with FixAtoms applied, energies [R, B]); entries of chain b beyond n_records[b] are unused."""
         p = params or FireParams.default(max_steps, fmax)
-        return self._relax_call(self._lib.vssr_batch_relax_fire, p, fixed, want)
+        return self._relax_call(self._lib.vssr_batch_relax_fire, p, fixed, want, record_interval)
 
     def debug_capacity(self, slots_per_atom=0, tight=-1):
         """Test hook (vssr_debug_capacity); returns the regrow count of the last relaxation."""
@@ -322,8 +363,9 @@ class _Handle:
         self._check(self._lib.vssr_debug_capacity(self._h, int(slots_per_atom), int(tight), C.byref(n)))
         return n.value
 
-    def _relax_call(self, fn, p, fixed, want):
+    def _relax_call(self, fn, p, fixed, want, record_interval=0):
         N, B = self._n_atoms, self._n_cfg
+        self._check(self._lib.vssr_batch_traj_configure(self._h, int(record_interval or 0)))
         fx = None
         if fixed is not None:
             fx = np.ascontiguousarray(fixed, dtype=np.uint8)
@@ -334,7 +376,19 @@ class _Handle:
         conv = np.zeros(B, np.uint8)
         self._check(fn(self._h, C.byref(p), _ptr(fx, C.c_uint8), int(want), _ptr(pos, C.c_double),
                        _ptr(steps, C.c_int32), _ptr(conv, C.c_uint8)))
-        return {"positions": pos, "n_steps": steps, "converged": conv.astype(bool)}
+        out = {"positions": pos, "n_steps": steps, "converged": conv.astype(bool)}
+        if record_interval:
+            R = C.c_int32(0)
+            self._check(self._lib.vssr_batch_traj_read(self._h, 0, None, None, None, None, C.byref(R)))
+            R = R.value
+            n_rec = np.zeros(B, np.int32)
+            tpos, tf, te = np.zeros((R, N, 3), np.float64), np.zeros((R, N, 3), np.float32), np.zeros((R, B), np.float64)
+            self._check(self._lib.vssr_batch_traj_read(self._h, R, _ptr(n_rec, C.c_int32), _ptr(tpos, C.c_double),
+                                                       _ptr(tf, C.c_float), _ptr(te, C.c_double), None))
+            self._check(self._lib.vssr_batch_traj_configure(self._h, 0))
+            out["traj"] = {"n_records": n_rec, "positions": tpos, "forces": tf, "energies": te,
+                           "record_interval": int(record_interval)}
+        return out
 
     # -- introspection -----------------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -201,14 +201,21 @@ class EnsembleNFFSurface(_Base):
         model_units / prediction_units / offset_units: as in the reference (``"kcal/mol"``, ``"eV"``,
             ``"atomic"``).
         cutoff: neighbor cutoff in Å (the reference passes it through ``get_atoms_batch``).
+        properties: like nff's ``NeuralFF(properties=[...])``; with ``"embedding"`` in it ``results["embedding"]`` holds the
+            per-atom latent features ``[N, 128]`` (final scalar state) of the first model -- the reference computes them
+            with ``NeuralFF(models[0], properties=["energy", "forces", "embedding"])`` -- and ``results["embedding_models"]``
+            those of every ensemble member ``[M, N, 128]``.
     """
 
-    implemented_properties = ("energy", "forces", "stress", "energy_std", "forces_std", "surface_energy")
+    implemented_properties = ("energy", "forces", "stress", "energy_std", "forces_std", "surface_energy", "embedding")
     name = "ensemble_nff_surface_mi355x"
 
     def __init__(self, models, device="cuda", model_units="kcal/mol", prediction_units="eV",
-                 offset_units="atomic", cutoff=5.0, hparams=None, logger=None, **kwargs):
+                 offset_units="atomic", cutoff=5.0, hparams=None, logger=None, properties=("energy", "forces"), **kwargs):
         self.models = [self._load_model(m, hparams) for m in models]
+        # like NeuralFF(properties=[...]) in the reference's clustering script (scripts/clustering.py:150-158): "embedding" in
+        # this list makes every calculate() also return the latent features
+        self.properties = tuple(properties)
         self.device = device
         self.model_units = model_units
         self.prediction_units = prediction_units
@@ -337,6 +344,8 @@ class EnsembleNFFSurface(_Base):
             # ensemble-mean per-atom energies in eV (the stoichiometric offset is not distributed over atoms); what the
             # reference's Boltzmann-weighted switch proposal reads from results["per_atom_energies"] (mcmc/slab.py:92)
             "per_atom_energies": res["energy_atoms"][a0:a1].copy(),
+            # the evaluation left the range of the fp16-split arithmetic (backend.saturated): finite, but not the model's
+            "saturated": bool(res["saturated"][b]) if "saturated" in res else False,
         }
 
     def calculate(self, atoms=None, properties=implemented_properties, system_changes=all_changes):
@@ -344,8 +353,16 @@ class EnsembleNFFSurface(_Base):
         if atoms is None:
             atoms = self.atoms
         _Base.calculate(self, atoms, properties, system_changes)
-        res = self._get_engine().evaluate([structures.as_arrays(atoms)])
+        eng = self._get_engine()
+        res = eng.evaluate([structures.as_arrays(atoms)])
         self.results.update(self._fill_results(res, 0))
+        if "embedding" in self.properties or "embedding" in tuple(properties) and tuple(properties) != tuple(self.implemented_properties):
+            emb = eng.embedding()
+            self.results["embedding"] = emb[0]
+            self.results["embedding_models"] = emb
+        if self.results["saturated"]:
+            self.logger.warning("activations left the fp16-split range (|x| > 65504): energy %.6g eV is not reliable",
+                                float(self.results["energy"][0]))
         if "surface_energy" in properties:
             self.results["surface_energy"] = self.surface_energy_of(self.results["energy"], atoms)
         if hasattr(atoms, "results") and isinstance(atoms.results, dict):
@@ -358,14 +375,23 @@ class EnsembleNFFSurface(_Base):
         return value
 
     # -- new capability: many independent chains in one lock-step evaluation ----------------------------
-    def calculate_batch(self, atoms_list, want_surface_energy: bool = False) -> list[dict]:
-        """Evaluate B independent configurations at once; returns one results dict per configuration."""
-        res = self._get_engine().evaluate([structures.as_arrays(a) for a in atoms_list])
+    def calculate_batch(self, atoms_list, want_surface_energy: bool = False, want_embedding: bool | None = None) -> list[dict]:
+        """Evaluate B independent configurations at once; returns one results dict per configuration
+        (``want_embedding``: default = ``"embedding" in self.properties``)."""
+        eng = self._get_engine()
+        res = eng.evaluate([structures.as_arrays(a) for a in atoms_list])
+        if want_embedding is None:
+            want_embedding = "embedding" in self.properties
+        emb = eng.embedding() if want_embedding else None
         out = []
         for b, atoms in enumerate(atoms_list):
             r = self._fill_results(res, b)
             if want_surface_energy:
                 r["surface_energy"] = self.surface_energy_of(r["energy"], atoms)
+            if emb is not None:
+                a0, a1 = int(res["cfg_start"][b]), int(res["cfg_start"][b + 1])
+                r["embedding"] = emb[0, a0:a1].copy()
+                r["embedding_models"] = emb[:, a0:a1].copy()
             out.append(r)
         return out
 
@@ -374,15 +400,19 @@ class EnsembleNFFSurface(_Base):
     ENERGY_THRESHOLD = 1000.0
     MAX_FORCE_THRESHOLD = 1000.0
 
-    def relax_batch(self, atoms_list, fixed_indices=None, relax_steps: int = 20, fmax: float = 0.01, optimizer=None):
+    def relax_batch(self, atoms_list, fixed_indices=None, relax_steps: int = 20, fmax: float = 0.01, optimizer=None,
+                    save_traj: bool = False, record_interval: int = 5):
         """Relax B independent slabs at once on the device — the batched counterpart of
-        ``optimize_slab(slab, optimizer=..., relax_steps=..., save_traj=False)`` (reference
+        ``optimize_slab(slab, optimizer=..., relax_steps=..., save_traj=..., record_interval=...)`` (reference
         ``mcmc/dynamics.py:83-170``).  ``optimizer``: "BFGS" (ASE BFGS, the reference's SrTiO3 setting,
         ``scripts/configs/sample_config_painn.json:26``) or "FIRE" (the reference's default); None takes
         ``parameters["optimizer"]`` (how ``calc_settings`` reach ``optimize_slab``), else "FIRE".
         ``fixed_indices``: per slab, the atom indices held by FixAtoms (or None).
-        Returns, per slab, the reference's tuple ``(relaxed_slab, traj=None, energy, energy_oob)`` where
-        ``energy_oob`` follows the same +-1000 guard, plus the results dict of the final evaluation."""
+        Returns, per slab, the reference's tuple ``(relaxed_slab, traj, energy, energy_oob)`` where ``energy_oob`` follows
+        the same +-1000 guard (a saturated evaluation counts as out of bounds), plus the results dict of the final
+        evaluation.  ``save_traj=True``: ``traj`` is the reference's dict ``{"atoms", "energies", "forces"}`` recorded like
+        its TrajectoryObserver attached with ``interval=record_interval`` (after 0, k, 2k, ... optimizer steps; forces with
+        FixAtoms applied); otherwise None."""
         eng = self._get_engine()
         packs = [structures.as_arrays(a) for a in atoms_list]
         eng.upload(packs)
@@ -396,24 +426,83 @@ class EnsembleNFFSurface(_Base):
                 o += len(p[0])
         if optimizer is None:
             optimizer = self.parameters.get("optimizer", "FIRE")
-        info = eng.relax(optimizer, fixed=fixed, max_steps=relax_steps, fmax=fmax)
+        info = eng.relax(optimizer, fixed=fixed, max_steps=relax_steps, fmax=fmax,
+                         record_interval=int(record_interval) if save_traj else 0)
         res = eng.download()
         out = []
         for b, atoms in enumerate(atoms_list):
             a0, a1 = int(res["cfg_start"][b]), int(res["cfg_start"][b + 1])
             relaxed = atoms.copy()
             relaxed.set_positions(info["positions"][a0:a1])
+            traj = _traj_of_chain(info.get("traj"), b, a0, a1, atoms) if save_traj else None
             r = self._fill_results(res, b)
             energy = float(r["energy"][0])
             max_force = float(np.abs(r["forces"]).max()) if a1 > a0 else 0.0
             oob = bool(not np.isfinite(energy) or not np.isfinite(max_force) or abs(energy) > self.ENERGY_THRESHOLD
-                       or max_force > self.MAX_FORCE_THRESHOLD)
+                       or max_force > self.MAX_FORCE_THRESHOLD or r["saturated"])
             if oob:
                 energy = self.ENERGY_THRESHOLD
             r["n_steps"] = int(info["n_steps"][b])
             r["converged"] = bool(info["converged"][b])
-            out.append((relaxed, None, energy, oob, r))
+            out.append((relaxed, traj, energy, oob, r))
         return out
+
+
+def _traj_of_chain(traj, b, a0, a1, atoms):
+    """Records of chain b in the layout of the reference's ``optimize_slab`` (``mcmc/dynamics.py:145-151``)."""
+    if traj is None:
+        return None
+    frames = []
+    n = int(traj["n_records"][b])
+    for r in range(n):
+        frame = atoms.copy()
+        frame.set_positions(traj["positions"][r, a0:a1])
+        if hasattr(frame, "calc"):
+            frame.calc = None   # the observer stores copies without the calculator
+        frames.append(frame)
+    return {"atoms": frames, "energies": [float(traj["energies"][r, b]) for r in range(n)],
+            "forces": [traj["forces"][r, a0:a1].copy() for r in range(n)]}
+
+
+# ---- helpers of the reference's clustering / uncertainty scripts (mcmc/calculators/calculators.py:34-135) ------------------
+def get_results_single(atoms_batch, calc) -> dict:
+    """One calculation of ``atoms_batch`` with ``calc``; returns ``calc.results`` (reference ``:34-47``)."""
+    atoms_batch.calc = calc
+    calc.calculate(atoms_batch)
+    return calc.results
+
+
+def get_embeddings_single(atoms_batch, calc, results_cache: dict | None = None, flatten: bool = True,
+                          flatten_axis: int = 0) -> np.ndarray:
+    """Latent-space embedding of one structure (reference ``:67-93``): the per-atom features ``results["embedding"]``
+    averaged over ``flatten_axis`` (atoms) when ``flatten``; ``results_cache`` avoids a second evaluation.  The calculator
+    must provide the embedding (``EnsembleNFFSurface(..., properties=[..., "embedding"])``)."""
+    results = results_cache if results_cache is not None and "embedding" in results_cache \
+        else get_results_single(atoms_batch, calc)
+    if "embedding" not in results:
+        raise KeyError('the calculator returns no "embedding": construct it with properties=(..., "embedding")')
+    emb = np.asarray(results["embedding"])
+    return emb.mean(axis=flatten_axis).squeeze() if flatten else emb.squeeze()
+
+
+def get_embeddings(atoms_batches, calc) -> np.ndarray:
+    """One embedding row per structure (reference ``:50-64``)."""
+    return np.stack([get_embeddings_single(a, calc) for a in atoms_batches])
+
+
+def get_std_devs_single(atoms_batch, calc):
+    """Mean ensemble standard deviation of the force components of one structure, 0.0 for a single model (reference
+    ``:117-135``)."""
+    if len(calc.models) > 1:
+        atoms_batch.calc = calc
+        calc.calculate(atoms_batch)
+        return calc.results.get("forces_std", np.array([0.0])).mean()
+    return 0.0
+
+
+def get_std_devs(atoms_batches, calc) -> np.ndarray:
+    """Force standard deviation of every structure (reference ``:96-114``)."""
+    return np.stack([get_std_devs_single(a, calc) for a in atoms_batches])
 
 
 @dataclasses.dataclass
@@ -615,6 +704,52 @@ class _AnalyticSurfCalc(_Base):
         relaxed.set_positions(new_pos)
         relaxed.calc = getattr(slab, "calc", None)
         return relaxed, float(e[0]), ea
+
+    ENERGY_THRESHOLD = 1000.0
+    MAX_FORCE_THRESHOLD = 1000.0
+
+    def relax_batch(self, atoms_list, fixed_indices=None, relax_steps: int | None = None, fmax: float = 0.01,
+                    optimizer=None, **kwargs):
+        """Relax B slabs in ONE lock-step call -- what ``mc.ChainEnsemble(relax=True)`` needs from a calculator.  Default
+        ``optimizer`` "LAMMPS" / "CG": the reference's GaN minimiser (``optimize_slab(optimizer="LAMMPS")`` ->
+        ``run_lammps_opt``, ``mcmc/dynamics.py:107-116``) for all slabs at once (``vssr_batch_relax_cg``); "FIRE" / "BFGS"
+        use the ASE-style optimizers with ``fmax``.  ``relax_steps`` defaults to ``self.relax_steps`` (the reference takes it
+        from ``calc.relax_steps``).  Returns per slab ``(relaxed, None, energy, energy_oob, results)`` like
+        ``EnsembleNFFSurface.relax_batch``; results carry ``per_atom_energies`` of the relaxed slab."""
+        if optimizer is None:
+            optimizer = self.parameters.get("optimizer", "LAMMPS")
+        steps = int(self.relax_steps if relax_steps is None else relax_steps)
+        packs = [self._pack(a) for a in atoms_list]
+        fixed = None
+        if fixed_indices is not None:
+            fixed = np.zeros(sum(len(p[0]) for p in packs), np.uint8)
+            o = 0
+            for p, idx in zip(packs, fixed_indices):
+                if idx is not None and len(idx):
+                    fixed[o + np.asarray(idx, dtype=np.int64)] = 1
+                o += len(p[0])
+        eng = self._get_engine()
+        if str(optimizer).upper() in ("CG", "LAMMPS"):
+            e, ea, f, pos, it, ev, why = eng.relax_cg_f64(packs, fixed=fixed, max_iter=steps, etol=kwargs.get("etol", 1e-5),
+                                                          ftol=kwargs.get("ftol", 1e-5))
+            extra = [{"iterations": int(it[b]), "evaluations": int(ev[b]),
+                      "stop": backend.CG_STOP_REASONS.get(int(why[b]), str(int(why[b])))} for b in range(len(packs))]
+        else:
+            e, ea, f, pos, nst, conv = eng.relax_f64(packs, fixed=fixed, max_steps=steps, fmax=fmax, optimizer=optimizer)
+            extra = [{"n_steps": int(nst[b]), "converged": bool(conv[b])} for b in range(len(packs))]
+        out, o = [], 0
+        for b, (atoms, p) in enumerate(zip(atoms_list, packs)):
+            n = len(p[0])
+            relaxed = atoms.copy()
+            relaxed.set_positions(pos[o:o + n])
+            energy = float(e[b])
+            max_force = float(np.abs(f[o:o + n]).max()) if n else 0.0
+            oob = bool(not np.isfinite(energy) or not np.isfinite(max_force) or abs(energy) > self.ENERGY_THRESHOLD
+                       or max_force > self.MAX_FORCE_THRESHOLD)
+            r = {"energy": energy, "per_atom_energies": ea[o:o + n].copy(), "forces": f[o:o + n].copy(), **extra[b]}
+            out.append((relaxed, None, self.ENERGY_THRESHOLD if oob else energy, oob, r))
+            o += n
+        return out
 
     def calculate_batch(self, atoms_list) -> list[dict]:
         packs = [self._pack(a) for a in atoms_list]

@@ -67,19 +67,72 @@ __device__ __forceinline__ Planes make_planes(_Float16 *base, int rows, int K) {
 }
 constexpr int plane_halves(int rows, int K) { return 2 * rows * (K + PADH); }
 
-__device__ __forceinline__ void split1(float x, _Float16 &h, _Float16 &l) {
-    const float xc = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
-    h = (_Float16)xc;
-    l = (_Float16)(xc - (float)h);
-}
-__device__ __forceinline__ void store_split(const Planes &P, int row, int col, float x) {
-    _Float16 h, l;
-    split1(x, h, l);
-    P.h[row * P.ld + col] = h;
-    P.l[row * P.ld + col] = l;
-}
+// Saturation of the fp16 split.  An activation beyond +-65504 cannot be represented by the h piece and is clamped (the
+// results stay finite, but they are no longer the model's).  Every split is watched and attributed to its ATOM (TA = 32 rows
+// per tile, tile row = x * TA + atom), so that a chain which shares an atom tile with a saturating neighbour is not
+// touched.  At the end of a kernel the (rare) hits raise the flag of the chain of exactly that atom;
+// vssr_batch_saturated() / results["saturated"] report the flags.  (NaN does not order: a non-finite energy is flagged by
+// k_finalize_energy instead.)
+// Cost matters: the reverse update kernel runs at the 256-register limit.  Measured there (same-box A/Bs, ms / step):
+// one running maximum per thread 2.40 -> 2.40; a per-thread bit mask of rows (compare / shift / select / or) -> 3.07
+// (125 spilled registers); lane masks of the compares folded on the scalar unit -> 284 spilled SGPRs.  So the node kernels
+// keep running maxima (two max3 per four elements), one per row a thread can meet: both row -> thread maps that occur
+// put a thread on the rows rho and rho + 16 of the tile,
+//   SAT_ACC   accumulator layout   row = 16 t + (lane & 15)     rho = lane & 15      (LaneGeo)
+//   SAT_COOP  cooperative passes   row = (tid >> 5) + 16 it      rho = tid >> 5       (load_rows_split)
+// and bit 4 of the row is a constant of the unrolled code, so the choice among the four maxima costs nothing.
+// SAT_ANY (arbitrary maps: the layer-0 staging pass, registers to spare) keeps a bit mask of rows.
+// A tracker only costs while it is live: the cooperative passes use their own instance, committed right behind the pass, and
+// a pass whose values another kernel of the same evaluation has already watched (the reverse update kernel re-reads the
+// forward kernel's inputs and recomputes its intermediates) takes SatNone.
+#ifndef VSSR_SAT_TRACK
+#define VSSR_SAT_TRACK 1   // 0: A/B builds that measure what the tracking costs (tools/build_variant.sh); never shipped
+#endif
+enum { SAT_ACC = 0, SAT_COOP = 1, SAT_ANY = 2 };
+struct SatTrack {
+    float acc_lo = 0.f, acc_hi = 0.f, coop_lo = 0.f, coop_hi = 0.f;
+    unsigned rows = 0u;   // SAT_ANY
+    static constexpr float LIM = 65504.f;
+    template <int LAYOUT>
+    __device__ __forceinline__ void see(int row, float a, float b, float c, float d) {
+        if (!VSSR_SAT_TRACK) return;
+        if (LAYOUT == SAT_ANY) {
+            const float mx = fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d)));
+            rows |= mx > LIM ? 1u << (row & (TA - 1)) : 0u;
+            return;
+        }
+        auto upd = [&](float m) { return fmaxf(fmaxf(fmaxf(fmaxf(m, fabsf(a)), fabsf(b)), fabsf(c)), fabsf(d)); };
+        const bool upper = (row >> 4) & 1;
+        if (LAYOUT == SAT_ACC) { acc_lo = upper ? acc_lo : upd(acc_lo); acc_hi = upper ? upd(acc_hi) : acc_hi; }
+        else { coop_lo = upper ? coop_lo : upd(coop_lo); coop_hi = upper ? upd(coop_hi) : coop_hi; }
+    }
+    // a0: first atom of the tile, N: atoms in the batch (tail rows are copies of the last atom)
+    __device__ __forceinline__ void commit(const ActiveView &av, int a0, int N) const {
+        if (!VSSR_SAT_TRACK || !av.sat) return;
+        const float worst = fmaxf(fmaxf(acc_lo, acc_hi), fmaxf(coop_lo, coop_hi));
+        if (!(worst > LIM) && rows == 0u) return;
+        auto raise = [&](int row) {
+            const int c = av.atom_cfg[min(a0 + (row & (TA - 1)), N - 1)];
+            if (av.chain(c)) atomicOr(av.sat + c, 1u);   // (a switched-off chain is not being evaluated)
+        };
+        const int r = threadIdx.x & 15, rho = (threadIdx.x & (NTHREADS - 1)) >> 5;
+        if (acc_lo > LIM) raise(r);
+        if (acc_hi > LIM) raise(16 + r);
+        if (coop_lo > LIM) raise(rho);
+        if (coop_hi > LIM) raise(16 + rho);
+        for (unsigned m = rows; m; m &= m - 1u) raise(__builtin_ctz(m));
+    }
+};
+
 // four consecutive columns at once (col multiple of 4): two 8-byte LDS stores
-__device__ __forceinline__ void store_split4(const Planes &P, int row, int col, float4 v) {
+struct SatNone {
+    template <int LAYOUT>
+    __device__ __forceinline__ void see(int, float, float, float, float) {}
+};
+
+template <int LAYOUT = SAT_ACC, class Sat>
+__device__ __forceinline__ void store_split4(const Planes &P, int row, int col, float4 v, Sat &sat) {
+    sat.template see<LAYOUT>(row, v.x, v.y, v.z, v.w);
     const f32x2 a = {__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f)};
     const f32x2 b = {__builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f)};
     const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
@@ -89,15 +142,16 @@ __device__ __forceinline__ void store_split4(const Planes &P, int row, int col, 
     *reinterpret_cast<u32x2 *>(P.l + row * P.ld + col) = (u32x2){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
 }
 
-__device__ __forceinline__ void store_split4(const Planes &P, int row, int col, f32x4 v) {
-    store_split4(P, row, col, make_float4(v[0], v[1], v[2], v[3]));
+template <int LAYOUT = SAT_ACC, class Sat>
+__device__ __forceinline__ void store_split4(const Planes &P, int row, int col, f32x4 v, Sat &sat) {
+    store_split4<LAYOUT>(P, row, col, make_float4(v[0], v[1], v[2], v[3]), sat);
 }
 
 // Cooperative tile load: NROWS rows of F floats from global, split, into plane columns [col0, col0 + F).  rowptr(row)
 // must always return a readable row (tail rows are clamped to the last atom; their results are never stored), so that
 // all loads are unconditional and issued back-to-back before the first LDS store.
-template <int NROWS, class RowPtr>
-__device__ __forceinline__ void load_rows_split(const Planes &P, int col0, RowPtr rowptr) {
+template <int NROWS, class RowPtr, class Sat>
+__device__ __forceinline__ void load_rows_split(const Planes &P, int col0, RowPtr rowptr, Sat &sat) {
     constexpr int NIT = NROWS * (F / 4) / NTHREADS;
     static_assert(NROWS * (F / 4) % NTHREADS == 0, "tile load must divide evenly");
     float4 v[NIT];
@@ -109,7 +163,7 @@ __device__ __forceinline__ void load_rows_split(const Planes &P, int col0, RowPt
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = threadIdx.x + it * NTHREADS;
-        store_split4(P, idx >> 5, col0 + 4 * (idx & 31), v[it]);
+        store_split4<SAT_COOP>(P, idx >> 5, col0 + 4 * (idx & 31), v[it], sat);
     }
 }
 // same in two halves, and the fp32 values stay with the threads that loaded them (residual operands of a later output
@@ -124,13 +178,14 @@ __device__ __forceinline__ void rows_request(RowPtr rowptr, float4 (&v)[NROWS * 
         v[it] = *reinterpret_cast<const float4 *>(rowptr(idx >> 5) + 4 * (idx & 31));
     }
 }
-template <int NROWS>
-__device__ __forceinline__ void rows_store_split(const Planes &P, int col0, const float4 (&v)[NROWS * (F / 4) / NTHREADS]) {
+template <int NROWS, class Sat>
+__device__ __forceinline__ void rows_store_split(const Planes &P, int col0, const float4 (&v)[NROWS * (F / 4) / NTHREADS],
+                                                 Sat &sat) {
     constexpr int NIT = NROWS * (F / 4) / NTHREADS;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = threadIdx.x + it * NTHREADS;
-        store_split4(P, idx >> 5, col0 + 4 * (idx & 31), v[it]);
+        store_split4<SAT_COOP>(P, idx >> 5, col0 + 4 * (idx & 31), v[it], sat);
     }
 }
 

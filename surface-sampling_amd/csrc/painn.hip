@@ -392,7 +392,8 @@ __global__ void __launch_bounds__(256)
 k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const int *__restrict__ cfg_start, const int *__restrict__ Z,
                   const float *__restrict__ e_atom, double units_per_ev, const double *__restrict__ offset_per_z,
                   double offset_const, float *__restrict__ energy, float *__restrict__ energy_std,
-                  float *__restrict__ energy_models, float *__restrict__ e_atoms_mean) {
+                  float *__restrict__ energy_models, float *__restrict__ e_atoms_mean, unsigned *__restrict__ sat,
+                  unsigned *__restrict__ sat_out) {
     __shared__ double red[256];
     __shared__ double em[MAX_MODELS];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -429,6 +430,10 @@ k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const 
         for (int m = 0; m < M; ++m) var += (em[m] - mu) * (em[m] - mu);
         energy[b] = (float)mu;
         energy_std[b] = (float)sqrt(var / M);
+        // saturation report of this evaluation (mfma16.h SatTrack): the node kernels' flag, or a non-finite energy; the run
+        // flag is cleared for the chain's next evaluation
+        sat_out[b] = (sat[b] != 0u || !isfinite((float)mu)) ? 1u : 0u;
+        sat[b] = 0u;
         for (int m = 0; m < M; ++m) energy_models[(size_t)b * M + m] = (float)em[m];
     }
     for (int i = a0 + tid; i < a1; i += blockDim.x) {
@@ -469,6 +474,12 @@ int painn_alloc_state(vssr_handle *h) {
         h->d_energy_models.ensure(sizeof(float) * h->n_cfg * M) || h->d_forces.ensure(sizeof(float) * 3 * N) ||
         h->d_forces_std.ensure(sizeof(float) * 3 * N) || h->d_e_atoms.ensure(sizeof(float) * N))
         return set_err(h, VSSR_E_NOMEM, "result buffers: out of device memory");
+    if (h->d_sat.bytes < sizeof(unsigned) * h->n_cfg || h->d_sat_out.bytes < sizeof(unsigned) * h->n_cfg) {
+        if (h->d_sat.ensure(sizeof(unsigned) * h->n_cfg) || h->d_sat_out.ensure(sizeof(unsigned) * h->n_cfg))
+            return set_err(h, VSSR_E_NOMEM, "saturation flags: out of device memory");
+        VSSR_HIP(h, hipMemsetAsync(h->d_sat.p, 0, h->d_sat.bytes, h->stream));
+        VSSR_HIP(h, hipMemsetAsync(h->d_sat_out.p, 0, h->d_sat_out.bytes, h->stream));
+    }
     return VSSR_OK;
 }
 
@@ -498,7 +509,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
     G.drho16 = h->d_drho16.as<uint4>();
     G.zslot = h->d_zslot.as<unsigned char>();
     G.bundle = h->d_bundle.as<int4>();
-    G.act = ActiveView{h->active_mask, h->d_atom_cfg.as<int>()};
+    G.act = ActiveView{h->active_mask, h->d_atom_cfg.as<int>(), h->d_sat.as<unsigned>()};
     const ActiveView &av = G.act;
     const ModelW *MW = h->model_table.as<ModelW>();
     const int *counters = h->d_counters.as<int>();
@@ -626,7 +637,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     hipLaunchKernelGGL(k_finalize_energy, dim3(h->n_cfg), dim3(256), 0, st, N, M, h->active_mask, G.cfg_start, Z, sv.e_atom,
                        h->units_per_ev, h->has_offset ? h->offset_per_z.as<double>() : (const double *)nullptr,
                        h->offset_const, h->d_energy.as<float>(), h->d_energy_std.as<float>(),
-                       h->d_energy_models.as<float>(), h->d_e_atoms.as<float>());
+                       h->d_energy_models.as<float>(), h->d_e_atoms.as<float>(), h->d_sat.as<unsigned>(),
+                       h->d_sat_out.as<unsigned>());
     P.end(st);
     VSSR_HIP(h, hipGetLastError());
     return VSSR_OK;

@@ -93,6 +93,7 @@ k_l0_fwd16(int N, int M, int nz, ActiveView av, const int *__restrict__ counters
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;
     const Planes Ts = make_planes(ldsh, TA, K), Tv = make_planes(ldsh + plane_halves(TA, K), 3 * TA, K);
     const LaneGeo L;
+    SatTrack sat;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     // T[(i nz + z) 96 + comp 24 + kappa] -> planes; the 8 pad entries of every species chunk are zero
     // (four entries per thread and pass: 16-byte loads, 8-byte plane stores; KP = 24 is a multiple of 4)
@@ -101,9 +102,10 @@ k_l0_fwd16(int N, int M, int nz, ActiveView av, const int *__restrict__ counters
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (4 * k4 < KP)
             val = *reinterpret_cast<const float4 *>(T + ((size_t)min(a0 + a, N - 1) * nz + z) * TBLK + comp * KP + 4 * k4);
-        if (comp == 0) store_split4(Ts, a, 32 * z + 4 * k4, val);
-        else store_split4(Tv, (comp - 1) * TA + a, 32 * z + 4 * k4, val);
+        if (comp == 0) store_split4<SAT_ANY>(Ts, a, 32 * z + 4 * k4, val, sat);
+        else store_split4<SAT_ANY>(Tv, (comp - 1) * TA + a, 32 * z + 4 * k4, val, sat);
     }
+    sat.commit(av, a0, N);
     __syncthreads();
     // weight pieces of step (m, q + 1) are requested before the matrix instructions of step (m, q)
     u32x4 bn[2][2];
@@ -170,11 +172,13 @@ k_l0_q16(int N, int nz, ActiveView av, const int *__restrict__ counters, const i
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;
     const size_t mN = (size_t)m * N;
     const Planes Xs = make_planes(ldsh, TA, F), Xv = make_planes(ldsh + plane_halves(TA, F), 3 * TA, F);
-    load_rows_split<TA>(Xs, 0, [&](int row) { return sbar_msg + (mN + min(a0 + row, N - 1)) * F; });
+    SatTrack sat;
+    load_rows_split<TA>(Xs, 0, [&](int row) { return sbar_msg + (mN + min(a0 + row, N - 1)) * F; }, sat);
     load_rows_split<3 * TA>(Xv, 0, [&](int row) {
         int x = row / TA, a = min(a0 + (row % TA), N - 1);
         return vbar_msg + ((mN + a) * 3 + x) * F;
-    });
+    }, sat);
+    sat.commit(av, a0, N);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
     for (int ct = w; ct < 2 * nz; ct += NW) {

@@ -241,9 +241,10 @@ k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
+    SatTrack sat;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
-    load_rows_split<TA>(xs, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; });
+    load_rows_split<TA>(xs, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; }, sat);
     __syncthreads();
     {
         f32x4 acc[2][1];
@@ -257,7 +258,7 @@ k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const
             f32x4 hv = acc[t][0] + b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = swish(hv[i]);
-            store_split4(hs, L.row(t), L.col0, hv);
+            store_split4(hs, L.row(t), L.col0, hv, sat);
         }
     }
     __syncthreads();
@@ -278,6 +279,7 @@ k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const
             if (a < N) *reinterpret_cast<f32x4 *>(phi + (mN + a) * F3 + c * F + L.col0) = acc[t][c] + b;
         }
     }
+    sat.commit(av, a0, N);
 }
 
 // ---- message MLP reverse: sbar_in = sbar_msg + W1^T[(W2^T phibar) * swish'(W1 s + b1)] ------------------------------
@@ -290,12 +292,13 @@ k_msg_mlp_bwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, c
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
+    SatTrack sat;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
-    load_rows_split<TA>(xs, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; });
+    load_rows_split<TA>(xs, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; }, sat);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        load_rows_split<TA>(pb, c * F, [&](int row) { return phibar + (mN + min(a0 + row, N - 1)) * F3 + c * F; });
+        load_rows_split<TA>(pb, c * F, [&](int row) { return phibar + (mN + min(a0 + row, N - 1)) * F3 + c * F; }, sat);
     __syncthreads();
     f32x4 h1[2][1], a1[2][1];
     zero_acc(h1);
@@ -316,7 +319,7 @@ k_msg_mlp_bwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, c
             f32x4 hv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = a1[t][0][i] * dswish(h1[t][0][i] + b[i]);
-            store_split4(xs, L.row(t), L.col0, hv);
+            store_split4(xs, L.row(t), L.col0, hv, sat);
         }
     }
     __syncthreads();
@@ -330,6 +333,7 @@ k_msg_mlp_bwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, c
         if (a < N)
             *reinterpret_cast<f32x4 *>(sbar_in + (mN + a) * F + L.col0) = gload4f(sbar_msg + (mN + a) * F + L.col0) + acc[t][0];
     }
+    sat.commit(av, a0, N);
 }
 
 // ---- update block -----------------------------------------------------------------------------------------------
@@ -357,8 +361,8 @@ struct UpdRegs {
 };
 
 // Shared forward part: needs vt (v_msg tile, rows x*TA+atom) and hs[:, :F] (s_msg tile) loaded + synced.
-template <int RT, int PHB>   // PHB: first phase-timing slot (debug builds)
-__device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, const LaneGeo &L, UpdRegs<RT> &R) {
+template <int RT, int PHB, class Sat>   // PHB: first phase-timing slot (debug builds)
+__device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, const LaneGeo &L, UpdRegs<RT> &R, Sat &sat) {
     constexpr int TA = 16 * RT, OFF_VT = UpdLds<RT>::OFF_VT, OFF_HS = UpdLds<RT>::OFF_HS, OFF_AS = UpdLds<RT>::OFF_AS;
     const Planes vt = make_planes(ldsh + OFF_VT, 3 * TA, F), hs = make_planes(ldsh + OFF_HS, TA, 2 * F),
                  as_ = make_planes(ldsh + OFF_AS, TA, F);
@@ -383,7 +387,7 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
             R.nrm[t][i] = sqrtf(n2);
             R.inner[t][i] = in;
         }
-        store_split4(hs, L.row(t), F + L.col0, R.nrm[t]);
+        store_split4(hs, L.row(t), F + L.col0, R.nrm[t], sat);
     }
     PH(PHB + 2)
     __syncthreads();
@@ -401,7 +405,7 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
             f32x4 sw;
 #pragma unroll
             for (int i = 0; i < 4; ++i) sw[i] = swish(R.h3[t][i]);
-            store_split4(as_, L.row(t), L.col0, sw);
+            store_split4(as_, L.row(t), L.col0, sw, sat);
         }
     }
     PH(PHB + 4)
@@ -425,20 +429,20 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
     PH(PHB + 6)
 }
 
-template <int RT>
-__device__ __forceinline__ void load_update_v(_Float16 *ldsh, const float *__restrict__ v_msg, size_t mN, int a0, int N) {
+template <int RT, class Sat>
+__device__ __forceinline__ void load_update_v(_Float16 *ldsh, const float *__restrict__ v_msg, size_t mN, int a0, int N, Sat &sat) {
     constexpr int TA = 16 * RT;
     const Planes vt = make_planes(ldsh + UpdLds<RT>::OFF_VT, 3 * TA, F);
     load_rows_split<3 * TA>(vt, 0, [&](int row) {
         int x = row / TA, a = min(a0 + (row % TA), N - 1);
         return v_msg + ((mN + a) * 3 + x) * F;
-    });
+    }, sat);
 }
-template <int RT>
-__device__ __forceinline__ void load_update_s(_Float16 *ldsh, const float *__restrict__ s_msg, size_t mN, int a0, int N) {
+template <int RT, class Sat>
+__device__ __forceinline__ void load_update_s(_Float16 *ldsh, const float *__restrict__ s_msg, size_t mN, int a0, int N, Sat &sat) {
     constexpr int TA = 16 * RT;
     const Planes hs = make_planes(ldsh + UpdLds<RT>::OFF_HS, TA, 2 * F);
-    load_rows_split<TA>(hs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; });
+    load_rows_split<TA>(hs, 0, [&](int row) { return s_msg + (mN + min(a0 + row, N - 1)) * F; }, sat);
 }
 
 // Forward kernel, compact LDS layout:
@@ -465,6 +469,7 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
+    SatTrack sat;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
     const Planes vt = make_planes(ldsh, 3 * TA, F), xs = make_planes(ldsh + CF_XS, TA, F);
@@ -488,8 +493,8 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     __builtin_amdgcn_sched_barrier(0);
     gemm16_preload(wUV, pUV);
     gemm16_preload(wW3a, pW3a);
-    rows_store_split<3 * TA>(vt, 0, keep_v);
-    rows_store_split<TA>(xs, 0, keep_s);
+    rows_store_split<3 * TA>(vt, 0, keep_v, sat);
+    rows_store_split<TA>(xs, 0, keep_s, sat);
     __syncthreads();
     PH(0)
     f32x4 uv[6][2];   // [2 x + t][0] = U v_x, [..][1] = V v_x
@@ -520,7 +525,7 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
             inner[t][i] = in;
             nv[i] = sqrtf(n2);
         }
-        store_split4(nr, L.row(t), L.col0, nv);
+        store_split4(nr, L.row(t), L.col0, nv, sat);
     }
     __syncthreads();
     PH(4)
@@ -535,7 +540,7 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
             f32x4 sw = h3[t][0] + b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) sw[i] = swish(sw[i]);
-            store_split4(as_, L.row(t), L.col0, sw);
+            store_split4(as_, L.row(t), L.col0, sw, sat);
         }
     }
     PH(5)
@@ -588,7 +593,7 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     const Planes xo = make_planes(ldsh + CF_LDS_HALVES, TA, F);   // TAIL: planes of s_out behind the output tile
     auto put = [&](int row, int col, const float4 &d, const float4 &r) {
         const float4 o = make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
-        if (TAIL && row < TA) store_split4(xo, row, col, o);   // (rows past the last atom: clamped copies, never stored)
+        if (TAIL && row < TA) store_split4<SAT_COOP>(xo, row, col, o, sat);   // (rows past the last atom: clamped copies, never stored)
         if (a0 + row % TA >= N) return;
         *reinterpret_cast<float4 *>((row < TA ? s_out : v_out) + gofs(row, col)) = o;
     };
@@ -618,7 +623,7 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
                 f32x4 hv = acc[t][0] + b;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hv[i] = swish(hv[i]);
-                store_split4(hn, L.row(t), L.col0, hv);
+                store_split4(hn, L.row(t), L.col0, hv, sat);
             }
         }
         __syncthreads();
@@ -640,6 +645,7 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
         }
         PH(11)
     }
+    sat.commit(av, a0, N);
 }
 
 // ---- readout on the matrix pipe ---------------------------------------------------------------
@@ -647,10 +653,10 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
 // `xs` (planes, synced).  hp: planes [TA][RH] for the hidden adjoint; red: [RH / 16][TA] floats.  The same code serves the
 // energy-only kernel and the head of the fused reverse kernel, so both produce identical per-atom energies.
 constexpr int RH = 64;   // hidden width of the compiled matrix-pipe readout (other widths use k_readout, painn.hip)
-template <int RT, bool WANT_SBAR>
+template <int RT, bool WANT_SBAR, class Sat>
 __device__ __forceinline__ void readout_head(const ModelW &W, const Planes &xs, const Planes &hp, float *red, const LaneGeo &L,
                                              int a0, int N, size_t mN, const float *__restrict__ e_excl,
-                                             float *__restrict__ e_atom, f32x4 (&sb)[RT]) {
+                                             float *__restrict__ e_atom, f32x4 (&sb)[RT], Sat &sat) {
     constexpr int NCW = RH / 16;   // waves that own a column tile of the hidden layer
     constexpr int TA = 16 * RT;
     const int lane = threadIdx.x & 63;
@@ -671,7 +677,7 @@ __device__ __forceinline__ void readout_head(const ModelW &W, const Planes &xs, 
                 es = fmaf(w6[i], swish(hval[i]), es);
                 hb[i] = w6[i] * dswish(hval[i]);
             }
-            if (WANT_SBAR) store_split4(hp, L.row(t), L.col0, hb);
+            if (WANT_SBAR) store_split4(hp, L.row(t), L.col0, hb, sat);
             es += __shfl_xor(es, 16, 64);
             es += __shfl_xor(es, 32, 64);
             if (lane < 16) red[L.w * TA + L.row(t)] = es;
@@ -706,13 +712,15 @@ k_readout_mfma(int N, ActiveView av, const ModelW *__restrict__ MW, const float 
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
+    SatTrack sat;
     const size_t mN = (size_t)m * N;
     const Planes xs = make_planes(ldsh, TA, F), hp = make_planes(ldsh + plane_halves(TA, F), TA, RH);
     float *red = reinterpret_cast<float *>(ldsh + plane_halves(TA, F) + plane_halves(TA, RH));
-    load_rows_split<TA>(xs, 0, [&](int row) { return s + (mN + min(a0 + row, N - 1)) * F; });
+    load_rows_split<TA>(xs, 0, [&](int row) { return s + (mN + min(a0 + row, N - 1)) * F; }, sat);
     __syncthreads();
     f32x4 sb[2];
-    readout_head<2, false>(MW[m], xs, hp, red, L, a0, N, mN, e_excl, e_atom, sb);
+    readout_head<2, false>(MW[m], xs, hp, red, L, a0, N, mN, e_excl, e_atom, sb, sat);
+    sat.commit(av, a0, N);
 }
 
 // reverse: (sbar, vbar) of the block outputs -> (sbar_msg, vbar_msg) of its inputs.
@@ -740,6 +748,11 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
+    // Saturation watch (mfma16.h).  s_msg, v_msg and the recomputed forward intermediates were watched by update_fwd(l) of this
+    // evaluation, s_in(l + 1) by its tail: SatNone.  What is new here are the adjoints: the cooperative loads (phibar; final s for
+    // the readout) and every epilogue that stores adjoints use an instance of their own, committed right behind the pass: no
+    // tracker register lives across a GEMM (the kernel runs at the 256-register limit: two registers across it cost 0.13 ms / step).
+    SatNone unwatched;
     const LayerW &W = MW[m].layer[l];
     const size_t mN = (size_t)m * N;
     PH_INIT
@@ -766,20 +779,28 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
             *reinterpret_cast<float4 *>(VB + row * FT + 4 * c4) = vv[it];
         }
     }
-    load_update_s<RT>(ldsh, s_msg, mN, a0, N);
+    load_update_s<RT>(ldsh, s_msg, mN, a0, N, unwatched);
     if (MODE == 0) {
-        load_update_v<RT>(ldsh, v_msg, mN, a0, N);
+        load_update_v<RT>(ldsh, v_msg, mN, a0, N, unwatched);
         __syncthreads();
     } else if (MODE == 1) {
         // head: readout of s_next (tile in the `as` region; hidden adjoint + reduction scratch in the unused vbar region)
-        load_update_v<RT>(ldsh, v_msg, mN, a0, N);
+        load_update_v<RT>(ldsh, v_msg, mN, a0, N, unwatched);
         const Planes xs = make_planes(ldsh + OFF_AS, TA, F);
         const Planes hp = make_planes(ldsh + UPD_LDS_HALVES, TA, RH);
         float *red = reinterpret_cast<float *>(ldsh + UPD_LDS_HALVES + plane_halves(TA, RH));
-        load_rows_split<TA>(xs, 0, [&](int row) { return s_next + (mN + min(a0 + row, N - 1)) * F; });
+        {
+            SatTrack satc;   // (the last layer's output is not split by update_fwd<0>)
+            load_rows_split<TA>(xs, 0, [&](int row) { return s_next + (mN + min(a0 + row, N - 1)) * F; }, satc);
+            satc.commit(av, a0, N);
+        }
         __syncthreads();
         PH(40)
-        readout_head<RT, true>(MW[m], xs, hp, red, L, a0, N, mN, e_excl, e_atom, sb);
+        {
+            SatTrack sate;
+            readout_head<RT, true>(MW[m], xs, hp, red, L, a0, N, mN, e_excl, e_atom, sb, sate);
+            sate.commit(av, a0, N);
+        }
         PH(41)
         // (the body's first barrier orders the last reads of xs before anything overwrites the `as` region)
     } else {
@@ -787,10 +808,14 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         // the `as` region; the v tile follows once the head is done with the region.
         const LayerW &Wn = MW[m].layer[l + 1];
         const Planes xs = make_planes(ldsh + OFF_AS, TA, F), pb = make_planes(ldsh + OFF_VT, TA, F3);
-        load_rows_split<TA>(xs, 0, [&](int row) { return s_next + (mN + min(a0 + row, N - 1)) * F; });
+        load_rows_split<TA>(xs, 0, [&](int row) { return s_next + (mN + min(a0 + row, N - 1)) * F; }, unwatched);
+        {
+            SatTrack satc;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            load_rows_split<TA>(pb, c * F, [&](int row) { return phibar + (mN + min(a0 + row, N - 1)) * F3 + c * F; });
+            for (int c = 0; c < 3; ++c)
+                load_rows_split<TA>(pb, c * F, [&](int row) { return phibar + (mN + min(a0 + row, N - 1)) * F3 + c * F; }, satc);
+            satc.commit(av, a0, N);
+        }
         __syncthreads();
         PH(42)
         f32x4 h1[RT][1], a1[RT][1];
@@ -806,17 +831,19 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         }
         PH(43)
         __syncthreads();   // everyone is done reading xs and pb
-        load_update_v<RT>(ldsh, v_msg, mN, a0, N);   // the v tile takes the place of the phibar tile
+        load_update_v<RT>(ldsh, v_msg, mN, a0, N, unwatched);   // the v tile takes the place of the phibar tile
         PH(44)
         {
             const f32x4 b = b1n;
+            SatTrack sate;
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 f32x4 hv;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hv[i] = a1[t][0][i] * dswish(h1[t][0][i] + b[i]);
-                store_split4(xs, L.row(t), L.col0, hv);
+                store_split4(xs, L.row(t), L.col0, hv, sate);
             }
+            sate.commit(av, a0, N);
         }
         __syncthreads();
         f32x4 acc[RT][1];
@@ -830,10 +857,11 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     }
     PH(16)
     UpdRegs<RT> R;
-    update_forward<RT, 16>(W, ldsh, L, R);
+    update_forward<RT, 16>(W, ldsh, L, R, unwatched);
     PH_RESET
     // Every wave has passed the barrier in front of GEMM3, i.e. finished GEMM1/GEMM2: vt and hs are free.
     const Planes qb = make_planes(ldsh + OFF_VT, TA, F3);    // overlays vt
+    SatTrack sat;   // (scoped to this epilogue; the next one starts afresh)
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         const int row = L.row(t);
@@ -846,10 +874,12 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
                 for (int i = 0; i < 4; ++i) abar_vv[i] = fmaf(vb[i], R.uv[RT * x + t][0][i], abar_vv[i]);
             }
         }
-        store_split4(qb, row, L.col0, abar_vv);
-        store_split4(qb, row, F + L.col0, sb[t] * R.inner[t]);
-        store_split4(qb, row, 2 * F + L.col0, sb[t]);
+        store_split4(qb, row, L.col0, abar_vv, sat);
+        store_split4(qb, row, F + L.col0, sb[t] * R.inner[t], sat);
+        store_split4(qb, row, 2 * F + L.col0, sb[t], sat);
     }
+    sat.commit(av, a0, N);
+    sat = SatTrack();
     PH(23)
     __syncthreads();   // qb complete; every wave is past GEMM3, so `as` may be overwritten
     PH(24)
@@ -864,8 +894,10 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
             f32x4 hv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = acc[t][0][i] * dswish(R.h3[t][i]);
-            store_split4(hb, L.row(t), L.col0, hv);
+            store_split4(hb, L.row(t), L.col0, hv, sat);
         }
+        sat.commit(av, a0, N);
+        sat = SatTrack();
     }
     PH(25)
     __syncthreads();
@@ -886,7 +918,15 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         f32x4 sc, sa;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sc[i] = hbar[t][1][i] / R.nrm[t][i];
+            // |Vv| is recomputed from Vv (same operations, same order as the forward part: bit-identical) instead of being
+            // carried in 8 registers across the W4^T / W3^T phases -- this kernel runs at the 256-register limit
+            float n2 = 0.f;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const float vv = R.uv[RT * x + t][1][i];
+                n2 += fmaf(vv, vv, 1e-15f);
+            }
+            sc[i] = hbar[t][1][i] / sqrtf(n2);
             sa[i] = sb[t][i] * R.gate[t][1][i];
         }
 #pragma unroll
@@ -900,10 +940,11 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
                 ub[i] = fmaf(vbo[i], R.gate[t][0][i], sa[i] * v);
                 vb2[i] = fmaf(sa[i], u, sc[i] * v);
             }
-            store_split4(ab, x * TA + row, L.col0, ub);
-            store_split4(ab, x * TA + row, F + L.col0, vb2);
+            store_split4(ab, x * TA + row, L.col0, ub, sat);
+            store_split4(ab, x * TA + row, F + L.col0, vb2, sat);
         }
     }
+    sat.commit(av, a0, N);
     PH(29)
     __syncthreads();
     PH(30)

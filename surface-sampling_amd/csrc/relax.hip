@@ -424,6 +424,37 @@ __global__ void k_relax_report(int B, const State *__restrict__ st, int *__restr
     conv[b] = (uint8_t)st[b].converged;
 }
 
+// ---- trajectory observer ----------------------------------------------------------------------------------------------------
+// Counterpart of TrajectoryObserver + dyn.attach(obs, interval=record_interval) (reference mcmc/dynamics.py:20-80,131-151): ASE
+// calls the observer after the initial evaluation (nsteps = 0) and after every step whose count is a multiple of the
+// interval, including the step after which the run stops.  Here: after the evaluation of an iteration and before its step
+// kernel, every chain that is still running and whose own step counter is a multiple of the interval copies its positions,
+// forces (FixAtoms applied, like atoms.get_forces()) and energy into record steps / interval.  The chain's counter is used,
+// not the driver's iteration index: the two part after a neighbor-capacity regrow.
+template <class State>
+__global__ void __launch_bounds__(256)
+k_traj_record(const int *__restrict__ cfg_start, const int *__restrict__ counters, const State *__restrict__ st,
+              const unsigned char *__restrict__ active, int interval, int nrec, int B, int N, const uint8_t *__restrict__ fixed,
+              const double *__restrict__ pos, const float *__restrict__ forces, const float *__restrict__ e32,
+              const double *__restrict__ e64, double *__restrict__ ring_pos, float *__restrict__ ring_f,
+              double *__restrict__ ring_e, int *__restrict__ ring_n) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (counters[2] || !active[b]) return;
+    const int steps = st[b].steps;
+    if (st[b].converged || steps % interval) return;
+    const int r = steps / interval;
+    if (r >= nrec) return;
+    const int a0 = cfg_start[b], a1 = cfg_start[b + 1];
+    for (int k = 3 * a0 + tid; k < 3 * a1; k += blockDim.x) {
+        ring_pos[(size_t)r * 3 * N + k] = pos[k];
+        ring_f[(size_t)r * 3 * N + k] = (fixed && fixed[k / 3]) ? 0.f : forces[k];
+    }
+    if (tid == 0) {
+        ring_e[(size_t)r * B + b] = e64 ? e64[b] : (double)e32[b];
+        if (ring_n[b] < r + 1) ring_n[b] = r + 1;
+    }
+}
+
 // ---- host driver ----------------------------------------------------------------------------------------------------------
 // Iteration i: evaluate energies / forces of the chains still active, then (device side) test convergence and step.  The host
 // only enqueues; every POLL iterations it reads the number of chains that took a step and the neighbor-capacity flag.  If
@@ -471,6 +502,15 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
         hipLaunchKernelGGL(k_bfgs_init, dim3((B + 127) / 128), dim3(128), 0, st, B, h->d_fire.as<BfgsState>(), active);
     h->active_mask = active;   // the evaluation kernels skip chains whose entry is 0
     int *n_active_d = h->d_counters.as<int>() + 3;   // counters[3] is free for this purpose
+    const int rec_iv = h->traj_interval, nrec = rec_iv > 0 ? max_steps / rec_iv + 1 : 0;
+    h->traj_records = 0;
+    if (nrec) {
+        if (h->d_traj_pos.ensure(sizeof(double) * 3 * (size_t)N * nrec) || h->d_traj_f.ensure(sizeof(float) * 3 * (size_t)N * nrec) ||
+            h->d_traj_e.ensure(sizeof(double) * (size_t)B * nrec) || h->d_traj_n.ensure(sizeof(int) * B))
+            return set_err(h, VSSR_E_NOMEM, "trajectory records: out of device memory");
+        VSSR_HIP(h, hipMemsetAsync(h->d_traj_n.p, 0, sizeof(int) * B, st));
+        h->traj_records = nrec; h->traj_B = B; h->traj_N = N;
+    }
     const int POLL = 4;
     int rc = VSSR_OK;
     auto evaluate = [&]() {
@@ -490,6 +530,19 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
                                    h->d_ters_f.as<double>(), h->d_forces.as<float>());
             }
             const float *forces = h->d_forces.as<float>();
+            if (nrec) {
+                const bool f64 = h->kind == 2 || h->kind == 3;
+                const float *e32 = f64 ? nullptr : h->d_energy.as<float>();
+                const double *e64 = f64 ? h->d_ters_e.as<double>() : nullptr;
+                if (method == 0)
+                    hipLaunchKernelGGL(k_traj_record<FireState>, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
+                                       h->d_fire.as<FireState>(), active, rec_iv, nrec, B, N, fixed, h->d_pos.as<double>(), forces, e32, e64,
+                                       h->d_traj_pos.as<double>(), h->d_traj_f.as<float>(), h->d_traj_e.as<double>(), h->d_traj_n.as<int>());
+                else
+                    hipLaunchKernelGGL(k_traj_record<BfgsState>, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
+                                       h->d_fire.as<BfgsState>(), active, rec_iv, nrec, B, N, fixed, h->d_pos.as<double>(), forces, e32, e64,
+                                       h->d_traj_pos.as<double>(), h->d_traj_f.as<float>(), h->d_traj_e.as<double>(), h->d_traj_n.as<int>());
+            }
             if (method == 0)
                 hipLaunchKernelGGL(k_fire_step, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
                                    forces, fixed, fmax_tol, (double)fp->maxstep, (double)fp->dtmax, (double)fp->finc,
@@ -528,6 +581,7 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
                            h->d_relax_steps.as<int>(), h->d_relax_conv.as<uint8_t>());
     VSSR_HIP(h, hipGetLastError());
     h->ran = true;
+    h->graph_partial = true;   // (the last evaluation covered only the chains still running: see vssr_batch_stats)
     return VSSR_OK;
 }
 
@@ -572,7 +626,10 @@ k_cg_step(const int *__restrict__ cfg_start, const int *__restrict__ counters, c
     const uint8_t *fx = fixed ? fixed + a0 : nullptr;
     auto F = [&](int k) -> double { return (fx && fx[k / 3]) ? 0.0 : fg[k]; };
     const double ecur = energy[b];
-    S.neval += 1;
+    // LAMMPS counts the evaluations of alpha_step() only (min.cpp zeroes neval after the setup evaluation) and tests
+    // max_eval once per iteration, after a completed line search (min_cg.cpp iterate)
+    if (S.started) S.neval += 1;
+    S.started = 1;
     // every exit stores the state; `stop` also switches the chain off
     auto stop = [&](int reason) {
         if (tid == 0) { S.reason = reason; st[b] = S; active[b] = 0; }
@@ -606,7 +663,6 @@ k_cg_step(const int *__restrict__ cfg_start, const int *__restrict__ counters, c
         __syncthreads();
         S.eoriginal = ecur; S.alpha = S.alphamax; S.alphaprev = 0.0; S.fhprev = fh; S.engprev = ecur;
         S.phase = PH_TRIAL;
-        if (S.neval >= max_eval) { stop(4); return; }
         move_to(S.alpha);
         keep_going();
     };
@@ -633,7 +689,6 @@ k_cg_step(const int *__restrict__ cfg_start, const int *__restrict__ counters, c
         if (relerr <= 0.1 && alpha0 > 0.0 && alpha0 < S.alphamax) {   // secant projection: evaluate x0 + alpha0 h next
             S.fh_trial = fh;
             S.phase = PH_PROJ;
-            if (S.neval >= max_eval) { stop(4); return; }
             move_to(alpha0);
             keep_going();
             return;
@@ -651,13 +706,13 @@ k_cg_step(const int *__restrict__ cfg_start, const int *__restrict__ counters, c
             S.alpha *= 0.5;
             if (S.alpha <= 0.0 || de_ideal >= -1e-8) { reset_to_start(8); return; }
             S.phase = PH_TRIAL;
-            if (S.neval >= max_eval) { stop(4); return; }
             move_to(S.alpha);
             keep_going();
             return;
         }
     }
     // ---- line search succeeded: tolerances and the next direction (min_cg.cpp iterate) ----
+    if (S.neval >= max_eval) { stop(4); return; }
     if (fabs(ecur - S.eprevious) < etol * 0.5 * (fabs(ecur) + fabs(S.eprevious) + 1e-8)) { stop(1); return; }
     double d0 = 0.0, d1 = 0.0;
     for (int k = tid; k < n; k += nt) { const double f = F(k); d0 += f * f; d1 += f * g[k]; }
@@ -702,26 +757,47 @@ int relax_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host
     int *n_active_d = h->d_counters.as<int>() + 3;
     const int POLL = 8;
     int rc = VSSR_OK;
-    const long long max_launch = (long long)cp->max_eval + 2;
-    for (long long it = 0; it < max_launch && !rc; ++it) {
-        rc = h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : eam_run(h, want | VSSR_WANT_FORCES);
-        if (rc) break;
-        VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_cg_step, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
-                           h->d_ters_e.as<double>(), h->d_ters_f.as<double>(), fixed, cp->max_iter, cp->max_eval, cp->etol,
-                           cp->ftol, cp->dmax, h->d_pos.as<double>(), h->d_vel.as<double>(), h->d_vel.as<double>() + 3 * (size_t)N,
-                           h->d_vel.as<double>() + 6 * (size_t)N, h->d_fire.as<CgState>(), active, n_active_d);
-        VSSR_HIP(h, hipMemcpyAsync(h->h_counters + 3, n_active_d, sizeof(int), hipMemcpyDeviceToHost, st));
-        if ((it + 1) % POLL == 0) {
-            VSSR_HIP(h, hipStreamSynchronize(st));
-            if (h->h_counters[2]) {
-                if (h->h_counters[0] <= 0) { rc = set_err(h, VSSR_E_CAPACITY, "neighbor list exceeds 2^31 slots"); break; }
-                h->slot_cap = (int64_t)h->h_counters[0] + (h->cap_tight ? 0 : (int64_t)h->h_counters[0] / 8) + 64;
-                if (++h->relax_regrows > 64) { rc = set_err(h, VSSR_E_CAPACITY, "neighbor capacity could not be satisfied"); break; }
-                continue;   // the step kernels behind the overflow did nothing: the state machines resume where they were
+    // every launch is one evaluation; max_eval is tested between line searches, and a line search ends after at most ~60
+    // halvings of alpha (fp64), so the launch budget is max_eval plus one line search plus setup / reset evaluations
+    const long long max_launch = (long long)cp->max_eval + 72;
+    auto regrow = [&]() -> int {   // capacity overflow seen at a poll: grow; the step kernels behind it did nothing
+        if (h->h_counters[0] <= 0) return set_err(h, VSSR_E_CAPACITY, "neighbor list exceeds 2^31 slots");
+        h->slot_cap = (int64_t)h->h_counters[0] + (h->cap_tight ? 0 : (int64_t)h->h_counters[0] / 8) + 64;
+        if (++h->relax_regrows > 64) return set_err(h, VSSR_E_CAPACITY, "neighbor capacity could not be satisfied");
+        return VSSR_OK;
+    };
+    long long it = 0;
+    bool finished = false;
+    while (!rc && !finished) {
+        for (; it < max_launch && !rc; ++it) {
+            rc = h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : eam_run(h, want | VSSR_WANT_FORCES);
+            if (rc) break;
+            VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_cg_step, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
+                               h->d_ters_e.as<double>(), h->d_ters_f.as<double>(), fixed, cp->max_iter, cp->max_eval, cp->etol,
+                               cp->ftol, cp->dmax, h->d_pos.as<double>(), h->d_vel.as<double>(), h->d_vel.as<double>() + 3 * (size_t)N,
+                               h->d_vel.as<double>() + 6 * (size_t)N, h->d_fire.as<CgState>(), active, n_active_d);
+            VSSR_HIP(h, hipMemcpyAsync(h->h_counters + 3, n_active_d, sizeof(int), hipMemcpyDeviceToHost, st));
+            if ((it + 1) % POLL == 0) {
+                VSSR_HIP(h, hipStreamSynchronize(st));
+                if (h->h_counters[2]) {
+                    rc = regrow();
+                    it -= POLL;   // the launches of this window are given back (those behind the overflow did nothing; a chain
+                                  // that did step is bounded by its own iteration / evaluation counters)
+                    continue;
+                }
+                if (h->h_counters[3] == 0) { finished = true; break; }   // every chain has finished
             }
-            if (h->h_counters[3] == 0) break;   // every chain has finished
         }
+        if (rc || finished) break;
+        // the budget ran out between two polls: look at the last window as well
+        VSSR_HIP(h, hipStreamSynchronize(st));
+        if (h->h_counters[2]) {
+            rc = regrow();
+            it -= POLL;
+            continue;
+        }
+        finished = true;
     }
     h->active_mask = nullptr;
     if (rc) return rc;

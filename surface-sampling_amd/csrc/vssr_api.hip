@@ -458,7 +458,7 @@ void vssr_destroy(vssr_handle *h) {
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
                       &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->d_zslot, &h->d_bundle, &h->d_excl, &h->d_hits, &h->wd16, &h->node16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv, &h->d_active, &h->d_bfgs_q, &h->d_bfgs_b,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
-                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f};
+                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n};
     for (DevBuf *b : bufs) b->release();
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -553,6 +553,7 @@ int vssr_batch_run(vssr_handle *h, uint32_t want) {
     int rc = run_any(h, want);
     if (rc) return rc;
     h->ran = true;
+    h->graph_partial = false;
     return VSSR_OK;
 }
 
@@ -645,8 +646,9 @@ int vssr_batch_relax_cg(vssr_handle *h, const vssr_cg_params *params, const uint
     h->last_want = want | VSSR_WANT_FORCES;
     int rc = relax_cg(h, params, fixed, want);
     if (rc) return rc;
-    VSSR_HIP(h, hipStreamSynchronize(h->stream));
-    h->prof.collect();
+    h->graph_partial = false;        // (the CG driver ends with a full evaluation of the final positions)
+    rc = sync_and_check(h);          // ... which may itself have overflowed the neighbor capacity: grow and repeat it
+    if (rc) return rc;
     if (pos_out) VSSR_HIP(h, hipMemcpy(pos_out, h->d_pos.p, sizeof(double) * 3 * h->n_atoms, hipMemcpyDeviceToHost));
     std::vector<int> rep((size_t)3 * h->n_cfg);
     VSSR_HIP(h, hipMemcpy(rep.data(), h->d_relax_steps.p, sizeof(int) * rep.size(), hipMemcpyDeviceToHost));
@@ -735,6 +737,8 @@ int vssr_profile_read(vssr_handle *h, int32_t cap, const char **names, int64_t *
 int vssr_batch_stats(vssr_handle *h, int64_t *n_atoms, int64_t *n_edges, int64_t *n_slots) {
     if (!h) return VSSR_E_BADARG;
     if (!h->ran) return set_err(h, VSSR_E_STATE, "no completed run");
+    if (h->graph_partial)
+        return set_err(h, VSSR_E_STATE, "the resident graph covers only the chains of the last relaxation iteration: run the batch once (vssr_batch_run) first");
     int rc = sync_and_check(h);
     if (rc) return rc;
     if (n_atoms) *n_atoms = h->n_atoms;
@@ -747,6 +751,8 @@ int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, 
                          int64_t *n_edges) {
     if (!h || !n_edges) return VSSR_E_BADARG;
     if (!h->ran) return set_err(h, VSSR_E_STATE, "no completed run");
+    if (h->graph_partial)
+        return set_err(h, VSSR_E_STATE, "the resident graph covers only the chains of the last relaxation iteration: run the batch once (vssr_batch_run) first");
     int rc = sync_and_check(h);
     if (rc) return rc;
     const int N = h->n_atoms;
@@ -786,6 +792,80 @@ int vssr_batch_device_results(vssr_handle *h, const float **energy, const float 
     return VSSR_OK;
 }
 
+int vssr_device_context(vssr_handle *h, int32_t *device, void **stream, const int32_t **overflow_flag) {
+    if (!h) return VSSR_E_BADARG;
+    if (device) *device = h->device;
+    if (stream) *stream = (void *)h->stream;
+    if (overflow_flag) *overflow_flag = h->d_counters.p ? h->d_counters.as<int>() + 2 : nullptr;
+    return VSSR_OK;
+}
+
+int vssr_batch_traj_configure(vssr_handle *h, int32_t record_interval) {
+    if (!h) return VSSR_E_BADARG;
+    if (record_interval < 0) return set_err(h, VSSR_E_BADARG, "record_interval must be >= 0");
+    h->traj_interval = record_interval;
+    return VSSR_OK;
+}
+
+int vssr_batch_traj_read(vssr_handle *h, int32_t cap_records, int32_t *n_records, double *pos, float *forces, double *energy,
+                         int32_t *max_records) {
+    if (!h) return VSSR_E_BADARG;
+    if (max_records) *max_records = h->traj_records;
+    if (!h->traj_records) {
+        if (n_records || pos || forces || energy) return set_err(h, VSSR_E_STATE, "the last relaxation recorded no trajectory");
+        return VSSR_OK;
+    }
+    if (!n_records && !pos && !forces && !energy) return VSSR_OK;
+    if (h->traj_B != h->n_cfg || h->traj_N != h->n_atoms) return set_err(h, VSSR_E_STATE, "the recorded trajectory belongs to another batch");
+    if (cap_records < h->traj_records) return set_err(h, VSSR_E_BADARG, "trajectory buffers hold %d records, %d are needed", cap_records, h->traj_records);
+    VSSR_HIP(h, hipSetDevice(h->device));
+    VSSR_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t R = h->traj_records, N3 = (size_t)3 * h->traj_N, B = h->traj_B;
+    if (n_records) VSSR_HIP(h, hipMemcpy(n_records, h->d_traj_n.p, sizeof(int) * B, hipMemcpyDeviceToHost));
+    if (pos) VSSR_HIP(h, hipMemcpy(pos, h->d_traj_pos.p, sizeof(double) * N3 * R, hipMemcpyDeviceToHost));
+    if (forces) VSSR_HIP(h, hipMemcpy(forces, h->d_traj_f.p, sizeof(float) * N3 * R, hipMemcpyDeviceToHost));
+    if (energy) VSSR_HIP(h, hipMemcpy(energy, h->d_traj_e.p, sizeof(double) * B * R, hipMemcpyDeviceToHost));
+    return VSSR_OK;
+}
+
+int vssr_batch_embedding(vssr_handle *h, int32_t model, float *dst, int64_t cap, int64_t *n_out) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->ran || h->kind != 1) return set_err(h, VSSR_E_STATE, "no completed PaiNN run");
+    if (model < -1 || model >= h->n_models) return set_err(h, VSSR_E_BADARG, "model index out of range");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    int rc = sync_and_check(h);
+    if (rc) return rc;
+    const size_t per_model = (size_t)h->n_atoms * F, n = model < 0 ? per_model * h->n_models : per_model;
+    if (n_out) *n_out = (int64_t)n;
+    if (!dst) return VSSR_OK;
+    if ((int64_t)n > cap) return set_err(h, VSSR_E_BADARG, "embedding buffer too small (%lld < %zu floats)", (long long)cap, n);
+    // the scalar features leaving the last update block: the state the readout consumes ([M][N][F], model-major)
+    const float *src = h->sv.s_in[h->num_conv] + (model < 0 ? 0 : (size_t)model * per_model);
+    VSSR_HIP(h, hipMemcpy(dst, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    return VSSR_OK;
+}
+
+int vssr_batch_saturated(vssr_handle *h, uint8_t *flags, int32_t *n_flagged) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->ran) return set_err(h, VSSR_E_STATE, "no completed run");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    int rc = sync_and_check(h);
+    if (rc) return rc;
+    int count = 0;
+    if (h->kind == 1) {   // the fp64 potentials have no reduced-precision stage
+        std::vector<unsigned> f(h->n_cfg);
+        VSSR_HIP(h, hipMemcpy(f.data(), h->d_sat_out.p, sizeof(unsigned) * h->n_cfg, hipMemcpyDeviceToHost));
+        for (int b = 0; b < h->n_cfg; ++b) {
+            if (flags) flags[b] = f[b] ? 1 : 0;
+            count += f[b] ? 1 : 0;
+        }
+    } else if (flags) {
+        memset(flags, 0, (size_t)h->n_cfg);
+    }
+    if (n_flagged) *n_flagged = count;
+    return VSSR_OK;
+}
+
 int vssr_debug_capacity(vssr_handle *h, int32_t slots_per_atom, int32_t tight, int32_t *n_regrows) {
     if (!h) return VSSR_E_BADARG;
     if (slots_per_atom > 0) {
@@ -801,6 +881,8 @@ int vssr_debug_read(vssr_handle *h, const char *name, int32_t model, float *dst,
     if (!h || !name || !n_out) return VSSR_E_BADARG;
     if (!h->ran || h->kind != 1) return set_err(h, VSSR_E_STATE, "no completed PaiNN run");
     if (model < 0 || model >= h->n_models) return set_err(h, VSSR_E_BADARG, "model index out of range");
+    if (h->graph_partial)
+        return set_err(h, VSSR_E_STATE, "the resident graph covers only the chains of the last relaxation iteration: run the batch once (vssr_batch_run) first");
     int rc = sync_and_check(h);
     if (rc) return rc;
     const size_t N = h->n_atoms;

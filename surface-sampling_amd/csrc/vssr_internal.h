@@ -48,6 +48,7 @@ struct ModelW {
 struct ActiveView {
     const unsigned char *mask;   // [n_cfg] 1 = evaluate
     const int *atom_cfg;         // [n_atoms]
+    unsigned *sat = nullptr;     // [n_cfg] raised by the node kernels when an activation left the fp16-split range (mfma16.h SatTrack)
     __device__ __forceinline__ bool chain(int c) const { return !mask || mask[c]; }
     __device__ __forceinline__ bool atom(int i) const { return !mask || mask[atom_cfg[i]]; }
     // any active chain among atoms [a0, a1]?  (chains are contiguous atom ranges)
@@ -211,6 +212,10 @@ struct vssr_handle {
     vssr::DevBuf d_vel, d_fire, d_fixed, d_relax_steps, d_relax_conv, d_active, d_bfgs_q, d_bfgs_b;
     const unsigned char *active_mask = nullptr;   // set by relax_run for the duration of a relaxation
     int relax_regrows = 0;
+    // trajectory recording of the lock-step relaxations (relax.hip k_traj_record): every traj_interval optimizer steps
+    int traj_interval = 0, traj_records = 0, traj_B = 0, traj_N = 0;
+    vssr::DevBuf d_traj_pos, d_traj_f, d_traj_e, d_traj_n;
+    bool graph_partial = false;   // the resident neighbor graph / activations cover only the chains of the last relaxation iteration
     bool l0T_by_geom = false;     // this evaluation's layer-0 T blocks were written by k_edge_geom (<= 4 species)
     int64_t zero_entry_cap = -1;  // capacity / table addresses for which the all-zero table entries were last cleared
     const void *zero_entry_tab[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -227,6 +232,7 @@ struct vssr_handle {
     // results (device)
     vssr::DevBuf d_energy, d_energy_std, d_energy_models, d_forces, d_forces_std, d_e_atoms;
     vssr::DevBuf d_ters_e, d_ters_ea, d_ters_f;  // fp64 Tersoff results
+    vssr::DevBuf d_sat, d_sat_out;   // [n_cfg] unsigned: saturation flags raised during a run / reported for the last evaluation of every chain
 };
 
 namespace vssr {

@@ -524,6 +524,14 @@ class ChainEnsemble:
         self.step_count += 1
         before = self.state
         site1, site2, type1, type2, valid, u_acc = self.propose_switch(self.step_count, before)
+        # what actually sits on the two sites is exchanged.  (With reference_groupby, adsorbates that share a first-atom
+        # symbol -- "HO" and "O" -- share one candidate entry and type1 / type2 name the entry's FIRST adsorbate: applying
+        # that representative would turn a plain O into an HO group and change the composition.)
+        rows = np.arange(len(site1))
+        code1 = before.species[rows, site1].astype(np.int64)
+        code2 = before.species[rows, site2].astype(np.int64)
+        type1 = np.where(valid, code1, type1)
+        type2 = np.where(valid, code2, type2)
         after = self.apply(self.apply(before, site1, type2), site2, type1)
         moved = np.flatnonzero(valid)
         after.energy = before.energy.copy()

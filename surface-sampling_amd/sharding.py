@@ -71,16 +71,33 @@ def gather_chain_scalars(local, n_chains: int, dist=None, device=None, keep_on_d
 class ShardedEnsemble:
     """One engine per rank on that rank's block of chains; per-chain energies gathered to every rank.
 
-    The engine needs ``upload(structs)``, ``run(want)``, ``synchronize()``, ``download(want)`` and either
-    ``device_results()`` (zero-copy device arrays: the collective reads the energies where the kernels wrote them) or only
-    ``download`` (host path; the CPU stand-in of the tests)."""
+    The engine needs ``upload(structs)``, ``run(want)``, ``synchronize()``, ``download(want)`` and, for the device result
+    path, ``device_results()`` + ``device_context()`` (zero-copy device arrays and the engine's stream: the collective reads
+    the energies where the kernels wrote them).
 
-    def __init__(self, engine, n_chains: int, dist=None, device=None):
+    ``result_path``: ``"device"`` -- the gather input never passes through the host and nothing synchronises the host: the
+    staging copy waits for the engine's stream on the device, the engine's NEXT run waits for the staging copy, so step n + 1
+    is enqueued while the gather of step n is still in flight (two staging buffers).  A neighbor-capacity overflow of a
+    run cannot be seen without the host: its flag travels with the results (third column) and :meth:`check` repairs it.
+    ``"host"`` -- ``download`` + numpy (the CPU stand-in of the tests; ``gloo`` groups; fp64 engines without device results).
+    ``"auto"``: device for an ``nccl`` group or a single rank when the engine can, host otherwise."""
+
+    def __init__(self, engine, n_chains: int, dist=None, device=None, result_path: str = "auto"):
         self.engine, self.n_chains, self.dist, self.device = engine, n_chains, dist, device
         self.world = _world(dist)
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.first, self.count = chain_range(n_chains, self.world, self.rank)
         self.gathered = None
+        if result_path not in ("auto", "device", "host"):
+            raise ValueError("result_path must be 'auto', 'device' or 'host'")
+        can_device = hasattr(self.engine, "device_results") and hasattr(self.engine, "device_context")
+        if result_path == "auto":
+            backend_name = dist.get_backend() if self.world > 1 else "nccl"
+            result_path = "device" if can_device and backend_name == "nccl" else "host"
+        if result_path == "device" and not can_device:
+            raise ValueError("this engine has no device result path")
+        self.result_path = result_path
+        self._staging, self._flip, self._ext = None, 0, None
 
     def local_slice(self, chains: list) -> list:
         return chains[self.first:self.first + self.count]
@@ -92,27 +109,52 @@ class ShardedEnsemble:
         if len(block) != self.count:
             raise ValueError("block does not match this rank's chain range")
         self.engine.upload(block)
+        self._staging = None
+
+    def _device_scalars(self):
+        """This rank's per-chain (E, sigma_E, overflow flag) as a ``[count, 3]`` tensor on the ENGINE's device, ordered
+        behind the engine's stream by events only."""
+        import torch
+
+        ordinal, stream_ptr, flag_ptr = self.engine.device_context()
+        dev = torch.device("cuda", ordinal)     # the engine's device, whatever torch's current device is
+        try:
+            e, s = self.engine.device_results()
+        except Exception:
+            return None                          # (an engine kind without device results: host path)
+        if self._ext is None or self._ext[0] != stream_ptr:
+            self._ext = (stream_ptr, torch.cuda.ExternalStream(stream_ptr, device=dev))
+        ext = self._ext[1]
+        if self._staging is None or self._staging[0].shape[0] != self.count or self._staging[0].device != dev:
+            self._staging = [torch.zeros(self.count, 3, dtype=torch.float32, device=dev) for _ in range(2)]
+        self._flip ^= 1
+        buf = self._staging[self._flip]
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(ext)                     # device side: behind everything the engine has enqueued
+        with torch.cuda.device(dev):
+            buf[:, 0].copy_(torch.as_tensor(e, device=dev), non_blocking=True)
+            buf[:, 1].copy_(torch.as_tensor(s, device=dev), non_blocking=True)
+            if flag_ptr:
+                from .backend import _DeviceArray
+
+                flag = torch.as_tensor(_DeviceArray(flag_ptr, 1, "<i4"), device=dev)
+                buf[:, 2] = flag.to(torch.float32)
+        ext.wait_stream(cur)                     # the engine's next run overwrites its result buffers only after this copy
+        return buf
 
     def _local_scalars(self, want_energy_flags):
-        """This rank's per-chain (E, sigma_E) as ``[count, 2]``: device tensor when the engine exposes its buffers."""
-        if hasattr(self.engine, "device_results"):
-            import torch
-
-            self.engine.synchronize()   # the engine runs on its own stream
-            e, s = self.engine.device_results()
-            dev = self.device if self.device is not None else "cuda"
-            out = torch.stack([torch.as_tensor(e, device=dev), torch.as_tensor(s, device=dev)], dim=1)
-            # the copy out of the engine's buffers has happened before the engine may overwrite them (its next run is
-            # enqueued on another stream); what the collective reads afterwards is torch-owned memory
-            torch.cuda.current_stream(out.device).synchronize()
-            return out
-        res = self.engine.download(want_energy_flags)
+        """This rank's per-chain (E, sigma_E[, overflow flag]) ``[count, 2 or 3]``: device tensor or numpy array."""
+        if self.result_path == "device":
+            out = self._device_scalars()
+            if out is not None:
+                return out
+        res = self.engine.download(want_energy_flags)   # synchronises, repairs a capacity overflow
         return np.stack([res["energy"], res["energy_std"]], axis=1)
 
     def step(self, want, gather: bool | None = None):
         """One lock-step evaluation of the resident block (asynchronous on one GPU) and, when the chains are sharded, the
-        path's only exchange: per-chain (E, sigma_E) to every rank.  Returns the gathered ``[n_chains, 2]`` (tensor or array)
-        or None when nothing was gathered."""
+        path's only exchange: per-chain (E, sigma_E) to every rank.  Returns the gathered ``[n_chains, 2 or 3]`` (tensor or
+        array; device path: stream-ordered, not yet complete on return) or None when nothing was gathered."""
         self.engine.run(want)
         if gather is None:
             gather = self.world > 1
@@ -123,6 +165,22 @@ class ShardedEnsemble:
         scal = self._local_scalars(backend.WANT_ENERGY | backend.WANT_STD)
         self.gathered = gather_chain_scalars(scal, self.n_chains, self.dist, self.device, keep_on_device=True)
         return self.gathered
+
+    def check(self) -> bool:
+        """Device result path: did any rank's last gathered evaluation overflow its neighbor capacity?  If so every rank
+        repairs (``engine.synchronize()`` reruns with grown buffers) and gathers again; returns True when that happened.
+        The host path repairs inside ``download`` and always returns False."""
+        g = self.gathered
+        if g is None or self.result_path != "device" or g.shape[1] < 3:
+            return False
+        if not bool((g[:, 2] != 0).any().item()):
+            return False
+        from . import backend
+
+        self.engine.synchronize()
+        scal = self._local_scalars(backend.WANT_ENERGY | backend.WANT_STD)
+        self.gathered = gather_chain_scalars(scal, self.n_chains, self.dist, self.device, keep_on_device=True)
+        return True
 
     # ---- one-shot form -------------------------------------------------------------------------------------
     def evaluate(self, all_chains: list) -> dict:

@@ -36,6 +36,7 @@ def cg_minimize(force_fn, pos, fixed=None, max_iter=100, max_eval=10000, etol=1e
         return float(e), np.where(mask, np.asarray(f, float).reshape(-1), 0.0)
 
     ecur, f = ef(x)
+    neval = 0   # LAMMPS zeroes the counter after the setup evaluation: only alpha_step() evaluations count
     g, h = f.copy(), f.copy()
     gg = f @ f
     ndof = len(x)
@@ -56,8 +57,6 @@ def cg_minimize(force_fn, pos, fixed=None, max_iter=100, max_eval=10000, etol=1e
         alpha, alphaprev, fhprev, engprev = alphamax, 0.0, fdothall, eorig
         fail = 0
         while True:
-            if neval >= max_eval:
-                return x.reshape(-1, 3), ecur, niter, neval, 4, trace
             x = x0 + alpha * h
             ecur, f = ef(x)
             fh = f @ h
@@ -68,8 +67,6 @@ def cg_minimize(force_fn, pos, fixed=None, max_iter=100, max_eval=10000, etol=1e
             relerr = abs(1.0 - (0.5 * (alpha - alphaprev) * (fh + fhprev) + ecur) / engprev)
             alpha0 = alpha - (alpha - alphaprev) * fh / delfh
             if relerr <= 0.1 and 0.0 < alpha0 < alphamax:
-                if neval >= max_eval:
-                    return x.reshape(-1, 3), ecur, niter, neval, 4, trace
                 x = x0 + alpha0 * h
                 ecur, f = ef(x)
                 if ecur - eorig < 1e-8:
@@ -88,6 +85,8 @@ def cg_minimize(force_fn, pos, fixed=None, max_iter=100, max_eval=10000, etol=1e
             ecur, f = ef(x)
             return x.reshape(-1, 3), ecur, niter, neval, fail, trace
         trace.append(ecur)
+        if neval >= max_eval:   # tested once per iteration, after the line search (min_cg.cpp iterate)
+            return x.reshape(-1, 3), ecur, niter, neval, 4, trace
         if abs(ecur - eprev) < etol * 0.5 * (abs(ecur) + abs(eprev) + 1e-8):
             return x.reshape(-1, 3), ecur, niter, neval, 1, trace
         d0, d1 = f @ f, f @ g

@@ -119,3 +119,43 @@ def test_cg_is_refused_for_the_fp32_painn_path(golden):
     rc = eng._lib.vssr_batch_relax_cg(eng._h, C.byref(p), None, 3, None, None, None, None)
     assert rc == -5 and b"fp64" in eng._lib.vssr_last_error(eng._h)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_gan_batched_mc_with_lammps_style_relaxation(golden, oracle_mod):
+    """The reference's GaN configuration (``optimizer: "LAMMPS"``: CG relaxation inside every MC step) through the batched MC:
+    ``TersoffSurfCalc.relax_batch`` packs all slabs into one ``vssr_batch_relax_cg`` call (advisor finding, round 2: the
+    analytic calculators had no ``relax_batch``).  Every stored energy is the oracle's energy of the stored relaxed slab,
+    relaxation lowers the energy of every proposal, held atoms stay, two runs agree."""
+    from surface_sampling_amd import mc
+    from surface_sampling_amd.calculators import TersoffSurfCalc
+
+    g = golden.structure("GaN_3x3_pristine")
+    ztop = g.positions[:, 2].max()
+    a, b = g.cell[0], g.cell[1]
+    coords = np.array([(i + 0.5) / 3 * a + (j + 0.5) / 3 * b for i in range(3) for j in range(3)], float)
+    coords[:, 2] = ztop + 1.8
+    fixed = np.flatnonzero(g.positions[:, 2] < ztop - 3.0)
+    runs = []
+    for _ in range(2):
+        calc = TersoffSurfCalc(golden.tersoff_params, ["Ga", "N"], device="cuda:0")
+        calc.set(relax_steps=30)
+        out = calc.relax_batch([g, g.copy()], fixed_indices=[fixed, fixed])
+        assert out[0][2] == out[1][2] and out[0][3] is False and out[0][4]["stop"] in (
+            "energy tolerance", "force tolerance", "max iterations", "forces are zero", "linesearch alpha is zero")
+        ens = mc.ChainEnsemble(g, coords, ("Ga", "N"), 6, calc, seed=2, relax=True, relax_steps=30, fixed_indices=fixed,
+                               temperature=0.3, optimizer="LAMMPS")
+        ens.initialize()
+        for _ in range(3):
+            ens.step_semigrand()
+        assert (ens.num_adsorbates() > 0).any()
+        static = calc.calculate_batch([ens.structure(b) for b in range(6)])
+        for b in range(6):
+            r = ens.relaxed[b]
+            types = np.array([0 if z == 31 else 1 for z in r.numbers], np.int32)
+            E, _, _ = oracle_mod.tersoff(golden.tersoff_params, types, r.positions, r.cell, [1, 1, 1])
+            assert abs(E - ens.state.energy[b]) <= 1e-9 * max(1.0, abs(E))
+            assert ens.state.energy[b] <= static[b]["energy"] + 1e-9            # relaxed <= unrelaxed proposal
+            assert np.array_equal(r.positions[fixed], g.positions[fixed])
+        runs.append((ens.state.species.copy(), ens.state.energy.copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])

@@ -111,8 +111,41 @@ def test_per_layer_intermediates_match_oracle(golden, oracle_mod, engine):
         got = engine.debug_read(f"{name}0", m).reshape(shape).astype(np.float64)
         want = d[name][0]
         report.append((f"{name}0", np.abs(got - want).max() / max(1.0, np.abs(want).max())))
+    # the latent embedding the reference's clustering helpers read = the final scalar features (vssr_batch_embedding)
+    emb = engine.embedding()
+    assert emb.shape == (3, n, 128) and np.array_equal(emb[m], engine.embedding(m))
+    assert np.array_equal(emb[m].reshape(-1), engine.debug_read("s_upd2", m))
+    report.append(("embedding", np.abs(emb[m].astype(np.float64) - d["s_upd"][2]).max() / max(1.0, np.abs(d["s_upd"][2]).max())))
     bad = [(k, v) for k, v in report if not v < 2e-5]
     assert not bad, f"intermediates off: {bad}; all: {report}"
+
+
+def test_embedding_through_the_calculator_and_helpers(golden, oracle_mod):
+    """``EnsembleNFFSurface(properties=(..., "embedding"))`` + the reference's helper functions
+    (``get_results_single / get_embeddings_single / get_std_devs_single``, mcmc/calculators/calculators.py:34-135; call
+    pattern of scripts/clustering.py:236-249) against the oracle's final scalar features of model 0."""
+    from surface_sampling_amd import calculators as calcs
+
+    s = golden.structure("O40Sr16Ti12")
+    single = calcs.EnsembleNFFSurface(golden.blobs[:1], device="cuda:0", properties=("energy", "forces", "embedding"))
+    ens = calcs.EnsembleNFFSurface(golden.blobs, device="cuda:0")
+    for c in (single, ens):   # (calculate() with the default property list includes the surface energy, like the reference's)
+        c.set(offset=True, offset_data=golden.offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0})
+    res = calcs.get_results_single(s, single)
+    emb = calcs.get_embeddings_single(s, single, results_cache=res, flatten=True, flatten_axis=0)
+    _, _, d = oracle_mod.painn(golden.blobs[0], s.numbers, s.positions, s.cell, s.pbc, 64, dump=True)
+    want = d["s_upd"][2]
+    ref = _oracle(golden, oracle_mod, s)
+    assert res["embedding"].shape == (len(s), 128) and emb.shape == (128,)
+    assert np.abs(res["embedding"] - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    assert np.allclose(emb, want.mean(axis=0), atol=2e-5)
+    assert "embedding" not in calcs.get_results_single(s, ens)           # not requested: not computed
+    fstd = calcs.get_std_devs_single(s, ens)
+    assert abs(float(fstd) - float(ref["forces_std"].mean())) <= 1e-5
+    assert calcs.get_std_devs_single(s, single) == 0.0
+    batch = ens.calculate_batch([s, golden.structure("O36Sr12Ti12")], want_embedding=True)
+    assert batch[0]["embedding_models"].shape == (3, len(s), 128) and batch[1]["embedding"].shape == (60, 128)
+    assert np.array_equal(batch[0]["embedding"], res["embedding"])       # model 0 of the ensemble = the single-model calculator
 
 
 def test_batched_ragged_chains_vs_oracle_and_vs_single(golden, oracle_mod, engine):
@@ -161,6 +194,7 @@ def test_full_size_properties_256_chains(golden, engine):
     chains = [structures.synth_chain(big, c) for c in range(256)]
     res = engine.evaluate([_arrays(s) for s in chains])
     assert np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()
+    assert not res["saturated"].any()
     cs = res["cfg_start"]
     # (1) translation invariance: net force on every chain vanishes
     net = np.array([res["forces"][cs[b]:cs[b + 1]].astype(np.float64).sum(0) for b in range(256)])
@@ -518,6 +552,7 @@ def test_bench_batch_subsample_vs_oracle_including_shard_chains(golden, oracle_m
         res = eng.evaluate([_arrays(s) for s in chains])
         cs = res["cfg_start"]
         assert np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()
+        assert res["saturated"].shape == (256,) and not res["saturated"].any()   # the bench batch stays inside the fp16-split range
         for c in which:
             b = c - first
             ref = _oracle(golden, oracle_mod, chains[b])
@@ -580,7 +615,10 @@ def test_precision_envelope_of_the_fp16_split(golden, oracle_mod, what, factor):
     eng.close()
     assert np.isfinite(r["energy"]).all() and np.isfinite(r["forces"]).all()
     if factor >= 2.0:
-        return   # outside the envelope: finite, no accuracy claim
+        # outside the envelope: finite, no accuracy claim -- and the caller is TOLD (vssr_batch_saturated): a clamp fired
+        assert r["saturated"].all(), "values beyond +-65504 were clamped without raising the saturation flag"
+        return
+    assert not r["saturated"].any(), "saturation flag raised inside the envelope"
     o = oracle_mod.ensemble(blobs, s.numbers, s.positions, s.cell, s.pbc, 64, None, 0.0, 1.0)
     rel_e = abs(float(r["energy"][0]) - o["energy"]) / np.abs(o["energy_models"]).max()
     rel_f = np.abs(r["forces"] - o["forces"]).max() / np.abs(o["forces"]).max()

@@ -258,3 +258,39 @@ def test_checkpoint_hyper_parameters_must_match_the_engine(monkeypatch):
         checkpoint.check_model_against_hparams("x", {**sd, n_key: np.arange(1, 21, dtype=np.float32) * 1.01})
     with pytest.raises(ValueError):
         checkpoint.check_model_against_hparams("x", {**sd, "extra.weight": np.zeros((3, 3), np.float32)})
+
+
+def test_embedding_and_uncertainty_helpers_mirror_the_reference_functions():
+    """``get_results_single / get_embeddings(_single) / get_std_devs(_single)`` (reference calculators.py:34-135): call
+    pattern and shapes, with a calculator stand-in that returns known arrays."""
+
+    class Calc:
+        def __init__(self, n_models):
+            self.models = [None] * n_models
+            self.results = {}
+            self.calls = 0
+
+        def calculate(self, atoms, *a, **k):
+            self.calls += 1
+            n = len(atoms.numbers)
+            self.results = {"energy": np.array([-1.0]), "embedding": np.arange(n * 4, dtype=np.float32).reshape(n, 4),
+                            "forces_std": np.full((n, 3), 0.25, np.float32)}
+
+    s = structures.Structure(np.array([8, 8, 22], np.int32), np.zeros((3, 3)), np.eye(3) * 10, np.array([True] * 3))
+    calc = Calc(3)
+    res = calcs.get_results_single(s, calc)
+    assert s.calc is calc and res is calc.results and calc.calls == 1
+    e = calcs.get_embeddings_single(s, calc, results_cache=res)                 # cached: no second evaluation
+    assert calc.calls == 1 and e.shape == (4,) and np.allclose(e, res["embedding"].mean(axis=0))
+    full = calcs.get_embeddings_single(s, calc, flatten=False)
+    assert calc.calls == 2 and full.shape == (3, 4)
+    assert calcs.get_embeddings([s, s], calc).shape == (2, 4)
+    assert calcs.get_std_devs_single(s, calc) == pytest.approx(0.25)
+    assert calcs.get_std_devs_single(s, Calc(1)) == 0.0                         # one model: no spread, no evaluation
+    assert calcs.get_std_devs([s, s, s], calc).shape == (3,)
+    class NoEmbedding(Calc):
+        def calculate(self, atoms, *a, **k):
+            self.results = {"energy": np.array([-1.0])}
+
+    with pytest.raises(KeyError):
+        calcs.get_embeddings_single(s, NoEmbedding(1))

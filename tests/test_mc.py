@@ -449,6 +449,35 @@ def test_group_and_atom_share_the_first_atom_key_in_reference_mode():
     assert np.flatnonzero(cand[SR]).tolist() == [2] and not cand[HO].any() and not cand[H2O].any()
 
 
+def test_canonical_exchange_conserves_composition_with_shared_first_atom_keys():
+    """("HO", "O") share the candidate key "O" in reference mode and propose_switch names the key's first adsorbate: the
+    exchange must move what actually sits on the two sites -- a plain O never becomes an HO group, the counts of every
+    adsorbate stay what they were (advisor finding, round 2)."""
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[1.5 * s, 0.0, 2.0] for s in range(7)], float)
+    calc = LatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02, Z["H"]: 0.01}, J=0.0)
+    n = 64
+    ens = mc.ChainEnsemble(base, coords, ("HO", "O", "Sr"), n, calc, seed=3, relax=False, temperature=50.0,
+                           reference_groupby=True)
+    HO, O, SR, E = 0, 1, 2, ens.n_ads
+    sp = np.tile(np.array([[SR, O, E, SR, E, HO, O]], np.int16), (n, 1))
+    order = np.where(sp != E, np.cumsum(sp != E, axis=1), 0).astype(np.int64)
+    ens.state = mc.ChainState(sp, order, np.full(n, 6, np.int64))
+    ens.initialize()
+    counts0 = np.stack([(ens.state.species == c).sum(axis=1) for c in range(ens.n_ads + 1)], axis=1)
+    atoms0 = ens.num_adsorbate_atoms()
+    moved = 0
+    for _ in range(12):
+        acc = ens.step_canonical()
+        moved += int(acc.sum())
+        counts = np.stack([(ens.state.species == c).sum(axis=1) for c in range(ens.n_ads + 1)], axis=1)
+        assert np.array_equal(counts, counts0)
+        assert np.array_equal(ens.num_adsorbate_atoms(), atoms0)
+    assert moved > n                                                     # T = 50: nearly every exchange is accepted
+
+
 def test_boltzmann_and_distance_decay_weights_match_the_reference_numbers():
     """``compute_boltzmann_weights`` on the reference's fixture (tests/test_slab.py:90-113): per-atom energies
     [1.0, 0.5, 1.0, 0.6], T = 1 -> As 0.1850956, Ga 0.30517106, empty 1; ``compute_distance_weight_matrix``

@@ -96,6 +96,67 @@ def test_relax_batch_front_end(golden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("optimizer", ["BFGS", "FIRE"])
+def test_relax_batch_records_the_trajectory_like_the_reference_observer(golden, optimizer):
+    """``relax_batch(save_traj=True, record_interval=k)`` = ``optimize_slab(save_traj=True, record_interval=k)`` (reference
+    mcmc/dynamics.py:131-151): the observer fires after 0, k, 2k, ... optimizer steps.  Checked against relaxations of the
+    same starts that STOP at those step counts, and against the single-point evaluation of the start."""
+    from surface_sampling_amd.calculators import EnsembleNFFSurface
+
+    calc = EnsembleNFFSurface(golden.blobs, device="cuda:0")
+    calc.set(offset=True, offset_data=golden.offset_data)
+    slabs = [golden.structure("O36Sr12Ti12"), golden.structure("O44Sr12Ti16"), golden.structure("O40Sr16Ti12")]
+    fixed = [np.setdiff1d(np.arange(len(s)), top_layer(s)) for s in slabs]
+    k, steps = 2, 5
+    out = calc.relax_batch(slabs, fixed_indices=fixed, relax_steps=steps, fmax=0.01, optimizer=optimizer, save_traj=True,
+                           record_interval=k)
+    start = calc.calculate_batch(slabs)
+    plain = calc.relax_batch(slabs, fixed_indices=fixed, relax_steps=steps, fmax=0.01, optimizer=optimizer)
+    for b, (slab, traj, energy, oob, r) in enumerate(out):
+        assert plain[b][1] is None and plain[b][2] == energy                # recording does not change the relaxation
+        assert set(traj) == {"atoms", "energies", "forces"}
+        n_rec = r["n_steps"] // k + 1
+        assert len(traj["atoms"]) == len(traj["energies"]) == len(traj["forces"]) == n_rec >= 2
+        assert traj["energies"][0] == float(start[b]["energy"][0])           # record 0 = the start, before any step
+        assert np.array_equal(traj["atoms"][0].positions, slabs[b].positions)
+        f0 = start[b]["forces"].copy()
+        f0[fixed[b]] = 0.0                                                   # atoms.get_forces() applies FixAtoms
+        assert np.array_equal(traj["forces"][0], f0)
+        for t in traj["forces"]:
+            assert not t[fixed[b]].any()
+    for rec in (1, 2):                                                       # records after k and 2k steps
+        part = calc.relax_batch(slabs, fixed_indices=fixed, relax_steps=rec * k, fmax=0.01, optimizer=optimizer)
+        for b in range(len(slabs)):
+            if len(out[b][1]["atoms"]) <= rec:
+                continue
+            assert np.abs(out[b][1]["atoms"][rec].positions - part[b][0].positions).max() < 1e-9
+            assert abs(out[b][1]["energies"][rec] - float(part[b][4]["energy"][0])) < 1e-5
+
+
+@pytest.mark.gpu
+def test_stats_after_a_relaxation_need_a_full_run(golden):
+    """After a lock-step relaxation the resident graph covers only the chains of its last iteration: the introspection calls
+    say so instead of returning partial data (advisor finding, round 2); one full run makes them valid again."""
+    from surface_sampling_amd import backend
+
+    table, const = golden.offset_table()
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    s = golden.structure("O36Sr12Ti12")
+    eng.upload([(s.numbers, s.positions, s.cell, s.pbc)] * 2)
+    eng.run()
+    before = eng.stats()
+    eng.relax("BFGS", max_steps=3)
+    res = eng.download()                                                      # results stay available
+    assert np.isfinite(res["energy"]).all()
+    for call in (eng.stats, eng.neighbors, lambda: eng.debug_read("e_atom", 0)):
+        with pytest.raises(backend.BackendError, match="last relaxation iteration"):
+            call()
+    eng.run()
+    assert eng.stats()["atoms"] == before["atoms"]
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_tersoff_relaxation(golden, oracle_mod):
     """GaN (config 2): run_lammps_opt (LAMMPS-style CG on the device, like the reference's LAMMPS minimiser; FIRE / BFGS on
     request) lowers the energy of a rattled slab back towards the pristine minimum."""

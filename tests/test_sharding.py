@@ -169,8 +169,20 @@ def test_device_results_reach_torch_and_rccl_without_a_host_copy():
     want = backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD
     got = sh.step(want, gather=True)                     # world 1: the local block, taken from the device buffers
     res = eng.download(want)
-    assert got.is_cuda and got.shape == (len(chains), 2)
+    assert sh.result_path == "device"
+    assert got.is_cuda and got.shape == (len(chains), 3)     # E, sigma_E and the run's capacity-overflow flag
     assert np.array_equal(got[:, 0].cpu().numpy(), res["energy"]) and np.array_equal(got[:, 1].cpu().numpy(), res["energy_std"])
+    assert not got[:, 2].any() and sh.check() is False
+    # step n + 1 is enqueued behind the staging copy of step n without a host synchronisation: ten back-to-back steps, results
+    # of every one identical (the same resident positions), the two staging buffers alternate
+    seen = []
+    outs = []
+    for _ in range(10):
+        outs.append(sh.step(want, gather=True))
+        seen.append(sh._staging[sh._flip].data_ptr())
+    assert len(set(seen)) == 2 and seen[0] != seen[1] and seen[0] == seen[2]
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[-1][:, 0].cpu().numpy(), res["energy"]) and np.array_equal(outs[-2][:, 0].cpu().numpy(), res["energy"])
     with _socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -188,3 +200,47 @@ def test_device_results_reach_torch_and_rccl_without_a_host_copy():
     finally:
         dist.destroy_process_group()
         eng.close()
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu(tmp_path, golden):
+    """World size 2 with REAL engines: two fresh interpreters (never a re-exec of this process), both on device 0, ``gloo``
+    group, host result path (tests/shard_worker.py).  (i) ``ShardedEnsemble.step`` on the two blocks gathers exactly what
+    one engine computes for the whole list; (ii) ``ChainEnsemble`` with ``first_chain = rank * n`` reproduces, chain for
+    chain, the trajectories of the unsharded run (Philox keyed by the global chain id)."""
+    import socket
+    import subprocess
+
+    import bench
+    from shard_worker import run_mc
+    from surface_sampling_amd import backend
+    from surface_sampling_amd.calculators import stoich_offset_table
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    worker = os.path.join(os.path.dirname(__file__), "shard_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in (0, 1))
+    assert (int(r0["first"]), int(r0["count"]), int(r1["first"]), int(r1["count"])) == (0, 3, 3, 3)
+    # (i) the unsharded evaluation of the same six chains in THIS process
+    blobs, S, offset_data = bench.load_golden()
+    table, const = stoich_offset_table(offset_data)
+    chains = bench.build_chains(S, 40, 6)
+    eng = backend.PainnEngine(blobs, device=0, offset_per_z=table, offset_const=const)
+    full = eng.evaluate([(c.numbers, c.positions, c.cell, c.pbc) for c in chains])
+    eng.close()
+    for r in (r0, r1):
+        assert r["gathered"].shape == (6, 2)
+        assert np.array_equal(r["gathered"][:, 0], full["energy"]) and np.array_equal(r["gathered"][:, 1], full["energy_std"])
+        assert np.array_equal(r["one_shot_energy"], full["energy"])
+    # (ii) world-1 trajectories of global chains 0..5
+    acc, species, energy = run_mc(golden, 6, 0)
+    assert np.array_equal(np.concatenate([r0["acc"], r1["acc"]], axis=1), acc)
+    assert np.array_equal(np.concatenate([r0["species"], r1["species"]]), species)
+    assert np.array_equal(np.concatenate([r0["energy"], r1["energy"]]), energy)
+    assert acc.any()
