@@ -101,9 +101,10 @@ __global__ void __launch_bounds__(128)
 k_edge_fwd(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *__restrict__ counters,
            float rc, int excl_vol, float excl_sigma, int excl_power, const float *__restrict__ s_in,
            const float *__restrict__ v_in, const float *__restrict__ phi, float *__restrict__ s_msg,
-           float *__restrict__ v_msg) {
+           float *__restrict__ v_msg, int only_class) {
     __shared__ EdgeChunk S;
     if (counters[2] || !G.act.atom(blockIdx.x)) return;
+    if (only_class >= 0 && G.chain_class[G.atom_cfg[blockIdx.x]] != only_class) return;   // (chains of the matrix-pipe classes)
     const int i = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
     const LayerW &W = MW[m].layer[l];
     float wa[RB], wb[RB], wc[RB];
@@ -222,11 +223,12 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
            const int *__restrict__ counters, float rc, int excl_vol, float excl_sigma, int excl_power,
            const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
            const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
-           float4 *__restrict__ gbar, long long gbar_stride) {
+           float4 *__restrict__ gbar, long long gbar_stride, int only_class) {
     __shared__ EdgeChunk S;
     __shared__ float red[ECHUNK][4][F + 1];
     __shared__ float tots[ECHUNK][4];
     if (counters[2] || !G.act.atom(blockIdx.x)) return;
+    if (only_class >= 0 && G.chain_class[G.atom_cfg[blockIdx.x]] != only_class) return;
     const int c = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
     const LayerW &W = MW[m].layer[l];
     float wa[RB], wb[RB], wc[RB];
@@ -333,20 +335,28 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
 // ---- ensemble reduction -----------------------------------------------------------------------------------------
 // forces: dE/dx_c = sum_{slots (c,n)} ( G[(n->c)] - G[(c->n)] ), G[(c->n)] lives at rev[slot].
 // Partial edge gradients of the feature slices (one buffer per workgroup group) -> one buffer per model (group 0, in place): a streaming,
-// coalesced pass in fixed group order, so that the gather through `rev` below touches one buffer per model only.
-__global__ void k_reduce_gbar_groups(int M, int n_groups, const int *__restrict__ counters, float4 *__restrict__ gbar,
-                                     long long gbar_stride) {
-    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (counters[2] || slot >= counters[0]) return;
-    for (int m = 0; m < M; ++m) {
-        float4 *g0 = gbar + (size_t)(m * n_groups) * gbar_stride + slot;
-        float4 acc = *g0;
-        for (int grp = 1; grp < n_groups; ++grp) {
-            const float4 v = g0[(size_t)grp * gbar_stride];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z;
+// coalesced pass in fixed group order, so that the gather through `rev` below touches one buffer per model only.  A chain's
+// slots carry as many partial buffers as its class has slices (grid.y = chain).
+__global__ void __launch_bounds__(256)
+k_reduce_gbar_groups(int M, int n_groups, GraphView G, const int *__restrict__ counters, float4 *__restrict__ gbar,
+                     long long gbar_stride) {
+    if (counters[2]) return;
+    const int b = blockIdx.y;
+    if (!G.act.chain(b)) return;
+    const int cls = G.chain_class[b];
+    const int ng = cls == EDGE_CLASS_FS16 ? 8 : cls == EDGE_CLASS_FS8 ? 16 : 1;   // buffers the chain's kernels wrote (edge_class_groups)
+    if (ng == 1) return;
+    const int s0 = G.row_start[G.cfg_start[b]], s1 = G.row_start[G.cfg_start[b + 1]];
+    for (int slot = s0 + blockIdx.x * blockDim.x + threadIdx.x; slot < s1; slot += gridDim.x * blockDim.x)
+        for (int m = 0; m < M; ++m) {
+            float4 *g0 = gbar + (size_t)(m * n_groups) * gbar_stride + slot;
+            float4 acc = *g0;
+            for (int grp = 1; grp < ng; ++grp) {
+                const float4 v = g0[(size_t)grp * gbar_stride];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z;
+            }
+            *g0 = acc;
         }
-        *g0 = acc;
-    }
 }
 
 // forces = - sum_slots (G[slot] - G[rev[slot]]) per model, then ensemble mean / std.  gbar_model_stride: distance between
@@ -444,6 +454,13 @@ k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const 
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
+// partial edge-gradient buffers per model: as many as the widest class present writes (one without the reverse edge kernels)
+int painn_gbar_groups(const vssr_handle *h) {
+    if (h->num_conv < 2) return 1;
+    return h->n_class[EDGE_CLASS_FS8] ? edge_class_groups(EDGE_CLASS_FS8)
+                                      : h->n_class[EDGE_CLASS_FS16] ? edge_class_groups(EDGE_CLASS_FS16) : 1;
+}
+
 int painn_alloc_state(vssr_handle *h) {
     const size_t N = h->n_atoms, M = h->n_models, L = h->num_conv;
     const size_t nS = M * N * F, nV = 3 * nS, nP = 3 * nS;
@@ -467,7 +484,7 @@ int painn_alloc_state(vssr_handle *h) {
     sv.sbar_msg = p; p += nS;
     sv.vbar_msg = p; p += nV;
     sv.phibar = p; p += nP;
-    if (h->d_gbar.ensure(sizeof(float4) * M * (size_t)edge_bwd_groups() * (size_t)h->slot_cap))
+    if (h->d_gbar.ensure(sizeof(float4) * M * (size_t)painn_gbar_groups(h) * (size_t)h->slot_cap))
         return set_err(h, VSSR_E_NOMEM, "edge-gradient buffer: out of device memory");
     sv.gbar = h->d_gbar.as<float4>();
     if (h->d_energy.ensure(sizeof(float) * h->n_cfg) || h->d_energy_std.ensure(sizeof(float) * h->n_cfg) ||
@@ -509,6 +526,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
     G.drho16 = h->d_drho16.as<uint4>();
     G.zslot = h->d_zslot.as<unsigned char>();
     G.bundle = h->d_bundle.as<int4>();
+    G.chain_class = h->d_chain_class.as<unsigned char>();
     G.act = ActiveView{h->active_mask, h->d_atom_cfg.as<int>(), h->d_sat.as<unsigned>()};
     const ActiveView &av = G.act;
     const ModelW *MW = h->model_table.as<ModelW>();
@@ -517,11 +535,14 @@ int painn_run(vssr_handle *h, uint32_t want) {
     dim3 blk(128);
     dim3 g_atom(N, M), g_tile((N + T - 1) / T, M);
     Profiler &P = h->prof;
-    const bool use_edge_mfma = h->edge_impl && edge_fwd_mfma_fits(h->max_cfg_atoms);   // chains fit the LDS slices
     const bool l0_fact = h->l0_enabled && h->l0_nz > 0;   // layer 0 by species factorisation (any chain size)
-    // The MFMA edge kernels serve layers >= 1.  Layer 0 is factorised by species (painn_l0.hip) or, with more than 8
-    // species / VSSR_L0_FACTORISE=0, runs the gather kernels (its v input is zero and only two filter sections matter).
-    const int n_groups = (use_edge_mfma && L > 1) ? edge_bwd_groups() : 1;   // partial gbar buffers per model
+    // The MFMA edge kernels serve layers >= 1, every chain through the instantiation of its own class (16- / 8-feature
+    // slices; larger chains: the gather kernels) -- up to three launches per layer and direction, each over the chains of one
+    // class.  Layer 0 is factorised by species (painn_l0.hip) or, with more than 8 species / VSSR_L0_FACTORISE=0, runs the
+    // gather kernels for every chain (its v input is zero and only two filter sections matter).
+    const int n_groups = painn_gbar_groups(h);   // partial gbar buffers per model
+    const int *cls_list[2] = {h->d_class_list.as<int>(), h->d_class_list.as<int>() + h->n_class[EDGE_CLASS_FS16]};
+    const int n_gather = h->n_class[EDGE_CLASS_GATHER];
     h->l0_used = l0_fact;
 
     if (!l0_fact) {   // s0 = Emb[Z], v0 = 0 (the factorised layer 0 reads the embedding directly)
@@ -547,17 +568,19 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.end(st);
         }
         P.begin(KC_EDGE_FWD, st);
-        if (use_edge_mfma && l > 0)
-            launch_edge_fwd_mfma(st, N, h->n_cfg, M, l, h->max_cfg_atoms, MW, G, counters, (int)(h->slot_cap - 1),
-                                 sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l], sv.v_msg[l]);
-        else if (l == 0)
+        if (l == 0)
             hipLaunchKernelGGL(k_edge_fwd<true>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
                                h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
-                               sv.v_msg[l]);
-        else
-            hipLaunchKernelGGL(k_edge_fwd<false>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
-                               h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
-                               sv.v_msg[l]);
+                               sv.v_msg[l], -1);
+        else {
+            for (int cls = 0; cls < 2; ++cls)
+                launch_edge_fwd_mfma(st, cls, N, cls_list[cls], h->n_class[cls], M, l, h->max_class_atoms[cls], MW, G, counters,
+                                     (int)(h->slot_cap - 1), sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l], sv.v_msg[l]);
+            if (n_gather)
+                hipLaunchKernelGGL(k_edge_fwd<false>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
+                                   h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
+                                   sv.v_msg[l], (int)EDGE_CLASS_GATHER);
+        }
         P.end(st);
         P.begin(KC_UPDATE_FWD, st);
         launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1],
@@ -604,19 +627,22 @@ int painn_run(vssr_handle *h, uint32_t want) {
                 rc = l0_run_reverse(h, G, (int)(L == 1), sbar_msg_l, sv.vbar_msg, sv.gbar, (long long)h->slot_cap,
                                     n_groups);
                 if (rc) return rc;
-            } else if (use_edge_mfma && l > 0)
-                launch_edge_bwd_mfma(st, N, h->n_cfg, M, l, (int)(l == L - 1), h->max_cfg_atoms, MW, G, counters,
-                                     (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l], sbar_msg_l,
-                                     sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap, n_groups);
-            else if (l == 0)   // adds into partial buffer 0 of every model (model stride = n_groups buffers)
+            } else if (l == 0)   // adds into partial buffer 0 of every model (model stride = n_groups buffers)
                 hipLaunchKernelGGL(k_edge_bwd<true>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                    h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
                                    sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
-                                   (long long)h->slot_cap * n_groups);
-            else
-                hipLaunchKernelGGL(k_edge_bwd<false>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
-                                   h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
-                                   sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap);
+                                   (long long)h->slot_cap * n_groups, -1);
+            else {
+                for (int cls = 0; cls < 2; ++cls)
+                    launch_edge_bwd_mfma(st, cls, N, cls_list[cls], h->n_class[cls], M, l, (int)(l == L - 1), h->max_class_atoms[cls],
+                                         MW, G, counters, (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l], sbar_msg_l,
+                                         sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap, n_groups);
+                if (n_gather)   // partial buffer 0 of every model
+                    hipLaunchKernelGGL(k_edge_bwd<false>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
+                                       h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
+                                       sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
+                                       (long long)h->slot_cap * n_groups, (int)EDGE_CLASS_GATHER);
+            }
             P.end(st);
             if (l > 0 && !fused) {
                 P.begin(KC_MSG_MLP_BWD, st);
@@ -628,8 +654,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     P.begin(KC_FINALIZE, st);
     if (want & VSSR_WANT_FORCES) {
         if (n_groups > 1)
-            hipLaunchKernelGGL(k_reduce_gbar_groups, dim3((unsigned)((h->slot_cap + 255) / 256)), dim3(256), 0, st, M, n_groups,
-                               counters, sv.gbar, (long long)h->slot_cap);
+            hipLaunchKernelGGL(k_reduce_gbar_groups, dim3(12, h->n_cfg), dim3(256), 0, st, M, n_groups, G, counters, sv.gbar,
+                               (long long)h->slot_cap);
         hipLaunchKernelGGL(k_finalize_forces, dim3((N + 3) / 4), dim3(256), 0, st, N, M, G, counters, sv.gbar,
                            (long long)h->slot_cap * n_groups, h->units_per_ev, h->d_forces.as<float>(),
                            h->d_forces_std.as<float>());

@@ -17,7 +17,8 @@
 // them; a centre is written once, after a 4-lane DPP reduction.  No atomics; the summation order per centre is the CSR
 // order regardless of batching.  What bounds these kernels and what was tried: DESIGN.md section 5,
 // profiles/r01/NOTES_edge_r1b.md.
-// Chains larger than the LDS capacity (N > ~400) fall back to the gather kernels in painn.hip.
+// Chains of 351 .. 682 atoms take the 8-feature-slice instantiation, larger ones the gather kernels in painn.hip; the choice
+// is per chain (edge_class_of), so a chain's results do not depend on what it is batched with.
 #include "vssr_internal.h"
 
 namespace vssr {
@@ -77,7 +78,7 @@ __device__ __forceinline__ void mfma_load_fence(int &index, float &a, float &b, 
     asm volatile("; mfma_load_fence" : "+v"(index), "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
-// D += W . rho for one 16 x 16 tile: six partial products, smallest first
+// D += W . rho for one 16 x 16 tile
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
@@ -89,22 +90,6 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 acc) {
 // retired when it reaches the pipe, nothing queues up, and the compiler's model holds.  The scheduling barriers pin
 // the issue order (without them the scheduler re-serialises the chains to save registers, or ends one round and starts
 // the next on the same tile).
-template <int NT>
-__device__ __forceinline__ void filter_tiles(const u32x4 (*const (&w)[NT])[2], const u32x4 (*const (&r)[NT])[2], f32x4 (&acc)[NT]) {
-    constexpr int wi[3] = {0, 1, 0}, ri[3] = {1, 0, 0};   // Wh rl, Wl rh, Wh rh
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = mfma_f16((*w[t])[wi[k]], (*r[t])[ri[k]], acc[t]);
-            if (NT < 3) asm volatile("s_nop 7");   // two tiles (layer-0 fallback path): keep the chain producer 2 MFMAs + 16 wait states back
-            __builtin_amdgcn_sched_barrier(0);       // fixed tile order inside the round as well
-        }
-    }
-}
-
 // The same rounds plus the selector tile: sel has a single 1.0 per lane (K entry 6 of quarter fq on feature row i with
 // i % 4 == fq), so D_sel[4 q + r][slot] = entry 6 of quarter r of the slot's record = {u_x, u_y, u_z, 1/d}[r]: lane (slot p,
 // any quarter) receives the four per-slot scalars in its 4 accumulator registers, h piece + l piece (22 bits), without
@@ -118,12 +103,16 @@ __device__ __forceinline__ void filter_tiles_sel(const u32x4 (*const (&w)[NT])[2
     accsel = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+        if (NT < 3 && k == 2) {   // two tiles: the selector's second product goes in FRONT of the last round, so that every
+            accsel = mfma_f16(sel, rs[ri[k]], accsel);   // product's predecessor in its chain stays three instructions back
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc[t] = mfma_f16((*w[t])[wi[k]], (*r[t])[ri[k]], acc[t]);
             __builtin_amdgcn_sched_barrier(0);       // fixed tile order inside the round as well
         }
-        if (k != 1) {
+        if (k == 0 || (k == 2 && NT >= 3)) {
             accsel = mfma_f16(sel, rs[ri[k]], accsel);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -156,22 +145,40 @@ void build_wd16(const float *Wd, const float *bd, unsigned *dst) {
         }
 }
 
-constexpr int FS = 16;           // features per slice
-constexpr int NSLICE = F / FS;   // 8
+// Feature slices come in two widths.  NF = features per lane: 4 -> a 16-feature slice (the default: 468 B of LDS per atom in
+// the forward kernel, chains up to 350 atoms), 2 -> an 8-feature slice (240 B per atom, chains up to 682 atoms: 4 x 4
+// slabs at full coverage, multi-atom adsorbate groups).  The 8-feature kernels keep the 16 x 16 matrix tile full by packing
+// two filter sections into one tile: tile row i = 4 q + j carries feature 2 q + (j & 1) of section 2 T + (j >> 1), so that lane
+// (slot, fq) -- which owns tile rows 4 fq .. 4 fq + 3 -- still finds the a, b and c filter values of ITS features in its own
+// accumulator registers (tile 0 = [a | b], tile 1 = [c | -]).  Every chain takes the path its own atom count selects
+// (vssr_api.hip classify_chains), whatever it is batched with.
 constexpr int EDGE_THREADS = 1024;   // 16 waves = 4 per SIMD (120 VGPRs): measured 512 -> 2.54, 768 -> 2.17, 1024 -> 2.03 ms / step
 
-// LDS slice layout: tile[atom][feature f][NSEG] with NSEG = {a, b, c, v_x, v_y, v_z}: the values a lane needs for its 4
-// features of one neighbor are 96 contiguous bytes = 6 ds_read_b128.  (Layer 0 never comes here: it is either
+// LDS slice layout: tile[atom][feature f][NSEG] with NSEG = {a, b, c, v_x, v_y, v_z}: the values a lane needs for its NF
+// features of one neighbor are NF * 24 contiguous bytes.  (Layer 0 never comes here: it is either
 // factorised by species, painn_l0.hip, or -- more than 8 species / VSSR_L0_FACTORISE=0 -- runs the gather kernels.)
-struct EdgeLayout {
+template <int NF>
+struct EdgeGeo {
+    static_assert(NF == 4 || NF == 2, "16- or 8-feature slices");
+    static constexpr int FS = 4 * NF;                // features per slice
+    static constexpr int NSLICE = F / FS;            // 8 or 16
     static constexpr int NSEC = 3;                   // filter sections a, b, c
+    static constexpr int NT = NF == 4 ? 3 : 2;       // filter tiles per table (rho; the reverse kernel adds as many for d rho)
     static constexpr int NSEG = 6;                   // values staged per (atom, feature): phi a, b, c and v x, y, z
-    static constexpr int ROW = NSEG * FS + 4;        // LDS row stride (floats); rows stay 16-B aligned
+    static constexpr int ROW = NSEG * FS + 4;        // forward LDS row stride (floats); rows stay 16-B aligned
+    static constexpr int ROWB = FS * 4 + 4;          // reverse LDS row: [feature][sbar, vbar_x, vbar_y, vbar_z] + pad
+    // filter section and slice feature carried by row i of tile T (-1: the row is empty)
+    __host__ __device__ static constexpr int row_section(int T, int i) { return NF == 4 ? T : (2 * T + ((i & 3) >> 1) < 3 ? 2 * T + ((i & 3) >> 1) : -1); }
+    __host__ __device__ static constexpr int row_feature(int i) { return NF == 4 ? i : 2 * (i >> 2) + (i & 1); }
 };
+// accumulator register r' of tile T that holds the filter of section sec for the lane's feature r (r < NF)
+template <int NF> __device__ __forceinline__ constexpr int sec_tile(int sec) { return NF == 4 ? sec : sec >> 1; }
+template <int NF> __device__ __forceinline__ constexpr int sec_reg(int sec, int r) { return NF == 4 ? r : 2 * (sec & 1) + r; }
 
 // LDS carve-up: tile [max_atoms][ROW] | s slice [max_atoms][FS] | row_start [max_atoms + 1] (ints)
-size_t edge_fwd_lds_bytes(int max_atoms) {
-    return sizeof(float) * ((size_t)max_atoms * (EdgeLayout::ROW + FS) + max_atoms + 4);
+template <int NF>
+size_t edge_fwd_lds_bytes_t(int max_atoms) {
+    return sizeof(float) * ((size_t)max_atoms * (EdgeGeo<NF>::ROW + EdgeGeo<NF>::FS) + max_atoms + 4);
 }
 
 // sum over the 4 lanes of a quad (lanes 4q..4q+3), result in every lane: two DPP quad_perm adds
@@ -185,10 +192,18 @@ __device__ __forceinline__ float quad_sum(float x) {
 // The sums are consumed only by the quad's first lane inside a branch; without the (empty) asm the compiler sinks the
 // second add into that branch and keeps a separate v_mov_b32_dpp outside (a DPP read of a lane the branch disabled
 // returns 0): 3 instructions per value instead of 2.  The asm pins the complete sum in front of the branch.
-__device__ __forceinline__ void quad_sum4(float (&x)[4]) {
+template <int NF>
+__device__ __forceinline__ void quad_sum_n(float (&x)[NF]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = quad_sum(x[r]);
-    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    for (int r = 0; r < NF; ++r) x[r] = quad_sum(x[r]);
+    if constexpr (NF == 4) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    else asm volatile("" : "+v"(x[0]), "+v"(x[1]));
+}
+// the NF values of a lane to NF consecutive floats (one 16- or 8-byte store)
+template <int NF>
+__device__ __forceinline__ void store_feat(float *dst, const float (&v)[NF]) {
+    if constexpr (NF == 4) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    else *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[1]);
 }
 
 // sum over the four 16-lane rows (lanes l, l^16, l^32, l^48), result in every lane: the gfx950 row-swap instructions
@@ -270,42 +285,54 @@ struct BundleWalk {
 // (A[i = feature][k]) and rho as B (B[k][j = slot]) the filter tile D[feature][slot] puts the 4 feature values of
 // slot p into the 4 accumulator registers of lane (p, fq): the lane that loaded rho for slot p (its k-quarter is
 // fq) also owns that slot's messages, so one table address serves both and no cross-lane traffic is needed.
+// Chains of this launch: `list` (chain indices of one slice-width class, built at upload) or, list == nullptr, all chains.
+// XCD-aware 1-D grid: workgroup id -> XCD id % 8 (observed dispatch rule).  All (slice, model) workgroups of one chain get
+// consecutive ids on ONE XCD, so the chain's rho / record tables (~1.3 MB) and its phi / v rows are fetched from HBM once and
+// then served by that XCD's L2.  Returns the chain, or -1 for a workgroup without one; t = (slice, model) index.
+__device__ __forceinline__ int chain_of_workgroup(const GraphView &G, const int *__restrict__ list, int n_list, int per_chain, int &t) {
+    const int wg = blockIdx.x, xcd = wg & 7, rest = wg >> 3;
+    t = rest % per_chain;
+    const int k = (rest / per_chain) * 8 + xcd;
+    if (k >= n_list) return -1;
+    const int b = list ? list[k] : k;
+    return G.act.chain(b) ? b : -1;
+}
+
+template <int NF>
 __global__ void __launch_bounds__(EDGE_THREADS)
 k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *__restrict__ counters,
-                int zero_slot, int n_models, int max_atoms, const float *__restrict__ s_in,
-                const float *__restrict__ v_in, const float *__restrict__ phi, float *__restrict__ s_msg,
-                float *__restrict__ v_msg) {
-    using LY = EdgeLayout;
+                int zero_slot, int n_models, int max_atoms, const int *__restrict__ list, int n_list,
+                const float *__restrict__ s_in, const float *__restrict__ v_in, const float *__restrict__ phi,
+                float *__restrict__ s_msg, float *__restrict__ v_msg) {
+    using LY = EdgeGeo<NF>;
+    constexpr int FS = LY::FS, NSLICE = LY::NSLICE, NT = LY::NT;
     extern __shared__ __attribute__((aligned(16))) float tile[];
     if (counters[2]) return;
-    // XCD-aware 1-D grid: workgroup id -> XCD id % 8 (observed dispatch rule).  All (slice, model) workgroups of
-    // one chain get consecutive ids on ONE XCD, so the chain's rho / record tables (~1.3 MB) and its phi / v
-    // rows are fetched from HBM once and then served by that XCD's L2.
-    const int wg = blockIdx.x, xcd = wg & 7, rest = wg >> 3;
-    const int per_chain = NSLICE * n_models;
-    const int t = rest % per_chain, b = (rest / per_chain) * 8 + xcd;
-    if (b >= G.n_cfg || !G.act.chain(b)) return;
+    int t;
+    const int b = chain_of_workgroup(G, list, n_list, NSLICE * n_models, t);
+    if (b < 0) return;
     const int fs = t % NSLICE, m = t / NSLICE;
     const int a0 = G.cfg_start[b], Nc = G.cfg_start[b + 1] - a0;
     const size_t mN = (size_t)m * N;
     const int tid = threadIdx.x;
 
     // ---- stage the chain's feature slice: tile[atom][f][seg], s slice, row_start ------------------------------
-    // (NSEG + 1) * 4 float4 per atom; loads are issued in batches of 4 per thread before any LDS store so that
+    // (NSEG + 1) * FS / 4 float4 per atom; loads are issued in batches of 4 per thread before any LDS store so that
     // the L2 / HBM round trips overlap (one workgroup per CU: nothing else hides them)
     float *s_tile = tile + (size_t)max_atoms * LY::ROW;                      // [atom][FS]
     {
-        constexpr int PER_ATOM = (LY::NSEG + 1) * 4;   // float4 per atom: NSEG slice segments + the s slice
+        constexpr int Q4 = FS / 4;                          // float4 per slice segment
+        constexpr int PER_ATOM = (LY::NSEG + 1) * Q4;       // float4 per atom: NSEG slice segments + the s slice
         const int total = Nc * PER_ATOM;
         auto src_of = [&](int idx) -> const float * {
-            int atom = idx / PER_ATOM, rem = idx - atom * PER_ATOM, seg = rem >> 2, q4 = rem & 3;
+            int atom = idx / PER_ATOM, rem = idx - atom * PER_ATOM, seg = rem / Q4, q4 = rem % Q4;
             const size_t ga = mN + a0 + atom;
             if (seg == LY::NSEG) return s_in + ga * F + fs * FS + q4 * 4;                  // s slice
             if (seg < 3) return phi + ga * F3 + seg * F + fs * FS + q4 * 4;                // sections a, b, c
             return v_in + (ga * 3 + (seg - 3)) * F + fs * FS + q4 * 4;                     // v_x, v_y, v_z
         };
         auto put = [&](int idx, const float4 &val) {
-            int atom = idx / PER_ATOM, rem = idx - atom * PER_ATOM, seg = rem >> 2, q4 = rem & 3;
+            int atom = idx / PER_ATOM, rem = idx - atom * PER_ATOM, seg = rem / Q4, q4 = rem % Q4;
             if (seg == LY::NSEG) {
                 *reinterpret_cast<float4 *>(s_tile + atom * FS + q4 * 4) = val;
             } else {
@@ -328,26 +355,27 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, p = lane & 15, fq = lane >> 4, e = p & 3;
-    // ---- A operand: Wd_ext[section row = feature (lane & 15)][k = 4 ks + (lane >> 4)] ---------------------------
+    // ---- A operand: fp16 pieces (h, l) of the filter weights carried by tile row p, quarter fq: 2 x 16 B per tile, bias
+    // column included (build_wd16); an empty row of the packed 8-feature tiles is all zero
     const LayerW &W = MW[m].layer[l];
-    // A operand: fp16 pieces (h, l) of the filter weights of feature row p, quarter fq: 2 x 16 B per section, bias
-    // column included (build_wd16)
-    u32x4 wA[LY::NSEC][2];
+    u32x4 wA[NT][2];
 #pragma unroll
-    for (int s = 0; s < LY::NSEC; ++s) {
-        const int row = s * F + fs * FS + p;
+    for (int T = 0; T < NT; ++T) {
+        const int sec = LY::row_section(T, p);
+        const int row = max(sec, 0) * F + fs * FS + LY::row_feature(p);
         const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 2;
 #pragma unroll
-        for (int i3 = 0; i3 < 2; ++i3) wA[s][i3] = wsrc[i3];
+        for (int i3 = 0; i3 < 2; ++i3) wA[T][i3] = sec < 0 ? (u32x4){0u, 0u, 0u, 0u} : wsrc[i3];
     }
 
     // ---- work list: bundles of 4 centres of (nearly) equal slot count, see BundleWalk --------------------------------
     BundleWalk<EDGE_THREADS / 64> bw;
     bw.init(G.bundle + a0, Nc, __builtin_amdgcn_readfirstlane(wave), p >> 2);
     if (bw.nj == 0) return;   // (no barrier below)
-    float ds[4] = {0.f, 0.f, 0.f, 0.f}, dvx[4] = {0.f, 0.f, 0.f, 0.f}, dvy[4] = {0.f, 0.f, 0.f, 0.f},
-          dvz[4] = {0.f, 0.f, 0.f, 0.f};
-    const int fcol = fs * FS + 4 * fq;            // first of this lane's 4 global feature columns
+    float ds[NF], dvx[NF], dvy[NF], dvz[NF];
+#pragma unroll
+    for (int r = 0; r < NF; ++r) { ds[r] = 0.f; dvx[r] = 0.f; dvy[r] = 0.f; dvz[r] = 0.f; }
+    const int fcol = fs * FS + NF * fq;            // first of this lane's NF global feature columns
 
     // quad-interleaved table (nbr.hip f16_unit): unit = quad * 32 + piece * 16 + fq * 4 + e -> the 4 slot lanes of a quad read
     // 64 contiguous bytes; exhausted streams read the reserved all-zero quad (filter = 0)
@@ -371,33 +399,32 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     }
 
     // The 4 centres of a bundle complete in the same step: reduce the 4 slot lanes of every quad, add the residual from
-    // the staged slices (no global loads), one float4 store per row; all lanes take part.
+    // the staged slices (no global loads), one vector store per row; all lanes take part.
     auto flush_bundle = [&]() {
-        float4 so, vxo, vyo, vzo;
-        quad_sum4(ds); quad_sum4(dvx); quad_sum4(dvy); quad_sum4(dvz);
-        so = make_float4(ds[0], ds[1], ds[2], ds[3]);
-        vxo = make_float4(dvx[0], dvx[1], dvx[2], dvx[3]);
-        vyo = make_float4(dvy[0], dvy[1], dvy[2], dvy[3]);
-        vzo = make_float4(dvz[0], dvz[1], dvz[2], dvz[3]);
+        quad_sum_n<NF>(ds); quad_sum_n<NF>(dvx); quad_sum_n<NF>(dvy); quad_sum_n<NF>(dvz);
         const int c = bw.cur.x;
         if (e == 0 && c >= 0) {
             const size_t ga = mN + a0 + c;
-            const float4 sr = *reinterpret_cast<const float4 *>(s_tile + c * FS + 4 * fq);
-            so.x += sr.x; so.y += sr.y; so.z += sr.z; so.w += sr.w;
-            const float *vc = tile + c * LY::ROW + (4 * fq) * LY::NSEG;
-            vxo.x += vc[3]; vxo.y += vc[9]; vxo.z += vc[15]; vxo.w += vc[21];
-            vyo.x += vc[4]; vyo.y += vc[10]; vyo.z += vc[16]; vyo.w += vc[22];
-            vzo.x += vc[5]; vzo.y += vc[11]; vzo.z += vc[17]; vzo.w += vc[23];
-            *reinterpret_cast<float4 *>(s_msg + ga * F + fcol) = so;
-            *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 0) * F + fcol) = vxo;
-            *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 1) * F + fcol) = vyo;
-            *reinterpret_cast<float4 *>(v_msg + (ga * 3 + 2) * F + fcol) = vzo;
+            float so[NF], xo[NF], yo[NF], zo[NF];
+            const float *sr = s_tile + c * FS + NF * fq;
+            const float *vc = tile + c * LY::ROW + (NF * fq) * LY::NSEG;
+#pragma unroll
+            for (int r = 0; r < NF; ++r) {
+                so[r] = ds[r] + sr[r];
+                xo[r] = dvx[r] + vc[r * LY::NSEG + 3];
+                yo[r] = dvy[r] + vc[r * LY::NSEG + 4];
+                zo[r] = dvz[r] + vc[r * LY::NSEG + 5];
+            }
+            store_feat<NF>(s_msg + ga * F + fcol, so);
+            store_feat<NF>(v_msg + (ga * 3 + 0) * F + fcol, xo);
+            store_feat<NF>(v_msg + (ga * 3 + 1) * F + fcol, yo);
+            store_feat<NF>(v_msg + (ga * 3 + 2) * F + fcol, zo);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ds[r] = 0.f; dvx[r] = 0.f; dvy[r] = 0.f; dvz[r] = 0.f; }
+        for (int r = 0; r < NF; ++r) { ds[r] = 0.f; dvx[r] = 0.f; dvy[r] = 0.f; dvz[r] = 0.f; }
     };
 
-    const float *trow = tile + (4 * fq) * LY::NSEG;
+    const float *trow = tile + (NF * fq) * LY::NSEG;
     while (bw.j < bw.nj) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: one table buffer per step parity
@@ -407,31 +434,32 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                 flush_bundle();
                 bw.advance();
             }
-            // gather this slot's neighbor row: 4 features x NSEG values, contiguous in LDS
-            float tv[4 * LY::NSEG];
+            // gather this slot's neighbor row: NF features x NSEG values, contiguous in LDS
+            float tv[NF * LY::NSEG];
             {
                 const float4 *row = reinterpret_cast<const float4 *>(trow + jn * LY::ROW);
 #pragma unroll
-                for (int q = 0; q < LY::NSEG; ++q) {
+                for (int q = 0; q < NF * LY::NSEG / 4; ++q) {
                     const float4 t4 = row[q];
                     tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
                 }
             }
             mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
-            // ---- filter GEMM  D[feature][slot] = Wd_ext[feature][k] rho[k][slot]  (bias . fc included) ---------------
-            f32x4 acc[LY::NSEC], usel;
+            // ---- filter GEMM  D[tile row][slot] = Wd_ext[row][k] rho[k][slot]  (bias . fc included) ---------------------
+            f32x4 acc[NT], usel;
             {
-                const u32x4 (*wp[LY::NSEC])[2], (*rp3[LY::NSEC])[2];
+                const u32x4 (*wp[NT])[2], (*rp3[NT])[2];
 #pragma unroll
-                for (int s2 = 0; s2 < LY::NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; }
-                filter_tiles_sel<LY::NSEC>(wp, rp3, acc, sel, rq[ph], usel);
+                for (int s2 = 0; s2 < NT; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; }
+                filter_tiles_sel<NT>(wp, rp3, acc, sel, rq[ph], usel);
             }
             __builtin_amdgcn_sched_barrier(0);
             const float ux = usel[0], uy = usel[1], uz = usel[2];   // unit vector of this lane's slot
-            // ---- messages of this lane's slot for its 4 features (filter = 0 exactly for pads / foreign slots) -----------
+            // ---- messages of this lane's slot for its NF features (filter = 0 exactly for pads / foreign slots) ----------
             auto message = [&](int r) {
                 const float *tr = tv + r * LY::NSEG;
-                const float wa = acc[0][r], wb = acc[1][r], wc = acc[2][r];
+                const float wa = acc[sec_tile<NF>(0)][sec_reg<NF>(0, r)], wb = acc[sec_tile<NF>(1)][sec_reg<NF>(1, r)],
+                            wc = acc[sec_tile<NF>(2)][sec_reg<NF>(2, r)];
                 ds[r] = fmaf(tr[1], wb, ds[r]);
                 const float mc = tr[2] * wc, ma = tr[0] * wa;
                 dvx[r] = fmaf(mc, ux, dvx[r]); dvy[r] = fmaf(mc, uy, dvy[r]); dvz[r] = fmaf(mc, uz, dvz[r]);
@@ -439,7 +467,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                 dvy[r] = fmaf(ma, tr[4], dvy[r]);
                 dvz[r] = fmaf(ma, tr[5], dvz[r]);
             };
-            message(0);   // consumes every accumulator tile
+            message(0);   // consumes every accumulator tile (NF = 2: wa, wb from tile 0, wc from tile 1)
             // table entries of the step after next, into the buffer this step has just consumed; see mfma_load_fence
             bool nv;
             int nq = bw.quad_ahead(2, nv);
@@ -447,7 +475,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             fetch(ph, nq, nv);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 1; r < 4; ++r) message(r);
+            for (int r = 1; r < NF; ++r) message(r);
             ++bw.t;
         }
     }
@@ -466,31 +494,39 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 // buffer G[m][group][slot]: within a layer every slot is written once per group, across layers the SAME lane adds to
 // it in a fixed order (deterministic read-modify-write, old value prefetched one step ahead); finalize reduces the
 // groups in a streaming pass.
-constexpr int BWD_THREADS = 256;   // 4 waves: two workgroups share a CU (81 KB of LDS each at 272 atoms), one stages its slice while the other computes (6.4 -> 6.0 ms / step)
-constexpr int SLICES_PER_WG = 1;   // measured: 1 -> 6.3 ms, 2 -> 6.7, 4 -> 7.1 per step (L2 locality of the tables); finalize reduces the 8 partial buffers in a streaming pass
-constexpr int NSG = NSLICE / SLICES_PER_WG;   // slice groups = partial edge-gradient buffers per model
-constexpr int ROWB = FS * 4 + 4;              // LDS row: [feature][sbar, vbar_x, vbar_y, vbar_z] + pad
-
-constexpr int BWD_STREAMS = (BWD_THREADS / 64) * 4;
-constexpr int CEN_FLOATS = BWD_STREAMS * 4 * 6 * 4;   // current-centre store: [stream][feature quarter][phi a, b, c, v x, y, z] float4
-size_t edge_bwd_lds_bytes(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * ROWB + CEN_FLOATS); }
-int edge_bwd_groups() { return NSG; }
+// 16-feature slices: 4 waves, two workgroups share a CU (81 KB of LDS each at 272 atoms), one stages its slice while the other
+// computes (6.4 -> 6.0 ms / step); 2 waves per SIMD with the 256-register budget.  8-feature slices (145 registers, 144 B of
+// LDS per atom) were measured with 4 / 6 / 8 waves per workgroup on 490-atom chains: 13.1 / 13.4 / 23.7 ms per step (8 waves
+// spill at 128 registers): 4 waves as well.
+#ifndef BWD8_WAVES
+#define BWD8_WAVES 4
+#endif
+template <int NF> constexpr int bwd_threads() { return NF == 4 ? 256 : 64 * BWD8_WAVES; }
+template <int NF> constexpr int bwd_waves_per_simd() { return NF == 4 ? 2 : (2 * BWD8_WAVES) / 4; }
+// (one slice per workgroup; measured with 16-feature slices: 1 -> 6.3 ms, 2 -> 6.7, 4 -> 7.1 per step -- L2 locality of the
+// tables; finalize reduces the partial buffers of a chain's slices in a streaming pass)
+template <int NF>
+constexpr int cen_floats() { return (bwd_threads<NF>() / 64) * 4 * 4 * 6 * NF; }   // current-centre store: [stream][feature quarter][phi a, b, c, v x, y, z][NF]
+template <int NF>
+size_t edge_bwd_lds_bytes_t(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * EdgeGeo<NF>::ROWB + cen_floats<NF>()); }
 
 // FIRST: the launch writes the partial edge-gradient buffers for the first time (last layer): nothing to add to.
-template <bool FIRST>
-__global__ void __launch_bounds__(BWD_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))   // two workgroups per CU = 2 waves per SIMD: use the 256 VGPRs
+template <int NF, bool FIRST>
+__global__ void __launch_bounds__(bwd_threads<NF>()) __attribute__((amdgpu_waves_per_eu(bwd_waves_per_simd<NF>(), bwd_waves_per_simd<NF>())))
 k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms,
+                const int *__restrict__ list, int n_list,
                 const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
                 const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
                 float4 *__restrict__ gbar, long long gbar_stride, int n_groups) {
-    constexpr int NSEC = 3;
+    using LY = EdgeGeo<NF>;
+    constexpr int FS = LY::FS, NSG = LY::NSLICE, NT = LY::NT, ROWB = LY::ROWB, BWD_THREADS = bwd_threads<NF>();
+    typedef float fvx __attribute__((ext_vector_type(NF)));   // the lane's NF features (ext vectors: arrays of HIP float4 stay in scratch memory)
     extern __shared__ __attribute__((aligned(16))) float tile[];
     if (counters[2]) return;
-    const int wg = blockIdx.x, xcd = wg & 7, rest = wg >> 3;
-    const int per_chain = NSG * n_models;
-    const int t = rest % per_chain, b = (rest / per_chain) * 8 + xcd;
-    if (b >= G.n_cfg || !G.act.chain(b)) return;
+    int t;
+    const int b = chain_of_workgroup(G, list, n_list, NSG * n_models, t);
+    if (b < 0) return;
     const int fs = t % NSG, m = t / NSG;   // feature slice = partial-gradient group
     const int a0 = G.cfg_start[b], Nc = G.cfg_start[b + 1] - a0;
     const size_t mN = (size_t)m * N;
@@ -503,7 +539,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;   // quad-interleaved tables, see forward
     const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 4 + e;
     const int zero_quad = (zero_slot + 1) / 4 - 1;
-    const int fcol = fs * FS + 4 * fq;
+    const int fcol = fs * FS + NF * fq;
 
     // which gradient component the reduce-scatter of the hot loop leaves in this lane's row: the same swap network run
     // once on tags (0, 1, 2 and 3 = the zero filler), so the mapping never depends on a reading of the ISA manual
@@ -520,13 +556,14 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 
     // ---- stage [atom][f][sbar, vbar_x, vbar_y, vbar_z] of this slice ------------------------------------------
     {
-        const int total = Nc * 16;   // 4 segments x 4 float4 per atom
+        constexpr int Q4 = FS / 4;           // float4 per segment
+        const int total = Nc * 4 * Q4;       // 4 segments per atom
         for (int base = tid; base < total; base += 4 * BWD_THREADS) {
             float4 v4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = min(base + u * BWD_THREADS, total - 1);
-                const int atom = idx >> 4, seg = (idx >> 2) & 3, q4 = idx & 3;
+                const int atom = idx / (4 * Q4), seg = (idx / Q4) & 3, q4 = idx % Q4;
                 const size_t ga = mN + a0 + atom;
                 const float *src = seg == 0 ? sbar_msg + ga * F + fs * FS + q4 * 4
                                             : vbar_msg + (ga * 3 + (seg - 1)) * F + fs * FS + q4 * 4;
@@ -536,21 +573,22 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             for (int u = 0; u < 4; ++u) {
                 const int idx = base + u * BWD_THREADS;
                 if (idx < total) {
-                    const int atom = idx >> 4, seg = (idx >> 2) & 3, q4 = idx & 3;
+                    const int atom = idx / (4 * Q4), seg = (idx / Q4) & 3, q4 = idx % Q4;
                     float *dst = tile + atom * ROWB + (q4 * 4) * 4 + seg;
                     dst[0] = v4[u].x; dst[4] = v4[u].y; dst[8] = v4[u].z; dst[12] = v4[u].w;
                 }
             }
         }
     }
-    // ---- A operand: Wd_ext rows of this slice ------------------------------------------------------------------
-    u32x4 wA[NSEC][2];   // fp16 pieces (h, l) of the slice's filter rows, bias column included (build_wd16)
+    // ---- A operand: the slice's filter rows in tile order (see the forward kernel) ------------------------------------------
+    u32x4 wA[NT][2];   // fp16 pieces (h, l), bias column included (build_wd16); empty rows of the packed 8-feature tiles are zero
 #pragma unroll
-    for (int s2 = 0; s2 < NSEC; ++s2) {
-        const int row = s2 * F + fs * FS + p;
+    for (int T = 0; T < NT; ++T) {
+        const int sec = LY::row_section(T, p);
+        const int row = max(sec, 0) * F + fs * FS + LY::row_feature(p);
         const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 2;
 #pragma unroll
-        for (int i3 = 0; i3 < 2; ++i3) wA[s2][i3] = wsrc[i3];
+        for (int i3 = 0; i3 < 2; ++i3) wA[T][i3] = sec < 0 ? (u32x4){0u, 0u, 0u, 0u} : wsrc[i3];
     }
     __syncthreads();
 
@@ -558,23 +596,23 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     bw.init(G.bundle + a0, Nc, __builtin_amdgcn_readfirstlane(wave), p >> 2);
     if (bw.nj == 0) return;   // (no barrier below)
 
-    // ---- per-centre data of this lane's 4 features: phi_c (a, b, c) and v_c -------------------------------------------
+    // ---- per-centre data of this lane's NF features: phi_c (a, b, c) and v_c -------------------------------------------
     // The CURRENT centre's values live in a small LDS record per (stream, feature quarter) and are re-read every step
-    // next to the neighbor gathers (6 broadcast ds_read_b128); the NEXT bundle's values are in flight in registers
+    // next to the neighbor gathers (6 broadcast LDS reads); the NEXT bundle's values are in flight in registers
     // and are parked in the record when the wave moves on.  (Keeping both sets in registers made the compiler
     // rotate ~50 registers per completed centre and wait on the prefetch it had just issued.)
-    const int cen_idx = max_atoms * ROWB + ((wave * 4 + (p >> 2)) * 4 + fq) * 24;   // float index in tile[]
-    f32x4 *cen = reinterpret_cast<f32x4 *>(tile + cen_idx);
-    f32x4 nx[6];   // (ext vectors: arrays of HIP float4 stay in scratch memory)
+    const int cen_idx = max_atoms * ROWB + ((wave * 4 + (p >> 2)) * 4 + fq) * 6 * NF;   // float index in tile[]
+    fvx *cen = reinterpret_cast<fvx *>(tile + cen_idx);
+    fvx nx[6];
     auto load_centre = [&](int cc) {   // always a load (any valid row for streams without a centre)
         const size_t ga = mN + a0 + min(max(cc, 0), Nc - 1);
         const float *pr = phi + ga * F3 + fcol;
-        nx[0] = *reinterpret_cast<const f32x4 *>(pr);
-        nx[1] = *reinterpret_cast<const f32x4 *>(pr + F);
-        nx[2] = *reinterpret_cast<const f32x4 *>(pr + 2 * F);
-        nx[3] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 0) * F + fcol);
-        nx[4] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 1) * F + fcol);
-        nx[5] = *reinterpret_cast<const f32x4 *>(v_in + (ga * 3 + 2) * F + fcol);
+        nx[0] = *reinterpret_cast<const fvx *>(pr);
+        nx[1] = *reinterpret_cast<const fvx *>(pr + F);
+        nx[2] = *reinterpret_cast<const fvx *>(pr + 2 * F);
+        nx[3] = *reinterpret_cast<const fvx *>(v_in + (ga * 3 + 0) * F + fcol);
+        nx[4] = *reinterpret_cast<const fvx *>(v_in + (ga * 3 + 1) * F + fcol);
+        nx[5] = *reinterpret_cast<const fvx *>(v_in + (ga * 3 + 2) * F + fcol);
     };
     auto park_centre = [&]() {   // the quad's 4 slot lanes hold identical values: any of them may write
 #pragma unroll
@@ -583,45 +621,37 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     load_centre(bw.cur.x);
     park_centre();
     load_centre(bw.nxt.x);
-    float accb[4] = {0.f, 0.f, 0.f, 0.f}, accc[4] = {0.f, 0.f, 0.f, 0.f};
-    float accx[4] = {0.f, 0.f, 0.f, 0.f}, accy[4] = {0.f, 0.f, 0.f, 0.f}, accz[4] = {0.f, 0.f, 0.f, 0.f};
+    float accb[NF], accc[NF], accx[NF], accy[NF], accz[NF];
+#pragma unroll
+    for (int r = 0; r < NF; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
 
     // the 4 centres of a bundle complete in the same step: all lanes reduce, the first lane of every quad writes
     auto flush_bundle = [&]() {
-        float4 pa, pb, pc2, ox, oy, oz;
-        quad_sum4(accb); quad_sum4(accc); quad_sum4(accx); quad_sum4(accy); quad_sum4(accz);
-        const float (&tb)[4] = accb, (&tc)[4] = accc, (&tx)[4] = accx, (&ty)[4] = accy, (&tz)[4] = accz;
+        quad_sum_n<NF>(accb); quad_sum_n<NF>(accc); quad_sum_n<NF>(accx); quad_sum_n<NF>(accy); quad_sum_n<NF>(accz);
+        const float (&tb)[NF] = accb, (&tc)[NF] = accc, (&tx)[NF] = accx, (&ty)[NF] = accy, (&tz)[NF] = accz;
         const int c = bw.cur.x;
         if (e == 0 && c >= 0) {
             const size_t ga = mN + a0 + c;
-            const f32x4 cv[6] = {cen[0], cen[1], cen[2], cen[3], cen[4], cen[5]};   // record of the completed centre
-            const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
-            const float vz_[4] = {cv[5].x, cv[5].y, cv[5].z, cv[5].w}, pa_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
-            float a_[4], x_[4], y_[4], z_[4];
-            const float *res = tile + c * ROWB + (4 * fq) * 4;   // [r][sbar, vbar_x, vbar_y, vbar_z]
+            const fvx cv[6] = {cen[0], cen[1], cen[2], cen[3], cen[4], cen[5]};   // record of the completed centre
+            float a_[NF], x_[NF], y_[NF], z_[NF];
+            const float *res = tile + c * ROWB + (NF * fq) * 4;   // [r][sbar, vbar_x, vbar_y, vbar_z]
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                a_[r] = fmaf(vz_[r], tz[r], fmaf(vy_[r], ty[r], vx_[r] * tx[r]));
-                x_[r] = fmaf(pa_[r], tx[r], res[4 * r + 1]);
-                y_[r] = fmaf(pa_[r], ty[r], res[4 * r + 2]);
-                z_[r] = fmaf(pa_[r], tz[r], res[4 * r + 3]);
+            for (int r = 0; r < NF; ++r) {
+                a_[r] = fmaf(cv[5][r], tz[r], fmaf(cv[4][r], ty[r], cv[3][r] * tx[r]));
+                x_[r] = fmaf(cv[0][r], tx[r], res[4 * r + 1]);
+                y_[r] = fmaf(cv[0][r], ty[r], res[4 * r + 2]);
+                z_[r] = fmaf(cv[0][r], tz[r], res[4 * r + 3]);
             }
-            pa = make_float4(a_[0], a_[1], a_[2], a_[3]);
-            pb = make_float4(tb[0], tb[1], tb[2], tb[3]);
-            pc2 = make_float4(tc[0], tc[1], tc[2], tc[3]);
-            ox = make_float4(x_[0], x_[1], x_[2], x_[3]);
-            oy = make_float4(y_[0], y_[1], y_[2], y_[3]);
-            oz = make_float4(z_[0], z_[1], z_[2], z_[3]);
             float *pbp = phibar + ga * F3 + fcol;
-            *reinterpret_cast<float4 *>(pbp) = pa;
-            *reinterpret_cast<float4 *>(pbp + F) = pb;
-            *reinterpret_cast<float4 *>(pbp + 2 * F) = pc2;
-            *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 0) * F + fcol) = ox;
-            *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 1) * F + fcol) = oy;
-            *reinterpret_cast<float4 *>(vbar_in + (ga * 3 + 2) * F + fcol) = oz;
+            store_feat<NF>(pbp, a_);
+            store_feat<NF>(pbp + F, tb);
+            store_feat<NF>(pbp + 2 * F, tc);
+            store_feat<NF>(vbar_in + (ga * 3 + 0) * F + fcol, x_);
+            store_feat<NF>(vbar_in + (ga * 3 + 1) * F + fcol, y_);
+            store_feat<NF>(vbar_in + (ga * 3 + 2) * F + fcol, z_);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
+        for (int r = 0; r < NF; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
     };
 
     // Table entries of this lane's slot; exhausted streams read the all-zero quad.  Two buffers, one per step parity:
@@ -644,7 +674,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         fetch(0, q0, v0);
         fetch(1, q1, v1);
     }
-    const float *trow = tile + (4 * fq) * 4;
+    const float *trow = tile + (NF * fq) * 4;
 
     while (bw.j < bw.nj) {
 #pragma unroll
@@ -661,11 +691,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             }
             bool real_slot;
             const int my_slot = bw.quad_ahead(0, real_slot) + e;
-            float tb[16];
+            float tb[4 * NF];
             {
                 const float4 *row = reinterpret_cast<const float4 *>(trow + jn * ROWB);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < NF; ++q) {
                     const float4 t4 = row[q];
                     tb[4 * q] = t4.x; tb[4 * q + 1] = t4.y; tb[4 * q + 2] = t4.z; tb[4 * q + 3] = t4.w;
                 }
@@ -673,48 +703,44 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             // (the record's index passes through an empty asm: otherwise the compiler forwards the parked registers to these
             // reads, hoists them into the tail of the previous step and shuffles / waits on the registers of the prefetch
             // it has just issued)
-            f32x4 cv[6];
+            fvx cv[6];
             {
                 int ci = cen_idx;   // (the INDEX is laundered: a laundered pointer loses its LDS address space -> flat loads)
                 asm volatile("" : "+v"(ci));
-                const f32x4 *cr = reinterpret_cast<const f32x4 *>(tile + ci);
+                const fvx *cr = reinterpret_cast<const fvx *>(tile + ci);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) cv[q] = cr[q];
             }
             mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
             mfma_pre_fence(dq[ph][0], dq[ph][1]);
-            // filter and its radial derivative for this lane's slot and 4 features (bias . fc / bias . fc' included)
-            f32x4 awd[2 * NSEC], usel;   // tiles [0, NSEC): filter w, [NSEC, 2 NSEC): radial derivative dw; usel: per-slot scalars
+            // filter and its radial derivative for this lane's slot and NF features (bias . fc / bias . fc' included)
+            f32x4 awd[2 * NT], usel;   // tiles [0, NT): filter w, [NT, 2 NT): radial derivative dw; usel: per-slot scalars
             {
-                const u32x4 (*wp[2 * NSEC])[2], (*rp3[2 * NSEC])[2];
+                const u32x4 (*wp[2 * NT])[2], (*rp3[2 * NT])[2];
 #pragma unroll
-                for (int s2 = 0; s2 < NSEC; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; wp[NSEC + s2] = &wA[s2]; rp3[NSEC + s2] = &dq[ph]; }
-                filter_tiles_sel<2 * NSEC>(wp, rp3, awd, sel, rq[ph], usel);
+                for (int s2 = 0; s2 < NT; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; wp[NT + s2] = &wA[s2]; rp3[NT + s2] = &dq[ph]; }
+                filter_tiles_sel<2 * NT>(wp, rp3, awd, sel, rq[ph], usel);
             }
-            const f32x4 *aw = awd, *ad = awd + NSEC;
+            const f32x4 *aw = awd, *ad = awd + NT;
             __builtin_amdgcn_sched_barrier(0);
             const float ux = usel[0], uy = usel[1], uz = usel[2], invd = usel[3];   // unit vector c -> n (edge (n -> c) has -u), 1 / d
-            const float pcb_[4] = {cv[1].x, cv[1].y, cv[1].z, cv[1].w}, pcc_[4] = {cv[2].x, cv[2].y, cv[2].z, cv[2].w};
-            const float pca_[4] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w};
-            const float vx_[4] = {cv[3].x, cv[3].y, cv[3].z, cv[3].w}, vy_[4] = {cv[4].x, cv[4].y, cv[4].z, cv[4].w};
-            const float vz_[4] = {cv[5].x, cv[5].y, cv[5].z, cv[5].w};
             float dpart = 0.f, ub0 = 0.f, ub1 = 0.f, ub2 = 0.f;
             auto feature = [&](int r) {
                 const float sbn = tb[4 * r], vb0 = tb[4 * r + 1], vb1 = tb[4 * r + 2], vb2 = tb[4 * r + 3];
-                const float wB = aw[1][r], wC = aw[2][r];
-                const float dB = ad[1][r], dC = ad[2][r];
+                const float wB = aw[sec_tile<NF>(1)][sec_reg<NF>(1, r)], wC = aw[sec_tile<NF>(2)][sec_reg<NF>(2, r)];
+                const float dB = ad[sec_tile<NF>(1)][sec_reg<NF>(1, r)], dC = ad[sec_tile<NF>(2)][sec_reg<NF>(2, r)];
                 const float pn = -fmaf(vb2, uz, fmaf(vb1, uy, vb0 * ux));   // vbar_n . u_(n->c)
                 accb[r] = fmaf(wB, sbn, accb[r]);
                 accc[r] = fmaf(wC, pn, accc[r]);
-                dpart = fmaf(pcb_[r] * sbn, dB, dpart);
-                dpart = fmaf(pcc_[r] * pn, dC, dpart);
-                const float wAa = aw[0][r], dA = ad[0][r];
-                const float q = fmaf(vb2, vz_[r], fmaf(vb1, vy_[r], vb0 * vx_[r]));
+                dpart = fmaf(cv[1][r] * sbn, dB, dpart);
+                dpart = fmaf(cv[2][r] * pn, dC, dpart);
+                const float wAa = aw[sec_tile<NF>(0)][sec_reg<NF>(0, r)], dA = ad[sec_tile<NF>(0)][sec_reg<NF>(0, r)];
+                const float q = fmaf(vb2, cv[5][r], fmaf(vb1, cv[4][r], vb0 * cv[3][r]));
                 accx[r] = fmaf(wAa, vb0, accx[r]);
                 accy[r] = fmaf(wAa, vb1, accy[r]);
                 accz[r] = fmaf(wAa, vb2, accz[r]);
-                dpart = fmaf(pca_[r] * q, dA, dpart);
-                const float mc = pcc_[r] * wC;
+                dpart = fmaf(cv[0][r] * q, dA, dpart);
+                const float mc = cv[2][r] * wC;
                 ub0 = fmaf(mc, vb0, ub0); ub1 = fmaf(mc, vb1, ub1); ub2 = fmaf(mc, vb2, ub2);
             };
             feature(0);   // consumes every accumulator tile
@@ -724,7 +750,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             fetch(ph, nq, nv);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 1; r < 4; ++r) feature(r);
+            for (int r = 1; r < NF; ++r) feature(r);
             // Gradient of edge (n -> c), unit vector -u:  g = -(dE/dd) u + (ub - (ub.u) u) / d, linear in (dpart, ub).
             // The map is applied to the lane's partial sums BEFORE the reduction over the 4 feature quarters (lanes
             // p, p+16, p+32, p+48), so only 3 values cross lanes, and the reduction is a reduce-scatter on the
@@ -753,34 +779,50 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 }
 
 int edge_mfma_init(vssr_handle *h) {
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_edge_bwd_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define SET_LDS(K) VSSR_HIP(h, hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    SET_LDS(k_edge_fwd_mfma<4>); SET_LDS(k_edge_fwd_mfma<2>);
+    SET_LDS((k_edge_bwd_mfma<4, true>)); SET_LDS((k_edge_bwd_mfma<4, false>));
+    SET_LDS((k_edge_bwd_mfma<2, true>)); SET_LDS((k_edge_bwd_mfma<2, false>));
+#undef SET_LDS
     return VSSR_OK;
 }
 
-bool edge_fwd_mfma_fits(int max_atoms) { return edge_fwd_lds_bytes(max_atoms) <= 160 * 1024; }
+// Slice-width class of a chain by its atom count (EDGE_CLASS_*): the widest slice whose forward LDS tile holds the chain
+// (the reverse tile is smaller).  nf = features per lane of the class (4 / 2).
+int edge_class_of(int n_atoms) {
+    if (edge_fwd_lds_bytes_t<4>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS16;
+    if (edge_fwd_lds_bytes_t<2>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS8;
+    return EDGE_CLASS_GATHER;
+}
+int edge_class_groups(int cls) { return cls == EDGE_CLASS_FS16 ? EdgeGeo<4>::NSLICE : cls == EDGE_CLASS_FS8 ? EdgeGeo<2>::NSLICE : 1; }
 
-// layers >= 1 only (layer 0: painn_l0.hip or the gather kernels, see painn_run)
-void launch_edge_bwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int layer_first, int max_atoms,
+// layers >= 1 only (layer 0: painn_l0.hip or the gather kernels, see painn_run).  cls: EDGE_CLASS_FS16 / _FS8; list / n_list:
+// the chains of that class; max_atoms: the largest of them.
+void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
                           float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups) {
-    dim3 grid(((n_cfg + 7) / 8) * 8 * NSG * M), blk(BWD_THREADS);
-    if (layer_first)
-        hipLaunchKernelGGL(k_edge_bwd_mfma<true>, grid, blk, edge_bwd_lds_bytes(max_atoms), st, N, l, MW, G, counters,
-                           zero_slot, M, max_atoms, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
-    else
-        hipLaunchKernelGGL(k_edge_bwd_mfma<false>, grid, blk, edge_bwd_lds_bytes(max_atoms), st, N, l, MW, G, counters,
-                           zero_slot, M, max_atoms, v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups);
+    if (n_list <= 0) return;
+#define LAUNCH_BWD(NF, FIRST)                                                                                                    \
+    hipLaunchKernelGGL((k_edge_bwd_mfma<NF, FIRST>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), dim3(bwd_threads<NF>()), \
+                       edge_bwd_lds_bytes_t<NF>(max_atoms), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list,     \
+                       v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups)
+    if (cls == EDGE_CLASS_FS16) { if (layer_first) LAUNCH_BWD(4, true); else LAUNCH_BWD(4, false); }
+    else { if (layer_first) LAUNCH_BWD(2, true); else LAUNCH_BWD(2, false); }
+#undef LAUNCH_BWD
 }
 
-void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,
+void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int max_atoms, const ModelW *MW,
                           const GraphView &G, const int *counters, int zero_slot, const float *s_in, const float *v_in,
                           const float *phi, float *s_msg, float *v_msg) {
-    dim3 grid(((n_cfg + 7) / 8) * 8 * NSLICE * M), blk(EDGE_THREADS);
-    hipLaunchKernelGGL(k_edge_fwd_mfma, grid, blk, edge_fwd_lds_bytes(max_atoms), st, N, l, MW, G, counters, zero_slot, M,
-                       max_atoms, s_in, v_in, phi, s_msg, v_msg);
+    if (n_list <= 0) return;
+    const dim3 blk(EDGE_THREADS);
+    if (cls == EDGE_CLASS_FS16)
+        hipLaunchKernelGGL(k_edge_fwd_mfma<4>, dim3(((n_list + 7) / 8) * 8 * EdgeGeo<4>::NSLICE * M), blk, edge_fwd_lds_bytes_t<4>(max_atoms),
+                           st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, s_in, v_in, phi, s_msg, v_msg);
+    else
+        hipLaunchKernelGGL(k_edge_fwd_mfma<2>, dim3(((n_list + 7) / 8) * 8 * EdgeGeo<2>::NSLICE * M), blk, edge_fwd_lds_bytes_t<2>(max_atoms),
+                           st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, s_in, v_in, phi, s_msg, v_msg);
 }
 
 }  // namespace vssr

@@ -310,6 +310,9 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     if (!rc) rc = l0_mfma_init(h);
     if (const char *e = getenv("VSSR_EDGE_IMPL")) h->edge_impl = (strcmp(e, "gather") == 0) ? 0 : 1;
     if (const char *e = getenv("VSSR_L0_FACTORISE")) h->l0_enabled = atoi(e);
+    // test knobs: send chains above these atom counts to the next class (8-feature slices / gather kernels) although they fit
+    if (const char *e = getenv("VSSR_EDGE_FS16_MAX")) h->fs16_max_atoms = atoi(e);
+    if (const char *e = getenv("VSSR_EDGE_FS8_MAX")) h->fs8_max_atoms = atoi(e);
     if (!rc && cfg->offset_per_z) {
         h->has_offset = true;
         h->offset_const = cfg->offset_const;
@@ -458,7 +461,7 @@ void vssr_destroy(vssr_handle *h) {
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
                       &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_drho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->d_zslot, &h->d_bundle, &h->d_excl, &h->d_hits, &h->wd16, &h->node16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv, &h->d_active, &h->d_bfgs_q, &h->d_bfgs_b,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
-                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n};
+                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n, &h->d_chain_class, &h->d_class_list};
     for (DevBuf *b : bufs) b->release();
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -529,6 +532,31 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
     }
     h->max_cfg_atoms = 0;
     for (int b = 0; b < n_cfg; ++b) h->max_cfg_atoms = n_atoms[b] > h->max_cfg_atoms ? n_atoms[b] : h->max_cfg_atoms;
+    if (h->kind == 1) {
+        // Neighbor-sum path of every chain, from its OWN atom count (so a chain's results do not depend on its batch):
+        // 16-feature slices, 8-feature slices, or the gather kernels.  (A batch whose largest chain exceeds what the bundle
+        // sort stages in LDS has no bundle tables at all: every chain gathers.)
+        const bool bundles = (size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024;
+        std::vector<unsigned char> cls(n_cfg);
+        std::vector<int> lists[2];
+        for (int c = 0; c < EDGE_CLASSES; ++c) { h->n_class[c] = 0; h->max_class_atoms[c] = 0; }
+        for (int b = 0; b < n_cfg; ++b) {
+            int c = (h->edge_impl && bundles) ? edge_class_of(n_atoms[b]) : EDGE_CLASS_GATHER;
+            if (c == EDGE_CLASS_FS16 && h->fs16_max_atoms >= 0 && n_atoms[b] > h->fs16_max_atoms) c = EDGE_CLASS_FS8;
+            if (c == EDGE_CLASS_FS8 && h->fs8_max_atoms >= 0 && n_atoms[b] > h->fs8_max_atoms) c = EDGE_CLASS_GATHER;
+            cls[b] = (unsigned char)c;
+            h->n_class[c] += 1;
+            if (n_atoms[b] > h->max_class_atoms[c]) h->max_class_atoms[c] = n_atoms[b];
+            if (c != EDGE_CLASS_GATHER) lists[c].push_back(b);
+        }
+        std::vector<int> cat(lists[0]);
+        cat.insert(cat.end(), lists[1].begin(), lists[1].end());
+        cat.push_back(0);
+        if (h->d_chain_class.ensure((size_t)n_cfg) || h->d_class_list.ensure(sizeof(int) * cat.size()))
+            return set_err(h, VSSR_E_NOMEM, "chain class tables");
+        VSSR_HIP(h, hipMemcpy(h->d_chain_class.p, cls.data(), (size_t)n_cfg, hipMemcpyHostToDevice));
+        VSSR_HIP(h, hipMemcpy(h->d_class_list.p, cat.data(), sizeof(int) * cat.size(), hipMemcpyHostToDevice));
+    }
     h->h_n_atoms.assign(n_atoms, n_atoms + n_cfg);
     h->h_cfg_start = start;
     h->batch_valid = true;

@@ -78,6 +78,7 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const unsigned char *zslot;   // [slots] species index (zmap) of the neighbor, 255 for pads / unmapped
     const float2 *dist2;     // [slots] {1 / edge length (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
     const int4 *bundle;      // [n_atoms] per chain: centres sorted by padded degree (descending): {centre (chain-local), first slot, padded slot count, 0}
+    const unsigned char *chain_class;   // [n_cfg] EDGE_CLASS_*: which neighbor-sum kernels serve the chain (layers >= 1)
     ActiveView act;          // chains switched off by the relaxation driver
 };
 
@@ -171,6 +172,11 @@ struct vssr_handle {
     int edge_impl = 1;  // 1 = LDS-slice + MFMA edge kernels for chains that fit LDS; 0 forces the gather kernels
                         // (VSSR_EDGE_IMPL=gather: debug knob, also the automatic path for very large chains)
     int max_cfg_atoms = 0;
+    // chains by neighbor-sum path (EDGE_CLASS_*), fixed at upload from every chain's own atom count: class of every chain,
+    // the chain lists of the two matrix-pipe classes (concatenated: FS16 first), counts and largest chain per class
+    vssr::DevBuf d_chain_class, d_class_list;
+    int n_class[3] = {0, 0, 0}, max_class_atoms[3] = {0, 0, 0};
+    int fs16_max_atoms = -1, fs8_max_atoms = -1;   // test knobs (VSSR_EDGE_FS16_MAX / VSSR_EDGE_FS8_MAX): lower the class limits
     int max_images = 0;          // largest number of periodic images any configuration of the batch scans per pair
 
     // configuration
@@ -290,13 +296,14 @@ int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const fl
                    float4 *gbar, long long gbar_stride, int n_groups);
 // LDS-slice + MFMA edge stages (painn_edge_mfma.hip)
 int edge_mfma_init(vssr_handle *h);
-int edge_bwd_groups();
-void launch_edge_bwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int layer_first, int max_atoms,
+enum { EDGE_CLASS_FS16 = 0, EDGE_CLASS_FS8 = 1, EDGE_CLASS_GATHER = 2, EDGE_CLASSES = 3 };
+int edge_class_of(int n_atoms);       // path of a chain by its own atom count
+int edge_class_groups(int cls);       // partial edge-gradient buffers a chain of that class writes per model
+void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
                           float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups);
-bool edge_fwd_mfma_fits(int max_atoms);
-void launch_edge_fwd_mfma(hipStream_t st, int N, int n_cfg, int M, int l, int max_atoms, const ModelW *MW,
+void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int max_atoms, const ModelW *MW,
                           const GraphView &G, const int *counters, int zero_slot, const float *s_in, const float *v_in,
                           const float *phi, float *s_msg, float *v_msg);
 

@@ -623,3 +623,77 @@ def test_precision_envelope_of_the_fp16_split(golden, oracle_mod, what, factor):
     rel_e = abs(float(r["energy"][0]) - o["energy"]) / np.abs(o["energy_models"]).max()
     rel_f = np.abs(r["forces"] - o["forces"]).max() / np.abs(o["forces"]).max()
     assert rel_e <= 1e-6 and rel_f <= 1e-4, (what, factor, rel_e, rel_f)
+
+
+# ---- slice-width classes of the neighbor-sum kernels (no batch-wide cliff at 351 atoms) -------------------
+def _sized_chains(golden):
+    """~260 (16-feature slices), ~370 and ~495 (8-feature slices) and ~735 atoms (gather kernels)."""
+    from surface_sampling_amd import structures
+
+    s60, s80 = golden.structure("SrTiO3_2x2_pristine"), golden.structure("SrTiO3_2x2x4_pristine")
+    return [structures.synth_chain(s60.repeat((2, 2, 1)), 4), structures.synth_chain(s60.repeat((3, 2, 1)), 2, grid=(12, 8)),
+            structures.synth_chain(s80.repeat((3, 2, 1)), 7, grid=(12, 8)), structures.synth_chain(s80.repeat((3, 3, 1)), 5, grid=(12, 12))]
+
+
+def test_mixed_chain_sizes_take_their_own_path(golden, oracle_mod, engine):
+    """One batch with chains of 260 / 370 / 495 / 735 atoms: every chain is served by the kernels its own size selects
+    (16-feature slices up to 350 atoms, 8-feature slices up to 682, gather kernels beyond), within the stated tolerances of
+    the fp64 oracle, and BIT-IDENTICAL to the same chain evaluated alone or in another order -- one large chain no longer
+    sends its whole batch to the slow path."""
+    chains = _sized_chains(golden)
+    sizes = [len(c) for c in chains]
+    assert sizes[0] <= 350 < sizes[1] < sizes[2] <= 682 < sizes[3], sizes
+    res = engine.evaluate([_arrays(c) for c in chains])
+    assert not res["saturated"].any()
+    cs = res["cfg_start"]
+    for b, c in enumerate(chains):
+        ref = _oracle(golden, oracle_mod, c)
+        tol_e = E_TOL if len(c) <= 300 else 4e-4      # (fp32 summation noise grows with |E|: -1.9e3 .. -5.6e3 eV here)
+        assert abs(float(res["energy"][b]) - ref["energy"]) <= tol_e, (b, len(c), float(res["energy"][b]), ref["energy"])
+        assert np.abs(res["forces"][cs[b]:cs[b + 1]] - ref["forces"]).max() <= F_TOL, (b, len(c))
+        assert abs(float(res["energy_std"][b]) - ref["energy_std"]) <= STD_TOL
+        alone = engine.evaluate([_arrays(c)])
+        assert float(alone["energy"][0]) == float(res["energy"][b]), (b, len(c))
+        assert np.array_equal(alone["forces"], res["forces"][cs[b]:cs[b + 1]])
+        assert np.array_equal(alone["forces_std"], res["forces_std"][cs[b]:cs[b + 1]])
+    rev = engine.evaluate([_arrays(c) for c in chains[::-1]])
+    assert np.array_equal(rev["energy"][::-1], res["energy"])
+
+
+def test_eight_feature_slices_match_the_oracle_on_the_small_structures(golden, oracle_mod, monkeypatch):
+    """The 8-feature-slice kernels on inputs every other test sends through the 16-feature ones (VSSR_EDGE_FS16_MAX=0 moves
+    every chain to the next class): reference KAT structure, per-layer intermediates, a ragged batch; results agree with the
+    default path to fp32 rounding (different summation tree inside a slot quad is NOT involved: same order, other slices)."""
+    from surface_sampling_amd import backend, structures
+
+    monkeypatch.setenv("VSSR_EDGE_FS16_MAX", "0")
+    table, const = golden.offset_table()
+    eng8 = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    monkeypatch.delenv("VSSR_EDGE_FS16_MAX")
+    eng16 = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    big = golden.structure("SrTiO3_2x2_pristine").repeat((2, 2, 1))
+    chains = [golden.structure("O44Sr12Ti16"), structures.synth_chain(big, 3), structures.synth_chain(big, 17),
+              structures.synth_chain(golden.structure("SrTiO3_2x2_pristine"), 2, grid=(4, 4))]
+    r8 = eng8.evaluate([_arrays(c) for c in chains])
+    r16 = eng16.evaluate([_arrays(c) for c in chains])
+    cs = r8["cfg_start"]
+    for b, c in enumerate(chains):
+        ref = _oracle(golden, oracle_mod, c)
+        assert abs(float(r8["energy"][b]) - ref["energy"]) <= E_TOL
+        assert np.abs(r8["forces"][cs[b]:cs[b + 1]] - ref["forces"]).max() <= F_TOL
+    assert np.abs(r8["energy"] - r16["energy"]).max() <= 1e-4 and np.abs(r8["forces"] - r16["forces"]).max() <= 2e-5
+    # per-layer activations of the last chain, model 1
+    s = chains[-1]
+    eng8.evaluate([_arrays(s)])
+    _, _, d = oracle_mod.painn(golden.blobs[1], s.numbers, s.positions, s.cell, s.pbc, 64, dump=True)
+    n = len(s)
+    for l in (1, 2):
+        for name, shape in (("s_msg", (n, 128)), ("v_msg", (n, 3, 128))):
+            got = eng8.debug_read(f"{name}{l}", 1).reshape(shape).astype(np.float64)
+            want = d[name][l]
+            assert np.abs(got - want).max() / max(1.0, np.abs(want).max()) < 2e-5, (name, l)
+    # determinism of the new instantiation
+    again = eng8.evaluate([_arrays(c) for c in chains])
+    assert np.array_equal(again["energy"], r8["energy"]) and np.array_equal(again["forces"], r8["forces"])
+    eng8.close()
+    eng16.close()

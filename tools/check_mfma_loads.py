@@ -3,7 +3,10 @@
 ISA.  Rule 1 (files with fences): no load (LDS, global, scratch, flat) may sit between the first MFMA of a step and the
 '; mfma_load_fence' marker that follows it.  Rule 2 (every file): no load inside a dense MFMA block, i.e. between two
 MFMAs that are at most DENSE_GAP instructions apart; a '; gemm16_group_end' marker (painn_node_mfma.hip, pipelined GEMMs)
-closes a block: the fragment loads of the next chunk group legitimately follow it.  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
+closes a block: the fragment loads of the next chunk group legitimately follow it.  Rule 3 (files with fences, i.e. the edge
+kernels): inside a dense block an MFMA never accumulates into the destination of one of the two MFMAs in front of it -- the
+producer of its accumulator is at least three matrix instructions back (dependent MFMAs issued closer stall inside the pipe
+and read their other sources late; profiles/r01/NOTES_mfma_hazards.md).  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
 import os, re, subprocess, sys, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -75,6 +78,26 @@ def check(hip):
             pending.append(i)
         elif last_mfma is not None and instr_idx - last_mfma > DENSE_GAP:
             pending = []
+    # rule 3: accumulator chains of the fenced kernels keep their distance
+    if groups:
+        kernel, recent, last_idx, idx = None, [], None, 0
+        for i, l in enumerate(lines):
+            m = re.match(r"^(_ZN\w+):", l)
+            if m:
+                kernel, recent, last_idx = m.group(1), [], None
+            t = l.strip()
+            if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+                continue
+            idx += 1
+            if t.startswith("v_mfma"):
+                dst = t.split()[1].rstrip(",")
+                if last_idx is not None and idx - last_idx > DENSE_GAP:
+                    recent = []
+                if dst in recent[-2:]:
+                    bad += 1
+                    print(f"VIOLATION in {kernel}: MFMA at line {i} accumulates into {dst}, written {len(recent) - recent.index(dst)} MFMA(s) earlier")
+                recent.append(dst)
+                last_idx = idx
     print(f"{os.path.basename(hip)}: {groups} MFMA groups checked, {dense_blocks} dense MFMA pairs, {bad} violations")
     return bad
 
