@@ -666,7 +666,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
         dq[buf][0] = dp[0]; dq[buf][1] = dp[16];
+#ifdef ABL_NO_GBAR   // ablation build (tools/build_variant.sh): same instruction stream, the partial edge-gradient buffers stay in L2
+        if (!FIRST) gold[buf] = gcomp[(size_t)min((quad_first_slot + e) & 1023, last_slot) * 4];
+#else
         if (!FIRST) gold[buf] = gcomp[(size_t)min(quad_first_slot + e, last_slot) * 4];
+#endif
     };
     {
         bool v0, v1;
@@ -771,7 +775,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 // three rows of a real slot write one component each; every other lane writes the spare entry, so the
                 // store is unconditional and the memory-operation count of a step does not depend on the path
                 const bool real = gcomp_id < 3 && real_slot && invd > 0.f;
+#ifdef ABL_NO_GBAR
+                gcomp[(size_t)(real ? (my_slot & 1023) : zero_slot) * 4] = gsum + gold_cur;
+#else
                 gcomp[(size_t)(real ? my_slot : zero_slot) * 4] = gsum + gold_cur;
+#endif
             }
             ++bw.t;
         }
