@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libvssr_oracle.so")
+# VSSR_ORACLE_LIB: another build of the same library (the AddressSanitizer build of `make -C oracle asan`, tests/test_oracle_asan.py)
+_LIB_PATH = os.environ.get("VSSR_ORACLE_LIB") or os.path.join(_HERE, "libvssr_oracle.so")
 
 EV_TO_KCAL_MOL = 23.0605   # nff/utils/constants.py (confirmed by the KATs)
 HARTREE_TO_EV = 27.2114
@@ -41,7 +42,7 @@ def build(force: bool = False) -> str:
     src = [os.path.join(_HERE, f) for f in ("vssr_oracle.c", "painn_impl.inc", "vssr_oracle.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src if os.path.exists(s))
-    if force or stale:
+    if (force or stale) and not os.environ.get("VSSR_ORACLE_LIB"):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libvssr_oracle.so"])
     return _LIB_PATH
 

@@ -47,7 +47,15 @@ def test_kat_structures_vs_reference_prints_and_oracle(golden, oracle_mod, engin
         assert abs(e - ref["energy"]) <= E_TOL
         free = top_layer(s) if case["free_atoms"] == "top_layer" else np.array(case["free_atoms"])
         fmax = np.linalg.norm(res["forces"][free].astype(np.float64), axis=1).max()
-        assert abs(fmax - case["fmax"]) <= 2e-5, (case["structure"], fmax)  # fp64-positions vs fp32 print
+        assert abs(fmax - case["fmax"]) <= 2e-5, (case["structure"], fmax)  # fp64 positions vs the reference's fp32 run
+        # the reference evaluates fp32 positions (nff AtomsBatch tensors): with the same rounding of the input the print is met
+        # at the tolerance SURVEY.md section 8(c) states
+        s32 = s.copy()
+        s32.positions = s.positions.astype(np.float32).astype(np.float64)
+        r32 = engine.evaluate([_arrays(s32)])
+        fmax32 = np.linalg.norm(r32["forces"][free].astype(np.float64), axis=1).max()
+        print(f"{case['structure']}: |fmax - print| fp64 positions {abs(fmax - case['fmax']):.2e}, fp32 positions {abs(fmax32 - case['fmax']):.2e}")
+        assert abs(fmax32 - case["fmax"]) <= tol["fmax_abs"], (case["structure"], fmax32)
         assert np.abs(res["forces"] - ref["forces"]).max() <= F_TOL
         assert abs(float(res["energy_std"][0]) - ref["energy_std"]) <= STD_TOL
         assert np.abs(res["forces_std"] - ref["forces_std"]).max() <= STD_TOL
