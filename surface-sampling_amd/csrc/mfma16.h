@@ -115,7 +115,11 @@ struct SatTrack {
             const int c = av.atom_cfg[min(a0 + (row & (TA - 1)), N - 1)];
             if (av.chain(c)) atomicOr(av.sat + c, 1u);   // (a switched-off chain is not being evaluated)
         };
-        const int r = threadIdx.x & 15, rho = (threadIdx.x & (NTHREADS - 1)) >> 5;
+        // (cold path.  The thread index is laundered so that the rows are recomputed HERE: otherwise the compiler reuses row
+        // indices of the kernel's prologue and keeps them alive -- in scratch memory -- for this branch alone.)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int r = tid & 15, rho = (tid & (NTHREADS - 1)) >> 5;
         if (acc_lo > LIM) raise(r);
         if (acc_hi > LIM) raise(16 + r);
         if (coop_lo > LIM) raise(rho);

@@ -484,6 +484,9 @@ int painn_alloc_state(vssr_handle *h) {
     sv.sbar_msg = p; p += nS;
     sv.vbar_msg = p; p += nV;
     sv.phibar = p; p += nP;
+    if (h->upd_save && readout_mfma_supported(h->readout_hidden) &&
+        h->d_upd_save.ensure(update_save_bytes((int)N, (int)M) * L))
+        return set_err(h, VSSR_E_NOMEM, "forward intermediates of the update blocks: out of device memory");
     if (h->d_gbar.ensure(sizeof(float4) * M * (size_t)painn_gbar_groups(h) * (size_t)h->slot_cap))
         return set_err(h, VSSR_E_NOMEM, "edge-gradient buffer: out of device memory");
     sv.gbar = h->d_gbar.as<float4>();
@@ -543,6 +546,9 @@ int painn_run(vssr_handle *h, uint32_t want) {
     const int n_groups = painn_gbar_groups(h);   // partial gbar buffers per model
     const int *cls_list[2] = {h->d_class_list.as<int>(), h->d_class_list.as<int>() + h->n_class[EDGE_CLASS_FS16]};
     const int n_gather = h->n_class[EDGE_CLASS_GATHER];
+    // forward intermediates of the update blocks for the reverse pass (fused reverse kernels and forces wanted only)
+    const bool keep = h->upd_save && (want & VSSR_WANT_FORCES) && readout_mfma_supported(H);
+    auto save_of = [&](int l) -> void * { return keep ? (char *)h->d_upd_save.p + update_save_bytes(N, M) * (size_t)l : nullptr; };
     h->l0_used = l0_fact;
 
     if (!l0_fact) {   // s0 = Emb[Z], v0 = 0 (the factorised layer 0 reads the embedding directly)
@@ -558,7 +564,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.end(st);
             P.begin(KC_UPDATE_FWD, st);
             launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1],
-                                   l + 1 < L ? sv.phi[l + 1] : nullptr);
+                                   l + 1 < L ? sv.phi[l + 1] : nullptr, save_of(l));
             P.end(st);
             continue;
         }
@@ -584,7 +590,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
         P.end(st);
         P.begin(KC_UPDATE_FWD, st);
         launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1],
-                               l + 1 < L ? sv.phi[l + 1] : nullptr);
+                               l + 1 < L ? sv.phi[l + 1] : nullptr, save_of(l));
         P.end(st);
     }
     // Readout.  With forces wanted (and the compiled readout width) it runs as the head of the last layer's reverse kernel;
@@ -612,13 +618,13 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.begin(KC_UPDATE_BWD, st);
             if (!fused)
                 launch_update_bwd_mfma(st, N, M, l, 0, (int)(l == L - 1), av, MW, sv.s_msg[l], sv.v_msg[l], sv.sbar, sv.vbar,
-                                       nullptr, nullptr, nullptr, nullptr, sbar_msg_l, sv.vbar_msg);
+                                       nullptr, nullptr, nullptr, nullptr, sbar_msg_l, sv.vbar_msg, nullptr);
             else if (l == L - 1)
                 launch_update_bwd_mfma(st, N, M, l, 1, 1, av, MW, sv.s_msg[l], sv.v_msg[l], nullptr, sv.vbar, sv.s_in[L], nullptr,
-                                       e_excl, sv.e_atom, sbar_msg_l, sv.vbar_msg);
+                                       e_excl, sv.e_atom, sbar_msg_l, sv.vbar_msg, save_of(l));
             else
                 launch_update_bwd_mfma(st, N, M, l, 2, 0, av, MW, sv.s_msg[l], sv.v_msg[l], sbar_msg_up, sv.vbar, sv.s_in[l + 1],
-                                       sv.phibar, nullptr, nullptr, sbar_msg_l, sv.vbar_msg);
+                                       sv.phibar, nullptr, nullptr, sbar_msg_l, sv.vbar_msg, save_of(l));
             P.end(st);
             sv.sbar_msg_l0 = sbar_msg_l;
             P.begin((l == 0 && l0_fact) ? KC_L0_BWD : KC_EDGE_BWD, st);

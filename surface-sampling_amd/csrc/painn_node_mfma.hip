@@ -356,7 +356,7 @@ template <int RT>
 struct UpdRegs {
     f32x4 uv[3 * RT][2];   // [RT x + t][0] = U v_x, [..][1] = V v_x for atom row 16 t + r, columns col0 .. col0 + 3
     f32x4 h3[RT];          // pre-activation of the gate MLP
-    f32x4 gate[RT][3];     // a_vv, a_sv, a_ss
+    f32x4 gate[RT][2];     // a_vv, a_sv (the reverse pass does not need a_ss)
     f32x4 nrm[RT], inner[RT];
 };
 
@@ -411,16 +411,16 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
     PH(PHB + 4)
     __syncthreads();
     PH(PHB + 5)
-    {
+    {   // only the gates the reverse pass reads: a_vv and a_sv (a_ss enters the forward output alone)
         zero_acc(R.gate);
-        const uint4 *wp[3] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F), WTILE(W4, 2 * NW + L.w, F)};
-        f32x4 b4[3];
+        const uint4 *wp[2] = {WTILE(W4, L.w, F), WTILE(W4, NW + L.w, F)};
+        f32x4 b4[2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) b4[c] = gload4f(W.b4 + c * F + L.col0);
+        for (int c = 0; c < 2; ++c) b4[c] = gload4f(W.b4 + c * F + L.col0);
         __builtin_amdgcn_sched_barrier(0);
-        gemm16<F, RT, 3, UPD_PF>(as_, wp, R.gate);
+        gemm16<F, RT, 2, UPD_PF>(as_, wp, R.gate);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < 2; ++c) {
             const f32x4 b = b4[c];
 #pragma unroll
             for (int t = 0; t < RT; ++t) R.gate[t][c] += b;
@@ -460,11 +460,26 @@ static_assert(4 * TA * FT * sizeof(float) <= CF_LDS_HALVES * sizeof(_Float16), "
 // TAIL = 1: the message MLP of the NEXT layer, phi = W2 swish(W1 s_out + b1) + b2 (weights of layer l + 1), runs as the
 // kernel's tail on the scalar output tile while it is still on the chip: its planes are written by the output pass, the
 // separate k_msg_mlp_mfma launch and its read of s disappear.
+// Optional (VSSR_UPD_SAVE=1, off by default): forward intermediates handed to the reverse update kernel instead of being
+// recomputed there -- per model, atom tile and thread UPD_SAVE_REGS f32x4: U v and V v (12), the gate MLP's pre-activation
+// (2), a_vv and a_sv (4).  Measured on MI355X (B = 256, ms / step): the reverse kernel gains 0.24 (2.45 -> 2.21: three GEMMs
+// and two tile loads less, 4.6 KB / atom more to read), the forward kernel loses 0.27 .. 0.30 (1.30 -> 1.57 with the stores
+// where the values are born, 1.60 with all of them at the end): with one workgroup per CU the drain of 147 KB of stores per
+// workgroup is as exposed as the loads they replace.  Bit-identical results either way (tests/test_gpu_parity.py).
+#ifndef UPD_SAVE_LATE
+#define UPD_SAVE_LATE 1
+#endif
+constexpr int UPD_SAVE_UV = 0, UPD_SAVE_H3 = 12, UPD_SAVE_GATE = 14, UPD_SAVE_REGS = 18;
+__device__ __forceinline__ f32x4 &save_slot(f32x4 *save, int m, int k) {
+    return save[(((size_t)m * gridDim.x + blockIdx.x) * UPD_SAVE_REGS + k) * NTHREADS + threadIdx.x];
+}
+size_t update_save_bytes(int N, int M) { return sizeof(f32x4) * (size_t)M * ((N + TA - 1) / TA) * UPD_SAVE_REGS * NTHREADS; }
+
 template <int TAIL>
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
                   const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out,
-                  float *__restrict__ phi_next) {
+                  float *__restrict__ phi_next, f32x4 *__restrict__ save) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
@@ -538,6 +553,7 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 sw = h3[t][0] + b;
+            h3[t][0] = sw;   // pre-activation of the gate MLP, kept for the reverse kernel (save_slot below)
 #pragma unroll
             for (int i = 0; i < 4; ++i) sw[i] = swish(sw[i]);
             store_split4(as_, L.row(t), L.col0, sw, sat);
@@ -569,6 +585,24 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
             for (int t = 0; t < 2; ++t) gate[t][c] += b4[c];
         }
     }
+    // What the reverse update kernel needs from this forward pass, in ACCUMULATOR order (both kernels cut the atoms into the
+    // same tiles and lanes: a coalesced 8 KB store per register and workgroup, read back the same way; 4.6 KB / atom).
+    auto save_all = [&]() {
+        if (!save) return;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) save_slot(save, m, UPD_SAVE_UV + 2 * j + c) = uv[j][c];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            save_slot(save, m, UPD_SAVE_H3 + t) = h3[t][0];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) save_slot(save, m, UPD_SAVE_GATE + 2 * t + c) = gate[t][c];
+        }
+    };
+#if UPD_SAVE_LATE == 0
+    save_all();
+#endif
     PH(7)
     __syncthreads();   // every wave is done with the planes: the region becomes the fp32 output tile
     PH(8)
@@ -645,6 +679,9 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
         }
         PH(11)
     }
+#if UPD_SAVE_LATE
+    save_all();   // behind everything that waits on vmcnt: loads queued behind these stores would wait for them as well
+#endif
     sat.commit(av, a0, N);
 }
 
@@ -737,12 +774,16 @@ k_readout_mfma(int N, ActiveView av, const ModelW *__restrict__ MW, const float 
 //           sbar = sbar_msg(l+1) + W1^T[(W2^T phibar) * swish'(W1 s_in(l+1) + b1)]   (weights of layer l + 1)
 // s_next: MODE 1: final scalar features, MODE 2: s_in(l+1); sbar_src: MODE 0: sbar, MODE 2: sbar_msg(l+1) (a different
 // buffer than the sbar_msg this launch writes).
-template <int MODE, int RT>
+// SAVED: the forward intermediates come from the buffer update_fwd wrote (save_slot) instead of being recomputed from
+// (s_msg, v_msg): no tile loads of s_msg / v_msg, no U / V / W3 / W4 GEMMs here.
+template <int MODE, int RT, bool SAVED = false>
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(RT == 1 ? 4 : 2, RT == 1 ? 4 : 2)))
 k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s_msg,
                   const float *__restrict__ v_msg, const float *__restrict__ sbar_src, const float *__restrict__ vbar,
                   const float *__restrict__ s_next, const float *__restrict__ phibar, const float *__restrict__ e_excl,
-                  float *__restrict__ e_atom, float *__restrict__ sbar_msg, float *__restrict__ vbar_msg) {
+                  float *__restrict__ e_atom, float *__restrict__ sbar_msg, float *__restrict__ vbar_msg,
+                  const f32x4 *__restrict__ save) {
+    static_assert(!SAVED || RT == 2, "the saved layout is that of the 32-atom forward kernel");
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
     constexpr int TA = 16 * RT, OFF_VT = UpdLds<RT>::OFF_VT, OFF_AS = UpdLds<RT>::OFF_AS, UPD_LDS_HALVES = UpdLds<RT>::HALVES;
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
@@ -779,13 +820,28 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
             *reinterpret_cast<float4 *>(VB + row * FT + 4 * c4) = vv[it];
         }
     }
-    load_update_s<RT>(ldsh, s_msg, mN, a0, N, unwatched);
+    UpdRegs<RT> R;
+    auto load_saved = [&]() {   // requested in front of the head, consumed behind it
+        const f32x4 *sv = save + (((size_t)m * gridDim.x + blockIdx.x) * UPD_SAVE_REGS) * NTHREADS + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < 3 * RT; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) R.uv[j][c] = gload4f(reinterpret_cast<const float *>(sv + (size_t)(UPD_SAVE_UV + 2 * j + c) * NTHREADS));
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            R.h3[t] = gload4f(reinterpret_cast<const float *>(sv + (size_t)(UPD_SAVE_H3 + t) * NTHREADS));
+#pragma unroll
+            for (int c = 0; c < 2; ++c) R.gate[t][c] = gload4f(reinterpret_cast<const float *>(sv + (size_t)(UPD_SAVE_GATE + 2 * t + c) * NTHREADS));
+        }
+    };
+    if (!SAVED) load_update_s<RT>(ldsh, s_msg, mN, a0, N, unwatched);
+    else load_saved();
     if (MODE == 0) {
         load_update_v<RT>(ldsh, v_msg, mN, a0, N, unwatched);
         __syncthreads();
     } else if (MODE == 1) {
         // head: readout of s_next (tile in the `as` region; hidden adjoint + reduction scratch in the unused vbar region)
-        load_update_v<RT>(ldsh, v_msg, mN, a0, N, unwatched);
+        if (!SAVED) load_update_v<RT>(ldsh, v_msg, mN, a0, N, unwatched);
         const Planes xs = make_planes(ldsh + OFF_AS, TA, F);
         const Planes hp = make_planes(ldsh + UPD_LDS_HALVES, TA, RH);
         float *red = reinterpret_cast<float *>(ldsh + UPD_LDS_HALVES + plane_halves(TA, RH));
@@ -831,7 +887,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         }
         PH(43)
         __syncthreads();   // everyone is done reading xs and pb
-        load_update_v<RT>(ldsh, v_msg, mN, a0, N, unwatched);   // the v tile takes the place of the phibar tile
+        if (!SAVED) load_update_v<RT>(ldsh, v_msg, mN, a0, N, unwatched);   // the v tile takes the place of the phibar tile
         PH(44)
         {
             const f32x4 b = b1n;
@@ -856,8 +912,21 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         // (the body's first barrier orders the last reads of xs before anything overwrites the `as` region)
     }
     PH(16)
-    UpdRegs<RT> R;
-    update_forward<RT, 16>(W, ldsh, L, R, unwatched);
+    if constexpr (!SAVED) {
+        update_forward<RT, 16>(W, ldsh, L, R, unwatched);
+    } else {
+        // <U v, V v> of the saved products (same operations, same order as update_forward: bit-identical)
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float in = 0.f;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) in = fmaf(R.uv[RT * x + t][0][i], R.uv[RT * x + t][1][i], in);
+                R.inner[t][i] = in;
+            }
+        __syncthreads();   // every wave is done with the head's tiles (the planes below overlay them)
+    }
     PH_RESET
     // Every wave has passed the barrier in front of GEMM3, i.e. finished GEMM1/GEMM2: vt and hs are free.
     const Planes qb = make_planes(ldsh + OFF_VT, TA, F3);    // overlays vt
@@ -1040,6 +1109,10 @@ int node_mfma_init(vssr_handle *h) {
                                     (int)node_mfma_lds_bytes(3)));
     SET_UPD(0) SET_UPD(1) SET_UPD(2)
 #undef SET_UPD
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(3)));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(3)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_readout_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(4)));
     return VSSR_OK;
@@ -1056,14 +1129,16 @@ void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ActiveVi
                        s_in, phibar, sbar_msg, sbar_in);
 }
 // phi_next != nullptr: also phi of layer l + 1 (the fused message MLP; layer l + 1 must exist)
+// save != nullptr: also the intermediates for the reverse kernel (update_save_bytes)
 void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_msg,
-                            const float *v_msg, float *s_out, float *v_out, float *phi_next) {
+                            const float *v_msg, float *s_out, float *v_out, float *phi_next, void *save) {
+    f32x4 *sv = reinterpret_cast<f32x4 *>(save);
     if (phi_next)
         hipLaunchKernelGGL(k_update_fwd_mfma<1>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(6), st, N, l,
-                           av, MW, s_msg, v_msg, s_out, v_out, phi_next);
+                           av, MW, s_msg, v_msg, s_out, v_out, phi_next, sv);
     else
         hipLaunchKernelGGL(k_update_fwd_mfma<0>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(6), st, N, l,
-                           av, MW, s_msg, v_msg, s_out, v_out, phi_next);
+                           av, MW, s_msg, v_msg, s_out, v_out, phi_next, sv);
 }
 void launch_readout_mfma(hipStream_t st, int N, int M, const ActiveView &av, const ModelW *MW, const float *s,
                          const float *e_excl, float *e_atom) {
@@ -1075,14 +1150,17 @@ void launch_readout_mfma(hipStream_t st, int N, int M, const ActiveView &av, con
 void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int vbar_is_zero, const ActiveView &av, const ModelW *MW,
                             const float *s_msg, const float *v_msg, const float *sbar_src, const float *vbar,
                             const float *s_next, const float *phibar, const float *e_excl, float *e_atom,
-                            float *sbar_msg, float *vbar_msg) {
+                            float *sbar_msg, float *vbar_msg, const void *save) {
     const dim3 grid((N + TA - 1) / TA, M), blk(NTHREADS);
     const size_t lds = node_mfma_lds_bytes(3);
+    const f32x4 *sv = reinterpret_cast<const f32x4 *>(save);
     if (mode == 1) vbar_is_zero = 1;
-#define LAUNCH_UPD(MODE)                                                                                                    \
-    hipLaunchKernelGGL((k_update_bwd_mfma<MODE, 2>), grid, blk, lds, st, N, l, vbar_is_zero, av, MW, s_msg, v_msg, sbar_src, vbar, \
-                       s_next, phibar, e_excl, e_atom, sbar_msg, vbar_msg)
-    if (mode == 1) LAUNCH_UPD(1); else if (mode == 2) LAUNCH_UPD(2); else LAUNCH_UPD(0);
+#define LAUNCH_UPD(MODE, SAVED)                                                                                             \
+    hipLaunchKernelGGL((k_update_bwd_mfma<MODE, 2, SAVED>), grid, blk, lds, st, N, l, vbar_is_zero, av, MW, s_msg, v_msg, sbar_src, \
+                       vbar, s_next, phibar, e_excl, e_atom, sbar_msg, vbar_msg, sv)
+    if (mode == 1) { if (sv) LAUNCH_UPD(1, true); else LAUNCH_UPD(1, false); }
+    else if (mode == 2) { if (sv) LAUNCH_UPD(2, true); else LAUNCH_UPD(2, false); }
+    else LAUNCH_UPD(0, false);
 #undef LAUNCH_UPD
 }
 

@@ -235,6 +235,10 @@ struct vssr_handle {
     vssr::DevBuf d_state;        // one arena for all activations
     vssr::StateView sv;
     vssr::DevBuf d_gbar;
+    vssr::DevBuf d_upd_save;     // forward intermediates of every update block for the reverse pass (update_save_bytes per layer)
+    int upd_save = 0;            // VSSR_UPD_SAVE=1: update_fwd stores its intermediates and the reverse kernel loads them instead of
+                                 // recomputing (measured: update_bwd 2.45 -> 2.21, update_fwd 1.30 -> 1.57..1.60 ms / step: no gain;
+                                 // profiles/r03/NOTES_node_kernels.md)
     // results (device)
     vssr::DevBuf d_energy, d_energy_std, d_energy_models, d_forces, d_forces_std, d_e_atoms;
     vssr::DevBuf d_ters_e, d_ters_ea, d_ters_f;  // fp64 Tersoff results
@@ -275,14 +279,15 @@ void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ActiveView &
 void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
                              const float *phibar, const float *sbar_msg, float *sbar_in);
 void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_msg,
-                            const float *v_msg, float *s_out, float *v_out, float *phi_next);
+                            const float *v_msg, float *s_out, float *v_out, float *phi_next, void *save);
+size_t update_save_bytes(int N, int M);   // per layer: forward intermediates of the update block kept for its reverse
 bool readout_mfma_supported(int hidden);
 void launch_readout_mfma(hipStream_t st, int N, int M, const ActiveView &av, const ModelW *MW, const float *s, const float *e_excl,
                          float *e_atom);
 void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int vbar_is_zero, const ActiveView &av, const ModelW *MW,
                             const float *s_msg, const float *v_msg, const float *sbar_src, const float *vbar,
                             const float *s_next, const float *phibar, const float *e_excl, float *e_atom,
-                            float *sbar_msg, float *vbar_msg);
+                            float *sbar_msg, float *vbar_msg, const void *save);
 // layer-0 species factorisation (painn_l0.hip)
 void pack_mfma_tiles16(const float *Wsrc, int rows, int K, unsigned *dst /*[rows/32][K/16][2][64][4]*/);
 void build_wd16(const float *Wd, const float *bd, unsigned *dst /*[3F][4][2][4]*/);

@@ -705,3 +705,24 @@ def test_eight_feature_slices_match_the_oracle_on_the_small_structures(golden, o
     assert np.array_equal(again["energy"], r8["energy"]) and np.array_equal(again["forces"], r8["forces"])
     eng8.close()
     eng16.close()
+
+
+def test_stored_forward_intermediates_give_identical_results(golden, monkeypatch):
+    """VSSR_UPD_SAVE=1: update_fwd stores U v, V v, the gate pre-activation and the gates; the reverse update kernel loads
+    them instead of recomputing three GEMMs.  Same numbers, bit for bit, as the default (recompute) path."""
+    from surface_sampling_amd import backend, structures
+
+    table, const = golden.offset_table()
+    big = golden.structure("SrTiO3_2x2_pristine").repeat((2, 2, 1))
+    chains = [_arrays(structures.synth_chain(big, c)) for c in (1, 9, 20)] + [_arrays(golden.structure("O40Sr16Ti12"))]
+    monkeypatch.setenv("VSSR_UPD_SAVE", "1")
+    e1 = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    monkeypatch.setenv("VSSR_UPD_SAVE", "0")
+    e0 = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    r1, r0 = e1.evaluate(chains), e0.evaluate(chains)
+    for k in ("energy", "forces", "energy_std", "forces_std", "energy_models"):
+        assert np.array_equal(r1[k], r0[k]), k
+    e_only = e1.evaluate(chains, want=backend.WANT_ENERGY)          # energy-only runs store nothing
+    assert np.array_equal(e_only["energy"], r0["energy"])
+    e1.close()
+    e0.close()
