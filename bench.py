@@ -110,7 +110,7 @@ def executed_mfma_flops(which, n_slots, n_models):
 def measured_traffic(kernel):
     """HBM bytes per launch from committed PMC passes (profiles/: FETCH_SIZE, WRITE_SIZE in KB, separate passes;
     FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM for 16-B/lane streams).  None when no profile is committed."""
-    for rel in (("profiles", "r02", "pmc_traffic_edge_kernels.json"), ("profiles", "r01", "pmc_traffic_edge_kernels_v10.json")):
+    for rel in (("profiles", "r03", "pmc_traffic_edge_kernels.json"), ("profiles", "r02", "pmc_traffic_edge_kernels.json")):
         path = os.path.join(ROOT, *rel)
         if not os.path.exists(path):
             continue
@@ -359,9 +359,10 @@ def main():
                          "binding_resource": "SIMD instruction issue: per 16-slot step ~130 vector + 20 matrix instructions whose "
                                              "issue times add up (130 x 4 + 20 x 17 cycles + LDS/VMEM/SALU = the measured ~1010 "
                                              "cycles; interleaving them across steps did not overlap them: "
-                                             "profiles/r02/NOTES_node_kernels.md); PMC of this build: matrix pipe 34 % + vector issue 38 % of the SIMD cycles, which do not overlap "
-                                             "for this MFMA shape (profiles/r02/pmc_sq_heavy_kernels.txt, micro_mfma_interleave.txt); TA 85-93 % busy "
-                                             "(profiles/r01/pmc_ta_all_kernels_v9.txt)",
+                                             "profiles/r02/NOTES_node_kernels.md); PMC: matrix pipe 34 % + vector issue 38 % of the SIMD cycles, which do not overlap "
+                                             "for this MFMA shape (profiles/r02/pmc_sq_heavy_kernels.txt, micro_mfma_interleave.txt); TA 87-93 % busy "
+                                             "on this build (profiles/r03/pmc_ta_all_kernels.txt); removing ALL partial-gradient HBM traffic buys "
+                                             "5.7 % (profiles/r03/NOTES_edge_traffic.md)",
                          "second_kernel": {"kernel": "edge_message_fwd (neighbor-sum, k_edge_fwd_mfma)",
                                            "avg_launch_ms": fwd_ms, "launches": fwd_n,
                                            "algorithmic_flops_per_launch": fwd_flops,

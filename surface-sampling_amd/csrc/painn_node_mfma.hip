@@ -465,7 +465,7 @@ static_assert(4 * TA * FT * sizeof(float) <= CF_LDS_HALVES * sizeof(_Float16), "
 // (2), a_vv and a_sv (4).  Measured on MI355X (B = 256, ms / step): the reverse kernel gains 0.24 (2.45 -> 2.21: three GEMMs
 // and two tile loads less, 4.6 KB / atom more to read), the forward kernel loses 0.27 .. 0.30 (1.30 -> 1.57 with the stores
 // where the values are born, 1.60 with all of them at the end): with one workgroup per CU the drain of 147 KB of stores per
-// workgroup is as exposed as the loads they replace.  Bit-identical results either way (tests/test_gpu_parity.py).
+// workgroup is as exposed as the loads they replace.  Energies bit-identical, forces to fp32 rounding (tests/test_gpu_parity.py).
 #ifndef UPD_SAVE_LATE
 #define UPD_SAVE_LATE 1
 #endif

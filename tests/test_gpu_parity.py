@@ -709,7 +709,9 @@ def test_eight_feature_slices_match_the_oracle_on_the_small_structures(golden, o
 
 def test_stored_forward_intermediates_give_identical_results(golden, monkeypatch):
     """VSSR_UPD_SAVE=1: update_fwd stores U v, V v, the gate pre-activation and the gates; the reverse update kernel loads
-    them instead of recomputing three GEMMs.  Same numbers, bit for bit, as the default (recompute) path."""
+    them instead of recomputing three GEMMs.  Energies are bit-identical (the forward pass is untouched); forces agree to fp32
+    rounding -- the recomputing reverse kernel sums the gate MLP's first layer in one K = 256 pass, the forward kernel in two
+    K = 128 halves, so the two paths differentiate forward values that differ in the last bit."""
     from surface_sampling_amd import backend, structures
 
     table, const = golden.offset_table()
@@ -720,8 +722,9 @@ def test_stored_forward_intermediates_give_identical_results(golden, monkeypatch
     monkeypatch.setenv("VSSR_UPD_SAVE", "0")
     e0 = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
     r1, r0 = e1.evaluate(chains), e0.evaluate(chains)
-    for k in ("energy", "forces", "energy_std", "forces_std", "energy_models"):
+    for k in ("energy", "energy_std", "energy_models"):
         assert np.array_equal(r1[k], r0[k]), k
+    assert np.abs(r1["forces"] - r0["forces"]).max() <= 5e-6 and np.abs(r1["forces_std"] - r0["forces_std"]).max() <= 5e-6
     e_only = e1.evaluate(chains, want=backend.WANT_ENERGY)          # energy-only runs store nothing
     assert np.array_equal(e_only["energy"], r0["energy"])
     e1.close()
