@@ -337,6 +337,22 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
 // Partial edge gradients of the feature slices (one buffer per workgroup group) -> one buffer per model (group 0, in place): a streaming,
 // coalesced pass in fixed group order, so that the gather through `rev` below touches one buffer per model only.  A chain's
 // slots carry as many partial buffers as its class has slices (grid.y = chain).
+// (every chain of the batch in one class -- the usual case: one thread per slot of the whole batch)
+__global__ void k_reduce_gbar_groups_uniform(int M, int n_groups, const int *__restrict__ counters, float4 *__restrict__ gbar,
+                                             long long gbar_stride) {
+    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (counters[2] || slot >= counters[0]) return;
+    for (int m = 0; m < M; ++m) {
+        float4 *g0 = gbar + (size_t)(m * n_groups) * gbar_stride + slot;
+        float4 acc = *g0;
+        for (int grp = 1; grp < n_groups; ++grp) {
+            const float4 v = g0[(size_t)grp * gbar_stride];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z;
+        }
+        *g0 = acc;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_reduce_gbar_groups(int M, int n_groups, GraphView G, const int *__restrict__ counters, float4 *__restrict__ gbar,
                      long long gbar_stride) {
@@ -659,9 +675,16 @@ int painn_run(vssr_handle *h, uint32_t want) {
     }
     P.begin(KC_FINALIZE, st);
     if (want & VSSR_WANT_FORCES) {
-        if (n_groups > 1)
-            hipLaunchKernelGGL(k_reduce_gbar_groups, dim3(12, h->n_cfg), dim3(256), 0, st, M, n_groups, G, counters, sv.gbar,
-                               (long long)h->slot_cap);
+        if (n_groups > 1) {
+            const int cls_only = h->n_class[EDGE_CLASS_FS16] == h->n_cfg ? EDGE_CLASS_FS16
+                                 : h->n_class[EDGE_CLASS_FS8] == h->n_cfg ? EDGE_CLASS_FS8 : -1;
+            if (cls_only >= 0 && !h->active_mask)   // (switched-off chains keep their reduced gradients: the per-chain form skips them)
+                hipLaunchKernelGGL(k_reduce_gbar_groups_uniform, dim3((unsigned)((h->slot_cap + 255) / 256)), dim3(256), 0, st, M,
+                                   n_groups, counters, sv.gbar, (long long)h->slot_cap);
+            else
+                hipLaunchKernelGGL(k_reduce_gbar_groups, dim3(12, h->n_cfg), dim3(256), 0, st, M, n_groups, G, counters, sv.gbar,
+                                   (long long)h->slot_cap);
+        }
         hipLaunchKernelGGL(k_finalize_forces, dim3((N + 3) / 4), dim3(256), 0, st, N, M, G, counters, sv.gbar,
                            (long long)h->slot_cap * n_groups, h->units_per_ev, h->d_forces.as<float>(),
                            h->d_forces_std.as<float>());
