@@ -175,10 +175,14 @@ struct EdgeGeo {
 template <int NF> __device__ __forceinline__ constexpr int sec_tile(int sec) { return NF == 4 ? sec : sec >> 1; }
 template <int NF> __device__ __forceinline__ constexpr int sec_reg(int sec, int r) { return NF == 4 ? r : 2 * (sec & 1) + r; }
 
-// LDS carve-up: tile [max_atoms][ROW] | s slice [max_atoms][FS] | row_start [max_atoms + 1] (ints)
-template <int NF>
+// LDS carve-up: tile [max_atoms][ROW] | SLDS: s slice [max_atoms][FS].  The scalar residual of a centre (its own s slice, which
+// no gather ever touches) either sits in LDS next to the tile (SLDS = true: 468 B per atom with 16-feature slices, <= 350
+// atoms; the fastest form: 2.09 vs 2.15 ms / step on the 260-atom workload) or is requested from memory when the wave
+// switches to the centre's bundle, one bundle ahead of its use (SLDS = false: 404 B per atom, <= 405 atoms -- 3 x 2 slabs with
+// adsorbates stay on the 16-feature kernels: 18.8 instead of 22.6 ms / step at 368 .. 392 atoms; 8-feature slices: 208 B, <= 787).
+template <int NF, bool SLDS>
 size_t edge_fwd_lds_bytes_t(int max_atoms) {
-    return sizeof(float) * ((size_t)max_atoms * (EdgeGeo<NF>::ROW + EdgeGeo<NF>::FS) + max_atoms + 4);
+    return sizeof(float) * ((size_t)max_atoms * (EdgeGeo<NF>::ROW + (SLDS ? EdgeGeo<NF>::FS : 0)) + 4);
 }
 
 // sum over the 4 lanes of a quad (lanes 4q..4q+3), result in every lane: two DPP quad_perm adds
@@ -298,7 +302,7 @@ __device__ __forceinline__ int chain_of_workgroup(const GraphView &G, const int 
     return G.act.chain(b) ? b : -1;
 }
 
-template <int NF>
+template <int NF, bool SLDS>
 __global__ void __launch_bounds__(EDGE_THREADS)
 k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *__restrict__ counters,
                 int zero_slot, int n_models, int max_atoms, const int *__restrict__ list, int n_list,
@@ -316,13 +320,13 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const size_t mN = (size_t)m * N;
     const int tid = threadIdx.x;
 
-    // ---- stage the chain's feature slice: tile[atom][f][seg], s slice, row_start ------------------------------
-    // (NSEG + 1) * FS / 4 float4 per atom; loads are issued in batches of 4 per thread before any LDS store so that
+    // ---- stage the chain's feature slice: tile[atom][f][seg] ---------------------------------------------------------
+    // NSEG * FS / 4 float4 per atom; loads are issued in batches of 4 per thread before any LDS store so that
     // the L2 / HBM round trips overlap (one workgroup per CU: nothing else hides them)
-    float *s_tile = tile + (size_t)max_atoms * LY::ROW;                      // [atom][FS]
+    float *s_tile = tile + (size_t)max_atoms * LY::ROW;                      // [atom][FS] (SLDS only)
     {
         constexpr int Q4 = FS / 4;                          // float4 per slice segment
-        constexpr int PER_ATOM = (LY::NSEG + 1) * Q4;       // float4 per atom: NSEG slice segments + the s slice
+        constexpr int PER_ATOM = (LY::NSEG + (SLDS ? 1 : 0)) * Q4;   // float4 per atom
         const int total = Nc * PER_ATOM;
         auto src_of = [&](int idx) -> const float * {
             int atom = idx / PER_ATOM, rem = idx - atom * PER_ATOM, seg = rem / Q4, q4 = rem % Q4;
@@ -376,6 +380,14 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 #pragma unroll
     for (int r = 0; r < NF; ++r) { ds[r] = 0.f; dvx[r] = 0.f; dvy[r] = 0.f; dvz[r] = 0.f; }
     const int fcol = fs * FS + NF * fq;            // first of this lane's NF global feature columns
+    // scalar residual of this stream's centre: requested when the wave switches to a bundle (for the bundle after it), used
+    // when that bundle completes -- always a load (clamped row for streams without a centre), like the bundle entries
+    typedef float fres __attribute__((ext_vector_type(NF)));
+    fres sres_cur, sres_nxt;
+    auto load_residual = [&](int cc) {
+        return *reinterpret_cast<const fres *>(s_in + (mN + a0 + min(max(cc, 0), Nc - 1)) * F + fcol);
+    };
+    if (!SLDS) { sres_cur = load_residual(bw.cur.x); sres_nxt = load_residual(bw.nxt.x); }
 
     // quad-interleaved table (nbr.hip f16_unit): unit = quad * 32 + piece * 16 + fq * 4 + e -> the 4 slot lanes of a quad read
     // 64 contiguous bytes; exhausted streams read the reserved all-zero quad (filter = 0)
@@ -410,7 +422,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             const float *vc = tile + c * LY::ROW + (NF * fq) * LY::NSEG;
 #pragma unroll
             for (int r = 0; r < NF; ++r) {
-                so[r] = ds[r] + sr[r];
+                so[r] = ds[r] + (SLDS ? sr[r] : sres_cur[r]);
                 xo[r] = dvx[r] + vc[r * LY::NSEG + 3];
                 yo[r] = dvy[r] + vc[r * LY::NSEG + 4];
                 zo[r] = dvz[r] + vc[r * LY::NSEG + 5];
@@ -433,6 +445,11 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
                 flush_bundle();
                 bw.advance();
+                if (!SLDS) {
+                    sres_cur = sres_nxt;
+                    __builtin_amdgcn_sched_barrier(0);   // the old value leaves its registers before the load that refills them
+                    sres_nxt = load_residual(bw.nxt.x);
+                }
             }
             // gather this slot's neighbor row: NF features x NSEG values, contiguous in LDS
             float tv[NF * LY::NSEG];
@@ -788,7 +805,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 
 int edge_mfma_init(vssr_handle *h) {
 #define SET_LDS(K) VSSR_HIP(h, hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-    SET_LDS(k_edge_fwd_mfma<4>); SET_LDS(k_edge_fwd_mfma<2>);
+    SET_LDS((k_edge_fwd_mfma<4, true>)); SET_LDS((k_edge_fwd_mfma<4, false>)); SET_LDS((k_edge_fwd_mfma<2, false>));
     SET_LDS((k_edge_bwd_mfma<4, true>)); SET_LDS((k_edge_bwd_mfma<4, false>));
     SET_LDS((k_edge_bwd_mfma<2, true>)); SET_LDS((k_edge_bwd_mfma<2, false>));
 #undef SET_LDS
@@ -798,13 +815,16 @@ int edge_mfma_init(vssr_handle *h) {
 // Slice-width class of a chain by its atom count (EDGE_CLASS_*): the widest slice whose forward LDS tile holds the chain
 // (the reverse tile is smaller).  nf = features per lane of the class (4 / 2).
 int edge_class_of(int n_atoms) {
-    if (edge_fwd_lds_bytes_t<4>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS16;
-    if (edge_fwd_lds_bytes_t<2>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS8;
+    if (edge_fwd_lds_bytes_t<4, true>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS16;
+    if (edge_fwd_lds_bytes_t<4, false>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS16M;
+    if (edge_fwd_lds_bytes_t<2, false>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS8;
     return EDGE_CLASS_GATHER;
 }
-int edge_class_groups(int cls) { return cls == EDGE_CLASS_FS16 ? EdgeGeo<4>::NSLICE : cls == EDGE_CLASS_FS8 ? EdgeGeo<2>::NSLICE : 1; }
+int edge_class_groups(int cls) {
+    return cls == EDGE_CLASS_FS16 || cls == EDGE_CLASS_FS16M ? EdgeGeo<4>::NSLICE : cls == EDGE_CLASS_FS8 ? EdgeGeo<2>::NSLICE : 1;
+}
 
-// layers >= 1 only (layer 0: painn_l0.hip or the gather kernels, see painn_run).  cls: EDGE_CLASS_FS16 / _FS8; list / n_list:
+// layers >= 1 only (layer 0: painn_l0.hip or the gather kernels, see painn_run).  cls: EDGE_CLASS_FS16 / _FS16M / _FS8; list / n_list:
 // the chains of that class; max_atoms: the largest of them.
 void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
@@ -815,8 +835,8 @@ void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
     hipLaunchKernelGGL((k_edge_bwd_mfma<NF, FIRST>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), dim3(bwd_threads<NF>()), \
                        edge_bwd_lds_bytes_t<NF>(max_atoms), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list,     \
                        v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups)
-    if (cls == EDGE_CLASS_FS16) { if (layer_first) LAUNCH_BWD(4, true); else LAUNCH_BWD(4, false); }
-    else { if (layer_first) LAUNCH_BWD(2, true); else LAUNCH_BWD(2, false); }
+    if (cls == EDGE_CLASS_FS8) { if (layer_first) LAUNCH_BWD(2, true); else LAUNCH_BWD(2, false); }
+    else { if (layer_first) LAUNCH_BWD(4, true); else LAUNCH_BWD(4, false); }
 #undef LAUNCH_BWD
 }
 
@@ -825,12 +845,14 @@ void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
                           const float *phi, float *s_msg, float *v_msg) {
     if (n_list <= 0) return;
     const dim3 blk(EDGE_THREADS);
-    if (cls == EDGE_CLASS_FS16)
-        hipLaunchKernelGGL(k_edge_fwd_mfma<4>, dim3(((n_list + 7) / 8) * 8 * EdgeGeo<4>::NSLICE * M), blk, edge_fwd_lds_bytes_t<4>(max_atoms),
-                           st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, s_in, v_in, phi, s_msg, v_msg);
-    else
-        hipLaunchKernelGGL(k_edge_fwd_mfma<2>, dim3(((n_list + 7) / 8) * 8 * EdgeGeo<2>::NSLICE * M), blk, edge_fwd_lds_bytes_t<2>(max_atoms),
-                           st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, s_in, v_in, phi, s_msg, v_msg);
+#define LAUNCH_FWD(NF, SLDS)                                                                                                       \
+    hipLaunchKernelGGL((k_edge_fwd_mfma<NF, SLDS>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), blk,                    \
+                       (edge_fwd_lds_bytes_t<NF, SLDS>(max_atoms)), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, \
+                       s_in, v_in, phi, s_msg, v_msg)
+    if (cls == EDGE_CLASS_FS16) LAUNCH_FWD(4, true);
+    else if (cls == EDGE_CLASS_FS16M) LAUNCH_FWD(4, false);
+    else LAUNCH_FWD(2, false);
+#undef LAUNCH_FWD
 }
 
 }  // namespace vssr

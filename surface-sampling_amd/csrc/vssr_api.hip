@@ -539,19 +539,19 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
         // sort stages in LDS has no bundle tables at all: every chain gathers.)
         const bool bundles = (size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024;
         std::vector<unsigned char> cls(n_cfg);
-        std::vector<int> lists[2];
+        std::vector<int> lists[EDGE_MFMA_CLASSES];
         for (int c = 0; c < EDGE_CLASSES; ++c) { h->n_class[c] = 0; h->max_class_atoms[c] = 0; }
         for (int b = 0; b < n_cfg; ++b) {
             int c = (h->edge_impl && bundles) ? edge_class_of(n_atoms[b]) : EDGE_CLASS_GATHER;
-            if (c == EDGE_CLASS_FS16 && h->fs16_max_atoms >= 0 && n_atoms[b] > h->fs16_max_atoms) c = EDGE_CLASS_FS8;
+            if (c <= EDGE_CLASS_FS16M && h->fs16_max_atoms >= 0 && n_atoms[b] > h->fs16_max_atoms) c = EDGE_CLASS_FS8;
             if (c == EDGE_CLASS_FS8 && h->fs8_max_atoms >= 0 && n_atoms[b] > h->fs8_max_atoms) c = EDGE_CLASS_GATHER;
             cls[b] = (unsigned char)c;
             h->n_class[c] += 1;
             if (n_atoms[b] > h->max_class_atoms[c]) h->max_class_atoms[c] = n_atoms[b];
             if (c != EDGE_CLASS_GATHER) lists[c].push_back(b);
         }
-        std::vector<int> cat(lists[0]);
-        cat.insert(cat.end(), lists[1].begin(), lists[1].end());
+        std::vector<int> cat;
+        for (int c = 0; c < EDGE_MFMA_CLASSES; ++c) cat.insert(cat.end(), lists[c].begin(), lists[c].end());
         cat.push_back(0);
         if (h->d_chain_class.ensure((size_t)n_cfg) || h->d_class_list.ensure(sizeof(int) * cat.size()))
             return set_err(h, VSSR_E_NOMEM, "chain class tables");

@@ -173,9 +173,9 @@ struct vssr_handle {
                         // (VSSR_EDGE_IMPL=gather: debug knob, also the automatic path for very large chains)
     int max_cfg_atoms = 0;
     // chains by neighbor-sum path (EDGE_CLASS_*), fixed at upload from every chain's own atom count: class of every chain,
-    // the chain lists of the two matrix-pipe classes (concatenated: FS16 first), counts and largest chain per class
+    // the chain lists of the matrix-pipe classes (concatenated in class order), counts and largest chain per class
     vssr::DevBuf d_chain_class, d_class_list;
-    int n_class[3] = {0, 0, 0}, max_class_atoms[3] = {0, 0, 0};
+    int n_class[4] = {0, 0, 0, 0}, max_class_atoms[4] = {0, 0, 0, 0};
     int fs16_max_atoms = -1, fs8_max_atoms = -1;   // test knobs (VSSR_EDGE_FS16_MAX / VSSR_EDGE_FS8_MAX): lower the class limits
     int max_images = 0;          // largest number of periodic images any configuration of the batch scans per pair
 
@@ -301,7 +301,8 @@ int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const fl
                    float4 *gbar, long long gbar_stride, int n_groups);
 // LDS-slice + MFMA edge stages (painn_edge_mfma.hip)
 int edge_mfma_init(vssr_handle *h);
-enum { EDGE_CLASS_FS16 = 0, EDGE_CLASS_FS8 = 1, EDGE_CLASS_GATHER = 2, EDGE_CLASSES = 3 };
+// neighbor-sum paths: 16-feature slices with / without the scalar residual in LDS, 8-feature slices, gather kernels
+enum { EDGE_CLASS_FS16 = 0, EDGE_CLASS_FS16M = 1, EDGE_CLASS_FS8 = 2, EDGE_CLASS_GATHER = 3, EDGE_CLASSES = 4, EDGE_MFMA_CLASSES = 3 };
 int edge_class_of(int n_atoms);       // path of a chain by its own atom count
 int edge_class_groups(int cls);       // partial edge-gradient buffers a chain of that class writes per model
 void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,

@@ -635,28 +635,30 @@ def test_precision_envelope_of_the_fp16_split(golden, oracle_mod, what, factor):
 
 # ---- slice-width classes of the neighbor-sum kernels (no batch-wide cliff at 351 atoms) -------------------
 def _sized_chains(golden):
-    """~260 (16-feature slices), ~370 and ~495 (8-feature slices) and ~735 atoms (gather kernels)."""
+    """~260 (16-feature slices, residual in LDS), ~370 (16-feature slices, residual from memory), ~495 and ~735 (8-feature
+    slices) and ~975 atoms (gather kernels)."""
     from surface_sampling_amd import structures
 
     s60, s80 = golden.structure("SrTiO3_2x2_pristine"), golden.structure("SrTiO3_2x2x4_pristine")
     return [structures.synth_chain(s60.repeat((2, 2, 1)), 4), structures.synth_chain(s60.repeat((3, 2, 1)), 2, grid=(12, 8)),
-            structures.synth_chain(s80.repeat((3, 2, 1)), 7, grid=(12, 8)), structures.synth_chain(s80.repeat((3, 3, 1)), 5, grid=(12, 12))]
+            structures.synth_chain(s80.repeat((3, 2, 1)), 7, grid=(12, 8)), structures.synth_chain(s80.repeat((3, 3, 1)), 5, grid=(12, 12)),
+            structures.synth_chain(s80.repeat((4, 3, 1)), 6, grid=(16, 12))]
 
 
 def test_mixed_chain_sizes_take_their_own_path(golden, oracle_mod, engine):
-    """One batch with chains of 260 / 370 / 495 / 735 atoms: every chain is served by the kernels its own size selects
-    (16-feature slices up to 350 atoms, 8-feature slices up to 682, gather kernels beyond), within the stated tolerances of
-    the fp64 oracle, and BIT-IDENTICAL to the same chain evaluated alone or in another order -- one large chain no longer
-    sends its whole batch to the slow path."""
+    """One batch with chains of 260 / 370 / 495 / 735 / 975 atoms: every chain is served by the kernels its own size selects
+    (16-feature slices up to 350 atoms, the same with the scalar residual read from memory up to 405, 8-feature slices up to
+    787, gather kernels beyond), within the stated tolerances of the fp64 oracle, and BIT-IDENTICAL to the same chain evaluated
+    alone or in another order -- one large chain no longer sends its whole batch to the slow path."""
     chains = _sized_chains(golden)
     sizes = [len(c) for c in chains]
-    assert sizes[0] <= 350 < sizes[1] < sizes[2] <= 682 < sizes[3], sizes
+    assert sizes[0] <= 350 < sizes[1] <= 405 < sizes[2] < sizes[3] <= 787 < sizes[4], sizes
     res = engine.evaluate([_arrays(c) for c in chains])
     assert not res["saturated"].any()
     cs = res["cfg_start"]
     for b, c in enumerate(chains):
         ref = _oracle(golden, oracle_mod, c)
-        tol_e = E_TOL if len(c) <= 300 else 4e-4      # (fp32 summation noise grows with |E|: -1.9e3 .. -5.6e3 eV here)
+        tol_e = E_TOL if len(c) <= 300 else 4e-4 if len(c) <= 800 else 6e-4   # (fp32 summation noise grows with |E|: -1.9e3 .. -7.5e3 eV here)
         assert abs(float(res["energy"][b]) - ref["energy"]) <= tol_e, (b, len(c), float(res["energy"][b]), ref["energy"])
         assert np.abs(res["forces"][cs[b]:cs[b + 1]] - ref["forces"]).max() <= F_TOL, (b, len(c))
         assert abs(float(res["energy_std"][b]) - ref["energy_std"]) <= STD_TOL
