@@ -360,7 +360,7 @@ k_reduce_gbar_groups(int M, int n_groups, GraphView G, const int *__restrict__ c
     const int b = blockIdx.y;
     if (!G.act.chain(b)) return;
     const int cls = G.chain_class[b];
-    const int ng = cls <= EDGE_CLASS_FS16M ? 8 : cls == EDGE_CLASS_FS8 ? 16 : 1;   // buffers the chain's kernels wrote (edge_class_groups)
+    const int ng = cls == EDGE_BCLASS_FS16 ? 8 : cls == EDGE_BCLASS_FS8 ? 16 : 1;   // buffers the chain's reverse kernels wrote (edge_class_groups)
     if (ng == 1) return;
     const int s0 = G.row_start[G.cfg_start[b]], s1 = G.row_start[G.cfg_start[b + 1]];
     for (int slot = s0 + blockIdx.x * blockDim.x + threadIdx.x; slot < s1; slot += gridDim.x * blockDim.x)
@@ -473,8 +473,8 @@ k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const 
 // partial edge-gradient buffers per model: as many as the widest class present writes (one without the reverse edge kernels)
 int painn_gbar_groups(const vssr_handle *h) {
     if (h->num_conv < 2) return 1;
-    return h->n_class[EDGE_CLASS_FS8] ? edge_class_groups(EDGE_CLASS_FS8)
-                                      : h->n_class[EDGE_CLASS_FS16] + h->n_class[EDGE_CLASS_FS16M] ? edge_class_groups(EDGE_CLASS_FS16) : 1;
+    return h->n_bclass[EDGE_BCLASS_FS8] ? edge_class_groups(EDGE_BCLASS_FS8)
+                                        : h->n_bclass[EDGE_BCLASS_FS16] ? edge_class_groups(EDGE_BCLASS_FS16) : 1;
 }
 
 int painn_alloc_state(vssr_handle *h) {
@@ -561,7 +561,12 @@ int painn_run(vssr_handle *h, uint32_t want) {
     // gather kernels for every chain (its v input is zero and only two filter sections matter).
     const int n_groups = painn_gbar_groups(h);   // partial gbar buffers per model
     const int *cls_list[EDGE_MFMA_CLASSES];
-    for (int c = 0, o = 0; c < EDGE_MFMA_CLASSES; o += h->n_class[c], ++c) cls_list[c] = h->d_class_list.as<int>() + o;
+    const int *bcls_list[2];
+    {
+        int o = 0;
+        for (int c = 0; c < EDGE_MFMA_CLASSES; o += h->n_class[c], ++c) cls_list[c] = h->d_class_list.as<int>() + o;
+        for (int c = 0; c < 2; o += h->n_bclass[c], ++c) bcls_list[c] = h->d_class_list.as<int>() + o;
+    }
     const int n_gather = h->n_class[EDGE_CLASS_GATHER];
     // forward intermediates of the update blocks for the reverse pass (fused reverse kernels and forces wanted only)
     const bool keep = h->upd_save && (want & VSSR_WANT_FORCES) && readout_mfma_supported(H);
@@ -602,7 +607,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
             if (n_gather)
                 hipLaunchKernelGGL(k_edge_fwd<false>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
                                    h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
-                                   sv.v_msg[l], (int)EDGE_CLASS_GATHER);
+                                   sv.v_msg[l], (int)EDGE_BCLASS_GATHER);
         }
         P.end(st);
         P.begin(KC_UPDATE_FWD, st);
@@ -656,15 +661,15 @@ int painn_run(vssr_handle *h, uint32_t want) {
                                    sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
                                    (long long)h->slot_cap * n_groups, -1);
             else {
-                for (int cls = 0; cls < EDGE_MFMA_CLASSES; ++cls)
-                    launch_edge_bwd_mfma(st, cls, N, cls_list[cls], h->n_class[cls], M, l, (int)(l == L - 1), h->max_class_atoms[cls],
+                for (int cls = 0; cls < 2; ++cls)
+                    launch_edge_bwd_mfma(st, cls, N, bcls_list[cls], h->n_bclass[cls], M, l, (int)(l == L - 1), h->max_bclass_atoms[cls],
                                          MW, G, counters, (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l], sbar_msg_l,
                                          sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap, n_groups);
                 if (n_gather)   // partial buffer 0 of every model
                     hipLaunchKernelGGL(k_edge_bwd<false>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                        h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
                                        sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
-                                       (long long)h->slot_cap * n_groups, (int)EDGE_CLASS_GATHER);
+                                       (long long)h->slot_cap * n_groups, (int)EDGE_BCLASS_GATHER);
             }
             P.end(st);
             if (l > 0 && !fused) {
@@ -677,8 +682,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     P.begin(KC_FINALIZE, st);
     if (want & VSSR_WANT_FORCES) {
         if (n_groups > 1) {
-            const int cls_only = h->n_class[EDGE_CLASS_FS16] + h->n_class[EDGE_CLASS_FS16M] == h->n_cfg ? EDGE_CLASS_FS16
-                                 : h->n_class[EDGE_CLASS_FS8] == h->n_cfg ? EDGE_CLASS_FS8 : -1;
+            const int cls_only = h->n_bclass[EDGE_BCLASS_FS16] == h->n_cfg ? EDGE_BCLASS_FS16
+                                 : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? EDGE_BCLASS_FS8 : -1;
             if (cls_only >= 0 && !h->active_mask)   // (switched-off chains keep their reduced gradients: the per-chain form skips them)
                 hipLaunchKernelGGL(k_reduce_gbar_groups_uniform, dim3((unsigned)((h->slot_cap + 255) / 256)), dim3(256), 0, st, M,
                                    n_groups, counters, sv.gbar, (long long)h->slot_cap);

@@ -511,25 +511,20 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 // buffer G[m][group][slot]: within a layer every slot is written once per group, across layers the SAME lane adds to
 // it in a fixed order (deterministic read-modify-write, old value prefetched one step ahead); finalize reduces the
 // groups in a streaming pass.
-// 16-feature slices: 4 waves, two workgroups share a CU (81 KB of LDS each at 272 atoms), one stages its slice while the other
-// computes (6.4 -> 6.0 ms / step); 2 waves per SIMD with the 256-register budget.  8-feature slices (145 registers, 144 B of
-// LDS per atom) were measured with 4 / 6 / 8 waves per workgroup on 490-atom chains: 13.1 / 13.4 / 23.7 ms per step (8 waves
-// spill at 128 registers): 4 waves as well.
-#ifndef BWD8_WAVES
-#define BWD8_WAVES 4
-#endif
-template <int NF> constexpr int bwd_threads() { return NF == 4 ? 256 : 64 * BWD8_WAVES; }
-template <int NF> constexpr int bwd_waves_per_simd() { return NF == 4 ? 2 : (2 * BWD8_WAVES) / 4; }
-// (one slice per workgroup; measured with 16-feature slices: 1 -> 6.3 ms, 2 -> 6.7, 4 -> 7.1 per step -- L2 locality of the
-// tables; finalize reduces the partial buffers of a chain's slices in a streaming pass)
-template <int NF>
-constexpr int cen_floats() { return (bwd_threads<NF>() / 64) * 4 * 4 * 6 * NF; }   // current-centre store: [stream][feature quarter][phi a, b, c, v x, y, z][NF]
-template <int NF>
-size_t edge_bwd_lds_bytes_t(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * EdgeGeo<NF>::ROWB + cen_floats<NF>()); }
+// Workgroup width WAVES.  4 waves: two workgroups share a CU (81 KB of LDS each at 272 atoms, 16-feature slices), one stages its
+// slice while the other computes (6.4 -> 6.0 ms / step), 2 waves per SIMD with the 256-register budget.  When the slice of the
+// launch's largest chain is too big for two workgroups per CU (> 301 atoms with 16-feature slices, > 573 with 8-feature
+// slices) a 4-wave workgroup would run alone with ONE wave per SIMD: those launches use 8 waves (same registers, one
+// workgroup per CU).  (8-feature slices, 145 registers: 4 / 6 / 8 waves at two workgroups per CU measured 13.1 / 13.4 / 23.7 ms
+// per step on 490-atom chains -- 8 waves x 2 workgroups spill at 128 registers.)
+template <int NF, int WAVES>
+constexpr int cen_floats() { return WAVES * 4 * 4 * 6 * NF; }   // current-centre store: [stream][feature quarter][phi a, b, c, v x, y, z][NF]
+template <int NF, int WAVES>
+size_t edge_bwd_lds_bytes_t(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * EdgeGeo<NF>::ROWB + cen_floats<NF, WAVES>()); }
 
 // FIRST: the launch writes the partial edge-gradient buffers for the first time (last layer): nothing to add to.
-template <int NF, bool FIRST>
-__global__ void __launch_bounds__(bwd_threads<NF>()) __attribute__((amdgpu_waves_per_eu(bwd_waves_per_simd<NF>(), bwd_waves_per_simd<NF>())))
+template <int NF, bool FIRST, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 2 waves per SIMD either way: use the 256 VGPRs
 k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms,
                 const int *__restrict__ list, int n_list,
@@ -537,7 +532,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
                 float4 *__restrict__ gbar, long long gbar_stride, int n_groups) {
     using LY = EdgeGeo<NF>;
-    constexpr int FS = LY::FS, NSG = LY::NSLICE, NT = LY::NT, ROWB = LY::ROWB, BWD_THREADS = bwd_threads<NF>();
+    constexpr int FS = LY::FS, NSG = LY::NSLICE, NT = LY::NT, ROWB = LY::ROWB, BWD_THREADS = 64 * WAVES;
     typedef float fvx __attribute__((ext_vector_type(NF)));   // the lane's NF features (ext vectors: arrays of HIP float4 stay in scratch memory)
     extern __shared__ __attribute__((aligned(16))) float tile[];
     if (counters[2]) return;
@@ -806,8 +801,10 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 int edge_mfma_init(vssr_handle *h) {
 #define SET_LDS(K) VSSR_HIP(h, hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     SET_LDS((k_edge_fwd_mfma<4, true>)); SET_LDS((k_edge_fwd_mfma<4, false>)); SET_LDS((k_edge_fwd_mfma<2, false>));
-    SET_LDS((k_edge_bwd_mfma<4, true>)); SET_LDS((k_edge_bwd_mfma<4, false>));
-    SET_LDS((k_edge_bwd_mfma<2, true>)); SET_LDS((k_edge_bwd_mfma<2, false>));
+    SET_LDS((k_edge_bwd_mfma<4, true, 4>)); SET_LDS((k_edge_bwd_mfma<4, false, 4>));
+    SET_LDS((k_edge_bwd_mfma<2, true, 4>)); SET_LDS((k_edge_bwd_mfma<2, false, 4>));
+    SET_LDS((k_edge_bwd_mfma<4, true, 8>)); SET_LDS((k_edge_bwd_mfma<4, false, 8>));
+    SET_LDS((k_edge_bwd_mfma<2, true, 8>)); SET_LDS((k_edge_bwd_mfma<2, false, 8>));
 #undef SET_LDS
     return VSSR_OK;
 }
@@ -820,23 +817,34 @@ int edge_class_of(int n_atoms) {
     if (edge_fwd_lds_bytes_t<2, false>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS8;
     return EDGE_CLASS_GATHER;
 }
-int edge_class_groups(int cls) {
-    return cls == EDGE_CLASS_FS16 || cls == EDGE_CLASS_FS16M ? EdgeGeo<4>::NSLICE : cls == EDGE_CLASS_FS8 ? EdgeGeo<2>::NSLICE : 1;
+// reverse path of a chain: 16-feature slices while the reverse tile fits LDS (8-wave workgroup), 8-feature slices for the rest
+// of the forward 8-feature class, gather kernels exactly where the forward pass gathers
+int edge_bclass_of(int n_atoms) {
+    const int fwd = edge_class_of(n_atoms);
+    if (fwd == EDGE_CLASS_GATHER) return EDGE_BCLASS_GATHER;
+    if (edge_bwd_lds_bytes_t<4, 8>(n_atoms) <= 160 * 1024) return EDGE_BCLASS_FS16;
+    return EDGE_BCLASS_FS8;
 }
+int edge_class_groups(int bcls) { return bcls == EDGE_BCLASS_FS16 ? EdgeGeo<4>::NSLICE : bcls == EDGE_BCLASS_FS8 ? EdgeGeo<2>::NSLICE : 1; }
 
-// layers >= 1 only (layer 0: painn_l0.hip or the gather kernels, see painn_run).  cls: EDGE_CLASS_FS16 / _FS16M / _FS8; list / n_list:
-// the chains of that class; max_atoms: the largest of them.
+// layers >= 1 only (layer 0: painn_l0.hip or the gather kernels, see painn_run).  cls: EDGE_BCLASS_FS16 / _FS8 (reverse) resp.
+// EDGE_CLASS_FS16 / _FS16M / _FS8 (forward); list / n_list: the chains of that class; max_atoms: the largest of them.
 void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
                           float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups) {
     if (n_list <= 0) return;
-#define LAUNCH_BWD(NF, FIRST)                                                                                                    \
-    hipLaunchKernelGGL((k_edge_bwd_mfma<NF, FIRST>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), dim3(bwd_threads<NF>()), \
-                       edge_bwd_lds_bytes_t<NF>(max_atoms), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list,     \
+#define LAUNCH_BWD(NF, FIRST, WAVES)                                                                                             \
+    hipLaunchKernelGGL((k_edge_bwd_mfma<NF, FIRST, WAVES>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), dim3(64 * WAVES), \
+                       (edge_bwd_lds_bytes_t<NF, WAVES>(max_atoms)), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, \
                        v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups)
-    if (cls == EDGE_CLASS_FS8) { if (layer_first) LAUNCH_BWD(2, true); else LAUNCH_BWD(2, false); }
-    else { if (layer_first) LAUNCH_BWD(4, true); else LAUNCH_BWD(4, false); }
+#define LAUNCH_BWD_W(NF, FIRST)                                                                                                  \
+    do {                                                                                                                         \
+        if (2 * edge_bwd_lds_bytes_t<NF, 4>(max_atoms) <= 160 * 1024) LAUNCH_BWD(NF, FIRST, 4); else LAUNCH_BWD(NF, FIRST, 8);   \
+    } while (0)
+    if (cls == EDGE_BCLASS_FS8) { if (layer_first) LAUNCH_BWD_W(2, true); else LAUNCH_BWD_W(2, false); }
+    else { if (layer_first) LAUNCH_BWD_W(4, true); else LAUNCH_BWD_W(4, false); }
+#undef LAUNCH_BWD_W
 #undef LAUNCH_BWD
 }
 

@@ -538,21 +538,29 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
         // 16-feature slices, 8-feature slices, or the gather kernels.  (A batch whose largest chain exceeds what the bundle
         // sort stages in LDS has no bundle tables at all: every chain gathers.)
         const bool bundles = (size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024;
-        std::vector<unsigned char> cls(n_cfg);
-        std::vector<int> lists[EDGE_MFMA_CLASSES];
+        std::vector<unsigned char> bcls(n_cfg);
+        std::vector<int> lists[EDGE_MFMA_CLASSES], blists[2];
         for (int c = 0; c < EDGE_CLASSES; ++c) { h->n_class[c] = 0; h->max_class_atoms[c] = 0; }
+        for (int c = 0; c < EDGE_BCLASSES; ++c) { h->n_bclass[c] = 0; h->max_bclass_atoms[c] = 0; }
         for (int b = 0; b < n_cfg; ++b) {
             int c = (h->edge_impl && bundles) ? edge_class_of(n_atoms[b]) : EDGE_CLASS_GATHER;
+            int bc = (h->edge_impl && bundles) ? edge_bclass_of(n_atoms[b]) : EDGE_BCLASS_GATHER;
             if (c <= EDGE_CLASS_FS16M && h->fs16_max_atoms >= 0 && n_atoms[b] > h->fs16_max_atoms) c = EDGE_CLASS_FS8;
-            if (c == EDGE_CLASS_FS8 && h->fs8_max_atoms >= 0 && n_atoms[b] > h->fs8_max_atoms) c = EDGE_CLASS_GATHER;
-            cls[b] = (unsigned char)c;
+            if (bc == EDGE_BCLASS_FS16 && h->fs16_max_atoms >= 0 && n_atoms[b] > h->fs16_max_atoms) bc = EDGE_BCLASS_FS8;
+            if (c == EDGE_CLASS_FS8 && h->fs8_max_atoms >= 0 && n_atoms[b] > h->fs8_max_atoms) { c = EDGE_CLASS_GATHER; bc = EDGE_BCLASS_GATHER; }
+            bcls[b] = (unsigned char)bc;
             h->n_class[c] += 1;
+            h->n_bclass[bc] += 1;
             if (n_atoms[b] > h->max_class_atoms[c]) h->max_class_atoms[c] = n_atoms[b];
+            if (n_atoms[b] > h->max_bclass_atoms[bc]) h->max_bclass_atoms[bc] = n_atoms[b];
             if (c != EDGE_CLASS_GATHER) lists[c].push_back(b);
+            if (bc != EDGE_BCLASS_GATHER) blists[bc].push_back(b);
         }
         std::vector<int> cat;
         for (int c = 0; c < EDGE_MFMA_CLASSES; ++c) cat.insert(cat.end(), lists[c].begin(), lists[c].end());
+        for (int c = 0; c < 2; ++c) cat.insert(cat.end(), blists[c].begin(), blists[c].end());
         cat.push_back(0);
+        const std::vector<unsigned char> &cls = bcls;
         if (h->d_chain_class.ensure((size_t)n_cfg) || h->d_class_list.ensure(sizeof(int) * cat.size()))
             return set_err(h, VSSR_E_NOMEM, "chain class tables");
         VSSR_HIP(h, hipMemcpy(h->d_chain_class.p, cls.data(), (size_t)n_cfg, hipMemcpyHostToDevice));

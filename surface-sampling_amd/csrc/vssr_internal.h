@@ -78,7 +78,8 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const unsigned char *zslot;   // [slots] species index (zmap) of the neighbor, 255 for pads / unmapped
     const float2 *dist2;     // [slots] {1 / edge length (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}
     const int4 *bundle;      // [n_atoms] per chain: centres sorted by padded degree (descending): {centre (chain-local), first slot, padded slot count, 0}
-    const unsigned char *chain_class;   // [n_cfg] EDGE_CLASS_*: which neighbor-sum kernels serve the chain (layers >= 1)
+    const unsigned char *chain_class;   // [n_cfg] EDGE_BCLASS_*: which reverse neighbor kernels serve the chain (layers >= 1); a chain
+                                        // gathers in the reverse pass exactly when it gathers in the forward pass
     ActiveView act;          // chains switched off by the relaxation driver
 };
 
@@ -175,7 +176,8 @@ struct vssr_handle {
     // chains by neighbor-sum path (EDGE_CLASS_*), fixed at upload from every chain's own atom count: class of every chain,
     // the chain lists of the matrix-pipe classes (concatenated in class order), counts and largest chain per class
     vssr::DevBuf d_chain_class, d_class_list;
-    int n_class[4] = {0, 0, 0, 0}, max_class_atoms[4] = {0, 0, 0, 0};
+    int n_class[4] = {0, 0, 0, 0}, max_class_atoms[4] = {0, 0, 0, 0};      // forward classes (EDGE_CLASS_*)
+    int n_bclass[3] = {0, 0, 0}, max_bclass_atoms[3] = {0, 0, 0};          // reverse classes (EDGE_BCLASS_*); lists follow the forward lists
     int fs16_max_atoms = -1, fs8_max_atoms = -1;   // test knobs (VSSR_EDGE_FS16_MAX / VSSR_EDGE_FS8_MAX): lower the class limits
     int max_images = 0;          // largest number of periodic images any configuration of the batch scans per pair
 
@@ -301,8 +303,11 @@ int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const fl
                    float4 *gbar, long long gbar_stride, int n_groups);
 // LDS-slice + MFMA edge stages (painn_edge_mfma.hip)
 int edge_mfma_init(vssr_handle *h);
-// neighbor-sum paths: 16-feature slices with / without the scalar residual in LDS, 8-feature slices, gather kernels
+// forward neighbor-sum paths: 16-feature slices with / without the scalar residual in LDS, 8-feature slices, gather kernels
 enum { EDGE_CLASS_FS16 = 0, EDGE_CLASS_FS16M = 1, EDGE_CLASS_FS8 = 2, EDGE_CLASS_GATHER = 3, EDGE_CLASSES = 4, EDGE_MFMA_CLASSES = 3 };
+// reverse paths (the reverse tile is smaller: 16-feature slices serve chains up to 557 atoms): what GraphView::chain_class holds
+enum { EDGE_BCLASS_FS16 = 0, EDGE_BCLASS_FS8 = 1, EDGE_BCLASS_GATHER = 2, EDGE_BCLASSES = 3 };
+int edge_bclass_of(int n_atoms);
 int edge_class_of(int n_atoms);       // path of a chain by its own atom count
 int edge_class_groups(int cls);       // partial edge-gradient buffers a chain of that class writes per model
 void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,
