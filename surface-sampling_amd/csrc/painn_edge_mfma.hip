@@ -152,7 +152,12 @@ void build_wd16(const float *Wd, const float *bd, unsigned *dst) {
 // (slot, fq) -- which owns tile rows 4 fq .. 4 fq + 3 -- still finds the a, b and c filter values of ITS features in its own
 // accumulator registers (tile 0 = [a | b], tile 1 = [c | -]).  Every chain takes the path its own atom count selects
 // (vssr_api.hip classify_chains), whatever it is batched with.
-constexpr int EDGE_THREADS = 1024;   // 16 waves = 4 per SIMD (120 VGPRs): measured 512 -> 2.54, 768 -> 2.17, 1024 -> 2.03 ms / step
+#ifndef STAGE_BATCH
+#define STAGE_BATCH 4   // slice staging: loads in flight per thread before the first LDS store
+#endif
+// Forward workgroup width: 16 waves per CU = 4 per SIMD (<= 128 VGPRs) in every case -- one workgroup of 16 waves when the
+// chain's slice fills the LDS (measured on 260-atom chains: 512 threads -> 2.54, 768 -> 2.17, 1024 -> 2.03 ms / step), two of 8
+// or four of 4 waves when two / four slices fit (small chains: a 74-atom chain has 19 bundles, which 16 waves share badly).
 
 // LDS slice layout: tile[atom][feature f][NSEG] with NSEG = {a, b, c, v_x, v_y, v_z}: the values a lane needs for its NF
 // features of one neighbor are NF * 24 contiguous bytes.  (Layer 0 never comes here: it is either
@@ -302,14 +307,14 @@ __device__ __forceinline__ int chain_of_workgroup(const GraphView &G, const int 
     return G.act.chain(b) ? b : -1;
 }
 
-template <int NF, bool SLDS>
-__global__ void __launch_bounds__(EDGE_THREADS)
+template <int NF, bool SLDS, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *__restrict__ counters,
                 int zero_slot, int n_models, int max_atoms, const int *__restrict__ list, int n_list,
                 const float *__restrict__ s_in, const float *__restrict__ v_in, const float *__restrict__ phi,
                 float *__restrict__ s_msg, float *__restrict__ v_msg) {
     using LY = EdgeGeo<NF>;
-    constexpr int FS = LY::FS, NSLICE = LY::NSLICE, NT = LY::NT;
+    constexpr int FS = LY::FS, NSLICE = LY::NSLICE, NT = LY::NT, EDGE_THREADS = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float tile[];
     if (counters[2]) return;
     int t;
@@ -344,15 +349,15 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                 dst[0] = val.x; dst[LY::NSEG] = val.y; dst[2 * LY::NSEG] = val.z; dst[3 * LY::NSEG] = val.w;
             }
         };
-        for (int base = tid; base < total; base += 4 * EDGE_THREADS) {
-            float4 v4[4];
+        for (int base = tid; base < total; base += STAGE_BATCH * EDGE_THREADS) {
+            float4 v4[STAGE_BATCH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < STAGE_BATCH; ++u) {
                 const int idx = min(base + u * EDGE_THREADS, total - 1);
                 v4[u] = *reinterpret_cast<const float4 *>(src_of(idx));
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < STAGE_BATCH; ++u)
                 if (base + u * EDGE_THREADS < total) put(base + u * EDGE_THREADS, v4[u]);
         }
     }
@@ -570,10 +575,10 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     {
         constexpr int Q4 = FS / 4;           // float4 per segment
         const int total = Nc * 4 * Q4;       // 4 segments per atom
-        for (int base = tid; base < total; base += 4 * BWD_THREADS) {
-            float4 v4[4];
+        for (int base = tid; base < total; base += STAGE_BATCH * BWD_THREADS) {
+            float4 v4[STAGE_BATCH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < STAGE_BATCH; ++u) {
                 const int idx = min(base + u * BWD_THREADS, total - 1);
                 const int atom = idx / (4 * Q4), seg = (idx / Q4) & 3, q4 = idx % Q4;
                 const size_t ga = mN + a0 + atom;
@@ -582,7 +587,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 v4[u] = *reinterpret_cast<const float4 *>(src);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < STAGE_BATCH; ++u) {
                 const int idx = base + u * BWD_THREADS;
                 if (idx < total) {
                     const int atom = idx / (4 * Q4), seg = (idx / Q4) & 3, q4 = idx % Q4;
@@ -800,7 +805,8 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 
 int edge_mfma_init(vssr_handle *h) {
 #define SET_LDS(K) VSSR_HIP(h, hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-    SET_LDS((k_edge_fwd_mfma<4, true>)); SET_LDS((k_edge_fwd_mfma<4, false>)); SET_LDS((k_edge_fwd_mfma<2, false>));
+    SET_LDS((k_edge_fwd_mfma<4, true, 16>)); SET_LDS((k_edge_fwd_mfma<4, false, 16>)); SET_LDS((k_edge_fwd_mfma<2, false, 16>));
+    SET_LDS((k_edge_fwd_mfma<4, true, 8>)); SET_LDS((k_edge_fwd_mfma<4, true, 4>));
     SET_LDS((k_edge_bwd_mfma<4, true, 4>)); SET_LDS((k_edge_bwd_mfma<4, false, 4>));
     SET_LDS((k_edge_bwd_mfma<2, true, 4>)); SET_LDS((k_edge_bwd_mfma<2, false, 4>));
     SET_LDS((k_edge_bwd_mfma<4, true, 8>)); SET_LDS((k_edge_bwd_mfma<4, false, 8>));
@@ -852,14 +858,17 @@ void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
                           const GraphView &G, const int *counters, int zero_slot, const float *s_in, const float *v_in,
                           const float *phi, float *s_msg, float *v_msg) {
     if (n_list <= 0) return;
-    const dim3 blk(EDGE_THREADS);
-#define LAUNCH_FWD(NF, SLDS)                                                                                                       \
-    hipLaunchKernelGGL((k_edge_fwd_mfma<NF, SLDS>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), blk,                    \
+#define LAUNCH_FWD(NF, SLDS, WAVES)                                                                                                \
+    hipLaunchKernelGGL((k_edge_fwd_mfma<NF, SLDS, WAVES>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), dim3(64 * WAVES), \
                        (edge_fwd_lds_bytes_t<NF, SLDS>(max_atoms)), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, \
                        s_in, v_in, phi, s_msg, v_msg)
-    if (cls == EDGE_CLASS_FS16) LAUNCH_FWD(4, true);
-    else if (cls == EDGE_CLASS_FS16M) LAUNCH_FWD(4, false);
-    else LAUNCH_FWD(2, false);
+    if (cls == EDGE_CLASS_FS16) {   // workgroups per CU that the launch's largest slice allows -> waves per workgroup
+        const size_t lds = edge_fwd_lds_bytes_t<4, true>(max_atoms);
+        if (4 * lds <= 160 * 1024) LAUNCH_FWD(4, true, 4);
+        else if (2 * lds <= 160 * 1024) LAUNCH_FWD(4, true, 8);
+        else LAUNCH_FWD(4, true, 16);
+    } else if (cls == EDGE_CLASS_FS16M) LAUNCH_FWD(4, false, 16);
+    else LAUNCH_FWD(2, false, 16);
 #undef LAUNCH_FWD
 }
 
