@@ -11,10 +11,14 @@ inputs resident in HBM before the timed region.  N > 1: every rank owns 256 more
 BASELINE configs[4]: rank r owns global chains [256 r, 256 r + 256)); the only collective is the RCCL all_gather of
 per-chain (E, sigma_E), read in place from the engine's device buffers (surface_sampling_amd.sharding).
 
+Secondary lines (never the headline): `--atoms-per-chain N` tiles the slab to ~N atoms per chain (74 .. 500: the four neighbor-sum
+paths), `--chains-per-gpu B`, `--streams S`.
+
 The ONE JSON line carries, besides the contract fields:
   roofline      dominant kernel = reverse neighbor pass; `achieved` = SURVEY §8(d) flops (2 x 17 408 per real directed edge
                 and model) / HIP-event launch time; `views` gives the same launch against three yardsticks (fp32 vector /
                 matrix peak, the fp16 matrix pipe it executes on, HBM) and names the binding resource;
+  north_star    the BASELINE target ">= 40 % of HBM roofline on the neighbor-sum kernel" as an explicit field (not met: 15 %);
   pcie_inclusive  the same evaluations with new host positions uploaded and energies + forces downloaded every step;
   cpu_baseline  CPU ports of the same evaluation timed on this host (the reference's own CPU path is not installable).
 """
