@@ -5,6 +5,8 @@ Stated tolerances: GPU fp32 vs the fp64 oracle |dE| <= 1e-4 e
 |d fmax| <= 1e-5 eV/A; neighbor edge sets identical; Tersoff (fp64 on device) <= 1e-9 relative.
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -731,3 +733,18 @@ def test_stored_forward_intermediates_give_identical_results(golden, monkeypatch
     assert np.array_equal(e_only["energy"], r0["energy"])
     e1.close()
     e0.close()
+
+
+def test_repeatability_of_every_neighbor_sum_path():
+    """Short form of tools/gpu_stress_classes.py (the builder-run soak: 6 configurations x 450 evaluations, 0 mismatches,
+    profiles/r03/NOTES_soak.md): every slice width / workgroup width of the edge kernels, three fresh engines each, every
+    evaluation bit-identical to the first (MFMA operand hazards show up as isolated run-to-run differences)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NCHAIN="16", REPS="6")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_stress_classes.py")], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("mismatches 0") == 6, r.stdout
