@@ -17,7 +17,8 @@
 // them; a centre is written once, after a 4-lane DPP reduction.  No atomics; the summation order per centre is the CSR
 // order regardless of batching.  What bounds these kernels and what was tried: DESIGN.md section 5,
 // profiles/r01/NOTES_edge_r1b.md.
-// Chains of 351 .. 682 atoms take the 8-feature-slice instantiation, larger ones the gather kernels in painn.hip; the choice
+// Larger chains take the residual-from-memory form (<= 405 atoms) or the 8-feature-slice instantiation (<= 787), beyond that the
+// gather kernels in painn.hip; the reverse pass keeps 16-feature slices up to 557 atoms (edge_class_of / edge_bclass_of); the choice
 // is per chain (edge_class_of), so a chain's results do not depend on what it is batched with.
 #include "vssr_internal.h"
 
@@ -146,7 +147,8 @@ void build_wd16(const float *Wd, const float *bd, unsigned *dst) {
 }
 
 // Feature slices come in two widths.  NF = features per lane: 4 -> a 16-feature slice (the default: 468 B of LDS per atom in
-// the forward kernel, chains up to 350 atoms), 2 -> an 8-feature slice (240 B per atom, chains up to 682 atoms: 4 x 4
+// the forward kernel, chains up to 350 atoms; 404 B and 405 atoms without the staged residual), 2 -> an 8-feature slice
+// (208 B per atom, chains up to 787 atoms: 4 x 4
 // slabs at full coverage, multi-atom adsorbate groups).  The 8-feature kernels keep the 16 x 16 matrix tile full by packing
 // two filter sections into one tile: tile row i = 4 q + j carries feature 2 q + (j & 1) of section 2 T + (j >> 1), so that lane
 // (slot, fq) -- which owns tile rows 4 fq .. 4 fq + 3 -- still finds the a, b and c filter values of ITS features in its own
