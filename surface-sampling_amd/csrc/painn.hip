@@ -336,7 +336,7 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
 // forces: dE/dx_c = sum_{slots (c,n)} ( G[(n->c)] - G[(c->n)] ), G[(c->n)] lives at rev[slot].
 // Partial edge gradients of the feature slices (one buffer per workgroup group) -> one buffer per model (group 0, in place): a streaming,
 // coalesced pass in fixed group order, so that the gather through `rev` below touches one buffer per model only.  A chain's
-// slots carry as many partial buffers as its class has slices (grid.y = chain).
+// slots carry as many partial buffers as its class has slices (grid.x = chain).
 // (every chain of the batch in one class -- the usual case: one thread per slot of the whole batch)
 __global__ void k_reduce_gbar_groups_uniform(int M, int n_groups, const int *__restrict__ counters, float4 *__restrict__ gbar,
                                              long long gbar_stride) {
@@ -357,13 +357,13 @@ __global__ void __launch_bounds__(256)
 k_reduce_gbar_groups(int M, int n_groups, GraphView G, const int *__restrict__ counters, float4 *__restrict__ gbar,
                      long long gbar_stride) {
     if (counters[2]) return;
-    const int b = blockIdx.y;
+    const int b = blockIdx.x;   // (x: no 65 535 limit on the chain count)
     if (!G.act.chain(b)) return;
     const int cls = G.chain_class[b];
     const int ng = cls == EDGE_BCLASS_FS16 ? 8 : cls == EDGE_BCLASS_FS8 ? 16 : 1;   // buffers the chain's reverse kernels wrote (edge_class_groups)
     if (ng == 1) return;
     const int s0 = G.row_start[G.cfg_start[b]], s1 = G.row_start[G.cfg_start[b + 1]];
-    for (int slot = s0 + blockIdx.x * blockDim.x + threadIdx.x; slot < s1; slot += gridDim.x * blockDim.x)
+    for (int slot = s0 + blockIdx.y * blockDim.x + threadIdx.x; slot < s1; slot += gridDim.y * blockDim.x)
         for (int m = 0; m < M; ++m) {
             float4 *g0 = gbar + (size_t)(m * n_groups) * gbar_stride + slot;
             float4 acc = *g0;
@@ -688,7 +688,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
                 hipLaunchKernelGGL(k_reduce_gbar_groups_uniform, dim3((unsigned)((h->slot_cap + 255) / 256)), dim3(256), 0, st, M,
                                    n_groups, counters, sv.gbar, (long long)h->slot_cap);
             else
-                hipLaunchKernelGGL(k_reduce_gbar_groups, dim3(12, h->n_cfg), dim3(256), 0, st, M, n_groups, G, counters, sv.gbar,
+                hipLaunchKernelGGL(k_reduce_gbar_groups, dim3(h->n_cfg, 12), dim3(256), 0, st, M, n_groups, G, counters, sv.gbar,
                                    (long long)h->slot_cap);
         }
         hipLaunchKernelGGL(k_finalize_forces, dim3((N + 3) / 4), dim3(256), 0, st, N, M, G, counters, sv.gbar,
