@@ -585,8 +585,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
             if (rc) return rc;
             P.end(st);
             P.begin(KC_UPDATE_FWD, st);
-            launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1],
-                                   l + 1 < L ? sv.phi[l + 1] : nullptr, save_of(l));
+            launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1],
+                                   (l + 1 < L || h->debug_keep) ? sv.v_in[l + 1] : nullptr, l + 1 < L ? sv.phi[l + 1] : nullptr, save_of(l));
             P.end(st);
             continue;
         }
@@ -611,8 +611,9 @@ int painn_run(vssr_handle *h, uint32_t want) {
         }
         P.end(st);
         P.begin(KC_UPDATE_FWD, st);
-        launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1], sv.v_in[l + 1],
-                               l + 1 < L ? sv.phi[l + 1] : nullptr, save_of(l));
+        // (nothing reads the vector output of the LAST block -- the readout takes s only: it is written for vssr_debug_read only)
+        launch_update_fwd_mfma(st, N, M, l, av, MW, sv.s_msg[l], sv.v_msg[l], sv.s_in[l + 1],
+                               (l + 1 < L || h->debug_keep) ? sv.v_in[l + 1] : nullptr, l + 1 < L ? sv.phi[l + 1] : nullptr, save_of(l));
         P.end(st);
     }
     // Readout.  With forces wanted (and the compiled readout width) it runs as the head of the last layer's reverse kernel;

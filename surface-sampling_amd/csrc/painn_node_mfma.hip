@@ -457,7 +457,8 @@ static_assert(4 * TA * FT * sizeof(float) <= CF_LDS_HALVES * sizeof(_Float16), "
 // it and serves as the residual of the output pass (no second read of s_msg / v_msg), and the GEMMs run the software
 // pipeline.  (A 128-register variant with two workgroups per CU re-read the residual and could not pipeline: 1.15 vs 1.09
 // ms / step, profiles/r02/NOTES_node_kernels.md.)
-// TAIL = 1: the message MLP of the NEXT layer, phi = W2 swish(W1 s_out + b1) + b2 (weights of layer l + 1), runs as the
+// TAIL = 2: the block's VECTOR output is not produced (the last block: only s reaches the readout -- no a_vv gate, no v rows in
+// the output pass: 1.5 KB per atom less to write).  TAIL = 1: the message MLP of the NEXT layer, phi = W2 swish(W1 s_out + b1) + b2 (weights of layer l + 1), runs as the
 // kernel's tail on the scalar output tile while it is still on the chip: its planes are written by the output pass, the
 // separate k_msg_mlp_mfma launch and its read of s disappear.
 // Optional (VSSR_UPD_SAVE=1, off by default): forward intermediates handed to the reverse update kernel instead of being
@@ -481,6 +482,7 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
                   const float *__restrict__ v_msg, float *__restrict__ s_out, float *__restrict__ v_out,
                   float *__restrict__ phi_next, f32x4 *__restrict__ save) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    constexpr bool NOV = TAIL == 2;   // last layer: only the scalar output is consumed (readout); v_out is not written
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
@@ -545,11 +547,13 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     __syncthreads();
     PH(4)
     WPre<2, 3, 1> pW4;
+    WPre<2, 2, 1> pW4n;   // NOV: only a_sv and a_ss
+    const uint4 *wW4n[2] = {wW4[1], wW4[2]};
     {
         const f32x4 b = gload4f(W.b3 + L.col0);
         __builtin_amdgcn_sched_barrier(0);   // the bias is requested in front of the GEMM whose epilogue adds it
         gemm16<F, 2, 1, PF, 2>(nr, wW3b, h3, &pW3b);
-        gemm16_preload(wW4, pW4);
+        if constexpr (NOV) gemm16_preload(wW4n, pW4n); else gemm16_preload(wW4, pW4);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 sw = h3[t][0] + b;
@@ -571,8 +575,16 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
 #pragma unroll
         for (int c = 0; c < 3; ++c) b4[c] = gload4f(W.b4 + c * F + L.col0);
         __builtin_amdgcn_sched_barrier(0);
-        gemm16<F, 2, 3, PF, 1>(as_, wW4, gate, &pW4);
-        if constexpr (TAIL != 0) {
+        if constexpr (NOV) {   // the vector output is not wanted: a_vv is not needed, 24 matrix instructions less per wave
+            f32x4 g2[2][2];
+            zero_acc(g2);
+            gemm16<F, 2, 2, PF, 1>(as_, wW4n, g2, &pW4n);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { gate[t][1] = g2[t][0]; gate[t][2] = g2[t][1]; }
+        } else {
+            gemm16<F, 2, 3, PF, 1>(as_, wW4, gate, &pW4);
+        }
+        if constexpr (TAIL == 1) {
             const LayerW &Wn = MW[m].layer[l + 1];
             wW1n[0] = Wn.qW1 + (size_t)L.w * 4 * F;
 #pragma unroll
@@ -615,8 +627,10 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
 #pragma unroll
         for (int i = 0; i < 4; ++i) ds[i] = fmaf(gate[t][1][i], inner[t][i], gate[t][2][i]);
         *reinterpret_cast<f32x4 *>(T + row * FT + L.col0) = ds;
+        if constexpr (!NOV) {
 #pragma unroll
-        for (int x = 0; x < 3; ++x) *reinterpret_cast<f32x4 *>(T + (TA * (1 + x) + row) * FT + L.col0) = gate[t][0] * uv[2 * x + t][0];
+            for (int x = 0; x < 3; ++x) *reinterpret_cast<f32x4 *>(T + (TA * (1 + x) + row) * FT + L.col0) = gate[t][0] * uv[2 * x + t][0];
+        }
     }
     __syncthreads();
     auto gofs = [&](int row, int col) -> size_t {   // q = row / TA: 0 = s, 1..3 = v_x, v_y, v_z (tail rows clamped to the last atom)
@@ -627,20 +641,21 @@ k_update_fwd_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, co
     const Planes xo = make_planes(ldsh + CF_LDS_HALVES, TA, F);   // TAIL: planes of s_out behind the output tile
     auto put = [&](int row, int col, const float4 &d, const float4 &r) {
         const float4 o = make_float4(r.x + d.x, r.y + d.y, r.z + d.z, r.w + d.w);
-        if (TAIL && row < TA) store_split4<SAT_COOP>(xo, row, col, o, sat);   // (rows past the last atom: clamped copies, never stored)
+        if (TAIL == 1 && row < TA) store_split4<SAT_COOP>(xo, row, col, o, sat);   // (rows past the last atom: clamped copies, never stored)
         if (a0 + row % TA >= N) return;
+        if (row >= TA && !v_out) return;   // (last block with the stored-intermediates option: a_vv is needed, the vector output is not)
         *reinterpret_cast<float4 *>((row < TA ? s_out : v_out) + gofs(row, col)) = o;
     };
     {   // the loading pass and this pass map (thread, iteration) to (row, column) identically: rows [0, TA) = s
         constexpr int NS = TA * (F / 4) / NTHREADS, NV = 3 * TA * (F / 4) / NTHREADS;
 #pragma unroll
-        for (int it = 0; it < NS + NV; ++it) {
+        for (int it = 0; it < (NOV ? NS : NS + NV); ++it) {
             const int idx = threadIdx.x + it * NTHREADS, row = idx >> 5, c4 = idx & 31;
             put(row, 4 * c4, *reinterpret_cast<const float4 *>(T + row * FT + 4 * c4), it < NS ? keep_s[it < NS ? it : 0] : keep_v[it < NS ? 0 : it - NS]);
         }
     }
     PH(10)
-    if constexpr (TAIL != 0) {
+    if constexpr (TAIL == 1) {
         const LayerW &Wn = MW[m].layer[l + 1];
         const Planes hn = make_planes(ldsh, TA, F);   // swish(W1 s + b1), over the (finished) output tile
         __syncthreads();   // s_out planes complete; every wave is done with the output tile
@@ -1104,6 +1119,8 @@ int node_mfma_init(vssr_handle *h) {
                                     (int)node_mfma_lds_bytes(6)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(6)));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(6)));
 #define SET_UPD(MODE)                                                                                                     \
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_bwd_mfma<MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)node_mfma_lds_bytes(3)));
@@ -1135,6 +1152,9 @@ void launch_update_fwd_mfma(hipStream_t st, int N, int M, int l, const ActiveVie
     f32x4 *sv = reinterpret_cast<f32x4 *>(save);
     if (phi_next)
         hipLaunchKernelGGL(k_update_fwd_mfma<1>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(6), st, N, l,
+                           av, MW, s_msg, v_msg, s_out, v_out, phi_next, sv);
+    else if (!v_out && !sv)   // (the stored-intermediates option needs a_vv)
+        hipLaunchKernelGGL(k_update_fwd_mfma<2>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(6), st, N, l,
                            av, MW, s_msg, v_msg, s_out, v_out, phi_next, sv);
     else
         hipLaunchKernelGGL(k_update_fwd_mfma<0>, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(6), st, N, l,

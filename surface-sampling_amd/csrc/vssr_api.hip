@@ -311,6 +311,7 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     if (const char *e = getenv("VSSR_EDGE_IMPL")) h->edge_impl = (strcmp(e, "gather") == 0) ? 0 : 1;
     if (const char *e = getenv("VSSR_L0_FACTORISE")) h->l0_enabled = atoi(e);
     if (const char *e = getenv("VSSR_UPD_SAVE")) h->upd_save = atoi(e);
+    if (const char *e = getenv("VSSR_DEBUG_KEEP")) h->debug_keep = atoi(e);
     // test knobs: send chains above these atom counts to the next class (8-feature slices / gather kernels) although they fit
     if (const char *e = getenv("VSSR_EDGE_FS16_MAX")) h->fs16_max_atoms = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_FS8_MAX")) h->fs8_max_atoms = atoi(e);
@@ -942,7 +943,11 @@ int vssr_debug_read(vssr_handle *h, const char *name, int32_t model, float *dst,
     else if ((l = layer_of("s_msg")) >= 0) { src = sv.s_msg[l]; per_atom = F; }
     else if ((l = layer_of("v_msg")) >= 0) { src = sv.v_msg[l]; per_atom = F3; }
     else if ((l = layer_of("s_upd")) >= 0) { src = sv.s_in[l + 1]; per_atom = F; }
-    else if ((l = layer_of("v_upd")) >= 0) { src = sv.v_in[l + 1]; per_atom = F3; }
+    else if ((l = layer_of("v_upd")) >= 0) {
+        if (l == h->num_conv - 1 && !h->debug_keep)
+            return set_err(h, VSSR_E_STATE, "v_upd of the last block is not materialised (nothing consumes it; create the handle with VSSR_DEBUG_KEEP=1)");
+        src = sv.v_in[l + 1]; per_atom = F3;
+    }
     else if (nm == "e_atom") { src = sv.e_atom; per_atom = 1; }
     else if (nm == "sbar_msg0") { src = sv.sbar_msg_l0; per_atom = F; }   // reverse buffers hold the LAST layer processed
     else if (nm == "vbar_msg0") { src = sv.vbar_msg; per_atom = F3; }

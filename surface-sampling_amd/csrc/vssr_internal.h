@@ -238,6 +238,7 @@ struct vssr_handle {
     vssr::StateView sv;
     vssr::DevBuf d_gbar;
     vssr::DevBuf d_upd_save;     // forward intermediates of every update block for the reverse pass (update_save_bytes per layer)
+    int debug_keep = 0;          // VSSR_DEBUG_KEEP=1: also materialise what only vssr_debug_read looks at (the last block's vector output)
     int upd_save = 0;            // VSSR_UPD_SAVE=1: update_fwd stores its intermediates and the reverse kernel loads them instead of
                                  // recomputing (measured: update_bwd 2.45 -> 2.21, update_fwd 1.30 -> 1.57..1.60 ms / step: no gain;
                                  // profiles/r03/NOTES_node_kernels.md)

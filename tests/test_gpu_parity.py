@@ -109,8 +109,9 @@ def test_per_layer_intermediates_match_oracle(golden, oracle_mod, engine):
                             ("s_upd", (n, 128)), ("v_upd", (n, 3, 128))):
             try:
                 got = engine.debug_read(f"{name}{l}", m).reshape(shape).astype(np.float64)
-            except Exception as exc:   # phi0 is not materialised when layer 0 is evaluated by species factorisation
-                assert name == "phi" and l == 0 and "not materialised" in str(exc)
+            except Exception as exc:   # phi0 is not materialised when layer 0 is evaluated by species factorisation, and
+                # nothing consumes the vector output of the last block (checked below on a handle that keeps it)
+                assert "not materialised" in str(exc) and ((name == "phi" and l == 0) or (name == "v_upd" and l == 2))
                 continue
             want = d[name][l]
             scale = max(1.0, np.abs(want).max())
@@ -128,6 +129,31 @@ def test_per_layer_intermediates_match_oracle(golden, oracle_mod, engine):
     report.append(("embedding", np.abs(emb[m].astype(np.float64) - d["s_upd"][2]).max() / max(1.0, np.abs(d["s_upd"][2]).max())))
     bad = [(k, v) for k, v in report if not v < 2e-5]
     assert not bad, f"intermediates off: {bad}; all: {report}"
+    assert len(report) >= 17
+
+
+def test_last_block_vector_output_on_request(golden, oracle_mod, monkeypatch):
+    """VSSR_DEBUG_KEEP=1 materialises the one activation the product path drops (the last update block's vector output: only
+    its scalar output reaches the readout): it matches the oracle, and keeping it changes no result."""
+    from surface_sampling_amd import backend, structures
+
+    s = structures.synth_chain(golden.structure("SrTiO3_2x2_pristine"), 2, grid=(4, 4))
+    table, const = golden.offset_table()
+    monkeypatch.setenv("VSSR_DEBUG_KEEP", "1")
+    keep = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    monkeypatch.delenv("VSSR_DEBUG_KEEP")
+    lean = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    rk, rl = keep.evaluate([_arrays(s)]), lean.evaluate([_arrays(s)])
+    for k in ("energy", "forces", "energy_std", "forces_std"):
+        assert np.array_equal(rk[k], rl[k]), k
+    _, _, d = oracle_mod.painn(golden.blobs[1], s.numbers, s.positions, s.cell, s.pbc, 64, dump=True)
+    got = keep.debug_read("v_upd2", 1).reshape(len(s), 3, 128).astype(np.float64)
+    want = d["v_upd"][2]
+    assert np.abs(got - want).max() / max(1.0, np.abs(want).max()) < 2e-5
+    with pytest.raises(backend.BackendError, match="not materialised"):
+        lean.debug_read("v_upd2", 1)
+    keep.close()
+    lean.close()
 
 
 def test_embedding_through_the_calculator_and_helpers(golden, oracle_mod):
