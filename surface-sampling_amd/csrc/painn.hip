@@ -223,12 +223,14 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
            const int *__restrict__ counters, float rc, int excl_vol, float excl_sigma, int excl_power,
            const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
            const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
-           float4 *__restrict__ gbar, long long gbar_stride, int only_class) {
+           float4 *__restrict__ gbar, long long gbar_stride, int only_class, int fresh_mfma) {
     __shared__ EdgeChunk S;
     __shared__ float red[ECHUNK][4][F + 1];
     __shared__ float tots[ECHUNK][4];
     if (counters[2] || !G.act.atom(blockIdx.x)) return;
     if (only_class >= 0 && G.chain_class[G.atom_cfg[blockIdx.x]] != only_class) return;
+    // (compact partial buffers: the final buffer of a matrix-pipe chain holds nothing yet when layer 0 arrives)
+    if (fresh_mfma && G.chain_class[G.atom_cfg[blockIdx.x]] != EDGE_BCLASS_GATHER) accumulate = 0;
     const int c = blockIdx.x, m = blockIdx.y, f = threadIdx.x;
     const LayerW &W = MW[m].layer[l];
     float wa[RB], wb[RB], wc[RB];
@@ -337,6 +339,39 @@ k_edge_bwd(int N, int l, int accumulate, const ModelW *__restrict__ MW, GraphVie
 // Partial edge gradients of the feature slices (one buffer per workgroup group) -> one buffer per model (group 0, in place): a streaming,
 // coalesced pass in fixed group order, so that the gather through `rev` below touches one buffer per model only.  A chain's
 // slots carry as many partial buffers as its class has slices (grid.x = chain).
+// Compact partial buffers (gbar_mode 2): P [M][n_groups][slot_cap][3] floats, one set of `per_set` groups per reverse layer;
+// a chain's slots carry `slices` groups per set.  final G [M][slot_cap] float4 already holds the layer-0 part.
+__global__ void __launch_bounds__(256)
+k_reduce_gpart(int M, int n_groups, int layer_sets, GraphView G, const int *__restrict__ counters, const float *__restrict__ P,
+               float4 *__restrict__ gbar, long long slot_cap, int uniform_slices) {
+    if (counters[2]) return;
+    const int per_set = n_groups / layer_sets;
+    long long s0, s1;
+    int slices;
+    if (uniform_slices) {   // every chain in one class: grid.x walks the slots of the whole batch
+        s0 = 0; s1 = counters[0]; slices = uniform_slices;
+    } else {                // grid (chains, blocks per chain)
+        const int b = blockIdx.x;
+        if (!G.act.chain(b)) return;
+        const int cls = G.chain_class[b];
+        slices = cls == EDGE_BCLASS_FS16 ? 8 : cls == EDGE_BCLASS_FS8 ? 16 : 1;
+        if (slices == 1) return;   // gather-class chains accumulate in the final buffer directly
+        s0 = G.row_start[G.cfg_start[b]]; s1 = G.row_start[G.cfg_start[b + 1]];
+    }
+    const long long first = uniform_slices ? (long long)blockIdx.x * blockDim.x : (long long)blockIdx.y * blockDim.x;
+    const long long step = uniform_slices ? (long long)gridDim.x * blockDim.x : (long long)gridDim.y * blockDim.x;
+    for (long long slot = s0 + first + threadIdx.x; slot < s1; slot += step)
+        for (int m = 0; m < M; ++m) {
+            float4 acc = gbar[(size_t)m * slot_cap + slot];
+            for (int k = 0; k < layer_sets; ++k)
+                for (int grp = 0; grp < slices; ++grp) {
+                    const float *p = P + ((size_t)(m * n_groups + k * per_set + grp) * slot_cap + slot) * 3;
+                    acc.x += p[0]; acc.y += p[1]; acc.z += p[2];
+                }
+            gbar[(size_t)m * slot_cap + slot] = acc;
+        }
+}
+
 // (every chain of the batch in one class -- the usual case: one thread per slot of the whole batch)
 __global__ void k_reduce_gbar_groups_uniform(int M, int n_groups, const int *__restrict__ counters, float4 *__restrict__ gbar,
                                              long long gbar_stride) {
@@ -354,23 +389,25 @@ __global__ void k_reduce_gbar_groups_uniform(int M, int n_groups, const int *__r
 }
 
 __global__ void __launch_bounds__(256)
-k_reduce_gbar_groups(int M, int n_groups, GraphView G, const int *__restrict__ counters, float4 *__restrict__ gbar,
+k_reduce_gbar_groups(int M, int n_groups, int layer_sets, GraphView G, const int *__restrict__ counters, float4 *__restrict__ gbar,
                      long long gbar_stride) {
     if (counters[2]) return;
     const int b = blockIdx.x;   // (x: no 65 535 limit on the chain count)
     if (!G.act.chain(b)) return;
     const int cls = G.chain_class[b];
-    const int ng = cls == EDGE_BCLASS_FS16 ? 8 : cls == EDGE_BCLASS_FS8 ? 16 : 1;   // buffers the chain's reverse kernels wrote (edge_class_groups)
-    if (ng == 1) return;
+    const int slices = cls == EDGE_BCLASS_FS16 ? 8 : cls == EDGE_BCLASS_FS8 ? 16 : 1;   // buffers the chain's reverse kernels wrote per layer set
+    if (slices == 1) return;
+    const int per_set = n_groups / layer_sets;   // group index of layer set k, slice f: k * per_set + f
     const int s0 = G.row_start[G.cfg_start[b]], s1 = G.row_start[G.cfg_start[b + 1]];
     for (int slot = s0 + blockIdx.y * blockDim.x + threadIdx.x; slot < s1; slot += gridDim.y * blockDim.x)
         for (int m = 0; m < M; ++m) {
             float4 *g0 = gbar + (size_t)(m * n_groups) * gbar_stride + slot;
             float4 acc = *g0;
-            for (int grp = 1; grp < ng; ++grp) {
-                const float4 v = g0[(size_t)grp * gbar_stride];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z;
-            }
+            for (int k = 0; k < layer_sets; ++k)
+                for (int grp = k ? 0 : 1; grp < slices; ++grp) {
+                    const float4 v = g0[(size_t)(k * per_set + grp) * gbar_stride];
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z;
+                }
             *g0 = acc;
         }
 }
@@ -471,10 +508,12 @@ k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const 
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 // partial edge-gradient buffers per model: as many as the widest class present writes (one without the reverse edge kernels)
+static int gbar_layer_sets(const vssr_handle *h) { return h->gbar_mode == 2 ? h->num_conv - 1 : h->gbar_mode == 1 && h->num_conv > 2 ? h->num_conv - 1 : 1; }
 int painn_gbar_groups(const vssr_handle *h) {
     if (h->num_conv < 2) return 1;
-    return h->n_bclass[EDGE_BCLASS_FS8] ? edge_class_groups(EDGE_BCLASS_FS8)
-                                        : h->n_bclass[EDGE_BCLASS_FS16] ? edge_class_groups(EDGE_BCLASS_FS16) : 1;
+    const int per_set = h->n_bclass[EDGE_BCLASS_FS8] ? edge_class_groups(EDGE_BCLASS_FS8)
+                                                     : h->n_bclass[EDGE_BCLASS_FS16] ? edge_class_groups(EDGE_BCLASS_FS16) : 1;
+    return per_set > 1 ? per_set * gbar_layer_sets(h) : 1;
 }
 
 int painn_alloc_state(vssr_handle *h) {
@@ -503,7 +542,10 @@ int painn_alloc_state(vssr_handle *h) {
     if (h->upd_save && readout_mfma_supported(h->readout_hidden) &&
         h->d_upd_save.ensure(update_save_bytes((int)N, (int)M) * L))
         return set_err(h, VSSR_E_NOMEM, "forward intermediates of the update blocks: out of device memory");
-    if (h->d_gbar.ensure(sizeof(float4) * M * (size_t)painn_gbar_groups(h) * (size_t)h->slot_cap))
+    const size_t groups = (size_t)painn_gbar_groups(h);
+    const bool compact = h->gbar_mode == 2 && groups > 1;
+    if (h->d_gbar.ensure(sizeof(float4) * M * (compact ? 1 : groups) * (size_t)h->slot_cap) ||
+        (compact && h->d_gpart.ensure(sizeof(float) * 3 * M * groups * (size_t)h->slot_cap + 256)))
         return set_err(h, VSSR_E_NOMEM, "edge-gradient buffer: out of device memory");
     sv.gbar = h->d_gbar.as<float4>();
     if (h->d_energy.ensure(sizeof(float) * h->n_cfg) || h->d_energy_std.ensure(sizeof(float) * h->n_cfg) ||
@@ -560,6 +602,9 @@ int painn_run(vssr_handle *h, uint32_t want) {
     // class.  Layer 0 is factorised by species (painn_l0.hip) or, with more than 8 species / VSSR_L0_FACTORISE=0, runs the
     // gather kernels for every chain (its v input is zero and only two filter sections matter).
     const int n_groups = painn_gbar_groups(h);   // partial gbar buffers per model
+    const int layer_sets = n_groups > 1 ? gbar_layer_sets(h) : 1;
+    const bool compact = h->gbar_mode == 2 && n_groups > 1;   // 12-byte partial records in d_gpart, final float4 buffer per model
+    const int fin_groups = compact ? 1 : n_groups;             // buffers between two models in the final float4 array
     const int *cls_list[EDGE_MFMA_CLASSES];
     const int *bcls_list[2];
     {
@@ -653,24 +698,26 @@ int painn_run(vssr_handle *h, uint32_t want) {
             P.begin((l == 0 && l0_fact) ? KC_L0_BWD : KC_EDGE_BWD, st);
             int accumulate = (l != L - 1);
             if (l == 0 && l0_fact) {
-                rc = l0_run_reverse(h, G, (int)(L == 1), sbar_msg_l, sv.vbar_msg, sv.gbar, (long long)h->slot_cap,
-                                    n_groups);
+                rc = l0_run_reverse(h, G, (int)(L == 1), (int)compact, sbar_msg_l, sv.vbar_msg, sv.gbar, (long long)h->slot_cap,
+                                    fin_groups);
                 if (rc) return rc;
             } else if (l == 0)   // adds into partial buffer 0 of every model (model stride = n_groups buffers)
                 hipLaunchKernelGGL(k_edge_bwd<true>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                    h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
                                    sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
-                                   (long long)h->slot_cap * n_groups, -1);
+                                   (long long)h->slot_cap * fin_groups, -1, (int)compact);
             else {
                 for (int cls = 0; cls < 2; ++cls)
-                    launch_edge_bwd_mfma(st, cls, N, bcls_list[cls], h->n_bclass[cls], M, l, (int)(l == L - 1), h->max_bclass_atoms[cls],
-                                         MW, G, counters, (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l], sbar_msg_l,
-                                         sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar, (long long)h->slot_cap, n_groups);
+                    launch_edge_bwd_mfma(st, cls, N, bcls_list[cls], h->n_bclass[cls], M, l, (int)(l == L - 1 || layer_sets > 1),
+                                         h->max_bclass_atoms[cls], MW, G, counters, (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l],
+                                         sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar,
+                                         compact ? h->d_gpart.as<float>() : reinterpret_cast<float *>(sv.gbar), (long long)h->slot_cap,
+                                         n_groups, layer_sets > 1 ? (L - 1 - l) * (n_groups / layer_sets) : 0, compact ? 3 : 4);
                 if (n_gather)   // partial buffer 0 of every model
                     hipLaunchKernelGGL(k_edge_bwd<false>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                        h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
                                        sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
-                                       (long long)h->slot_cap * n_groups, (int)EDGE_BCLASS_GATHER);
+                                       (long long)h->slot_cap * fin_groups, (int)EDGE_BCLASS_GATHER, 0);
             }
             P.end(st);
             if (l > 0 && !fused) {
@@ -682,18 +729,23 @@ int painn_run(vssr_handle *h, uint32_t want) {
     }
     P.begin(KC_FINALIZE, st);
     if (want & VSSR_WANT_FORCES) {
-        if (n_groups > 1) {
+        if (compact) {
+            const int uni = h->active_mask ? 0 : h->n_bclass[EDGE_BCLASS_FS16] == h->n_cfg ? 8 : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? 16 : 0;
+            const dim3 grid = uni ? dim3((unsigned)((h->slot_cap + 255) / 256), 1) : dim3(h->n_cfg, 12);
+            hipLaunchKernelGGL(k_reduce_gpart, grid, dim3(256), 0, st, M, n_groups, layer_sets, G, counters, h->d_gpart.as<float>(),
+                               sv.gbar, (long long)h->slot_cap, uni);
+        } else if (n_groups > 1) {
             const int cls_only = h->n_bclass[EDGE_BCLASS_FS16] == h->n_cfg ? EDGE_BCLASS_FS16
                                  : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? EDGE_BCLASS_FS8 : -1;
-            if (cls_only >= 0 && !h->active_mask)   // (switched-off chains keep their reduced gradients: the per-chain form skips them)
+            if (cls_only >= 0 && !h->active_mask && (layer_sets == 1 || n_gather == 0))   // (switched-off chains keep their reduced gradients: the per-chain form skips them)
                 hipLaunchKernelGGL(k_reduce_gbar_groups_uniform, dim3((unsigned)((h->slot_cap + 255) / 256)), dim3(256), 0, st, M,
                                    n_groups, counters, sv.gbar, (long long)h->slot_cap);
             else
-                hipLaunchKernelGGL(k_reduce_gbar_groups, dim3(h->n_cfg, 12), dim3(256), 0, st, M, n_groups, G, counters, sv.gbar,
+                hipLaunchKernelGGL(k_reduce_gbar_groups, dim3(h->n_cfg, 12), dim3(256), 0, st, M, n_groups, layer_sets, G, counters, sv.gbar,
                                    (long long)h->slot_cap);
         }
         hipLaunchKernelGGL(k_finalize_forces, dim3((N + 3) / 4), dim3(256), 0, st, N, M, G, counters, sv.gbar,
-                           (long long)h->slot_cap * n_groups, h->units_per_ev, h->d_forces.as<float>(),
+                           (long long)h->slot_cap * fin_groups, h->units_per_ev, h->d_forces.as<float>(),
                            h->d_forces_std.as<float>());
     }
     hipLaunchKernelGGL(k_finalize_energy, dim3(h->n_cfg), dim3(256), 0, st, N, M, h->active_mask, G.cfg_start, Z, sv.e_atom,

@@ -537,7 +537,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 const int *__restrict__ list, int n_list,
                 const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
                 const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
-                float4 *__restrict__ gbar, long long gbar_stride, int n_groups) {
+                float *__restrict__ gbar, long long gbar_stride, int n_groups, int group_off, int rec) {
     using LY = EdgeGeo<NF>;
     constexpr int FS = LY::FS, NSG = LY::NSLICE, NT = LY::NT, ROWB = LY::ROWB, BWD_THREADS = 64 * WAVES;
     typedef float fvx __attribute__((ext_vector_type(NF)));   // the lane's NF features (ext vectors: arrays of HIP float4 stay in scratch memory)
@@ -554,7 +554,9 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     const int last_slot = max(G.row_start[a0 + Nc] - 1, 0);
     const u32x4 sel = {0u, 0u, 0u, fq == (p & 3) ? 0x3C00u : 0u};   // selector tile (filter_tiles_sel): 1.0 at K entry 6
     const LayerW &W = MW[m].layer[l];
-    float4 *gb = gbar + (size_t)(m * n_groups + fs) * gbar_stride;
+    // partial edge-gradient buffer of this (model, layer set, slice): rec floats per slot -- 4 (float4 records, group 0 doubles
+    // as the final buffer) or 3 (compact per-layer buffers, reduced into the separate final buffer by k_reduce_gpart)
+    float *gb = gbar + (size_t)(m * n_groups + group_off + fs) * gbar_stride * rec;
     const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;   // quad-interleaved tables, see forward
     const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 4 + e;
     const int zero_quad = (zero_slot + 1) / 4 - 1;
@@ -677,7 +679,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     // buffer ph is consumed by the step of parity ph and refilled right after that step's MFMAs for the step after next
     // (~1.6 steps for a load to arrive).  The old partial edge gradient of the slot (written by the previous layer for
     // this lane's slot; a slot is visited once per launch, so the early read is safe) travels with the tables.
-    float *gcomp = reinterpret_cast<float *>(gb) + gcomp_id;   // component this row ends up with (3: none)
+    float *gcomp = gb + min(gcomp_id, rec - 1);   // component this row ends up with (id 3: none -- that row only ever writes the spare entry)
     u32x4 rq[2][2], dq[2][2];
     float gold[2] = {0.f, 0.f};
     auto fetch = [&](int buf, int quad_first_slot, bool valid) {
@@ -686,9 +688,9 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
         dq[buf][0] = dp[0]; dq[buf][1] = dp[16];
 #ifdef ABL_NO_GBAR   // ablation build (tools/build_variant.sh): same instruction stream, the partial edge-gradient buffers stay in L2
-        if (!FIRST) gold[buf] = gcomp[(size_t)min((quad_first_slot + e) & 1023, last_slot) * 4];
+        if (!FIRST) gold[buf] = gcomp[(size_t)min((quad_first_slot + e) & 1023, last_slot) * rec];
 #else
-        if (!FIRST) gold[buf] = gcomp[(size_t)min(quad_first_slot + e, last_slot) * 4];
+        if (!FIRST) gold[buf] = gcomp[(size_t)min(quad_first_slot + e, last_slot) * rec];
 #endif
     };
     {
@@ -795,9 +797,9 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 // store is unconditional and the memory-operation count of a step does not depend on the path
                 const bool real = gcomp_id < 3 && real_slot && invd > 0.f;
 #ifdef ABL_NO_GBAR
-                gcomp[(size_t)(real ? (my_slot & 1023) : zero_slot) * 4] = gsum + gold_cur;
+                gcomp[(size_t)(real ? (my_slot & 1023) : zero_slot) * rec] = gsum + gold_cur;
 #else
-                gcomp[(size_t)(real ? my_slot : zero_slot) * 4] = gsum + gold_cur;
+                gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;
 #endif
             }
             ++bw.t;
@@ -840,12 +842,12 @@ int edge_class_groups(int bcls) { return bcls == EDGE_BCLASS_FS16 ? EdgeGeo<4>::
 void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
-                          float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups) {
+                          float *phibar, float *vbar_in, float *gbar, long long gbar_stride, int n_groups, int group_off, int rec) {
     if (n_list <= 0) return;
 #define LAUNCH_BWD(NF, FIRST, WAVES)                                                                                             \
     hipLaunchKernelGGL((k_edge_bwd_mfma<NF, FIRST, WAVES>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), dim3(64 * WAVES), \
                        (edge_bwd_lds_bytes_t<NF, WAVES>(max_atoms)), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, \
-                       v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups)
+                       v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups, group_off, rec)
 #define LAUNCH_BWD_W(NF, FIRST)                                                                                                  \
     do {                                                                                                                         \
         if (2 * edge_bwd_lds_bytes_t<NF, 4>(max_atoms) <= 160 * 1024) LAUNCH_BWD(NF, FIRST, 4); else LAUNCH_BWD(NF, FIRST, 8);   \

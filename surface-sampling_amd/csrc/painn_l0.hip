@@ -238,13 +238,16 @@ k_l0_q16(int N, int nz, ActiveView av, const int *__restrict__ counters, const i
 // 1.15 KB gather per slot from a different atom (the previous formulation: 3.3 GB of L2 gathers per launch).  Same
 // distance, hence the same radial values; unit vector negated; the result is written to slot rev[e'].
 __global__ void __launch_bounds__(256)
-k_l0_bwd(int N, int M, int nz, int first_write, int excl_vol, GraphView G, const int *__restrict__ counters,
+k_l0_bwd(int N, int M, int nz, int first_write, int fresh_mfma, int excl_vol, GraphView G, const int *__restrict__ counters,
          const float *__restrict__ Q, float4 *__restrict__ gbar, long long gbar_group_stride, int n_groups) {
     extern __shared__ __attribute__((aligned(16))) float qs_all[];   // [wave][m][species][4][24]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane >> 2, kq = lane & 3;
     const int n = blockIdx.x * (blockDim.x >> 6) + wave;
     if (n >= N || counters[2] || !G.act.atom(n)) return;
     const int per_model = nz * TBLK;
+    // nothing to add to: the first write of the launch sequence, or (compact partial buffers) a chain whose reverse neighbor
+    // kernels wrote elsewhere -- all slots of a row belong to the row owner's chain, and so do their reverse slots
+    const bool fw = first_write || (fresh_mfma && G.chain_class[G.atom_cfg[n]] != EDGE_BCLASS_GATHER);
     float *qs = qs_all + (size_t)wave * M * per_model;
     for (int m = 0; m < M; ++m) {
         const float4 *src = reinterpret_cast<const float4 *>(Q + ((size_t)m * N + n) * per_model);
@@ -305,7 +308,7 @@ k_l0_bwd(int N, int M, int nz, int first_write, int excl_vol, GraphView G, const
                 float g1 = fmaf(-db, uy, (by - dotu * uy) * invd);
                 float g2 = fmaf(-db, uz, (bz - dotu * uz) * invd);
                 float4 *gb = gbar + (size_t)m * n_groups * gbar_group_stride;   // group 0 of model m
-                if (!first_write) {
+                if (!fw) {
                     const float4 old = gb[re];
                     g0 += old.x; g1 += old.y; g2 += old.z;
                 }
@@ -405,7 +408,7 @@ int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_ms
     return VSSR_OK;
 }
 
-int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const float *sbar_msg, const float *vbar_msg,
+int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, int fresh_mfma, const float *sbar_msg, const float *vbar_msg,
                    float4 *gbar, long long gbar_stride, int n_groups) {
     const int N = h->n_atoms, M = h->n_models, nz = h->l0_nz;
     hipStream_t st = h->stream;
@@ -414,7 +417,7 @@ int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const fl
                        h->d_zlist.as<int>(), h->d_l0At.as<uint4>(), h->n_embed, sbar_msg, vbar_msg, h->d_l0Q.as<float>());
     if (sizeof(float) * 4 * M * nz * TBLK > 48 * 1024)   // (3 models x 3 species: 13.8 KB)
         VSSR_HIP(h, hipFuncSetAttribute((const void *)k_l0_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(k_l0_bwd, dim3((N + 3) / 4), dim3(256), sizeof(float) * 4 * M * nz * TBLK, st, N, M, nz, first_write,
+    hipLaunchKernelGGL(k_l0_bwd, dim3((N + 3) / 4), dim3(256), sizeof(float) * 4 * M * nz * TBLK, st, N, M, nz, first_write, fresh_mfma,
                        h->excl_vol, G, h->d_counters.as<int>(), h->d_l0Q.as<float>(), gbar, gbar_stride, n_groups);
     return VSSR_OK;
 }

@@ -238,6 +238,12 @@ struct vssr_handle {
     vssr::StateView sv;
     vssr::DevBuf d_gbar;
     vssr::DevBuf d_upd_save;     // forward intermediates of every update block for the reverse pass (update_save_bytes per layer)
+    // Partial edge gradients of the reverse neighbor pass (VSSR_GBAR_MODE):
+    //   0  one set of float4 buffers per model, the second reverse layer adds to it (read-modify-write), group 0 is reduced in place
+    //   1  one set per reverse layer (no read-modify-write: TA relief in the second launch), float4 records
+    //   2  one set per reverse layer, 12-byte records in a separate buffer, reduced into the final float4 buffer  (default)
+    int gbar_mode = 2;
+    vssr::DevBuf d_gpart;        // mode 2: [M][groups][slot_cap][3] floats
     int debug_keep = 0;          // VSSR_DEBUG_KEEP=1: also materialise what only vssr_debug_read looks at (the last block's vector output)
     int upd_save = 0;            // VSSR_UPD_SAVE=1: update_fwd stores its intermediates and the reverse kernel loads them instead of
                                  // recomputing (measured: update_bwd 2.45 -> 2.21, update_fwd 1.30 -> 1.57..1.60 ms / step: no gain;
@@ -300,7 +306,8 @@ void l0_pack_tables(const float *A, int n_embed, unsigned *A16, unsigned *At16);
 size_t l0_packed_dwords(int n_embed);
 int l0_mfma_init(vssr_handle *h);
 int l0_run_forward(vssr_handle *h, const GraphView &G, float *s_msg, float *v_msg);
-int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, const float *sbar_msg, const float *vbar_msg,
+// fresh_mfma: chains of the matrix-pipe classes have nothing in the final buffer yet (overwrite), gather-class chains accumulate
+int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, int fresh_mfma, const float *sbar_msg, const float *vbar_msg,
                    float4 *gbar, long long gbar_stride, int n_groups);
 // LDS-slice + MFMA edge stages (painn_edge_mfma.hip)
 int edge_mfma_init(vssr_handle *h);
@@ -314,7 +321,7 @@ int edge_class_groups(int cls);       // partial edge-gradient buffers a chain o
 void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
-                          float *phibar, float *vbar_in, float4 *gbar, long long gbar_stride, int n_groups);
+                          float *phibar, float *vbar_in, float *gbar, long long gbar_stride, int n_groups, int group_off, int rec);
 void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int max_atoms, const ModelW *MW,
                           const GraphView &G, const int *counters, int zero_slot, const float *s_in, const float *v_in,
                           const float *phi, float *s_msg, float *v_msg);

@@ -754,7 +754,7 @@ def test_stored_forward_intermediates_give_identical_results(golden, monkeypatch
     r1, r0 = e1.evaluate(chains), e0.evaluate(chains)
     for k in ("energy", "energy_std", "energy_models"):
         assert np.array_equal(r1[k], r0[k]), k
-    assert np.abs(r1["forces"] - r0["forces"]).max() <= 5e-6 and np.abs(r1["forces_std"] - r0["forces_std"]).max() <= 5e-6
+    assert np.abs(r1["forces"] - r0["forces"]).max() <= 2e-5 and np.abs(r1["forces_std"] - r0["forces_std"]).max() <= 2e-5   # (a few ulp of 30 eV/A forces)
     e_only = e1.evaluate(chains, want=backend.WANT_ENERGY)          # energy-only runs store nothing
     assert np.array_equal(e_only["energy"], r0["energy"])
     e1.close()
