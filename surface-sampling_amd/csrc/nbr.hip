@@ -336,7 +336,7 @@ template <int NZ>
 __global__ void __launch_bounds__(64) k_edge_geom(int n_atoms, const int *__restrict__ row_start, const int *__restrict__ atom_cfg,
                             const int *__restrict__ cfg_start, const float4 *__restrict__ edge,
                             const int *__restrict__ counters, float rc, float excl_sigma, int excl_power,
-                            float4 *__restrict__ erec, float *__restrict__ rho, float *__restrict__ drho,
+                            float4 *__restrict__ erec, float *__restrict__ rho,
                             float2 *__restrict__ dist2, uint4 *__restrict__ rho16, uint4 *__restrict__ drho16,
                             const int *__restrict__ Z, const int *__restrict__ zmap, unsigned char *__restrict__ zslot,
                             float *__restrict__ e_excl, const unsigned char *__restrict__ active, float *__restrict__ l0T) {
@@ -352,46 +352,19 @@ __global__ void __launch_bounds__(64) k_edge_geom(int n_atoms, const int *__rest
     if (active && !active[atom_cfg[i]]) return;
     const int a0 = cfg_start[atom_cfg[i]];
     const int e0 = row_start[i], e1 = row_start[i + 1];
-    const float alpha = 3.14159265358979323846f / rc;
     float ex = 0.f;   // excluded-volume energy of the centre: sum over its slots of (sigma / d)^p
     for (int t = threadIdx.x; t < (e1 - e0) * 4; t += blockDim.x) {
         const int slot = e0 + (t >> 2), kq = t & 3;
         const float4 ed = edge[slot];
         const int j = __float_as_int(ed.w);
-        const bool valid = j >= 0;
-        const float d2 = fmaf(ed.z, ed.z, fmaf(ed.y, ed.y, ed.x * ed.x));
-        const float d = valid ? sqrtf(d2) : 1.f;
-        const float inv = valid ? 1.f / d : 0.f;
-        float s1, c1;
-        sincosf(alpha * d, &s1, &c1);
-        const bool inside = valid && d < rc;
-        const float fc = inside ? 0.5f * (c1 + 1.f) : 0.f;
-        const float dfc = inside ? -0.5f * alpha * s1 : 0.f;
-        const float s2 = 2.f * s1 * c1, c2 = fmaf(c1, c1, -s1 * s1);
-        const float s3 = fmaf(s2, c1, c2 * s1), c3 = fmaf(c2, c1, -s2 * s1);
-        const float s4 = 2.f * s2 * c2, c4 = fmaf(c2, c2, -s2 * s2);
-        float sn = kq == 0 ? s1 : kq == 1 ? s2 : kq == 2 ? s3 : s4;
-        float cn = kq == 0 ? c1 : kq == 1 ? c2 : kq == 2 ? c3 : c4;
-        float nf = (float)(kq + 1);
-        float r[6], dr[6];   // this quarter's values; stored below as three 8-byte pieces per table (24-byte records)
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-            const float rb = sn * inv;
-            r[ks] = rb * fc;
-            dr[ks] = fmaf(nf * alpha * cn * inv - rb * inv, fc, rb * dfc);
-            const float sn2 = fmaf(sn, c4, cn * s4), cn2 = fmaf(cn, c4, -sn * s4);
-            sn = sn2; cn = cn2; nf += 4.f;
-        }
-        r[5] = fc;      // envelope (bias column) replicated in every quarter
-        dr[5] = dfc;
-        {
+        float r[6], dr[6], inv;   // this quarter's values (radial_quarter, vssr_internal.h)
+        bool valid;
+        radial_quarter(ed, kq, rc, r, dr, inv, valid);
+        const float fc = r[5], dfc = dr[5];
+        if (rho) {   // fp32 table: only the layer-0 kernel of batches with more than 4 species reads it (painn_l0.hip k_l0_table)
             float2 *rg = reinterpret_cast<float2 *>(rho + (size_t)slot * 24 + kq * 6);
-            float2 *dg = reinterpret_cast<float2 *>(drho + (size_t)slot * 24 + kq * 6);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                rg[q] = make_float2(r[2 * q], r[2 * q + 1]);
-                dg[q] = make_float2(dr[2 * q], dr[2 * q + 1]);
-            }
+            for (int q = 0; q < 3; ++q) rg[q] = make_float2(r[2 * q], r[2 * q + 1]);
         }
         {
             const float rv[5] = {r[0], r[1], r[2], r[3], r[4]}, dv[5] = {dr[0], dr[1], dr[2], dr[3], dr[4]};
@@ -416,7 +389,7 @@ __global__ void __launch_bounds__(64) k_edge_geom(int n_atoms, const int *__rest
         }
         if (kq == 0) {
             zslot[slot] = (unsigned char)(zi >= 0 ? zi : 255);
-            erec[slot] = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, __int_as_float(valid ? j - a0 : 0));
+            if (erec) erec[slot] = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, __int_as_float(valid ? j - a0 : 0));
             const float rep = valid ? powf(excl_sigma * inv, (float)excl_power) : 0.f;
             ex += rep;
             dist2[slot] = valid ? make_float2(inv, -(float)excl_power * rep * inv) : make_float2(-1.f, 0.f);
@@ -507,8 +480,12 @@ int build_neighbors(vssr_handle *h, double cutoff) {
                        h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>(),
                        ActiveView{h->active_mask, h->d_atom_cfg.as<int>()});
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
-        if (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap) ||
-            h->d_drho.ensure(sizeof(float) * 24 * h->slot_cap) || h->d_dist.ensure(sizeof(float2) * h->slot_cap) ||
+        // layer-0 factorisation with at most 4 species: its T blocks are accumulated by k_edge_geom (h->l0T_by_geom); with more species
+        // a separate kernel builds them from the fp32 table and the per-slot unit vectors, which are only written for it
+        const int nzf = (h->l0_enabled && h->l0_nz >= 1 && h->l0_nz <= 4) ? h->l0_nz : 0;
+        const bool want_f32 = h->l0_enabled && nzf == 0;
+        if ((want_f32 && (h->d_erec.ensure(sizeof(float4) * h->slot_cap) || h->d_rho.ensure(sizeof(float) * 24 * h->slot_cap))) ||
+            h->d_dist.ensure(sizeof(float2) * h->slot_cap) ||
             h->d_rho16.ensure(sizeof(uint4) * 8 * h->slot_cap) || h->d_drho16.ensure(sizeof(uint4) * 8 * h->slot_cap) ||
             h->d_zslot.ensure((size_t)h->slot_cap) || h->d_bundle.ensure(sizeof(int4) * (size_t)n) ||
             h->d_excl.ensure(sizeof(float) * (size_t)n))
@@ -516,28 +493,24 @@ int build_neighbors(vssr_handle *h, double cutoff) {
         // the last slot of the capacity is never used by the CSR (counters[2] flags slots > cap - 64): it is the
         // all-zero table entry that exhausted lanes of the edge kernels read
         // (nothing ever writes them: cleared once per allocation / capacity, not once per evaluation)
-        const void *tabs[4] = {h->d_rho.as<float>(), h->d_drho.as<float>(), h->d_rho16.as<uint4>(), h->d_drho16.as<uint4>()};
+        const void *tabs[2] = {h->d_rho16.as<uint4>(), h->d_drho16.as<uint4>()};
         bool cleared = h->zero_entry_cap == h->slot_cap;
-        for (int k = 0; k < 4; ++k) cleared = cleared && h->zero_entry_tab[k] == tabs[k];
+        for (int k = 0; k < 2; ++k) cleared = cleared && h->zero_entry_tab[k] == tabs[k];
         if (!cleared) {
-            VSSR_HIP(h, hipMemsetAsync(h->d_rho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
-            VSSR_HIP(h, hipMemsetAsync(h->d_drho.as<float>() + 24 * (size_t)(h->slot_cap - 1), 0, 24 * sizeof(float), st));
             // fp16 tables: the last complete QUAD of the capacity is the all-zero entry (quad-interleaved layout, f16_unit)
             VSSR_HIP(h, hipMemsetAsync(h->d_rho16.as<uint4>() + 32 * (size_t)((h->slot_cap >> 2) - 1), 0, 32 * sizeof(uint4), st));
             VSSR_HIP(h, hipMemsetAsync(h->d_drho16.as<uint4>() + 32 * (size_t)((h->slot_cap >> 2) - 1), 0, 32 * sizeof(uint4), st));
             h->zero_entry_cap = h->slot_cap;
-            for (int k = 0; k < 4; ++k) h->zero_entry_tab[k] = tabs[k];
+            for (int k = 0; k < 2; ++k) h->zero_entry_tab[k] = tabs[k];
         }
-        // layer-0 factorisation with at most 4 species: its T blocks are accumulated by k_edge_geom (h->l0T_by_geom)
-        const int nzf = (h->l0_enabled && h->l0_nz >= 1 && h->l0_nz <= 4) ? h->l0_nz : 0;
         if (nzf && h->d_l0T.ensure(sizeof(float) * (size_t)n * nzf * 96))
             return set_err(h, VSSR_E_NOMEM, "layer-0 factorisation buffers: out of device memory");
         h->l0T_by_geom = nzf > 0;
 #define LAUNCH_GEOM(NZ)                                                                                                          \
         hipLaunchKernelGGL(k_edge_geom<NZ>, dim3(n), dim3(64), 0, st, n, h->d_row_start.as<int>(), h->d_atom_cfg.as<int>(),      \
                            h->d_cfg_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), h->cutoff,               \
-                           h->excl_sigma, h->excl_power, h->d_erec.as<float4>(), h->d_rho.as<float>(),                         \
-                           h->d_drho.as<float>(), h->d_dist.as<float2>(), h->d_rho16.as<uint4>(),                              \
+                           h->excl_sigma, h->excl_power, want_f32 ? h->d_erec.as<float4>() : (float4 *)nullptr,                \
+                           want_f32 ? h->d_rho.as<float>() : (float *)nullptr, h->d_dist.as<float2>(), h->d_rho16.as<uint4>(), \
                            h->d_drho16.as<uint4>(), h->d_Z.as<int>(), h->d_zmap.as<int>(), h->d_zslot.as<unsigned char>(),     \
                            h->d_excl.as<float>(), h->active_mask, nzf ? h->d_l0T.as<float>() : (float *)nullptr)
         switch (nzf) {

@@ -581,7 +581,6 @@ int painn_run(vssr_handle *h, uint32_t want) {
     G.rev = h->d_rev.as<int>();
     G.erec = h->d_erec.as<float4>();
     G.rho = h->d_rho.as<float>();
-    G.drho = h->d_drho.as<float>();
     G.dist2 = h->d_dist.as<float2>();
     G.rho16 = h->d_rho16.as<uint4>();
     G.drho16 = h->d_drho16.as<uint4>();

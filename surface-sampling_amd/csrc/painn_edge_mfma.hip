@@ -796,7 +796,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 // three rows of a real slot write one component each; every other lane writes the spare entry, so the
                 // store is unconditional and the memory-operation count of a step does not depend on the path
                 const bool real = gcomp_id < 3 && real_slot && invd > 0.f;
-#ifdef ABL_NO_GBAR
+#if defined(ABL_NO_GSTORE)   // ablation: the store only happens for a value the arithmetic never produces
+                if (gsum == 1.2345e33f) gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;
+#elif defined(ABL_ROW3_NO_GSTORE)   // ablation: the row without a component does not store
+                if (gcomp_id < 3) gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;
+#elif defined(ABL_NO_GBAR)
                 gcomp[(size_t)(real ? (my_slot & 1023) : zero_slot) * rec] = gsum + gold_cur;
 #else
                 gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;

@@ -238,7 +238,7 @@ k_l0_q16(int N, int nz, ActiveView av, const int *__restrict__ counters, const i
 // 1.15 KB gather per slot from a different atom (the previous formulation: 3.3 GB of L2 gathers per launch).  Same
 // distance, hence the same radial values; unit vector negated; the result is written to slot rev[e'].
 __global__ void __launch_bounds__(256)
-k_l0_bwd(int N, int M, int nz, int first_write, int fresh_mfma, int excl_vol, GraphView G, const int *__restrict__ counters,
+k_l0_bwd(int N, int M, int nz, int first_write, int fresh_mfma, int excl_vol, float rc, GraphView G, const int *__restrict__ counters,
          const float *__restrict__ Q, float4 *__restrict__ gbar, long long gbar_group_stride, int n_groups) {
     extern __shared__ __attribute__((aligned(16))) float qs_all[];   // [wave][m][species][4][24]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane >> 2, kq = lane & 3;
@@ -260,18 +260,17 @@ k_l0_bwd(int N, int M, int nz, int first_write, int fresh_mfma, int excl_vol, Gr
     for (int eb = e0; eb < e1; eb += 16) {
         const int e = min(eb + sl, e1 - 1);
         const bool live = eb + sl < e1;
-        const float4 er = G.erec[e];
+        const float4 ed = G.edge[e];
         const float2 dd = G.dist2[e];
         const int zi = G.zslot[e];          // species index of c' (255: pad)
         const int re = G.rev[e];            // slot of (c' -> n)
-        const float *rp = G.rho + (size_t)e * KP + kq * 6, *dp = G.drho + (size_t)e * KP + kq * 6;
-        float rho[6], drho[6];   // 24-byte records, 8-byte aligned
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float2 r2 = reinterpret_cast<const float2 *>(rp)[k], d2 = reinterpret_cast<const float2 *>(dp)[k];
-            rho[2 * k] = r2.x; rho[2 * k + 1] = r2.y; drho[2 * k] = d2.x; drho[2 * k + 1] = d2.y;
-        }
-        const bool real = live && zi < nz && re >= 0 && dd.x > 0.f;
+        // this quarter's radial values, rebuilt from the edge vector exactly as k_edge_geom computed them (radial_quarter): 16 bytes
+        // per slot instead of the 192 bytes of two fp32 tables that no other kernel reads
+        float rho[6], drho[6], inv;
+        bool valid;
+        radial_quarter(ed, kq, rc, rho, drho, inv, valid);
+        const float4 er = make_float4(ed.x * inv, ed.y * inv, ed.z * inv, 0.f);
+        const bool real = live && zi < nz && re >= 0 && valid;
         const int zq = zi < nz ? zi : 0;
         for (int m = 0; m < M; ++m) {
             const float *q = qs + m * per_model + zq * TBLK + kq * 6;
@@ -302,7 +301,7 @@ k_l0_bwd(int N, int M, int nz, int first_write, int fresh_mfma, int excl_vol, Gr
                 const float ux = -er.x, uy = -er.y, uz = -er.z;   // unit vector c' -> n; the edge (n -> c') has -u
                 float db = d0 - (dx * ux + dy * uy + dz * uz);
                 if (excl_vol) db += dd.y;
-                const float invd = dd.x;
+                const float invd = inv;
                 const float dotu = fmaf(bz, uz, fmaf(by, uy, bx * ux));
                 float g0 = fmaf(-db, ux, (bx - dotu * ux) * invd);
                 float g1 = fmaf(-db, uy, (by - dotu * uy) * invd);
@@ -418,7 +417,7 @@ int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, int fres
     if (sizeof(float) * 4 * M * nz * TBLK > 48 * 1024)   // (3 models x 3 species: 13.8 KB)
         VSSR_HIP(h, hipFuncSetAttribute((const void *)k_l0_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k_l0_bwd, dim3((N + 3) / 4), dim3(256), sizeof(float) * 4 * M * nz * TBLK, st, N, M, nz, first_write, fresh_mfma,
-                       h->excl_vol, G, h->d_counters.as<int>(), h->d_l0Q.as<float>(), gbar, gbar_stride, n_groups);
+                       h->excl_vol, h->cutoff, G, h->d_counters.as<int>(), h->d_l0Q.as<float>(), gbar, gbar_stride, n_groups);
     return VSSR_OK;
 }
 

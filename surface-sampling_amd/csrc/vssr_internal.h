@@ -70,9 +70,8 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     const float4 *edge;      // [slots] {r_x, r_y, r_z, bitcast(j)} ; j < 0 marks a pad slot
     const int *rev;          // [slots] slot of the reverse edge (j -> i, -S)
     // per-slot geometry tables, computed once per evaluation and shared by every layer / model / feature slice
-    const float4 *erec;      // [slots] {u_x, u_y, u_z, bitcast(j local to its chain)} ; pads: u = 0, j = 0
-    const float *rho;        // [slots][4][6]  radial basis * envelope in MFMA A-fragment order: [kq][ks] = rho_{kq+4ks}
-    const float *drho;       // [slots][4][6]  d rho / d d, same order
+    const float4 *erec;      // [slots] {u_x, u_y, u_z, bitcast(j local to its chain)} ; pads: u = 0, j = 0 (same condition as rho, else null)
+    const float *rho;        // [slots][4][6]  radial basis * envelope, [kq][ks] = rho_{kq+4ks}: only for the layer-0 kernel of batches with > 4 species (else null)
     const uint4 *rho16;      // operand-ready 2-way fp16 split of rho, quad-interleaved: [slot / 4][piece h, l][quarter][slot % 4] x 16 B (nbr.hip f16_unit)
     const uint4 *drho16;     // same for d rho / d d
     const unsigned char *zslot;   // [slots] species index (zmap) of the neighbor, 255 for pads / unmapped
@@ -82,6 +81,42 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
                                         // gathers in the reverse pass exactly when it gathers in the forward pass
     ActiveView act;          // chains switched off by the relaxation driver
 };
+
+// Radial basis of one slot for one table quarter kq (radial indices n = kq + 1 + 4 ks, ks = 0..4, then the envelope):
+//   r[ks] = sin(n pi d / rc) / d * fc(d),  dr[ks] = d r[ks] / d d,  r[5] = fc,  dr[5] = fc'   
+// ONE definition for the kernel that writes the per-slot tables (k_edge_geom, nbr.hip) and for the kernel that rebuilds the fp32
+// values instead of reading them (k_l0_bwd, painn_l0.hip): both see bit-identical numbers (no contraction, same operation order).
+// ed: {r_x, r_y, r_z, bitcast(j)}, j < 0 marks a pad slot (everything zero, inv = 0).
+#if defined(__HIPCC__)
+__device__ __forceinline__ void radial_quarter(const float4 &ed, int kq, float rc, float (&r)[6], float (&dr)[6], float &inv, bool &valid) {
+    const float alpha = 3.14159265358979323846f / rc;
+    valid = __float_as_int(ed.w) >= 0;
+    const float d2 = fmaf(ed.z, ed.z, fmaf(ed.y, ed.y, ed.x * ed.x));
+    const float d = valid ? sqrtf(d2) : 1.f;
+    inv = valid ? 1.f / d : 0.f;
+    float s1, c1;
+    sincosf(alpha * d, &s1, &c1);
+    const bool inside = valid && d < rc;
+    const float fc = inside ? 0.5f * (c1 + 1.f) : 0.f;
+    const float dfc = inside ? -0.5f * alpha * s1 : 0.f;
+    const float s2 = 2.f * s1 * c1, c2 = fmaf(c1, c1, -s1 * s1);
+    const float s3 = fmaf(s2, c1, c2 * s1), c3 = fmaf(c2, c1, -s2 * s1);
+    const float s4 = 2.f * s2 * c2, c4 = fmaf(c2, c2, -s2 * s2);
+    float sn = kq == 0 ? s1 : kq == 1 ? s2 : kq == 2 ? s3 : s4;
+    float cn = kq == 0 ? c1 : kq == 1 ? c2 : kq == 2 ? c3 : c4;
+    float nf = (float)(kq + 1);
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const float rb = sn * inv;
+        r[ks] = rb * fc;
+        dr[ks] = fmaf(nf * alpha * cn * inv - rb * inv, fc, rb * dfc);
+        const float sn2 = fmaf(sn, c4, cn * s4), cn2 = fmaf(cn, c4, -sn * s4);
+        sn = sn2; cn = cn2; nf += 4.f;
+    }
+    r[5] = fc;      // envelope (bias column) replicated in every quarter
+    dr[5] = dfc;
+}
+#endif
 
 struct StateView {  // activations of all models: index [m][atom][...]
     int n_atoms;
@@ -208,7 +243,7 @@ struct vssr_handle {
     std::vector<int> h_n_atoms, h_cfg_start;
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
     vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
-    vssr::DevBuf d_erec, d_rho, d_drho, d_dist, d_rho16, d_drho16, d_zslot, d_bundle, d_excl;
+    vssr::DevBuf d_erec, d_rho, d_dist, d_rho16, d_drho16, d_zslot, d_bundle, d_excl;
     vssr::DevBuf d_hits;         // neighbor search: per (centre, candidate) 64-bit hit masks of the counting pass
     // layer-0 species factorisation (painn_l0.hip)
     int l0_enabled = 1, l0_nz = 0;
@@ -226,7 +261,7 @@ struct vssr_handle {
     bool graph_partial = false;   // the resident neighbor graph / activations cover only the chains of the last relaxation iteration
     bool l0T_by_geom = false;     // this evaluation's layer-0 T blocks were written by k_edge_geom (<= 4 species)
     int64_t zero_entry_cap = -1;  // capacity / table addresses for which the all-zero table entries were last cleared
-    const void *zero_entry_tab[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void *zero_entry_tab[2] = {nullptr, nullptr};
     int cap_per_atom = 64;        // initial neighbor capacity (slots per atom); vssr_debug_capacity
     bool cap_tight = false;       // regrow to the exact need only (tests: forces repeated overflows)
     uint32_t last_want = 0;                       // outputs produced by the last run
