@@ -498,8 +498,13 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             mfma_load_fence(nq, ds[0], dvx[0], dvy[0]);
             fetch(ph, nq, nv);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef ABL_HALF_VALU
+#pragma unroll
+            for (int r = 1; r < NF / 2; ++r) message(r);
+#else
 #pragma unroll
             for (int r = 1; r < NF; ++r) message(r);
+#endif
             ++bw.t;
         }
     }
@@ -774,8 +779,13 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             mfma_load_fence(nq, accb[0], accc[0], dpart, ub0);
             fetch(ph, nq, nv);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef ABL_HALF_VALU   // ablation: half of the per-feature arithmetic (results wrong; profiles/r03/NOTES_packed_fp32.md)
+#pragma unroll
+            for (int r = 1; r < NF / 2; ++r) feature(r);
+#else
 #pragma unroll
             for (int r = 1; r < NF; ++r) feature(r);
+#endif
             // Gradient of edge (n -> c), unit vector -u:  g = -(dE/dd) u + (ub - (ub.u) u) / d, linear in (dpart, ub).
             // The map is applied to the lane's partial sums BEFORE the reduction over the 4 feature quarters (lanes
             // p, p+16, p+32, p+48), so only 3 values cross lanes, and the reduction is a reduce-scatter on the

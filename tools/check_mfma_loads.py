@@ -6,7 +6,8 @@ MFMAs that are at most DENSE_GAP instructions apart; a '; gemm16_group_end' mark
 closes a block: the fragment loads of the next chunk group legitimately follow it.  Rule 3 (files with fences, i.e. the edge
 kernels): inside a dense block an MFMA never accumulates into the destination of one of the two MFMAs in front of it -- the
 producer of its accumulator is at least three matrix instructions back (dependent MFMAs issued closer stall inside the pipe
-and read their other sources late; profiles/r01/NOTES_mfma_hazards.md).  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
+and read their other sources late; profiles/r01/NOTES_mfma_hazards.md).  Rule 4 (same files): a product that is not the first of its
+chain never overwrites its own A / B operand.  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
 import os, re, subprocess, sys, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -98,6 +99,26 @@ def check(hip):
                     print(f"VIOLATION in {kernel}: MFMA at line {i} accumulates into {dst}, written {len(recent) - recent.index(dst)} MFMA(s) earlier")
                 recent.append(dst)
                 last_idx = idx
+    # rule 4: a product that continues an accumulator chain never writes over its own A / B operand.  Known-good (soaked): a chain's
+    # first product (accumulator constant 0) overwrites its B operand; later products accumulate in place or into other registers
+    # (also registers the instructions in front of them read).  Observed bad (round 3, packed-fp32 experiment, 8-feature forward
+    # kernel): `v_mfma D = A, B, C` with D == B and C a register -> run-to-run differences in the forces.
+    if groups:
+        def regs(tok):
+            m = re.match(r"^[va]\[(\d+):(\d+)\]$", tok)
+            return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+        kernel = None
+        for i, l in enumerate(lines):
+            m = re.match(r"^(_ZN\w+):", l)
+            if m:
+                kernel = m.group(1)
+            t = l.strip()
+            if t.startswith("v_mfma"):
+                ops = [o.strip() for o in t.split(None, 1)[1].split(",")][:4]
+                dst, a, b, c = (regs(o) for o in ops)
+                if c and ops[0] != ops[3] and dst & (a | b):
+                    bad += 1
+                    print(f"VIOLATION in {kernel}: MFMA at line {i} continues a chain and overwrites its own operand: {t}")
     print(f"{os.path.basename(hip)}: {groups} MFMA groups checked, {dense_blocks} dense MFMA pairs, {bad} violations")
     return bad
 
