@@ -808,6 +808,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 const bool real = gcomp_id < 3 && real_slot && invd > 0.f;
 #if defined(ABL_NO_GSTORE)   // ablation: the store only happens for a value the arithmetic never produces
                 if (gsum == 1.2345e33f) gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;
+#elif defined(ABL_STORE4)   // ablation: one 16-byte store every fourth step instead of a dword store per step (same bytes, results wrong)
+                if ((bw.t & 3) == 3) {
+                    float *dst = gcomp + (size_t)(real ? my_slot : zero_slot) * rec;
+                    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"((f32x4){gsum, gsum, gsum, gsum}) : "memory");
+                }
 #elif defined(ABL_ROW3_NO_GSTORE)   // ablation: the row without a component does not store
                 if (gcomp_id < 3) gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;
 #elif defined(ABL_NO_GBAR)
