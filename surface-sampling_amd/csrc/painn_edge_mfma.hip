@@ -102,8 +102,13 @@ __device__ __forceinline__ void filter_tiles_sel(const u32x4 (*const (&w)[NT])[2
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     accsel = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef ABL_THIRD_MFMA   // ablation: only the first of the three products (results wrong)
+    constexpr int NPROD = 1;
+#else
+    constexpr int NPROD = 3;
+#endif
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NPROD; ++k) {
         if (NT < 3 && k == 2) {   // two tiles: the selector's second product goes in FRONT of the last round, so that every
             accsel = mfma_f16(sel, rs[ri[k]], accsel);   // product's predecessor in its chain stays three instructions back
             __builtin_amdgcn_sched_barrier(0);
@@ -260,7 +265,11 @@ struct BundleWalk {
     __device__ __forceinline__ static int steps(const int4 &q) { return max(__builtin_amdgcn_readfirstlane(q.z) >> 2, 2); }
     __device__ __forceinline__ void init(const int4 *table, int n, int w, int stream) {
         tab = table; Nc = n; wave = w; st = stream;
+#ifdef ABL_NO_TAIL   // ablation: the bundles beyond the last full round of the workgroup's waves are dropped (results wrong)
+        const int NB0 = (n + 3) >> 2, NB = NB0 >= NW ? NB0 - NB0 % NW : NB0, full = NB / NW, rem = NB - full * NW;
+#else
         const int NB = (n + 3) >> 2, full = NB / NW, rem = NB - full * NW;
+#endif
         nj = full + ((((full & 1) ? NW - 1 - w : w) < rem) ? 1 : 0);
         j = 0; t = 0;
         bool ok0, ok1;
@@ -383,6 +392,9 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     BundleWalk<EDGE_THREADS / 64> bw;
     bw.init(G.bundle + a0, Nc, __builtin_amdgcn_readfirstlane(wave), p >> 2);
     if (bw.nj == 0) return;   // (no barrier below)
+#ifdef ABL_STAGE_ONLY   // ablation: staging + prologue only (results wrong)
+    if (bw.nj > 0) return;
+#endif
     float ds[NF], dvx[NF], dvy[NF], dvz[NF];
 #pragma unroll
     for (int r = 0; r < NF; ++r) { ds[r] = 0.f; dvx[r] = 0.f; dvy[r] = 0.f; dvz[r] = 0.f; }
@@ -407,7 +419,11 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     // so a table load has ~1.6 steps to arrive (L2 / HBM latency is of the order of one step).
     u32x4 rq[2][2];
     auto fetch = [&](int buf, int quad_first_slot, bool valid) {   // quad_first_slot: first slot of the stream's quad
+#ifdef ABL_TABLE_L2   // ablation: every table read hits a 256 KB window (results wrong)
+        const u32x4 *rp = rho_lane + (size_t)(valid ? ((quad_first_slot >> 2) & 511) : zero_quad) * 32;
+#else
         const u32x4 *rp = rho_lane + (size_t)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;
+#endif
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
     };
     {
@@ -448,7 +464,11 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: one table buffer per step parity
             arrival_fence(rq[ph][0], rq[ph][1]);
+#ifdef ABL_LDS_BCAST   // ablation: every gather reads row 0 or 1 (no LDS bank conflicts; results wrong)
+            const int jn = (int)(rq[ph][0][3] >> 16) & 1;
+#else
             const int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
+#endif
             if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
                 flush_bundle();
                 bw.advance();
@@ -621,6 +641,9 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     BundleWalk<BWD_THREADS / 64> bw;   // work list: bundles of 4 centres, see the forward kernel
     bw.init(G.bundle + a0, Nc, __builtin_amdgcn_readfirstlane(wave), p >> 2);
     if (bw.nj == 0) return;   // (no barrier below)
+#ifdef ABL_STAGE_ONLY   // ablation: staging + prologue only (results wrong)
+    if (bw.nj > 0) return;
+#endif
 
     // ---- per-centre data of this lane's NF features: phi_c (a, b, c) and v_c -------------------------------------------
     // The CURRENT centre's values live in a small LDS record per (stream, feature quarter) and are re-read every step
@@ -688,7 +711,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     u32x4 rq[2][2], dq[2][2];
     float gold[2] = {0.f, 0.f};
     auto fetch = [&](int buf, int quad_first_slot, bool valid) {
+#ifdef ABL_TABLE_L2
+        const size_t off = (size_t)(valid ? ((quad_first_slot >> 2) & 511) : zero_quad) * 32;
+#else
         const size_t off = (size_t)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;
+#endif
         const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
         dq[buf][0] = dp[0]; dq[buf][1] = dp[16];
@@ -710,7 +737,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             arrival_fence(rq[ph][0], rq[ph][1], dq[ph][0], dq[ph][1], gold[ph]);
+#ifdef ABL_LDS_BCAST   // ablation: every gather reads row 0 or 1 (no LDS bank conflicts; results wrong)
+            const int jn = (int)(rq[ph][0][3] >> 16) & 1;
+#else
             const int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
+#endif
             const float gold_cur = FIRST ? 0.f : take(gold[ph]);
             if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
                 flush_bundle();
