@@ -405,7 +405,8 @@ class EnsembleNFFSurface(_Base):
         """Relax B independent slabs at once on the device — the batched counterpart of
         ``optimize_slab(slab, optimizer=..., relax_steps=..., save_traj=..., record_interval=...)`` (reference
         ``mcmc/dynamics.py:83-170``).  ``optimizer``: "BFGS" (ASE BFGS, the reference's SrTiO3 setting,
-        ``scripts/configs/sample_config_painn.json:26``) or "FIRE" (the reference's default); None takes
+        ``scripts/configs/sample_config_painn.json:26``), "FIRE" (the reference's default) or "CG" (ASE SciPyFminCG: host-driven scipy
+        optimizers over lock-step device evaluations, ``host_opt.py``); None takes
         ``parameters["optimizer"]`` (how ``calc_settings`` reach ``optimize_slab``), else "FIRE".
         ``fixed_indices``: per slab, the atom indices held by FixAtoms (or None).
         Returns, per slab, the reference's tuple ``(relaxed_slab, traj, energy, energy_oob)`` where ``energy_oob`` follows
@@ -426,15 +427,46 @@ class EnsembleNFFSurface(_Base):
                 o += len(p[0])
         if optimizer is None:
             optimizer = self.parameters.get("optimizer", "FIRE")
-        info = eng.relax(optimizer, fixed=fixed, max_steps=relax_steps, fmax=fmax,
-                         record_interval=int(record_interval) if save_traj else 0)
+        host_traj = None
+        if "CG" in str(optimizer) and "LAMMPS" not in str(optimizer):
+            # the reference maps "CG" to ASE's SciPyFminCG (mcmc/dynamics.py:123-124): scipy owns the control flow, so every chain's
+            # optimizer runs on the host and their energy / force requests are served by lock-step evaluations (host_opt.py)
+            from . import host_opt
+
+            def evaluate(pos_all):
+                eng.set_positions(pos_all)
+                eng.run()
+                r = eng.download()
+                return np.asarray(r["energy"], dtype=np.float64), np.asarray(r["forces"], dtype=np.float64)
+
+            cfg = np.concatenate([[0], np.cumsum([len(p[0]) for p in packs])])
+            pos0 = np.concatenate([np.asarray(p[1], dtype=np.float64).reshape(-1, 3) for p in packs])
+            info = host_opt.scipy_cg_batch(evaluate, cfg, pos0, fixed=fixed, steps=relax_steps, fmax=fmax,
+                                           record_interval=int(record_interval) if save_traj else 0)
+            host_traj = info["traj"]
+            eng.set_positions(info["positions"])
+            eng.run()
+        else:
+            info = eng.relax(optimizer, fixed=fixed, max_steps=relax_steps, fmax=fmax,
+                             record_interval=int(record_interval) if save_traj else 0)
         res = eng.download()
         out = []
         for b, atoms in enumerate(atoms_list):
             a0, a1 = int(res["cfg_start"][b]), int(res["cfg_start"][b + 1])
             relaxed = atoms.copy()
             relaxed.set_positions(info["positions"][a0:a1])
-            traj = _traj_of_chain(info.get("traj"), b, a0, a1, atoms) if save_traj else None
+            if host_traj is not None:
+                frames = []
+                for fpos, _, _ in host_traj[b]:
+                    frame = atoms.copy()
+                    frame.set_positions(fpos)
+                    if hasattr(frame, "calc"):
+                        frame.calc = None
+                    frames.append(frame)
+                traj = {"atoms": frames, "energies": [float(e) for _, e, _ in host_traj[b]],
+                        "forces": [np.asarray(f, dtype=np.float32) for _, _, f in host_traj[b]]}
+            else:
+                traj = _traj_of_chain(info.get("traj"), b, a0, a1, atoms) if save_traj else None
             r = self._fill_results(res, b)
             energy = float(r["energy"][0])
             max_force = float(np.abs(r["forces"]).max()) if a1 > a0 else 0.0
