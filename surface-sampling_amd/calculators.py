@@ -191,6 +191,23 @@ def surface_energy_from_energy(energy: float, symbols, chem_pots: dict, offset_d
     return surface_energy - pot
 
 
+class _LockstepProxy(_Base):
+    """Calculator of ONE chain inside a host-driven optimizer (host_opt.optimizer_class_batch): energy and forces come from the
+    lock-step evaluation of the whole resident batch."""
+
+    implemented_properties = ("energy", "forces")
+    name = "vssr_lockstep_proxy"
+
+    def __init__(self, request, **kwargs):
+        super().__init__(**kwargs)
+        self._request = request
+
+    def calculate(self, atoms=None, properties=("energy",), system_changes=all_changes):
+        super().calculate(atoms, properties, system_changes)
+        e, f = self._request(atoms)
+        self.results = {"energy": float(e), "forces": np.asarray(f, dtype=np.float64)}
+
+
 class EnsembleNFFSurface(_Base):
     """PaiNN-ensemble surface calculator on MI355X (drop-in for the reference class of the same name).
 
@@ -428,7 +445,35 @@ class EnsembleNFFSurface(_Base):
         if optimizer is None:
             optimizer = self.parameters.get("optimizer", "FIRE")
         host_traj = None
-        if "CG" in str(optimizer) and "LAMMPS" not in str(optimizer):
+        opt_cls = optimizer if callable(optimizer) else None
+        if opt_cls is None and "BFGSLineSearch" in str(optimizer):
+            try:   # the reference's import (mcmc/dynamics.py:7): only where ASE is installed
+                from ase.optimize import BFGSLineSearch as opt_cls
+            except Exception as exc:
+                raise backend.BackendError('optimizer "BFGSLineSearch" is ASE\'s class and ASE is not importable here; pass an '
+                                           "optimizer class, or use BFGS / FIRE / CG") from exc
+        if opt_cls is not None:
+            # any optimizer of the ASE protocol, one per chain on the host, served by lock-step evaluations (host_opt.py)
+            from . import host_opt
+
+            def evaluate(pos_all):
+                eng.set_positions(pos_all)
+                eng.run()
+                r = eng.download()
+                return np.asarray(r["energy"], dtype=np.float64), np.asarray(r["forces"], dtype=np.float64)
+
+            cfg = np.concatenate([[0], np.cumsum([len(p[0]) for p in packs])])
+            kw = {"logfile": None} if HAVE_ASE and not callable(optimizer) else {}
+            info = host_opt.optimizer_class_batch(opt_cls, atoms_list, _LockstepProxy, evaluate, cfg, fixed_indices=fixed_indices,
+                                                  steps=relax_steps, fmax=fmax, record_interval=int(record_interval) if save_traj else 0,
+                                                  optimizer_kwargs=kw)
+            info["n_steps"] = np.array([int(getattr(d, "nsteps", -1)) for d in info["optimizers"]], np.int32)   # ASE optimizers count
+            info["converged"] = np.zeros(len(packs), bool)   # judged below from the final forces
+            class_traj = info["traj"]
+            info["traj"] = None
+            eng.set_positions(info["positions"])
+            eng.run()
+        elif "CG" in str(optimizer) and "LAMMPS" not in str(optimizer):
             # the reference maps "CG" to ASE's SciPyFminCG (mcmc/dynamics.py:123-124): scipy owns the control flow, so every chain's
             # optimizer runs on the host and their energy / force requests are served by lock-step evaluations (host_opt.py)
             from . import host_opt
@@ -455,7 +500,9 @@ class EnsembleNFFSurface(_Base):
             a0, a1 = int(res["cfg_start"][b]), int(res["cfg_start"][b + 1])
             relaxed = atoms.copy()
             relaxed.set_positions(info["positions"][a0:a1])
-            if host_traj is not None:
+            if opt_cls is not None:
+                traj = class_traj[b] if (save_traj and class_traj is not None) else None
+            elif host_traj is not None:
                 frames = []
                 for fpos, _, _ in host_traj[b]:
                     frame = atoms.copy()
@@ -476,6 +523,11 @@ class EnsembleNFFSurface(_Base):
                 energy = self.ENERGY_THRESHOLD
             r["n_steps"] = int(info["n_steps"][b])
             r["converged"] = bool(info["converged"][b])
+            if opt_cls is not None:   # ASE's criterion on the final forces (constraints applied)
+                ff = np.array(r["forces"], dtype=np.float64, copy=True)
+                if fixed_indices is not None and fixed_indices[b] is not None and len(fixed_indices[b]):
+                    ff[np.asarray(fixed_indices[b], dtype=np.int64)] = 0.0
+                r["converged"] = bool((ff ** 2).sum(axis=1).max() < fmax ** 2) if len(ff) else True
             out.append((relaxed, traj, energy, oob, r))
         return out
 

@@ -157,3 +157,61 @@ def scipy_cg_batch(evaluate, cfg_start, positions, fixed=None, steps=20, fmax=0.
     pos = ev.run(chain)
     return {"positions": pos, "energy": final_e, "forces": final_f, "n_steps": n_steps, "converged": converged, "traj": traj,
             "rounds": ev.n_rounds}
+
+
+def optimizer_class_batch(optimizer_cls, atoms_list, make_calculator, evaluate, cfg_start, fixed_indices=None, steps=20, fmax=0.01,
+                          record_interval=0, optimizer_kwargs=None):
+    """Any optimizer that follows the ASE protocol -- ``dyn = optimizer_cls(atoms, **kw); dyn.attach(fn, interval=k);
+    dyn.run(fmax=..., steps=...)`` talking to ``atoms.get_forces() / get_potential_energy() / get_positions() / set_positions()`` --
+    for every chain of a resident batch, one thread per chain, lock-step evaluations (``LockstepEvaluator``).  This is how
+    ``relax_batch`` serves ``optimizer="BFGSLineSearch"`` (reference ``mcmc/dynamics.py:119-120``) where ASE is installed, and any
+    optimizer class passed directly.
+
+    make_calculator(request) -> a calculator whose energy / forces come from ``request(atoms) -> (energy, forces)`` (the caller's
+    Calculator base class: ``calculators._LockstepProxy``).  fixed_indices: per chain, indices held fixed IN ADDITION to whatever
+    constraints the atoms objects carry themselves (ase.Atoms apply their own FixAtoms; plain Structures have none).
+    Returns dict(positions, atoms (the optimised copies), optimizers, traj (reference layout per chain or None), rounds)."""
+    cfg = np.asarray(cfg_start, dtype=np.int64)
+    B = len(cfg) - 1
+    start = np.concatenate([np.asarray(a.get_positions(), dtype=np.float64).reshape(-1, 3) for a in atoms_list])
+    ev = LockstepEvaluator(evaluate, cfg, start)
+    work = [None] * B
+    dyns = [None] * B
+    traj = [None] * B
+
+    def chain(b):
+        a0, a1 = int(cfg[b]), int(cfg[b + 1])
+        fixed = np.zeros(a1 - a0, bool)
+        if fixed_indices is not None and fixed_indices[b] is not None and len(fixed_indices[b]):
+            fixed[np.asarray(fixed_indices[b], dtype=np.int64)] = True
+        atoms = atoms_list[b].copy()
+
+        def request(at):
+            pos = np.where(fixed[:, None], start[a0:a1], np.asarray(at.get_positions(), dtype=np.float64).reshape(-1, 3))
+            e, f = ev.request(b, pos)
+            return e, np.where(fixed[:, None], 0.0, f)
+
+        atoms.calc = make_calculator(request)
+        dyn = optimizer_cls(atoms, **(optimizer_kwargs or {}))
+        if record_interval:
+            rec = {"atoms": [], "energies": [], "forces": []}
+
+            def observe():   # the reference's TrajectoryObserver (mcmc/dynamics.py:20-80)
+                frame = atoms.copy()
+                if hasattr(frame, "calc"):
+                    frame.calc = None
+                rec["atoms"].append(frame)
+                rec["energies"].append(float(atoms.get_potential_energy()))
+                rec["forces"].append(np.array(atoms.get_forces(), copy=True))
+
+            dyn.attach(observe, interval=int(record_interval))
+            traj[b] = rec
+        dyns[b] = dyn
+        dyn.run(fmax=fmax, steps=int(steps))
+        pos = np.where(fixed[:, None], start[a0:a1], np.asarray(atoms.get_positions(), dtype=np.float64).reshape(-1, 3))
+        ev._pos[a0:a1] = pos
+        atoms.set_positions(pos)
+        work[b] = atoms
+
+    pos = ev.run(chain)
+    return {"positions": pos, "atoms": work, "optimizers": dyns, "traj": traj if record_interval else None, "rounds": ev.n_rounds}

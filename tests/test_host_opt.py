@@ -101,3 +101,71 @@ def test_cg_optimizer_through_relax_batch_on_the_gpu(golden):
         assert traj is not None and len(traj["atoms"]) == len(traj["energies"]) >= 2
         assert traj["energies"][-1] <= traj["energies"][0]
         assert abs(energy - bfgs[b][2]) < 0.15 * abs(e0[b] - bfgs[b][2]) + 0.3   # comparable progress in 12 steps (60 eV downhill from these starts)
+
+
+class _Descent:
+    """Stand-in for an ASE optimizer class (ASE is not installable here): the protocol relax_batch relies on -- constructed with the
+    atoms, observers attached with an interval, run(fmax, steps) driving atoms.get_forces() / set_positions()."""
+
+    def __init__(self, atoms, step=0.05):
+        self.atoms, self.step, self.nsteps, self.observers = atoms, step, 0, []
+
+    def attach(self, fn, interval=1):
+        self.observers.append((fn, interval))
+
+    def run(self, fmax=0.05, steps=100):
+        while True:
+            f = self.atoms.get_forces()
+            for fn, k in self.observers:
+                if self.nsteps % k == 0:
+                    fn()
+            if (f ** 2).sum(axis=1).max() < fmax ** 2 or self.nsteps >= steps:
+                return
+            self.atoms.set_positions(self.atoms.get_positions() + self.step * f)
+            self.nsteps += 1
+
+
+def test_any_ase_protocol_optimizer_runs_in_lockstep():
+    from surface_sampling_amd import structures
+    from surface_sampling_amd.calculators import _LockstepProxy
+
+    n_atoms = [4, 6, 5]
+    cfg, centres, evaluate, calls = _wells(n_atoms, 21)
+    start = centres + 0.3
+    atoms = [structures.Structure(np.full(n, 8), start[cfg[b]:cfg[b + 1]], np.eye(3) * 20) for b, n in enumerate(n_atoms)]
+    fixed = [np.array([0]), None, np.array([1, 2])]
+    out = host_opt.optimizer_class_batch(_Descent, atoms, _LockstepProxy, evaluate, cfg, fixed_indices=fixed, steps=400, fmax=1e-3,
+                                         record_interval=50, optimizer_kwargs={"step": 0.1})
+    free = np.ones(len(start), bool)
+    free[[0, cfg[2] + 1, cfg[2] + 2]] = False
+    assert np.abs(out["positions"][free] - centres[free]).max() < 2e-3
+    assert np.array_equal(out["positions"][~free], start[~free])
+    assert len(calls) == out["rounds"] <= max(d.nsteps for d in out["optimizers"]) + 2   # lock-step: rounds = the longest chain's steps
+    for b in range(3):
+        rec = out["traj"][b]
+        assert len(rec["atoms"]) == len(rec["energies"]) == len(rec["forces"]) >= 2
+        assert all(e1 <= e0 for e0, e1 in zip(rec["energies"], rec["energies"][1:]))
+        assert np.array_equal(rec["atoms"][0].positions, start[cfg[b]:cfg[b + 1]])
+        assert np.array_equal(atoms[b].positions, start[cfg[b]:cfg[b + 1]])      # the caller's objects are untouched
+
+
+@pytest.mark.gpu
+def test_optimizer_class_through_relax_batch_on_the_gpu(golden):
+    from surface_sampling_amd import structures
+    from surface_sampling_amd.calculators import EnsembleNFFSurface
+
+    base = golden.structure("SrTiO3_2x2_pristine")
+    slabs = [structures.synth_chain(base, c, grid=(4, 4)) for c in range(3)]
+    fixed = [np.flatnonzero(s.positions[:, 2] < base.positions[:, 2].max() - 4.0) for s in slabs]
+    calc = EnsembleNFFSurface(golden.blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV", offset_units="atomic")
+    calc.set(offset=True, offset_data=golden.offset_data)
+    e0 = [float(r["energy"][0]) for r in calc.calculate_batch(slabs)]
+    res = calc.relax_batch(slabs, fixed_indices=fixed, relax_steps=10, fmax=0.05,
+                           optimizer=lambda atoms: _Descent(atoms, step=5e-4), save_traj=True, record_interval=5)
+    for b, (relaxed, traj, energy, oob, r) in enumerate(res):
+        assert not oob and energy < e0[b] - 0.05 and r["n_steps"] == 10, (energy, e0[b], r["n_steps"])
+        assert np.array_equal(relaxed.positions[fixed[b]], slabs[b].positions[fixed[b]])
+        assert abs(float(calc.calculate_batch([relaxed])[0]["energy"][0]) - energy) <= 2e-4
+        assert len(traj["atoms"]) == 3 and traj["energies"][0] == pytest.approx(e0[b], abs=2e-4)
+    with pytest.raises(Exception, match="BFGSLineSearch"):
+        calc.relax_batch(slabs, optimizer="BFGSLineSearch")
