@@ -22,6 +22,23 @@
 // is per chain (edge_class_of), so a chain's results do not depend on what it is batched with.
 #include "vssr_internal.h"
 
+#ifdef EDGE_PHASE_TIMING   // debug build only (tools/gpu_edge_phase.py): wall-clock ticks (100 MHz) between marks inside the hot loops,
+// accumulated per wave and added to the global counters when the wave leaves; slots [0, 8): forward kernel, [8, 16): reverse kernel
+__device__ unsigned long long g_edge_phase[16];
+#define EPH_INIT unsigned long long eph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, eph_t = wall_clock64();
+#define EPH(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long eph_n = wall_clock64(); eph_acc[k] += eph_n - eph_t; eph_t = eph_n; __builtin_amdgcn_sched_barrier(0); }
+#define EPH_FLUSH(base) if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_edge_phase[(base) + q_], eph_acc[q_]); }
+extern "C" int vssr_debug_edge_phases(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_edge_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_edge_phase), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define EPH_INIT
+#define EPH(k)
+#define EPH_FLUSH(base)
+#endif
+
 namespace vssr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -79,6 +96,20 @@ __device__ __forceinline__ void mfma_load_fence(int &index, float &a, float &b, 
     asm volatile("; mfma_load_fence" : "+v"(index), "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
+// The weight pointer comes out of the ModelW table in memory, so the compiler treats it as FLAT; a flat load ticks vmcnt AND lgkmcnt,
+// and while one is pending every wait the compiler inserts is a full drain.  The forward kernel loads its weights right in front of
+// the hot loop: the pending flat loads reached the loop header, whose wait became vmcnt(0) for EVERY iteration (the merge of the
+// pre-header and the back edge) -- the two-step table prefetch was drained every second step (found with the phase clocks of
+// tools/gpu_edge_phase.py: 43 % of a forward wave's time sat in that wait).  Through an explicit global pointer the loads are
+// global_load, the header wait is the exact vmcnt(2).
+__device__ __forceinline__ u32x4 gload_u32x4(const u32x4 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const u32x4 __attribute__((address_space(1))) *gptr;
+    return *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
+#else
+    return *p;
+#endif
+}
 // D += W . rho for one 16 x 16 tile
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
@@ -385,7 +416,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
         const int row = max(sec, 0) * F + fs * FS + LY::row_feature(p);
         const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 2;
 #pragma unroll
-        for (int i3 = 0; i3 < 2; ++i3) wA[T][i3] = sec < 0 ? (u32x4){0u, 0u, 0u, 0u} : wsrc[i3];
+        for (int i3 = 0; i3 < 2; ++i3) wA[T][i3] = sec < 0 ? (u32x4){0u, 0u, 0u, 0u} : gload_u32x4(wsrc + i3);
     }
 
     // ---- work list: bundles of 4 centres of (nearly) equal slot count, see BundleWalk --------------------------------
@@ -430,6 +461,10 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
         bool v0, v1;
         const int q0 = bw.quad_ahead(0, v0), q1 = bw.quad_ahead(1, v1);
         fetch(0, q0, v0);
+        // issue order = consumption order.  Without the barrier the scheduler hoisted the second buffer's loads above the first's in
+        // the forward kernel; seen from the loop header the first buffer was then the YOUNGEST pending load, its wait vmcnt(0), and
+        // -- the header wait being the merge of pre-header and back edge -- every iteration drained the whole prefetch queue.
+        __builtin_amdgcn_sched_barrier(0);
         fetch(1, q1, v1);
     }
 
@@ -460,10 +495,13 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     };
 
     const float *trow = tile + (NF * fq) * LY::NSEG;
+    EPH_INIT
+    EPH(0)   // (the prologue is not timed: the clock starts here)
     while (bw.j < bw.nj) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {   // two steps per iteration: one table buffer per step parity
             arrival_fence(rq[ph][0], rq[ph][1]);
+            EPH(1)   // wait for this step's table entries
 #ifdef ABL_LDS_BCAST   // ablation: every gather reads row 0 or 1 (no LDS bank conflicts; results wrong)
             const int jn = (int)(rq[ph][0][3] >> 16) & 1;
 #else
@@ -477,6 +515,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                     __builtin_amdgcn_sched_barrier(0);   // the old value leaves its registers before the load that refills them
                     sres_nxt = load_residual(bw.nxt.x);
                 }
+                EPH(2)   // bundle completion
             }
             // gather this slot's neighbor row: NF features x NSEG values, contiguous in LDS
             float tv[NF * LY::NSEG];
@@ -489,6 +528,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                 }
             }
             mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
+            EPH(3)   // gather issue (+ the LDS wait the clock read implies)
             // ---- filter GEMM  D[tile row][slot] = Wd_ext[row][k] rho[k][slot]  (bias . fc included) ---------------------
             f32x4 acc[NT], usel;
             {
@@ -498,6 +538,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                 filter_tiles_sel<NT>(wp, rp3, acc, sel, rq[ph], usel);
             }
             __builtin_amdgcn_sched_barrier(0);
+            EPH(4)   // matrix instructions issued
             const float ux = usel[0], uy = usel[1], uz = usel[2];   // unit vector of this lane's slot
             // ---- messages of this lane's slot for its NF features (filter = 0 exactly for pads / foreign slots) ----------
             auto message = [&](int r) {
@@ -516,6 +557,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             bool nv;
             int nq = bw.quad_ahead(2, nv);
             mfma_load_fence(nq, ds[0], dvx[0], dvy[0]);
+            EPH(5)   // matrix results arrive + first feature
             fetch(ph, nq, nv);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef ABL_HALF_VALU
@@ -526,8 +568,10 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             for (int r = 1; r < NF; ++r) message(r);
 #endif
             ++bw.t;
+            EPH(6)   // prefetch issue + remaining features
         }
     }
+    EPH_FLUSH(0)
 }
 
 // ======================================================================================================
@@ -634,7 +678,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         const int row = max(sec, 0) * F + fs * FS + LY::row_feature(p);
         const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W.wd16) + ((size_t)row * 4 + fq) * 2;
 #pragma unroll
-        for (int i3 = 0; i3 < 2; ++i3) wA[T][i3] = sec < 0 ? (u32x4){0u, 0u, 0u, 0u} : wsrc[i3];
+        for (int i3 = 0; i3 < 2; ++i3) wA[T][i3] = sec < 0 ? (u32x4){0u, 0u, 0u, 0u} : gload_u32x4(wsrc + i3);
     }
     __syncthreads();
 
@@ -729,14 +773,20 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         bool v0, v1;
         const int q0 = bw.quad_ahead(0, v0), q1 = bw.quad_ahead(1, v1);
         fetch(0, q0, v0);
+        // issue order = consumption order.  Without the barrier the scheduler hoisted the second buffer's loads above the first's in
+        // the forward kernel; seen from the loop header the first buffer was then the YOUNGEST pending load, its wait vmcnt(0), and
+        // -- the header wait being the merge of pre-header and back edge -- every iteration drained the whole prefetch queue.
+        __builtin_amdgcn_sched_barrier(0);
         fetch(1, q1, v1);
     }
     const float *trow = tile + (NF * fq) * 4;
-
+    EPH_INIT
+    EPH(0)
     while (bw.j < bw.nj) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             arrival_fence(rq[ph][0], rq[ph][1], dq[ph][0], dq[ph][1], gold[ph]);
+            EPH(1)
 #ifdef ABL_LDS_BCAST   // ablation: every gather reads row 0 or 1 (no LDS bank conflicts; results wrong)
             const int jn = (int)(rq[ph][0][3] >> 16) & 1;
 #else
@@ -749,6 +799,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 park_centre();                       // centre data of the bundle that starts now
                 __builtin_amdgcn_sched_barrier(0);   // the old values leave their registers before the loads that refill them are issued
                 load_centre(bw.nxt.x);
+                EPH(2)
             }
             bool real_slot;
             const int my_slot = bw.quad_ahead(0, real_slot) + e;
@@ -774,6 +825,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             }
             mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
             mfma_pre_fence(dq[ph][0], dq[ph][1]);
+            EPH(3)
             // filter and its radial derivative for this lane's slot and NF features (bias . fc / bias . fc' included)
             f32x4 awd[2 * NT], usel;   // tiles [0, NT): filter w, [NT, 2 NT): radial derivative dw; usel: per-slot scalars
             {
@@ -784,6 +836,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             }
             const f32x4 *aw = awd, *ad = awd + NT;
             __builtin_amdgcn_sched_barrier(0);
+            EPH(4)
             const float ux = usel[0], uy = usel[1], uz = usel[2], invd = usel[3];   // unit vector c -> n (edge (n -> c) has -u), 1 / d
             float dpart = 0.f, ub0 = 0.f, ub1 = 0.f, ub2 = 0.f;
             auto feature = [&](int r) {
@@ -808,6 +861,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             bool nv;
             int nq = bw.quad_ahead(2, nv);   // the step after next, into the buffer this step has just consumed
             mfma_load_fence(nq, accb[0], accc[0], dpart, ub0);
+            EPH(5)
             fetch(ph, nq, nv);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef ABL_HALF_VALU   // ablation: half of the per-feature arithmetic (results wrong; profiles/r03/NOTES_packed_fp32.md)
@@ -817,6 +871,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 #pragma unroll
             for (int r = 1; r < NF; ++r) feature(r);
 #endif
+            EPH(6)   // prefetch issue + remaining features
             // Gradient of edge (n -> c), unit vector -u:  g = -(dE/dd) u + (ub - (ub.u) u) / d, linear in (dpart, ub).
             // The map is applied to the lane's partial sums BEFORE the reduction over the 4 feature quarters (lanes
             // p, p+16, p+32, p+48), so only 3 values cross lanes, and the reduction is a reduce-scatter on the
@@ -853,8 +908,10 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 #endif
             }
             ++bw.t;
+            EPH(7)   // reduce-scatter + store
         }
     }
+    EPH_FLUSH(8)
 }
 
 int edge_mfma_init(vssr_handle *h) {
