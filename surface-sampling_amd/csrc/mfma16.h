@@ -258,5 +258,14 @@ __device__ __forceinline__ f32x4 gload4f(const float *p) {
 #endif
 }
 
+__device__ __forceinline__ float gload1f(const float *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const float __attribute__((address_space(1))) *gptr;
+    return *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
+#else
+    return *p;
+#endif
+}
+
 }  // namespace vssr
 #endif

@@ -739,7 +739,7 @@ __device__ __forceinline__ void readout_head(const ModelW &W, const Planes &xs, 
     if (threadIdx.x < TA) {
         const int atom = a0 + threadIdx.x;
         if (atom < N) {
-            float e = W.b6[0];
+            float e = gload1f(W.b6);   // (a plain W.b6[0] is a FLAT load: the pointer comes out of the ModelW table)
 #pragma unroll
             for (int k = 0; k < NCW; ++k) e += red[k * TA + threadIdx.x];
             if (e_excl) e += e_excl[atom];

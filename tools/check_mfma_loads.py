@@ -7,7 +7,7 @@ closes a block: the fragment loads of the next chunk group legitimately follow i
 kernels): inside a dense block an MFMA never accumulates into the destination of one of the two MFMAs in front of it -- the
 producer of its accumulator is at least three matrix instructions back (dependent MFMAs issued closer stall inside the pipe
 and read their other sources late; profiles/r01/NOTES_mfma_hazards.md).  Rule 4 (same files): a product that is not the first of its
-chain never overwrites its own A / B operand.  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
+chain never overwrites its own A / B operand.  Rule 5 (every file): no FLAT memory instructions.  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
 import os, re, subprocess, sys, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -119,6 +119,18 @@ def check(hip):
                 if c and ops[0] != ops[3] and dst & (a | b):
                     bad += 1
                     print(f"VIOLATION in {kernel}: MFMA at line {i} continues a chain and overwrites its own operand: {t}")
+    # rule 5: no FLAT memory instructions.  A flat access ticks vmcnt AND lgkmcnt; while one is pending every wait the compiler inserts
+    # is a full drain -- pending flat weight loads in front of the forward neighbor loop turned its header wait into vmcnt(0) for
+    # every iteration (profiles/r03/NOTES_edge_traffic.md).  Pointers read out of tables in memory must be dereferenced through the
+    # global address space (gload4u / gload4f / gload1f / gload_u32x4).
+    kernel = None
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\w+):", l)
+        if m:
+            kernel = m.group(1)
+        if re.match(r"^\s*flat_(load|store|atomic)", l):
+            bad += 1
+            print(f"VIOLATION in {kernel}: FLAT memory instruction at line {i}: {l.strip()}")
     print(f"{os.path.basename(hip)}: {groups} MFMA groups checked, {dense_blocks} dense MFMA pairs, {bad} violations")
     return bad
 
