@@ -92,7 +92,7 @@ class LockstepEvaluator:
                     self._cv.wait()
         for t in threads:
             t.join()
-        if self._error is not None and not isinstance(self._error, _Converged):
+        if self._error is not None:
             raise self._error
         return self._pos
 
