@@ -138,3 +138,53 @@ def test_tersoff_create_from_text_and_state_errors(golden, oracle_mod):
     with pytest.raises(backend.BackendError):
         eng.download(backend.WANT_ENERGY)                                   # results belong to the old positions
     eng.close()
+
+
+def test_distinct_handles_are_independent_interleaved_and_from_two_threads(golden):
+    """SURVEY §8(b) threading contract: a handle is not re-entrant, DISTINCT handles are independent.  Two engines in one process,
+    (a) calls interleaved on one thread, (b) each driven by its own Python thread (ctypes releases the GIL during the calls, the
+    engines own separate HIP streams): every result is bit-identical to the same batch evaluated alone."""
+    import threading
+    from surface_sampling_amd import backend, structures
+
+    table, const = golden.offset_table()
+    base = golden.structure("SrTiO3_2x2_pristine")
+    batches = [[structures.as_arrays(structures.synth_chain(base, c, grid=(4, 4))) for c in range(k, k + 6)] for k in (0, 40)]
+
+    def alone(packs):
+        eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+        r = eng.evaluate(packs)
+        out = (r["energy"].copy(), r["forces"].copy(), r["energy_std"].copy())
+        eng.close()
+        return out
+
+    ref = [alone(b) for b in batches]
+    engines = [backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const) for _ in batches]
+    for eng, b in zip(engines, batches):        # (a) interleaved: upload A, upload B, run A, run B, download A, download B
+        eng.upload(b)
+    for eng in engines:
+        eng.run()
+    for eng, want in zip(engines, ref):
+        r = eng.download()
+        assert np.array_equal(r["energy"], want[0]) and np.array_equal(r["forces"], want[1])
+    errors = []
+
+    def drive(eng, packs, want):                # (b) two threads, 25 evaluations each
+        try:
+            for _ in range(25):
+                r = eng.evaluate(packs)
+                if not (np.array_equal(r["energy"], want[0]) and np.array_equal(r["forces"], want[1])
+                        and np.array_equal(r["energy_std"], want[2])):
+                    errors.append("mismatch")
+                    return
+        except Exception as exc:   # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=drive, args=(e, b, w)) for e, b, w in zip(engines, batches, ref)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for eng in engines:
+        eng.close()
+    assert not errors, errors
