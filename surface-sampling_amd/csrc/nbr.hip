@@ -400,19 +400,44 @@ __global__ void __launch_bounds__(64) k_edge_geom(int n_atoms, const int *__rest
     for (int off = 32; off > 0; off >>= 1) ex += __shfl_xor(ex, off, 64);
     if (threadIdx.x == 0) e_excl[i] = ex;
     if constexpr (NZ > 0) {
-        const int kq = threadIdx.x & 3;
+        // Sum over the 16 lanes of a quarter class (lane & 3) as a REDUCE-SCATTER: the 24 NZ values are halved across the two
+        // 32-lane halves (v_permlane32_swap: one swap + one add per PAIR of values), halved again across odd / even 16-lane rows
+        // (v_permlane16_swap), and only the remaining quarter is summed inside the row (two DPP rotations): 2 x 24 NZ instructions
+        // instead of 10 per value, a fixed order.  Row rho ends up with values [rho Q, (rho + 1) Q), Q = 6 NZ, i.e. the (species,
+        // component) blocks rho NZ .. rho NZ + NZ - 1, complete in all of its lanes; its four lanes with slot position 0 write them.
+        constexpr int CNT = NZ * 24, H = CNT / 2, Q = CNT / 4;
+        float val[CNT];
 #pragma unroll
         for (int z = 0; z < NZ; ++z)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float v[6];
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int k = 0; k < 6; ++k) v[k] = quarter_class_sum(tacc[z][c][k]);
-                if (threadIdx.x < 4) {   // lane = quarter: its six entries of T[i][z][c][24], 8-byte aligned
-                    float2 *dst = reinterpret_cast<float2 *>(l0T + ((size_t)i * NZ + z) * 96 + c * 24 + kq * 6);
-                    dst[0] = make_float2(v[0], v[1]); dst[1] = make_float2(v[2], v[3]); dst[2] = make_float2(v[4], v[5]);
-                }
+                for (int k = 0; k < 6; ++k) val[(z * 4 + c) * 6 + k] = tacc[z][c][k];
+        float half[H], quart[Q];
+#pragma unroll
+        for (int v = 0; v < H; ++v) {
+            const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(val[v]), __float_as_uint(val[v + H]), false, false);
+            half[v] = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+        }
+#pragma unroll
+        for (int w = 0; w < Q; ++w) {
+            const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(half[w]), __float_as_uint(half[w + Q]), false, false);
+            float x = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));   // row_ror:8
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, true));   // row_ror:4
+            quart[w] = x;
+        }
+        const int lane = threadIdx.x, rho = lane >> 4, kq = lane & 3;
+        if ((lane & 12) == 0) {   // slot position 0 of every row: lane = 16 rho + kq
+#pragma unroll
+            for (int b = 0; b < NZ; ++b) {   // block zc = rho NZ + b = (species z, component c)
+                const int zc = rho * NZ + b, z = zc >> 2, c = zc & 3;
+                float2 *dst = reinterpret_cast<float2 *>(l0T + ((size_t)i * NZ + z) * 96 + c * 24 + kq * 6);
+                dst[0] = make_float2(quart[6 * b], quart[6 * b + 1]);
+                dst[1] = make_float2(quart[6 * b + 2], quart[6 * b + 3]);
+                dst[2] = make_float2(quart[6 * b + 4], quart[6 * b + 5]);
             }
+        }
     }
 }
 
