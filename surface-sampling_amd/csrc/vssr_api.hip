@@ -294,6 +294,9 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
         cfg->readout_hidden < 1 || cfg->readout_hidden > F || cfg->n_embed < 1 || !cfg->weights ||
         !(cfg->cutoff > 0) || !(cfg->model_units_per_ev > 0))
         return set_err(nullptr, VSSR_E_BADARG, "bad PaiNN configuration");
+    if (cfg->excl_vol && (cfg->excl_power < 1 || cfg->excl_power > 64 || !(cfg->excl_sigma > 0)))
+        return set_err(nullptr, VSSR_E_BADARG, "excluded volume: power %d (1 .. 64) / sigma %g out of range", cfg->excl_power,
+                       (double)cfg->excl_sigma);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return set_err(nullptr, VSSR_E_DEVICE, "no HIP device available (this backend has no CPU fallback)");
