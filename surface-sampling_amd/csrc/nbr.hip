@@ -51,13 +51,17 @@ __global__ void k_wrap(int n, const double *__restrict__ pos, const int *__restr
 // lexicographic), reproduced exactly by an exclusive wave scan of the per-lane hit counts, so the CSR is
 // identical however the work is spread over lanes.
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    // inclusive scan on the DPP network (gfx9 row shifts + row broadcasts): 6 dependent vector adds instead of 6 dependent LDS
+    // permutes (__shfl_up = ds_bpermute, ~100 cycles each) -- the neighbor kernels run 5 of these per centre and are latency-bound
     int x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int y = __shfl_up(x, off, 64);
-        if (lane >= off) x += y;
-    }
-    total = __shfl(x, 63, 64);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);    // row_shr:1 (lanes without a source add 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);    // row_shr:8   -> inclusive inside every 16-lane row
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    total = __builtin_amdgcn_readlane(x, 63);
+    (void)lane;
     return x - v;
 }
 
