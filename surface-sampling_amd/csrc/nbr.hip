@@ -51,15 +51,7 @@ __global__ void k_wrap(int n, const double *__restrict__ pos, const int *__restr
 // lexicographic), reproduced exactly by an exclusive wave scan of the per-lane hit counts, so the CSR is
 // identical however the work is spread over lanes.
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
-    // inclusive scan on the DPP network (gfx9 row shifts + row broadcasts): 6 dependent vector adds instead of 6 dependent LDS
-    // permutes (__shfl_up = ds_bpermute, ~100 cycles each) -- the neighbor kernels run 5 of these per centre and are latency-bound
-    int x = v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);    // row_shr:1 (lanes without a source add 0)
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);    // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);    // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);    // row_shr:8   -> inclusive inside every 16-lane row
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    const int x = wave_incl_scan_i32(v);   // DPP network (vssr_internal.h): the neighbor kernels run 5 of these per centre and are latency-bound
     total = __builtin_amdgcn_readlane(x, 63);
     (void)lane;
     return x - v;
@@ -209,12 +201,7 @@ k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int
 #pragma unroll
         for (int u = 0; u < 4; ++u) pd[u] = i0 + u < n ? max((d[u] + 3) & ~3, 8) : 0;
         const int p = pd[0] + pd[1] + pd[2] + pd[3];
-        int x = p, xr = d[0] + d[1] + d[2] + d[3];   // inclusive scan of the thread sums inside the wave
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int y = __shfl_up(x, off, 64), yr = __shfl_up(xr, off, 64);
-            if (lane >= off) { x += y; xr += yr; }
-        }
+        const int x = wave_incl_scan_i32(p), xr = wave_incl_scan_i32(d[0] + d[1] + d[2] + d[3]);   // inclusive scans of the thread sums inside the wave
         if (lane == 63) { wsum[w] = x; wreal[w] = xr; }
         __syncthreads();
         int woff = 0, tile = 0, tile_real = 0;
@@ -409,9 +396,7 @@ __global__ void __launch_bounds__(64) k_edge_geom(int n_atoms, const int *__rest
             dist2[slot] = valid ? make_float2(inv, -(float)excl_power * rep * inv) : make_float2(-1.f, 0.f);
         }
     }
-    // one wave per centre (launch: 64 threads): fixed-order butterfly, so the sum does not depend on batching
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ex += __shfl_xor(ex, off, 64);
+    ex = wave_sum_f32(ex);   // fixed order (DPP + row swaps), so the sum does not depend on batching
     if (threadIdx.x == 0) e_excl[i] = ex;
     if constexpr (NZ > 0) {
         // Sum over the 16 lanes of a quarter class (lane & 3) as a REDUCE-SCATTER: the 24 NZ values are halved across the two

@@ -434,10 +434,7 @@ k_finalize_forces(int N, int M, GraphView G, const int *__restrict__ counters,
             const float4 a = gb[e], b = gb[r];
             g0 += a.x - b.x; g1 += a.y - b.y; g2 += a.z - b.z;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            g0 += __shfl_xor(g0, off, 64); g1 += __shfl_xor(g1, off, 64); g2 += __shfl_xor(g2, off, 64);
-        }
+        g0 = wave_sum_f32(g0); g1 = wave_sum_f32(g1); g2 = wave_sum_f32(g2);   // DPP + row swaps (vssr_internal.h), fixed order
         double f[3] = {-(double)g0 / units_per_ev, -(double)g1 / units_per_ev, -(double)g2 / units_per_ev};
         for (int x = 0; x < 3; ++x) { fm[x] += f[x]; f2[x] += f[x] * f[x]; }
     }

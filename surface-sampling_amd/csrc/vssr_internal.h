@@ -82,6 +82,32 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     ActiveView act;          // chains switched off by the relaxation driver
 };
 
+// Wave-wide integer prefix sum and float sum on the DPP network / the gfx950 row swaps (no LDS permutes: a __shfl is a ds_bpermute,
+// ~100 cycles, and a scan / butterfly is six of them in a dependent chain).  Fixed orders, independent of what else runs.
+#if defined(__HIPCC__)
+__device__ __forceinline__ int wave_incl_scan_i32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);    // row_shr:1 (lanes without a source add 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);    // row_shr:8   -> inclusive inside every 16-lane row
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ float wave_sum_f32(float x) {   // result in every lane
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, true));   // row_ror:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));   // row_ror:8
+    const unsigned u = __float_as_uint(x);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float y = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+    const unsigned v = __float_as_uint(y);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+}
+#endif
+
 // Radial basis of one slot for one table quarter kq (radial indices n = kq + 1 + 4 ks, ks = 0..4, then the envelope):
 //   r[ks] = sin(n pi d / rc) / d * fc(d),  dr[ks] = d r[ks] / d d,  r[5] = fc,  dr[5] = fc'   
 // ONE definition for the kernel that writes the per-slot tables (k_edge_geom, nbr.hip) and for the kernel that rebuilds the fp32
