@@ -730,8 +730,7 @@ __device__ __forceinline__ void readout_head(const ModelW &W, const Planes &xs, 
                 hb[i] = w6[i] * dswish(hval[i]);
             }
             if (WANT_SBAR) store_split4(hp, L.row(t), L.col0, hb, sat);
-            es += __shfl_xor(es, 16, 64);
-            es += __shfl_xor(es, 32, 64);
+            es = xrow_sum_f32(es);   // gfx950 row swaps (vssr_internal.h) instead of two dependent LDS permutes
             if (lane < 16) red[L.w * TA + L.row(t)] = es;
         }
     }

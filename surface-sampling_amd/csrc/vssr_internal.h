@@ -94,6 +94,14 @@ __device__ __forceinline__ int wave_incl_scan_i32(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
     return x;
 }
+__device__ __forceinline__ float xrow_sum_f32(float x) {   // sum over the four 16-lane rows (lanes l, l^16, l^32, l^48), result in every lane
+    const unsigned u = __float_as_uint(x);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float y = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+    const unsigned v = __float_as_uint(y);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+}
 __device__ __forceinline__ float wave_sum_f32(float x) {   // result in every lane
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
