@@ -955,9 +955,15 @@ void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
     hipLaunchKernelGGL((k_edge_bwd_mfma<NF, FIRST, WAVES>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), dim3(64 * WAVES), \
                        (edge_bwd_lds_bytes_t<NF, WAVES>(max_atoms)), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, \
                        v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups, group_off, rec)
+    // 4-wave workgroups when two of them can share a CU (LDS) AND there are enough workgroups to give every CU two; a small batch (a
+    // single chain = 24 workgroups) takes 8 waves so that a lone workgroup still fills its CU's SIMDs: the per-workgroup walk is the
+    // latency of the launch (1 chain of 260 atoms: 103 -> 55 us).  The width never changes a result (a centre's sums run in slot order
+    // inside one wave whichever wave that is).
 #define LAUNCH_BWD_W(NF, FIRST)                                                                                                  \
     do {                                                                                                                         \
-        if (2 * edge_bwd_lds_bytes_t<NF, 4>(max_atoms) <= 160 * 1024) LAUNCH_BWD(NF, FIRST, 4); else LAUNCH_BWD(NF, FIRST, 8);   \
+        const bool two_fit = 2 * edge_bwd_lds_bytes_t<NF, 4>(max_atoms) <= 160 * 1024;                                           \
+        const bool many = (long long)n_list * EdgeGeo<NF>::NSLICE * M > 256;                                                     \
+        if (two_fit && many) LAUNCH_BWD(NF, FIRST, 4); else LAUNCH_BWD(NF, FIRST, 8);                                            \
     } while (0)
     if (cls == EDGE_BCLASS_FS8) { if (layer_first) LAUNCH_BWD_W(2, true); else LAUNCH_BWD_W(2, false); }
     else { if (layer_first) LAUNCH_BWD_W(4, true); else LAUNCH_BWD_W(4, false); }
