@@ -980,9 +980,11 @@ void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
                        (edge_fwd_lds_bytes_t<NF, SLDS>(max_atoms)), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, \
                        s_in, v_in, phi, s_msg, v_msg)
     if (cls == EDGE_CLASS_FS16) {   // workgroups per CU that the launch's largest slice allows -> waves per workgroup
+        // (a launch with fewer workgroups than CUs -- a single chain -- takes the widest form: its latency is one workgroup's walk)
         const size_t lds = edge_fwd_lds_bytes_t<4, true>(max_atoms);
-        if (4 * lds <= 160 * 1024) LAUNCH_FWD(4, true, 4);
-        else if (2 * lds <= 160 * 1024) LAUNCH_FWD(4, true, 8);
+        const long long wgs = (long long)n_list * EdgeGeo<4>::NSLICE * M;
+        if (4 * lds <= 160 * 1024 && wgs > 4 * 256) LAUNCH_FWD(4, true, 4);
+        else if (2 * lds <= 160 * 1024 && wgs > 2 * 256) LAUNCH_FWD(4, true, 8);
         else LAUNCH_FWD(4, true, 16);
     } else if (cls == EDGE_CLASS_FS16M) LAUNCH_FWD(4, false, 16);
     else LAUNCH_FWD(2, false, 16);
