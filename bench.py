@@ -11,13 +11,19 @@ inputs resident in HBM before the timed region.  N > 1: every rank owns 256 more
 BASELINE configs[4]: rank r owns global chains [256 r, 256 r + 256)); the only collective is the RCCL all_gather of
 per-chain (E, sigma_E), read in place from the engine's device buffers (surface_sampling_amd.sharding).
 
-Secondary lines (never the headline): `--atoms-per-chain N` tiles the slab to ~N atoms per chain (74 .. 500: the four neighbor-sum
-paths), `--chains-per-gpu B`, `--streams S`.
+Secondary lines (never the headline): `--atoms-per-chain N` tiles the slab to ~N atoms per chain (74 .. 1000: the neighbor-sum
+paths), `--chains-per-gpu B`.  `--streams S` (default 2): a GPU's chains are split over S engines (own HIP streams, one C-ABI
+handle each) that run concurrently -- the latency-bound node kernels of one half fill issue slots under the edge kernels of
+the other; `config.streams_per_gpu` says what ran.
 
 The ONE JSON line carries, besides the contract fields:
-  roofline      dominant kernel = reverse neighbor pass; `achieved` = SURVEY §8(d) flops (2 x 17 408 per real directed edge
-                and model) / HIP-event launch time; `views` gives the same launch against three yardsticks (fp32 vector /
-                matrix peak, the fp16 matrix pipe it executes on, HBM) and names the binding resource;
+  roofline      dominant kernel = reverse neighbor pass, priced on the pipe it EXECUTES on: `achieved` = matrix-pipe flops
+                executed per launch (static MFMA count x 16x16x32x2) / launch time, `peak` = 2.5 PFLOP/s dense fp16;
+                `views` gives the same launch as fp32-equivalent algorithmic work (2 x 17 408 flop per real
+                directed edge and model; a yardstick, not a ceiling) and against HBM; `binding_resource` is built from the
+                committed PMC passes (profiles/r04/pmc_summary.json).  Launch times = HIP events on the engine's stream in a
+                SEPARATE single-stream pass after the timed region (with S > 1 launches of the two engines overlap, so
+                per-kernel durations inside the timed region are not clean);
   north_star    the BASELINE target ">= 40 % of HBM roofline on the neighbor-sum kernel" as an explicit field (not met: 15 %);
   pcie_inclusive  the same evaluations with new host positions uploaded and energies + forces downloaded every step;
   cpu_baseline  CPU ports of the same evaluation timed on this host (the reference's own CPU path is not installable).
@@ -111,9 +117,54 @@ def executed_mfma_flops(which, n_slots, n_models):
     return n_models * 8 * (n_slots / 16.0) * MFMA_PER_STEP[which] * MFMA_FLOP
 
 
+PMC_SUMMARY = ("profiles", "r04", "pmc_summary.json")   # tools/gpu_pmc_r4.sh -> tools/pmc_summarize.py
+
+
+def pmc_of(kernel):
+    """Derived PMC figures of the (largest) instantiation of `kernel` from the committed summary, or None."""
+    path = os.path.join(ROOT, *PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None
+    best = None
+    for name, d in json.load(open(path)).items():
+        if kernel in name and (best is None or d.get("cycles_per_launch", 0) > best[1].get("cycles_per_launch", 0)):
+            best = (name, d)
+    return best
+
+
+def binding_resource(kernel):
+    """What binds the kernel, every number read from profiles/r04/pmc_summary.json (nothing hard-coded)."""
+    hit = pmc_of(kernel)
+    if hit is None:
+        return None
+    name, d = hit
+    src = "/".join(PMC_SUMMARY)
+    keys = ("matrix_pipe_busy_pct_of_simd_cycles", "valu_active_pct_of_simd_cycles", "wait_inst_any_pct_of_wave_cycles",
+            "ta_busy_pct", "l1_accesses_per_cu_cycle", "mfma_insts_per_simd_cycle", "valu_insts_per_simd_cycle")
+    out = {k: d[k] for k in keys if k in d}
+    mp, va = d.get("matrix_pipe_busy_pct_of_simd_cycles"), d.get("valu_active_pct_of_simd_cycles")
+    parts = []
+    if va is not None:
+        parts.append(f"SIMD instruction issue: vector-ALU instructions (incl. the issue of matrix instructions) occupy {va:.0f} % of the "
+                     f"SIMD cycles ({d.get('valu_insts_per_simd_cycle', 0):.3f} instructions per SIMD cycle x 4-cycle wave64 issue)")
+    if mp is not None:
+        parts.append(f"matrix pipe busy {mp:.0f} % of the SIMD cycles")
+    if "wait_inst_any_pct_of_wave_cycles" in d:
+        parts.append(f"waves wait on an instruction {d['wait_inst_any_pct_of_wave_cycles']:.0f} % of their cycles")
+    if "ta_busy_pct" in d:
+        parts.append(f"L1 address unit (TA) busy {d['ta_busy_pct']:.0f} %")
+    out["summary"] = "; ".join(parts)
+    out["instantiation"] = name
+    out["source"] = f"{src} (tools/gpu_pmc_r4.sh: rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1 --streams 1`)"
+    return out
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch from committed PMC passes (profiles/: FETCH_SIZE, WRITE_SIZE in KB, separate passes;
     FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM for 16-B/lane streams).  None when no profile is committed."""
+    hit = pmc_of(kernel)
+    if hit is not None and "hbm_traffic_bytes_per_launch" in hit[1]:
+        return hit[1]["hbm_traffic_bytes_per_launch"]
     for rel in (("profiles", "r03", "pmc_traffic_edge_kernels.json"), ("profiles", "r02", "pmc_traffic_edge_kernels.json")):
         path = os.path.join(ROOT, *rel)
         if not os.path.exists(path):
@@ -170,34 +221,6 @@ def cpu_baseline(blobs, chains, table, const, budget_s=12.0):
     return out
 
 
-class EngineGroup:
-    """--streams S: this rank's block split over S engines (own HIP streams) that run concurrently; engine interface of
-    ShardedEnsemble (host result path)."""
-
-    def __init__(self, engines):
-        self.engines = engines
-        self.bounds = None
-
-    def upload(self, structs):
-        n, s = len(structs), len(self.engines)
-        self.bounds = [((k * n) // s, ((k + 1) * n) // s) for k in range(s)]
-        for e, (lo, hi) in zip(self.engines, self.bounds):
-            e.upload(structs[lo:hi])
-
-    def run(self, want):
-        for e in self.engines:
-            e.run(want)
-
-    def synchronize(self):
-        for e in self.engines:
-            e.synchronize()
-
-    def download(self, want):
-        parts = [e.download(want) for e in self.engines]
-        out = {k: np.concatenate([p[k] for p in parts]) for k in ("energy", "energy_std", "forces", "forces_std")}
-        return out
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,9 +231,13 @@ def main():
     ap.add_argument("--atoms-per-chain", type=int, default=260,
                     help="secondary lines: larger slabs (e.g. 480: 4 x 2 tiling, served by the 8-feature-slice neighbor kernels); "
                          "the default 260 is the BASELINE workload")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="split this GPU's chains over S engines (own HIP streams) that run concurrently; default 1 keeps "
-                         "the per-kernel launch durations of the roofline free of overlap (DESIGN.md section 5)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="split this GPU's chains over S engines (own HIP streams) that run concurrently (default 2: +2.5 .. 4 %% "
+                         "over one stream, DESIGN.md section 5); the per-kernel launch times of `roofline` always come from a "
+                         "separate single-stream pass after the timed region")
+    ap.add_argument("--profile-steps", type=int, default=20, help="steps of the single-stream per-kernel timing pass")
+    ap.add_argument("--dump-gathered", default=None,
+                    help="rank 0 writes the last step's gathered per-chain [n_chains, >= 2] (E, sigma_E) array to this .npy (tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -220,20 +247,29 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Rehearsal switches (tests only; the driver never sets them): VSSR_DIST_BACKEND=gloo lets N ranks share ONE GPU (RCCL
+    # refuses two ranks on one device), VSSR_LOCAL_DEVICE pins every rank to that GPU.  Everything else -- rank / chain
+    # arithmetic, ShardedEnsemble.step, the max-over-ranks clock, barriers -- is the code the 8-GPU run executes.
+    dist_backend = os.environ.get("VSSR_DIST_BACKEND", "nccl")
+    device_ordinal = int(os.environ.get("VSSR_LOCAL_DEVICE", local_rank))
 
     import torch
 
     from surface_sampling_amd import backend
     from surface_sampling_amd.calculators import stoich_offset_table
-    from surface_sampling_amd.sharding import ShardedEnsemble
+    from surface_sampling_amd.sharding import EngineGroup, ShardedEnsemble
 
     dist = None
+    dev = torch.device("cuda", device_ordinal)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_ordinal)
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     blobs, S, offset_data = load_golden()
     table, const = stoich_offset_table(offset_data)
@@ -242,10 +278,12 @@ def main():
     chains = build_chains(S, first, count, args.atoms_per_chain)
     packs = [(s.numbers, s.positions, s.cell, s.pbc) for s in chains]
 
+    def new_engine():
+        return backend.PainnEngine(blobs, device=device_ordinal, offset_per_z=table, offset_const=const)
+
     n_str = max(1, min(args.streams, count))
-    engs = [backend.PainnEngine(blobs, device=local_rank, offset_per_z=table, offset_const=const) for _ in range(n_str)]
+    engs = [new_engine() for _ in range(n_str)]
     engine = engs[0] if n_str == 1 else EngineGroup(engs)
-    dev = torch.device("cuda", local_rank)
     sharded = ShardedEnsemble(engine, world * B, dist, dev)
     assert (sharded.first, sharded.count) == (first, count)
     sharded.upload(local_chains=packs)                    # inputs resident in HBM
@@ -261,49 +299,70 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    for e in engs:
-        e.profile_enable(True)
-        e.profile_reset()
-    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        gathered = step()
     if sharded.check():   # (device result path: a neighbor-capacity overflow of the last gathered step would be repaired here)
         raise SystemExit("neighbor capacity overflow inside the timed region")
     fence()
     elapsed = time.perf_counter() - t0
-    prof = {}
-    for e in engs:   # HIP-event times of every engine's own stream, summed per kernel class
-        for name, v in e.profile_read().items():
-            acc = prof.setdefault(name, {"launches": 0, "total_ms": 0.0})
-            acc["launches"] += v["launches"]
-            acc["total_ms"] += v["total_ms"]
-        e.profile_enable(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    stats = {"atoms": 0, "edges": 0, "slots": 0}
-    for e in engs:
-        for k, v in e.stats().items():
-            stats[k] += v
+    stats = engine.stats()
     res = engine.download(want)
     if not (np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()):
         raise SystemExit("non-finite results in the timed region")
+    if world > 1:
+        g = gathered.detach().cpu().numpy()
+        if not (np.array_equal(g[first:first + count, 0], res["energy"]) and np.array_equal(g[first:first + count, 1], res["energy_std"])):
+            raise SystemExit("the gathered block of this rank differs from its own results")
+        if rank == 0 and args.dump_gathered:
+            np.save(args.dump_gathered, g)
+    elif args.dump_gathered:
+        np.save(args.dump_gathered, np.stack([res["energy"], res["energy_std"]], axis=1))
+
+    # ---- per-kernel launch times: a separate single-stream pass over the same resident chains (HIP events on that engine's
+    # stream; with S > 1 the launches of the timed region overlap and their durations are not a kernel's own) -----------------
+    if n_str == 1:
+        one = engs[0]
+    else:
+        for e in engs:
+            e.close()
+        one = new_engine()
+        one.upload(packs)
+    k_prof = max(1, min(args.profile_steps, args.steps))
+    for _ in range(2):
+        one.run(want)
+    one.synchronize()
+    one.profile_enable(True)
+    one.profile_reset()
+    t1 = time.perf_counter()
+    for _ in range(k_prof):
+        one.run(want)
+    one.synchronize()
+    one_ms = 1e3 * (time.perf_counter() - t1) / k_prof
+    prof = one.profile_read()
+    one.profile_enable(False)
+    res1 = one.download(want)
+    split_identical = bool(np.array_equal(res1["energy"], res["energy"]) and np.array_equal(res1["forces"], res["forces"]))
+    if not split_identical:
+        raise SystemExit("the engine split changed a chain's results (must be bit-identical)")
 
     # ---- the same evaluations with the host round trip the reference's calculate() makes: positions up, E + F down ---------
     pcie = None
-    if world == 1 and n_str == 1:
+    if world == 1:
         pos_host = np.concatenate([s.positions for s in chains])
         k2 = max(5, min(args.steps, 50))
-        fence()
+        one.synchronize()
         t1 = time.perf_counter()
         for _ in range(k2):
-            engine.set_positions(pos_host)
-            engine.run(want)
-            engine.download(want)
+            one.set_positions(pos_host)
+            one.run(want)
+            one.download(want)
         dt2 = time.perf_counter() - t1
-        pcie = {"value": count * k2 / dt2, "unit": "evaluations/s", "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
+        pcie = {"value": count * k2 / dt2, "unit": "evaluations/s", "ms_per_step": 1e3 * dt2 / k2, "steps": k2, "streams": 1,
                 "per_step": "vssr_batch_set_positions (66.5 k x 24 B up) + run + vssr_batch_download (E, sigma_E, F, sigma_F down)"}
 
     if rank == 0:
@@ -319,22 +378,27 @@ def main():
             t = ms * 1e-3
             if t <= 0:
                 return {}
-            return {"fp32_yardstick": {"achieved_TFLOPs": flops / t / 1e12, "peak_TFLOPs": FP32_PEAK_TFLOPS,
-                                       "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
-                    "executed_matrix_pipe": {"achieved_TFLOPs": mfma_flops / t / 1e12, "peak_TFLOPs": F16_MFMA_PEAK_TFLOPS,
+            return {"executed_matrix_pipe": {"achieved_TFLOPs": mfma_flops / t / 1e12, "peak_TFLOPs": F16_MFMA_PEAK_TFLOPS,
                                              "frac": mfma_flops / t / 1e12 / F16_MFMA_PEAK_TFLOPS},
+                    "algorithmic_on_matrix_pipe": {"achieved_TFLOPs": flops / t / 1e12, "peak_TFLOPs": F16_MFMA_PEAK_TFLOPS,
+                                                   "frac": flops / t / 1e12 / F16_MFMA_PEAK_TFLOPS},
+                    "fp32_equivalent": {"achieved_TFLOPs": flops / t / 1e12, "peak_TFLOPs": FP32_PEAK_TFLOPS,
+                                        "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS,
+                                        "note": "yardstick only: fp32-accurate work that executes as 3 fp16 products on the matrix "
+                                                "pipe; the fp32 vector peak is not this kernel's ceiling"},
                     "hbm": {"achieved_GBps": nbytes / t / 1e9, "peak_GBps": HBM_PEAK_GBS, "frac": nbytes / t / 1e9 / HBM_PEAK_GBS}}
 
-        # (per launch = per engine: with --streams S a launch covers 1/S of this GPU's chains and overlaps the other engines)
-        E, N, SL = stats["edges"] / n_str, stats["atoms"] / n_str, stats["slots"] / n_str
+        E, N, SL = stats["edges"], stats["atoms"], stats["slots"]
         bwd_ms, bwd_n = launch_ms("edge_message_bwd")
         fwd_ms, fwd_n = launch_ms("edge_message_fwd")
         bwd_flops, bwd_bytes = reverse_pass_flops(E, M), reverse_pass_bytes(N, E, M)
         fwd_flops, fwd_bytes = neighbor_sum_flops(E, M), neighbor_sum_bytes(N, E, M)
-        bwd_views = view(bwd_flops, bwd_bytes, executed_mfma_flops("bwd", SL, M), bwd_ms)
-        fwd_views = view(fwd_flops, fwd_bytes, executed_mfma_flops("fwd", SL, M), fwd_ms)
-        achieved = bwd_flops / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
-        step_ms = sum(v["total_ms"] for v in prof.values()) / args.steps
+        bwd_exec, fwd_exec = executed_mfma_flops("bwd", SL, M), executed_mfma_flops("fwd", SL, M)
+        bwd_views = view(bwd_flops, bwd_bytes, bwd_exec, bwd_ms)
+        fwd_views = view(fwd_flops, fwd_bytes, fwd_exec, fwd_ms)
+        achieved = bwd_exec / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+        step_ms = sum(v["total_ms"] for v in prof.values()) / k_prof
+        step_flops = 33.0e6 * N     # 33 MFLOP per atom and ensemble evaluation (fp32-equivalent algorithmic work)
         line = {
             "metric": "MC energy-evaluations/sec (SrTiO3(001) ~250-atom slabs, 3-model PaiNN ensemble E+F incl. neighbor list)",
             "value": value, "unit": "evaluations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -347,39 +411,61 @@ def main():
                                     f"{min(len(c) for c in chains)}-{max(len(c) for c in chains)} atoms/chain"),
                        "chains_per_gpu": count, "atoms_per_gpu": stats["atoms"], "edges_per_gpu": stats["edges"],
                        "slots_per_gpu": stats["slots"], "models": M, "streams_per_gpu": n_str,
+                       "streams_note": (f"the {count} chains of a GPU are split over {n_str} engines (own HIP streams) that run "
+                                        "concurrently; results bit-identical to one engine (checked in this run)"
+                                        if n_str > 1 else "one engine, one HIP stream"),
+                       "result_path": sharded.result_path, "dist_backend": dist_backend if world > 1 else None,
                        "parallelism": ("one GPU, no collective" if world == 1 else
                                        f"chains sharded x{world} (rank r owns chains [{count} r, {count} r + {count})), "
-                                       "RCCL all_gather of per-chain (E, sigma_E) from device buffers")},
+                                       + ("RCCL" if dist_backend == "nccl" else dist_backend)
+                                       + " all_gather of per-chain (E, sigma_E)"
+                                       + (" from device buffers" if sharded.result_path == "device" else " (host result path)"))},
             # Dominant kernel: the reverse neighbor pass (k_edge_bwd_mfma, layers 2 and 1; layer 0 is factorised by species and
-            # has its own profiler class).  achieved = algorithmic flops of SURVEY §8(d) (reverse = 2 x 17 408 per real
-            # directed edge and model) / avg_launch_ms, launch times = HIP events on the handle's stream.
-            "roofline": {"bound": "mfma", "kernel": "edge_message_bwd (reverse neighbor pass, k_edge_bwd_mfma)",
-                         "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": measured_traffic("k_edge_bwd_mfma"),
-                         "formula": "achieved = models x edges_per_gpu x 2 x 17408 / avg_launch_ms ; peak = fp32 vector/matrix "
-                                    "peak (a yardstick: the filter GEMVs execute as 3 fp16 products on the 2.5 PF matrix pipe)",
-                         "avg_launch_ms": bwd_ms, "launches": bwd_n, "algorithmic_flops_per_launch": bwd_flops,
+            # has its own profiler class), priced on the pipe it executes on.
+            "roofline": {"bound": "mfma",
+                         "pipe": "fp16 matrix pipe (v_mfma_f32_16x16x32_f16, dense peak 2.5 PFLOP/s); what binds is SIMD "
+                                 "instruction issue -- see binding_resource",
+                         "kernel": "edge_message_bwd (reverse neighbor pass, k_edge_bwd_mfma)",
+                         "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F16_MFMA_PEAK_TFLOPS, "traffic": measured_traffic("k_edge_bwd_mfma"),
+                         "formula": "achieved = executed matrix-pipe flops per launch / avg_launch_ms; executed = models x 8 feature "
+                                    "slices x slots_per_gpu / 16 steps x 20 v_mfma_f32_16x16x32_f16 per 16-slot step (static count "
+                                    "of the ISA) x 16384 flop.  The filter products are exact 3-way fp16 splits of fp32 operands, so "
+                                    "the ALGORITHMIC flops (views.fp32_equivalent / algorithmic_on_matrix_pipe: SURVEY 8(d), "
+                                    "2 x 17408 per real directed edge and model) are ~1/5 of the executed ones",
+                         "avg_launch_ms": bwd_ms, "launches": bwd_n,
+                         "launch_times_from": f"separate single-stream pass of {k_prof} steps after the timed region "
+                                              "(HIP events on the engine's stream)",
+                         "executed_matrix_flops_per_launch": bwd_exec,
+                         "algorithmic_flops_per_launch": bwd_flops,
                          "algorithmic_bytes_per_launch": bwd_bytes, "views": bwd_views,
-                         "binding_resource": "SIMD instruction issue: per 16-slot step ~130 vector + 20 matrix instructions whose "
-                                             "issue times add up (130 x 4 + 20 x 17 cycles + LDS/VMEM/SALU = the measured ~1010 "
-                                             "cycles; interleaving them across steps did not overlap them: "
-                                             "profiles/r02/NOTES_node_kernels.md); PMC: matrix pipe 34 % + vector issue 38 % of the SIMD cycles, which do not overlap "
-                                             "for this MFMA shape (profiles/r02/pmc_sq_heavy_kernels.txt, micro_mfma_interleave.txt); TA 87-93 % busy "
-                                             "on this build (profiles/r03/pmc_ta_all_kernels.txt); removing ALL partial-gradient HBM traffic buys "
-                                             "5.7 % (profiles/r03/NOTES_edge_traffic.md)",
+                         "binding_resource": binding_resource("k_edge_bwd_mfma"),
                          "second_kernel": {"kernel": "edge_message_fwd (neighbor-sum, k_edge_fwd_mfma)",
                                            "avg_launch_ms": fwd_ms, "launches": fwd_n,
+                                           "achieved": fwd_exec / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0,
+                                           "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": (fwd_exec / (fwd_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS) if fwd_ms > 0 else 0.0,
+                                           "executed_matrix_flops_per_launch": fwd_exec,
                                            "algorithmic_flops_per_launch": fwd_flops,
                                            "algorithmic_bytes_per_launch": fwd_bytes,
-                                           "traffic": measured_traffic("k_edge_fwd_mfma"), "views": fwd_views}},
+                                           "traffic": measured_traffic("k_edge_fwd_mfma"), "views": fwd_views,
+                                           "binding_resource": binding_resource("k_edge_fwd_mfma")},
+                         "whole_step": {"single_stream_ms": step_ms,
+                                        "algorithmic_TFLOPs": step_flops / (step_ms * 1e-3) / 1e12 if step_ms > 0 else 0.0,
+                                        "frac_of_fp16_matrix_peak": (step_flops / (step_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS)
+                                        if step_ms > 0 else 0.0,
+                                        "note": "33 MFLOP per atom (SURVEY 8(d), fp32-equivalent) x atoms_per_gpu / device time of "
+                                                "one single-stream step, against the 2.5 PFLOP/s pipe the contractions execute on"}},
             # BASELINE north_star: ">= 40 % of HBM roofline on the neighbor-sum kernel" -- stated, not buried in `views`: the
             # fused neighbor-sum runs at 115 FLOP/B and is bound by instruction issue, not by HBM
             "north_star": {"neighbor_sum_hbm_frac": (fwd_views.get("hbm") or {}).get("frac"), "target": 0.40,
                            "met": bool(fwd_views) and fwd_views["hbm"]["frac"] >= 0.40,
                            "kernel": "edge_message_fwd (k_edge_fwd_mfma)", "algorithmic_bytes_per_launch": fwd_bytes,
                            "avg_launch_ms": fwd_ms},
-            "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]},
+            "kernel_ms_per_step": {k: v["total_ms"] / k_prof for k, v in prof.items() if v["launches"]},
             "device_ms_per_step": step_ms,
+            "single_stream": {"ms_per_step": one_ms, "value": count / (one_ms * 1e-3), "steps": k_prof,
+                              "note": "the per-kernel pass: one engine, HIP events around every kernel class"},
             "pcie_inclusive": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -387,8 +473,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    for e in engs:
-        e.close()
+    one.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

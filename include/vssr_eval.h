@@ -226,6 +226,14 @@ int vssr_batch_embedding(vssr_handle *h, int32_t model, float *dst, int64_t cap,
  * energy, n_flagged (may be NULL) their count.  The reference has no counterpart (fp32 torch arithmetic overflows at 3e38);
  * callers treat a flagged chain like the out-of-bounds energies of mcmc/dynamics.py:159-168.  Tersoff / EAM: always 0. */
 int vssr_batch_saturated(vssr_handle *h, uint8_t *flags, int32_t *n_flagged);
+/* Virial stress of every chain of the resident batch from its LAST evaluation (which must have produced forces): the
+ * "stress" property that nff's EnsembleNFF / the reference's EnsembleNFFSurface list in implemented_properties
+ * (mcmc/calculators/calculators.py:369) and ASE's Atoms.get_stress() asks a calculator for.  Nothing is re-evaluated: the
+ * reverse pass leaves dE/d r for every directed edge on the device, and sigma_ab = (1/V) sum_edges (dE/d r_a) r_b.
+ * stress, stress_std (may be NULL): [B][6] fp64, Voigt order xx yy zz yz xz xy, eV / A^3, ASE's sign convention; ensemble
+ * mean and population standard deviation over the models.  V = |det cell| (also for slabs with a vacuum axis, as ASE).
+ * PaiNN handles only (VSSR_E_STATE otherwise, after an energies-only run, or after a relaxation that left a partial graph). */
+int vssr_batch_stress(vssr_handle *h, double *stress, double *stress_std);
 /* The handle's HIP device ordinal, its stream (hipStream_t: every kernel of the handle is enqueued there) and the device
  * address of the neighbor-capacity overflow flag of the last run (int32, non-zero = the run's results are void and
  * vssr_synchronize will repeat it with grown buffers; NULL before the first run).  For consumers that order their own device

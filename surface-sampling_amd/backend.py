@@ -29,7 +29,7 @@ EXPORTS = (
     "vssr_batch_device_results", "vssr_eam_create", "vssr_eam_eval_batch",
     "vssr_tersoff_create_from_text", "vssr_batch_relax_cg", "vssr_batch_saturated",
     "vssr_batch_embedding", "vssr_batch_traj_configure", "vssr_batch_traj_read",
-    "vssr_device_context",
+    "vssr_device_context", "vssr_batch_stress",
 )
 
 
@@ -190,6 +190,8 @@ def load_library():
     L.vssr_batch_embedding.argtypes = [vp, C.c_int32, fp, C.c_int64, i64p]
     L.vssr_batch_saturated.restype = C.c_int
     L.vssr_batch_saturated.argtypes = [vp, u8p, ip]
+    L.vssr_batch_stress.restype = C.c_int
+    L.vssr_batch_stress.argtypes = [vp, dp, dp]
     L.vssr_device_context.restype = C.c_int
     L.vssr_device_context.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(vp)]
     L.vssr_debug_capacity.restype = C.c_int
@@ -313,6 +315,14 @@ class _Handle:
         self._check(self._lib.vssr_batch_saturated(self._h, _ptr(flags, C.c_uint8), C.byref(n)))
         return flags.astype(bool)
 
+    def stress(self):
+        """``(stress [B, 6], stress_std [B, 6])`` float64, Voigt order xx yy zz yz xz xy in eV / A^3 (ASE's convention): the
+        virial of the LAST evaluation of every chain, from the edge gradients its reverse pass left on the device
+        (vssr_batch_stress; the run must have produced forces)."""
+        st, sd = np.zeros((self._n_cfg, 6)), np.zeros((self._n_cfg, 6))
+        self._check(self._lib.vssr_batch_stress(self._h, _ptr(st, C.c_double), _ptr(sd, C.c_double)))
+        return st, sd
+
     def device_results(self):
         """``(energy, energy_std)`` of the resident batch as zero-copy device arrays (objects with
         ``__cuda_array_interface__``: ``torch.as_tensor(x, device="cuda")`` wraps them).  Valid after a synchronised run."""
@@ -435,6 +445,8 @@ class _Handle:
 class PainnEngine(_Handle):
     """PaiNN-ensemble evaluator on one GPU (one handle = one HIP stream)."""
 
+    has_device_results = True     # vssr_batch_device_results serves fp32 PaiNN handles (sharding.ShardedEnsemble's device path)
+
     def __init__(self, blobs, device=0, cutoff=5.0, model_units_per_ev=23.0605, offset_per_z=None,
                  offset_const=0.0, hparams=None):
         super().__init__()
@@ -466,6 +478,8 @@ class PainnEngine(_Handle):
 
 class _AnalyticEngine(_Handle):
     """Shared fp64 interface of the analytic potentials (Tersoff, EAM): types instead of atomic numbers."""
+
+    has_device_results = False    # fp64 results: sharding uses the host result path
 
     def relax_f64(self, structs, fixed=None, max_steps=100, fmax=0.01, optimizer="FIRE"):
         """Relax (types, positions, cell, pbc) structures with FIRE / BFGS; returns (energy [B], e_atom [N], forces [N,3],

@@ -224,7 +224,9 @@ class EnsembleNFFSurface(_Base):
             those of every ensemble member ``[M, N, 128]``.
     """
 
-    implemented_properties = ("energy", "forces", "stress", "energy_std", "forces_std", "surface_energy", "embedding")
+    # "stress" / "stress_std" like nff's EnsembleNFF (the reference's class attribute, calculators.py:369, inherits them): the
+    # virial of the same evaluation, Voigt 6-vector in eV / A^3 (what ase.Atoms.get_stress asks a calculator for)
+    implemented_properties = ("energy", "forces", "stress", "energy_std", "forces_std", "stress_std", "surface_energy", "embedding")
     name = "ensemble_nff_surface_mi355x"
 
     def __init__(self, models, device="cuda", model_units="kcal/mol", prediction_units="eV",
@@ -372,7 +374,12 @@ class EnsembleNFFSurface(_Base):
         _Base.calculate(self, atoms, properties, system_changes)
         eng = self._get_engine()
         res = eng.evaluate([structures.as_arrays(atoms)])
-        self.results.update(self._fill_results(res, 0))
+        # a fresh dict per calculation, like nff's NeuralFF / EnsembleNFF.calculate: entries of an earlier structure that this
+        # call does not produce (surface_energy, stress, embedding) must not survive a direct calculate() on another one
+        self.results = dict(self._fill_results(res, 0))
+        if "stress" in properties or "stress_std" in properties:
+            st, sd = eng.stress()
+            self.results["stress"], self.results["stress_std"] = st[0], sd[0]
         if "embedding" in self.properties or "embedding" in tuple(properties) and tuple(properties) != tuple(self.implemented_properties):
             emb = eng.embedding()
             self.results["embedding"] = emb[0]
@@ -392,11 +399,13 @@ class EnsembleNFFSurface(_Base):
         return value
 
     # -- new capability: many independent chains in one lock-step evaluation ----------------------------
-    def calculate_batch(self, atoms_list, want_surface_energy: bool = False, want_embedding: bool | None = None) -> list[dict]:
+    def calculate_batch(self, atoms_list, want_surface_energy: bool = False, want_embedding: bool | None = None,
+                        want_stress: bool = False) -> list[dict]:
         """Evaluate B independent configurations at once; returns one results dict per configuration
-        (``want_embedding``: default = ``"embedding" in self.properties``)."""
+        (``want_embedding``: default = ``"embedding" in self.properties``; ``want_stress``: also ``stress`` / ``stress_std``)."""
         eng = self._get_engine()
         res = eng.evaluate([structures.as_arrays(a) for a in atoms_list])
+        stress = eng.stress() if want_stress else None
         if want_embedding is None:
             want_embedding = "embedding" in self.properties
         emb = eng.embedding() if want_embedding else None
@@ -405,6 +414,8 @@ class EnsembleNFFSurface(_Base):
             r = self._fill_results(res, b)
             if want_surface_energy:
                 r["surface_energy"] = self.surface_energy_of(r["energy"], atoms)
+            if stress is not None:
+                r["stress"], r["stress_std"] = stress[0][b].copy(), stress[1][b].copy()
             if emb is not None:
                 a0, a1 = int(res["cfg_start"][b]), int(res["cfg_start"][b + 1])
                 r["embedding"] = emb[0, a0:a1].copy()

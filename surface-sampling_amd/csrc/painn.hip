@@ -448,6 +448,57 @@ k_finalize_forces(int N, int M, GraphView G, const int *__restrict__ counters,
     }
 }
 
+// Virial stress of every chain from the per-slot edge gradients the reverse pass left in `gbar` (nothing is re-evaluated):
+// the energy depends on positions and cell only through the edge vectors r_e = x_j + S cell - x_i, and gbar[e] holds
+// dE/d(-r_e) (the gradient for the edge j -> i, stored at slot (i, j)), so under a homogeneous strain r -> (1 + eps) r
+//   dE/d eps_ab = - sum_e gbar[e]_a r_e,b ,      sigma = (1 / V) dE/d eps  (ASE sign convention: tensile positive),
+// symmetrised, Voigt order xx yy zz yz xz xy, eV / A^3; ensemble mean and population std over the models (like the forces).
+// The stoichiometric offset does not depend on the strain.  One workgroup per chain, fp64 accumulation, fixed order.
+__global__ void __launch_bounds__(256)
+k_stress(int M, GraphView G, const int *__restrict__ counters, const float4 *__restrict__ gbar, long long gbar_model_stride,
+         const double *__restrict__ cell, double units_per_ev, double *__restrict__ stress, double *__restrict__ stress_std) {
+    __shared__ double red[9][256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (counters[2]) return;
+    const int s0 = G.row_start[G.cfg_start[b]], s1 = G.row_start[G.cfg_start[b + 1]];
+    const double *c = cell + 9 * (size_t)b;
+    const double vol = fabs(c[0] * (c[4] * c[8] - c[5] * c[7]) - c[1] * (c[3] * c[8] - c[5] * c[6]) + c[2] * (c[3] * c[7] - c[4] * c[6]));
+    double mean[6] = {0, 0, 0, 0, 0, 0}, sq[6] = {0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < M; ++m) {
+        const float4 *gb = gbar + (size_t)m * gbar_model_stride;
+        double w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e = s0 + tid; e < s1; e += 256) {
+            const float4 r = G.edge[e];
+            if (__float_as_int(r.w) < 0) continue;   // pad slot
+            const float4 g = gb[e];
+            const double gx = g.x, gy = g.y, gz = g.z, rx = r.x, ry = r.y, rz = r.z;
+            w[0] -= gx * rx; w[1] -= gx * ry; w[2] -= gx * rz;
+            w[3] -= gy * rx; w[4] -= gy * ry; w[5] -= gy * rz;
+            w[6] -= gz * rx; w[7] -= gz * ry; w[8] -= gz * rz;
+        }
+        for (int k = 0; k < 9; ++k) red[k][tid] = w[k];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s)
+                for (int k = 0; k < 9; ++k) red[k][tid] += red[k][tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double f = 1.0 / (units_per_ev * vol);
+            const double v[6] = {red[0][0] * f, red[4][0] * f, red[8][0] * f, 0.5 * (red[5][0] + red[7][0]) * f,
+                                 0.5 * (red[2][0] + red[6][0]) * f, 0.5 * (red[1][0] + red[3][0]) * f};
+            for (int k = 0; k < 6; ++k) { mean[k] += v[k]; sq[k] += v[k] * v[k]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+        for (int k = 0; k < 6; ++k) {
+            const double mu = mean[k] / M, var = sq[k] / M - mu * mu;
+            stress[6 * (size_t)b + k] = mu;
+            if (stress_std) stress_std[6 * (size_t)b + k] = sqrt(var > 0 ? var : 0.0);
+        }
+}
+
 __global__ void __launch_bounds__(256)
 k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const int *__restrict__ cfg_start, const int *__restrict__ Z,
                   const float *__restrict__ e_atom, double units_per_ev, const double *__restrict__ offset_per_z,
@@ -561,6 +612,7 @@ int painn_alloc_state(vssr_handle *h) {
 int painn_run(vssr_handle *h, uint32_t want) {
     const int N = h->n_atoms, M = h->n_models, L = h->num_conv, H = h->readout_hidden;
     hipStream_t st = h->stream;
+    h->h_sat_valid = false;   // (the host copy of the saturation report belongs to the previous evaluation)
     int rc = build_neighbors(h, (double)h->cutoff);
     if (rc) return rc;
     rc = painn_alloc_state(h);
@@ -750,6 +802,23 @@ int painn_run(vssr_handle *h, uint32_t want) {
                        h->d_energy_models.as<float>(), h->d_e_atoms.as<float>(), h->d_sat.as<unsigned>(),
                        h->d_sat_out.as<unsigned>());
     P.end(st);
+    VSSR_HIP(h, hipGetLastError());
+    return VSSR_OK;
+}
+
+// vssr_batch_stress: the virial of the last evaluation (forces must have been computed: gbar holds the reduced edge gradients)
+int painn_stress(vssr_handle *h) {
+    if (h->d_stress.ensure(sizeof(double) * 12 * (size_t)h->n_cfg)) return set_err(h, VSSR_E_DEVICE, "out of device memory (stress)");
+    GraphView G{};
+    G.n_atoms = h->n_atoms;
+    G.n_cfg = h->n_cfg;
+    G.cfg_start = h->d_cfg_start.as<int>();
+    G.row_start = h->d_row_start.as<int>();
+    G.edge = h->d_edge.as<float4>();
+    const int fin_groups = h->gbar_mode == 2 ? 1 : painn_gbar_groups(h);
+    double *out = h->d_stress.as<double>();
+    hipLaunchKernelGGL(k_stress, dim3(h->n_cfg), dim3(256), 0, h->stream, h->n_models, G, h->d_counters.as<int>(), h->sv.gbar,
+                       (long long)h->slot_cap * fin_groups, h->d_cell.as<double>(), h->units_per_ev, out, out + 6 * (size_t)h->n_cfg);
     VSSR_HIP(h, hipGetLastError());
     return VSSR_OK;
 }

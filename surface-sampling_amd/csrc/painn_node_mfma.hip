@@ -233,10 +233,15 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRT][NCT]) {
 #define WTILE(name, tile, K) (W.q##name + (size_t)(tile) * 4 * (K))
 
 // ---- message MLP forward: phi = W2 swish(W1 s + b1) + b2 ---------------------------------------------------
+// RT = 16-row tiles per wave: 2 = the 32-atom tile of every node kernel; 4 = 64 atoms per workgroup (the weight stream per atom
+// halves; VSSR_MSG_MLP_RT=4, the row-scaling experiment of round 4, profiles/r04/NOTES_node_rows.md).  The saturation watch
+// attributes rows modulo 32 (mfma16.h), exact for RT = 2 only: the RT = 4 form is an experiment, never the default.
+template <int RT, int PF>
 __global__ void __launch_bounds__(NTHREADS)
 k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const float *__restrict__ s_in,
                float *__restrict__ phi) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    constexpr int TA = 16 * RT;
     const Planes xs = make_planes(ldsh, TA, F), hs = make_planes(ldsh + plane_halves(TA, F), TA, F);
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
@@ -247,14 +252,14 @@ k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const
     load_rows_split<TA>(xs, 0, [&](int row) { return s_in + (mN + min(a0 + row, N - 1)) * F; }, sat);
     __syncthreads();
     {
-        f32x4 acc[2][1];
+        f32x4 acc[RT][1];
         zero_acc(acc);
         const uint4 *wp[1] = {WTILE(W1, L.w, F)};
         const f32x4 b = gload4f(W.b1 + L.col0);
         __builtin_amdgcn_sched_barrier(0);   // the bias is requested in front of the GEMM whose epilogue adds it
-        gemm16<F, 2, 1>(xs, wp, acc);
+        gemm16<F, RT, 1, PF>(xs, wp, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < RT; ++t) {
             f32x4 hv = acc[t][0] + b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = swish(hv[i]);
@@ -262,19 +267,19 @@ k_msg_mlp_mfma(int N, int l, ActiveView av, const ModelW *__restrict__ MW, const
         }
     }
     __syncthreads();
-    f32x4 acc[2][3];
+    f32x4 acc[RT][3];
     zero_acc(acc);
     const uint4 *wp[3] = {WTILE(W2, L.w, F), WTILE(W2, NW + L.w, F), WTILE(W2, 2 * NW + L.w, F)};
     f32x4 b2[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) b2[c] = gload4f(W.b2 + c * F + L.col0);
     __builtin_amdgcn_sched_barrier(0);
-    gemm16<F, 2, 3>(hs, wp, acc);
+    gemm16<F, RT, 3, PF>(hs, wp, acc);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const f32x4 b = b2[c];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < RT; ++t) {
             const int a = a0 + L.row(t);
             if (a < N) *reinterpret_cast<f32x4 *>(phi + (mN + a) * F3 + c * F + L.col0) = acc[t][c] + b;
         }
@@ -1110,8 +1115,14 @@ static_assert(sizeof(_Float16) * (CF_LDS_HALVES + plane_halves(TA, F)) <= 96 * 1
 bool readout_mfma_supported(int hidden) { return hidden == RH; }
 
 int node_mfma_init(vssr_handle *h) {
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(0)));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)node_mfma_lds_bytes(0)));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(2 * node_mfma_lds_bytes(0))));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(2 * node_mfma_lds_bytes(0))));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(1)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1136,8 +1147,15 @@ int node_mfma_init(vssr_handle *h) {
 
 void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
                          float *phi) {
-    hipLaunchKernelGGL(k_msg_mlp_mfma, dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(0), st, N, l, av, MW,
-                       s_in, phi);
+    // VSSR_MSG_MLP_RT = 4 / VSSR_MSG_MLP_PF = 1: row-scaling experiment (64-atom tiles / pipelined GEMMs); default 2 / 0
+    static const int rt = [] { const char *e = getenv("VSSR_MSG_MLP_RT"); return e ? atoi(e) : 2; }();
+    static const int pf = [] { const char *e = getenv("VSSR_MSG_MLP_PF"); return e ? atoi(e) : 0; }();
+#define LAUNCH_MLP(RT_, PF_)                                                                                                  \
+    hipLaunchKernelGGL((k_msg_mlp_mfma<RT_, PF_>), dim3((N + 16 * RT_ - 1) / (16 * RT_), M), dim3(NTHREADS),                      \
+                       (RT_ / 2) * node_mfma_lds_bytes(0), st, N, l, av, MW, s_in, phi)
+    if (rt == 4) { if (pf) LAUNCH_MLP(4, 1); else LAUNCH_MLP(4, 0); }
+    else { if (pf) LAUNCH_MLP(2, 1); else LAUNCH_MLP(2, 0); }
+#undef LAUNCH_MLP
 }
 void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
                              const float *phibar, const float *sbar_msg, float *sbar_in) {

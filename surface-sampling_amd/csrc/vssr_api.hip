@@ -467,7 +467,7 @@ void vssr_destroy(vssr_handle *h) {
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
                       &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_erec, &h->d_rho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->d_zslot, &h->d_bundle, &h->d_excl, &h->d_hits, &h->wd16, &h->node16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv, &h->d_active, &h->d_bfgs_q, &h->d_bfgs_b,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
-                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n, &h->d_chain_class, &h->d_class_list, &h->d_upd_save, &h->d_gpart};
+                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_stress, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n, &h->d_chain_class, &h->d_class_list, &h->d_upd_save, &h->d_gpart};
     for (DevBuf *b : bufs) b->release();
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -641,6 +641,10 @@ int vssr_batch_download(vssr_handle *h, uint32_t want, vssr_out *out) {
         if (out->forces_std && (want & VSSR_WANT_STD))
             VSSR_HIP(h, hipMemcpy(out->forces_std, h->d_forces_std.p, sizeof(float) * 3 * N, hipMemcpyDeviceToHost));
     }
+    // the saturation report travels with the results (vssr_batch_saturated then needs no synchronisation / copy of its own)
+    h->h_sat.resize(B);
+    VSSR_HIP(h, hipMemcpy(h->h_sat.data(), h->d_sat_out.p, sizeof(unsigned) * B, hipMemcpyDeviceToHost));
+    h->h_sat_valid = true;
     return VSSR_OK;
 }
 
@@ -874,6 +878,8 @@ int vssr_batch_embedding(vssr_handle *h, int32_t model, float *dst, int64_t cap,
     if (!h) return VSSR_E_BADARG;
     if (!h->ran || h->kind != 1) return set_err(h, VSSR_E_STATE, "no completed PaiNN run");
     if (model < -1 || model >= h->n_models) return set_err(h, VSSR_E_BADARG, "model index out of range");
+    if (h->graph_partial)   // (chains that converged early keep the features of THEIR last iteration, or of a buffer a regrow replaced)
+        return set_err(h, VSSR_E_STATE, "the resident activations cover only the chains of the last relaxation iteration: run the batch once (vssr_batch_run) first");
     VSSR_HIP(h, hipSetDevice(h->device));
     int rc = sync_and_check(h);
     if (rc) return rc;
@@ -887,16 +893,39 @@ int vssr_batch_embedding(vssr_handle *h, int32_t model, float *dst, int64_t cap,
     return VSSR_OK;
 }
 
+int vssr_batch_stress(vssr_handle *h, double *stress, double *stress_std) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->ran || h->kind != 1) return set_err(h, VSSR_E_STATE, "no completed PaiNN run");
+    if (!(h->last_want & VSSR_WANT_FORCES))
+        return set_err(h, VSSR_E_STATE, "stress needs the edge gradients of a run that produced forces; the last run was asked for energies only");
+    if (h->graph_partial)
+        return set_err(h, VSSR_E_STATE, "the resident graph covers only the chains of the last relaxation iteration: run the batch once (vssr_batch_run) first");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    int rc = sync_and_check(h);   // (a capacity overflow is repaired here: the gradients below are those of the repeated run)
+    if (rc) return rc;
+    rc = painn_stress(h);
+    if (rc) return rc;
+    VSSR_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t n = 6 * (size_t)h->n_cfg;
+    if (stress) VSSR_HIP(h, hipMemcpy(stress, h->d_stress.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (stress_std) VSSR_HIP(h, hipMemcpy(stress_std, h->d_stress.as<double>() + n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return VSSR_OK;
+}
+
 int vssr_batch_saturated(vssr_handle *h, uint8_t *flags, int32_t *n_flagged) {
     if (!h) return VSSR_E_BADARG;
     if (!h->ran) return set_err(h, VSSR_E_STATE, "no completed run");
     VSSR_HIP(h, hipSetDevice(h->device));
-    int rc = sync_and_check(h);
-    if (rc) return rc;
     int count = 0;
     if (h->kind == 1) {   // the fp64 potentials have no reduced-precision stage
-        std::vector<unsigned> f(h->n_cfg);
-        VSSR_HIP(h, hipMemcpy(f.data(), h->d_sat_out.p, sizeof(unsigned) * h->n_cfg, hipMemcpyDeviceToHost));
+        if (!h->h_sat_valid || (int)h->h_sat.size() != h->n_cfg) {
+            int rc = sync_and_check(h);
+            if (rc) return rc;
+            h->h_sat.resize(h->n_cfg);
+            VSSR_HIP(h, hipMemcpy(h->h_sat.data(), h->d_sat_out.p, sizeof(unsigned) * h->n_cfg, hipMemcpyDeviceToHost));
+            h->h_sat_valid = true;
+        }
+        const std::vector<unsigned> &f = h->h_sat;
         for (int b = 0; b < h->n_cfg; ++b) {
             if (flags) flags[b] = f[b] ? 1 : 0;
             count += f[b] ? 1 : 0;

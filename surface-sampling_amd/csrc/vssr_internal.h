@@ -321,6 +321,9 @@ struct vssr_handle {
     vssr::DevBuf d_energy, d_energy_std, d_energy_models, d_forces, d_forces_std, d_e_atoms;
     vssr::DevBuf d_ters_e, d_ters_ea, d_ters_f;  // fp64 Tersoff results
     vssr::DevBuf d_sat, d_sat_out;   // [n_cfg] unsigned: saturation flags raised during a run / reported for the last evaluation of every chain
+    std::vector<unsigned> h_sat;     // host copy of d_sat_out taken by vssr_batch_download (vssr_batch_saturated serves it: no second
+    bool h_sat_valid = false;        // synchronisation / copy per download, advisor r3); void after every run
+    vssr::DevBuf d_stress;           // [2][n_cfg][6] double: virial stress (mean, std over models) of the last evaluation (vssr_batch_stress)
 };
 
 namespace vssr {
@@ -339,6 +342,7 @@ int build_neighbors(vssr_handle *h, double cutoff);
 // PaiNN pipeline (painn.hip)
 int painn_alloc_state(vssr_handle *h);
 int painn_run(vssr_handle *h, uint32_t want);
+int painn_stress(vssr_handle *h);   // enqueues k_stress: d_stress from the edge gradients of the last run (forces wanted)
 // Tersoff (tersoff.hip)
 int tersoff_run(vssr_handle *h, uint32_t want);
 // EAM (eam.hip)

@@ -131,6 +131,81 @@ def test_single_rank_step_has_no_collective():
     assert bench.make_step(sh, 7)() is None and eng.runs == 1
 
 
+def _gather_worker(rank, world, port, n_chains, out_dir):
+    """ChainGather over gloo: buffers allocated once, the even case hands the caller's tensor straight to the collective."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from surface_sampling_amd.sharding import ChainGather, all_ranges
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = all_ranges(n_chains, world)[rank]
+    g = ChainGather(n_chains, 3, dist)
+    ok = g.even == (n_chains % world == 0)
+    seen = set()
+    for k in range(6):
+        local = torch.arange(first, first + count, dtype=torch.float32)[:, None] * torch.tensor([1.0, 10.0, 100.0]) + k
+        full = g(local)
+        want = torch.arange(n_chains, dtype=torch.float32)[:, None] * torch.tensor([1.0, 10.0, 100.0]) + k
+        ok = ok and torch.equal(full, want)
+        seen.add(full.data_ptr())
+        if k:
+            ok = ok and torch.equal(prev, want - 1.0)      # the previous result is still intact (two buffers alternate)
+        prev = full
+    ok = ok and len(seen) == 2                              # ... and nothing else was ever allocated for results
+    ok = ok and (g.n_staging_copies == 0) == g.even         # even blocks: the caller's tensor goes to the collective as is
+    np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_chains", [8, 7])
+def test_chain_gather_is_allocation_free_world_size_2_gloo(tmp_path, n_chains):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gather_worker, args=(2, port, n_chains, str(tmp_path)), nprocs=2, join=True)
+    assert all(np.load(tmp_path / f"ok{r}.npy")[0] == 1 for r in (0, 1))
+
+
+def test_sharded_ensemble_decides_its_result_path_once():
+    """The result path is a property of (engine kind, backend), fixed at construction: an engine whose device_results()
+    fails must raise in step(), not silently contribute a host block to the collective (advisor r3)."""
+    from surface_sampling_amd.sharding import ShardedEnsemble
+
+    class _NoDevice(_FakeResidentEngine):
+        has_device_results = False
+
+        def device_results(self):
+            raise AssertionError("must not be asked")
+
+        def device_context(self):
+            raise AssertionError("must not be asked")
+
+    sh = ShardedEnsemble(_NoDevice(), 4, None)
+    assert sh.result_path == "host"
+    with pytest.raises(ValueError):
+        ShardedEnsemble(_NoDevice(), 4, None, result_path="device")
+
+    class _Broken(_FakeResidentEngine):
+        def device_results(self):
+            raise RuntimeError("boom")
+
+        def device_context(self):
+            return 0, 0, None
+
+    sh = ShardedEnsemble(_Broken(), 4, None)
+    assert sh.result_path == "device"
+    sh.upload(local_chains=[(np.ones(2, np.int32), np.zeros((2, 3)), np.eye(3), [1, 1, 1])] * 4)
+    with pytest.raises(RuntimeError):
+        sh.step(7, gather=True)
+
+
 @pytest.mark.parametrize("n_chains", [8, 7])
 def test_gather_world_size_2_gloo(tmp_path, n_chains):
     import torch.multiprocessing as mp
@@ -200,6 +275,87 @@ def test_device_results_reach_torch_and_rccl_without_a_host_copy():
     finally:
         dist.destroy_process_group()
         eng.close()
+
+
+@pytest.mark.gpu
+def test_bench_entry_point_two_ranks_on_one_gpu(tmp_path):
+    """BASELINE configs[4]'s entry point, rehearsed end to end on the one GPU there is: ``python -m torch.distributed.run
+    --nproc-per-node 2 bench.py --gpus 2 ...`` as a FRESH subprocess (torchrun starts the ranks before anything touches the
+    GPU; this process never re-execs).  RCCL refuses two ranks on one device, so the rehearsal switches select gloo and pin
+    both ranks to device 0 (``VSSR_DIST_BACKEND`` / ``VSSR_LOCAL_DEVICE``, read by bench.py only); rank / chain arithmetic,
+    ``ShardedEnsemble.step``, the max-over-ranks clock, barriers and the JSON line are the code the 8-GPU run executes."""
+    import json
+    import subprocess
+
+    import bench
+    from surface_sampling_amd import backend
+    from surface_sampling_amd.calculators import stoich_offset_table
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dump = tmp_path / "gathered.npy"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VSSR_DIST_BACKEND="gloo", VSSR_LOCAL_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--chains-per-gpu", "16", "--no-cpu-baseline", "--dump-gathered", str(dump)]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                      # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["chains_per_gpu"] == 16 and "sharded x2" in line["config"]["parallelism"]
+    assert "gloo" in line["config"]["parallelism"] and line["config"]["dist_backend"] == "gloo"
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    assert abs(line["value"] - 2 * 16 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]     # whole-job aggregate
+    assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["second_kernel"]["frac"] <= 1.0
+    gathered = np.load(dump)
+    assert gathered.shape[0] == 32 and gathered.shape[1] >= 2
+    # one engine, all 32 global chains, in THIS process (after the ranks have gone)
+    blobs, S, offset_data = bench.load_golden()
+    table, const = stoich_offset_table(offset_data)
+    chains = bench.build_chains(S, 0, 32)
+    eng = backend.PainnEngine(blobs, device=0, offset_per_z=table, offset_const=const)
+    full = eng.evaluate([(c.numbers, c.positions, c.cell, c.pbc) for c in chains])
+    eng.close()
+    assert np.array_equal(gathered[:, 0], full["energy"]) and np.array_equal(gathered[:, 1], full["energy_std"])
+
+
+@pytest.mark.gpu
+def test_engine_group_device_path_gathers_what_one_engine_computes():
+    """--streams 2 on the device result path (what every rank of the N > 1 bench runs): two engines on one GPU, their
+    result buffers staged by events only into one [count, 3] block, a one-rank RCCL group as the transport."""
+    import torch
+
+    import bench
+    from surface_sampling_amd import backend, sharding
+    from surface_sampling_amd.calculators import stoich_offset_table
+
+    blobs, S, offset_data = bench.load_golden()
+    table, const = stoich_offset_table(offset_data)
+    chains = bench.build_chains(S, 500, 7)
+    packs = [(s.numbers, s.positions, s.cell, s.pbc) for s in chains]
+    engs = [backend.PainnEngine(blobs, device=0, offset_per_z=table, offset_const=const) for _ in range(2)]
+    grp = sharding.EngineGroup(engs)
+    sh = sharding.ShardedEnsemble(grp, len(chains), None, torch.device("cuda", 0))
+    assert sh.result_path == "device"
+    sh.upload(local_chains=packs)
+    want = backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD
+    outs = [sh.step(want, gather=True) for _ in range(4)]
+    torch.cuda.synchronize()
+    one = backend.PainnEngine(blobs, device=0, offset_per_z=table, offset_const=const)
+    full = one.evaluate(packs, want)
+    for o in outs[-2:]:
+        assert o.shape == (7, 3) and not o[:, 2].any()
+        assert np.array_equal(o[:, 0].cpu().numpy(), full["energy"]) and np.array_equal(o[:, 1].cpu().numpy(), full["energy_std"])
+    res = grp.download(want)
+    assert np.array_equal(res["forces"], full["forces"]) and np.array_equal(res["cfg_start"], full["cfg_start"])
+    assert sh.check() is False and sh._gather.n_staging_copies == 0
+    one.close()
+    grp.close()
 
 
 @pytest.mark.gpu

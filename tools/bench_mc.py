@@ -1,6 +1,18 @@
 """Secondary measurement (not the BASELINE metric): batched semigrand MC steps per second, B chains on one GPU, every
-step = propose + change + lock-step device relaxation (ChainEnsemble default: BFGS, <= relax_steps evaluations) + Metropolis.  Prints one JSON
-line.  Usage: python tools/bench_mc.py [--chains 256] [--steps 5] [--relax-steps 20]"""
+step = propose + change + lock-step device relaxation (ChainEnsemble default: BFGS, <= relax_steps evaluations) + Metropolis.
+The wall time of the MC steps is split into the phases of ChainEnsemble.step_semigrand (wrappers around the methods, so the
+split is of the code that ships, not of a copy):
+
+    device_relax      the vssr_batch_relax_* call (lock-step evaluations + optimizer steps, host blocked on the device)
+    upload / download vssr_batch_upload (incl. packing the B slabs into the ABI arrays) / vssr_batch_download
+    host_structures   ChainEnsemble.structure(): the B unrelaxed slabs as arrays
+    host_results      relax_batch's per-chain result tuples (relaxed slab copies, result dicts, out-of-bounds guard)
+    host_energy       surface-energy arithmetic per chain
+    host_mc           proposal, change_site, Metropolis, state bookkeeping (everything else)
+
+Prints one JSON line.  Usage: python tools/bench_mc.py [--chains 256] [--steps 10] [--relax-steps 20]
+The reference's own figure for the same loop: 606 s for 50 proposals of ONE 72-atom chain = 12.1 s per proposal
+(/root/reference/tutorials/SrTiO3_001.ipynb:1558, RTX 2080 Ti + nff)."""
 import argparse, json, os, sys, time
 
 import numpy as np
@@ -10,11 +22,38 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (golden loaders)
 
 
+class Phases:
+    def __init__(self):
+        self.t = {}
+        self.stack = []
+
+    def wrap(self, obj, name, phase):
+        fn = getattr(obj, name)
+
+        def timed(*a, **k):
+            t0 = time.perf_counter()
+            self.stack.append(0.0)
+            try:
+                return fn(*a, **k)
+            finally:
+                dt = time.perf_counter() - t0
+                inner = self.stack.pop()
+                self.t[phase] = self.t.get(phase, 0.0) + dt - inner     # exclusive time
+                if self.stack:
+                    self.stack[-1] += dt
+
+        setattr(obj, name, timed)
+
+    def reset(self):
+        self.t = {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chains", type=int, default=256)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--relax-steps", type=int, default=20)
+    ap.add_argument("--optimizer", default="BFGS")
     args = ap.parse_args()
     from surface_sampling_amd import mc, structures
     from surface_sampling_amd.calculators import EnsembleNFFSurface
@@ -33,24 +72,52 @@ def main():
     calc = EnsembleNFFSurface(blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV", offset_units="atomic")
     calc.set(offset=True, offset_data=offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0})
     ens = mc.ChainEnsemble(base, np.array(coords), ("Sr", "O"), args.chains, calc, seed=1, relax=True,
-                           relax_steps=args.relax_steps, fmax=0.01, fixed_indices=fixed, temperature=0.1)
+                           relax_steps=args.relax_steps, fmax=0.01, fixed_indices=fixed, temperature=0.1,
+                           optimizer=args.optimizer)
     # pre-populate so that chains look like mid-run states (8..32 adsorbates)
     state = ens.state
     for s in range(1, 21):
         site, end, _, _ = ens.propose(10_000 + s, state)
         state = ens.apply(state, site, end)
     ens.state = state
+    ph = Phases()
+    eng = calc._get_engine()
+    for name, phase in (("relax_bfgs", "device_relax"), ("relax_fire", "device_relax"), ("upload", "upload"),
+                        ("download", "download"), ("set_positions", "upload"), ("run", "device_relax")):
+        if hasattr(eng, name):
+            ph.wrap(eng, name, phase)
+    for name, phase in (("relax_positions", "device_relax"),):
+        if hasattr(eng, name):
+            ph.wrap(eng, name, phase)
+    ph.wrap(ens, "structure", "host_structures")
+    ph.wrap(calc, "relax_batch", "host_results")
+    ph.wrap(ens, "surface_energy_fn", "host_energy")
+    for name in ("relax_chains",):
+        if hasattr(calc, name):
+            ph.wrap(calc, name, "host_results")
     ens.initialize()
-    t_host = 0.0
+    ph.reset()
+    n_eval0 = getattr(ens, "n_chain_evaluations", 0)
     t0 = time.perf_counter()
     acc = []
     for _ in range(args.steps):
         acc.append(ens.step_semigrand().mean())
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "batched semigrand MC steps/s (all chains advance one Change event incl. the lock-step BFGS relaxation)",
-                      "chains": args.chains, "atoms_per_chain": int(len(base) + ens.num_adsorbates().mean()),
-                      "relax_steps": args.relax_steps, "mc_steps": args.steps, "s_per_lockstep": dt / args.steps,
-                      "chain_steps_per_s": args.chains * args.steps / dt, "acceptance": float(np.mean(acc))}))
+    split = {k: v / args.steps for k, v in ph.t.items()}
+    split["host_mc"] = dt / args.steps - sum(split.values())
+    dev = split.get("device_relax", 0.0)
+    host = sum(v for k, v in split.items() if k.startswith("host_"))
+    line = {"metric": "batched semigrand MC steps/s (all chains advance one Change event incl. the lock-step relaxation)",
+            "chains": args.chains, "atoms_per_chain": int(len(base) + ens.num_adsorbates().mean()),
+            "optimizer": args.optimizer, "relax_steps": args.relax_steps, "mc_steps": args.steps,
+            "s_per_lockstep": dt / args.steps, "proposals_per_s": args.chains * args.steps / dt,
+            "acceptance": float(np.mean(acc)),
+            "split_s_per_lockstep": {k: round(v, 5) for k, v in sorted(split.items())},
+            "device_share": dev / (dt / args.steps), "transfer_share": (split.get("upload", 0) + split.get("download", 0)) / (dt / args.steps),
+            "host_share": host / (dt / args.steps),
+            "reference": {"s_per_proposal": 606.0 / 50, "where": "tutorials/SrTiO3_001.ipynb:1558 (one 72-atom chain, RTX 2080 Ti, nff)"}}
+    line["speedup_vs_reference_per_proposal"] = line["proposals_per_s"] * line["reference"]["s_per_proposal"]
+    print(json.dumps(line))
 
 
 if __name__ == "__main__":
