@@ -366,7 +366,7 @@ struct UpdRegs {
 };
 
 // Shared forward part: needs vt (v_msg tile, rows x*TA+atom) and hs[:, :F] (s_msg tile) loaded + synced.
-template <int RT, int PHB, class Sat>   // PHB: first phase-timing slot (debug builds)
+template <int RT, int PHB, int PF, class Sat>   // PHB: first phase-timing slot (debug builds); PF: pipelined GEMMs
 __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, const LaneGeo &L, UpdRegs<RT> &R, Sat &sat) {
     constexpr int TA = 16 * RT, OFF_VT = UpdLds<RT>::OFF_VT, OFF_HS = UpdLds<RT>::OFF_HS, OFF_AS = UpdLds<RT>::OFF_AS;
     const Planes vt = make_planes(ldsh + OFF_VT, 3 * TA, F), hs = make_planes(ldsh + OFF_HS, TA, 2 * F),
@@ -375,7 +375,7 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
     PH_INIT
     {
         const uint4 *wp[2] = {WTILE(U, L.w, F), WTILE(V, L.w, F)};
-        gemm16<F, 3 * RT, 2, UPD_PF>(vt, wp, R.uv);
+        gemm16<F, 3 * RT, 2, PF>(vt, wp, R.uv);
     }
     PH(PHB + 1)
 #pragma unroll
@@ -403,7 +403,7 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
         const uint4 *wp[1] = {WTILE(W3, L.w, 2 * F)};
         const f32x4 b = gload4f(W.b3 + L.col0);
         __builtin_amdgcn_sched_barrier(0);   // the bias is requested in front of the GEMM whose epilogue adds it
-        gemm16<2 * F, RT, 1, UPD_PF>(hs, wp, acc);
+        gemm16<2 * F, RT, 1, PF>(hs, wp, acc);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             R.h3[t] = acc[t][0] + b;
@@ -423,7 +423,7 @@ __device__ __forceinline__ void update_forward(const LayerW &W, _Float16 *ldsh, 
 #pragma unroll
         for (int c = 0; c < 2; ++c) b4[c] = gload4f(W.b4 + c * F + L.col0);
         __builtin_amdgcn_sched_barrier(0);
-        gemm16<F, RT, 2, UPD_PF>(as_, wp, R.gate);
+        gemm16<F, RT, 2, PF>(as_, wp, R.gate);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const f32x4 b = b4[c];
@@ -808,6 +808,9 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     const int m = blockIdx.y, a0 = blockIdx.x * TA;
     if (!av.tile(min(a0, N - 1), min(a0 + TA - 1, N - 1))) return;   // every chain of this atom tile is switched off
     const LaneGeo L;
+    // MODE 0 is the cold instantiation (readout widths other than RH): the pipelined GEMMs cost it 4 spilled registers, the rolled
+    // ones none; the hot modes keep the pipeline
+    constexpr int BPF = MODE == 0 ? 0 : UPD_PF;
     // Saturation watch (mfma16.h).  s_msg, v_msg and the recomputed forward intermediates were watched by update_fwd(l) of this
     // evaluation, s_in(l + 1) by its tail: SatNone.  What is new here are the adjoints: the cooperative loads (phibar; final s for
     // the readout) and every epilogue that stores adjoints use an instance of their own, committed right behind the pass: no
@@ -900,9 +903,9 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         __builtin_amdgcn_sched_barrier(0);
         {
             const uint4 *wp[1] = {Wn.qW1 + (size_t)L.w * 4 * F};
-            gemm16<F, RT, 1, UPD_PF>(xs, wp, h1);
+            gemm16<F, RT, 1, BPF>(xs, wp, h1);
             const uint4 *wq[1] = {Wn.qW2t + (size_t)L.w * 4 * F3};
-            gemm16<F3, RT, 1, UPD_PF>(pb, wq, a1);
+            gemm16<F3, RT, 1, BPF>(pb, wq, a1);
         }
         PH(43)
         __syncthreads();   // everyone is done reading xs and pb
@@ -924,7 +927,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         f32x4 acc[RT][1];
         zero_acc(acc);
         const uint4 *wp[1] = {Wn.qW1t + (size_t)L.w * 4 * F};
-        gemm16<F, RT, 1, UPD_PF>(xs, wp, acc);
+        gemm16<F, RT, 1, BPF>(xs, wp, acc);
 #pragma unroll
         for (int t = 0; t < RT; ++t) sb[t] += acc[t][0];
         PH(45)
@@ -932,7 +935,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     }
     PH(16)
     if constexpr (!SAVED) {
-        update_forward<RT, 16>(W, ldsh, L, R, unwatched);
+        update_forward<RT, 16, BPF>(W, ldsh, L, R, unwatched);
     } else {
         // <U v, V v> of the saved products (same operations, same order as update_forward: bit-identical)
 #pragma unroll
@@ -976,7 +979,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
         f32x4 acc[RT][1];
         zero_acc(acc);
         const uint4 *wp[1] = {WTILE(W4t, L.w, F3)};
-        gemm16<F3, RT, 1, UPD_PF>(qb, wp, acc);
+        gemm16<F3, RT, 1, BPF>(qb, wp, acc);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             f32x4 hv;
@@ -994,7 +997,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     zero_acc(hbar);
     {
         const uint4 *wp[2] = {WTILE(W3t, L.w, F), WTILE(W3t, NW + L.w, F)};
-        gemm16<F, RT, 2, UPD_PF>(hb, wp, hbar);
+        gemm16<F, RT, 2, BPF>(hb, wp, hbar);
     }
     PH(27)
     __syncthreads();   // all waves are done with qb / hb: the whole region becomes the [Ubar | Vbar] tile
@@ -1040,7 +1043,7 @@ k_update_bwd_mfma(int N, int l, int vbar_is_zero, ActiveView av, const ModelW *_
     zero_acc(out);
     {
         const uint4 *wp[1] = {WTILE(UVt, L.w, 2 * F)};
-        gemm16<2 * F, 3 * RT, 1, UPD_PF>(ab, wp, out);
+        gemm16<2 * F, 3 * RT, 1, BPF>(ab, wp, out);
     }
     PH(31)
     __syncthreads();   // every wave is done with the [Ubar | Vbar] planes: the region becomes the fp32 output tile
@@ -1115,14 +1118,10 @@ static_assert(sizeof(_Float16) * (CF_LDS_HALVES + plane_halves(TA, F)) <= 96 * 1
 bool readout_mfma_supported(int hidden) { return hidden == RH; }
 
 int node_mfma_init(vssr_handle *h) {
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)node_mfma_lds_bytes(0)));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)node_mfma_lds_bytes(0)));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(2 * node_mfma_lds_bytes(0))));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(2 * node_mfma_lds_bytes(0))));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(1)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1150,9 +1149,11 @@ void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ActiveView &
     // VSSR_MSG_MLP_RT = 4 / VSSR_MSG_MLP_PF = 1: row-scaling experiment (64-atom tiles / pipelined GEMMs); default 2 / 0
     static const int rt = [] { const char *e = getenv("VSSR_MSG_MLP_RT"); return e ? atoi(e) : 2; }();
     static const int pf = [] { const char *e = getenv("VSSR_MSG_MLP_PF"); return e ? atoi(e) : 0; }();
+    // VSSR_MSG_MLP_ONE_WG=1: request 96 KB of LDS so that ONE workgroup fits a CU (the occupancy of the fused update kernels)
+    static const int one_wg = [] { const char *e = getenv("VSSR_MSG_MLP_ONE_WG"); return e ? atoi(e) : 0; }();
 #define LAUNCH_MLP(RT_, PF_)                                                                                                  \
     hipLaunchKernelGGL((k_msg_mlp_mfma<RT_, PF_>), dim3((N + 16 * RT_ - 1) / (16 * RT_), M), dim3(NTHREADS),                      \
-                       (RT_ / 2) * node_mfma_lds_bytes(0), st, N, l, av, MW, s_in, phi)
+                       one_wg ? (size_t)96 * 1024 : (RT_ / 2) * node_mfma_lds_bytes(0), st, N, l, av, MW, s_in, phi)
     if (rt == 4) { if (pf) LAUNCH_MLP(4, 1); else LAUNCH_MLP(4, 0); }
     else { if (pf) LAUNCH_MLP(2, 1); else LAUNCH_MLP(2, 0); }
 #undef LAUNCH_MLP
