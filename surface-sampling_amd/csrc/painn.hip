@@ -777,7 +777,11 @@ int painn_run(vssr_handle *h, uint32_t want) {
     }
     P.begin(KC_FINALIZE, st);
     if (want & VSSR_WANT_FORCES) {
+#ifdef ABL_LDS_FORCE
+        if (false) {
+#else
         if (compact) {
+#endif
             const int uni = h->active_mask ? 0 : h->n_bclass[EDGE_BCLASS_FS16] == h->n_cfg ? 8 : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? 16 : 0;
             const dim3 grid = uni ? dim3((unsigned)((h->slot_cap + 255) / 256), 1) : dim3(h->n_cfg, 12);
             hipLaunchKernelGGL(k_reduce_gpart, grid, dim3(256), 0, st, M, n_groups, layer_sets, G, counters, h->d_gpart.as<float>(),

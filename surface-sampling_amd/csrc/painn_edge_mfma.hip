@@ -596,7 +596,11 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 template <int NF, int WAVES>
 constexpr int cen_floats() { return WAVES * 4 * 4 * 6 * NF; }   // current-centre store: [stream][feature quarter][phi a, b, c, v x, y, z][NF]
 template <int NF, int WAVES>
+#ifdef ABL_LDS_FORCE   // ablation (profiles/r04/NOTES_force_accum.md): per-atom fixed-point force accumulators in LDS instead of per-slot records
+size_t edge_bwd_lds_bytes_t(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * EdgeGeo<NF>::ROWB + cen_floats<NF, WAVES>()) + 24 * (size_t)max_atoms + 32; }
+#else
 size_t edge_bwd_lds_bytes_t(int max_atoms) { return sizeof(float) * ((size_t)max_atoms * EdgeGeo<NF>::ROWB + cen_floats<NF, WAVES>()); }
+#endif
 
 // FIRST: the launch writes the partial edge-gradient buffers for the first time (last layer): nothing to add to.
 template <int NF, bool FIRST, int WAVES>
@@ -680,6 +684,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 #pragma unroll
         for (int i3 = 0; i3 < 2; ++i3) wA[T][i3] = sec < 0 ? (u32x4){0u, 0u, 0u, 0u} : gload_u32x4(wsrc + i3);
     }
+#ifdef ABL_LDS_FORCE
+    unsigned long long *facc = reinterpret_cast<unsigned long long *>(tile + (((size_t)max_atoms * ROWB + cen_floats<NF, WAVES>() + 1) & ~(size_t)1));
+    for (int i = tid; i < 3 * Nc + 3; i += BWD_THREADS) facc[i] = 0ull;
+    float gown = 0.f;
+#endif
     __syncthreads();
 
     BundleWalk<BWD_THREADS / 64> bw;   // work list: bundles of 4 centres, see the forward kernel
@@ -723,6 +732,14 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         quad_sum_n<NF>(accb); quad_sum_n<NF>(accc); quad_sum_n<NF>(accx); quad_sum_n<NF>(accy); quad_sum_n<NF>(accz);
         const float (&tb)[NF] = accb, (&tc)[NF] = accc, (&tx)[NF] = accx, (&ty)[NF] = accy, (&tz)[NF] = accz;
         const int c = bw.cur.x;
+#ifdef ABL_LDS_FORCE
+        {
+            const float go = quad_sum(gown);
+            gown = 0.f;
+            if (e == 0 && c >= 0 && gcomp_id < 3)
+                atomicAdd(&facc[3 * c + gcomp_id], (unsigned long long)__float2ll_rn(go * 4294967296.f));
+        }
+#endif
         if (e == 0 && c >= 0) {
             const size_t ga = mN + a0 + c;
             const fvx cv[6] = {cen[0], cen[1], cen[2], cen[3], cen[4], cen[5]};   // record of the completed centre
@@ -892,7 +909,10 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 // three rows of a real slot write one component each; every other lane writes the spare entry, so the
                 // store is unconditional and the memory-operation count of a step does not depend on the path
                 const bool real = gcomp_id < 3 && real_slot && invd > 0.f;
-#if defined(ABL_NO_GSTORE)   // ablation: the store only happens for a value the arithmetic never produces
+#if defined(ABL_LDS_FORCE)
+                gown += real ? gsum : 0.f;
+                atomicAdd(&facc[real ? 3 * jn + gcomp_id : 3 * Nc], (unsigned long long)__float2ll_rn(-gsum * 4294967296.f));
+#elif defined(ABL_NO_GSTORE)   // ablation: the store only happens for a value the arithmetic never produces
                 if (gsum == 1.2345e33f) gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;
 #elif defined(ABL_STORE4)   // ablation: one 16-byte store every fourth step instead of a dword store per step (same bytes, results wrong)
                 if ((bw.t & 3) == 3) {
@@ -912,6 +932,13 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         }
     }
     EPH_FLUSH(8)
+#ifdef ABL_LDS_FORCE   // partial forces of this (chain, slice, model, layer) leave as Nc x 3 fixed-point values (here: into the head of its gradient buffer)
+    __syncthreads();
+    {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(gb) + (size_t)3 * a0;
+        for (int i = tid; i < 3 * Nc; i += BWD_THREADS) dst[i] = facc[i];
+    }
+#endif
 }
 
 int edge_mfma_init(vssr_handle *h) {

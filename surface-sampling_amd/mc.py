@@ -245,7 +245,8 @@ class ChainEnsemble:
                  relax: bool = True, relax_steps: int = 20, fmax: float = 0.01, fixed_indices=None,
                  surface_energy_fn=None, temperature: float = 1.0, optimizer: str = "BFGS",
                  reference_groupby: bool = False, require_per_atom_energies: bool = False,
-                 require_distance_decay: bool = False, distance_decay_factor: float = 1.0):
+                 require_distance_decay: bool = False, distance_decay_factor: float = 1.0,
+                 exchange_by_group_key: bool = False):
         self.base = base
         self.ads_coords = np.asarray(ads_coords, float).reshape(-1, 3)
         self.adsorbates = list(adsorbates)
@@ -261,6 +262,21 @@ class ChainEnsemble:
         # key of an adsorbate in the reference's grouping = symbol of its FIRST atom ("HO" and "O" share the key "O")
         first = [int(z[0]) for z, _ in self.ads_atoms]
         self.group_key = np.array([first.index(f) for f in first] + [self.n_ads], np.int64)
+        # Canonical exchange: WHAT is exchanged.  Default (False): the adsorbates that actually sit on the two sites -- the
+        # composition is conserved whatever the grouping.  True reproduces the reference to the letter: its Exchange event passes
+        # the GROUP KEYS type1 / type2 (the symbol of an adsorbate's first atom, get_complementary_idx mcmc/slab.py:168-232 ->
+        # mcmc/events/event.py:138-151) to change_site, so with adsorbates that share a first-atom symbol ("HO" and "O") an
+        # exchanged "HO" arrives as the plain atom "O" and the composition changes.  The key must then name an adsorbate of the
+        # list (the state arrays cannot hold a species outside it).  A deliberate divergence of the default, DESIGN.md section 7.
+        self.exchange_by_group_key = bool(exchange_by_group_key)
+        self.key_adsorbate = np.arange(self.n_ads + 1, dtype=np.int64)
+        if self.exchange_by_group_key:
+            for c, (z, _) in enumerate(self.ads_atoms):
+                sym = structures.SYMBOLS[int(z[0])]
+                if sym not in self.adsorbates:
+                    raise ValueError(f'exchange_by_group_key: the reference would adsorb the plain atom "{sym}" (group key of '
+                                     f'"{self.adsorbates[c]}"), which is not in the adsorbate list {self.adsorbates}')
+                self.key_adsorbate[c] = self.adsorbates.index(sym)
         self.calc = calc
         self.seed, self.first_chain = int(seed), int(first_chain)
         self.relax, self.relax_steps, self.fmax = bool(relax), int(relax_steps), float(fmax)
@@ -530,8 +546,12 @@ class ChainEnsemble:
         rows = np.arange(len(site1))
         code1 = before.species[rows, site1].astype(np.int64)
         code2 = before.species[rows, site2].astype(np.int64)
-        type1 = np.where(valid, code1, type1)
-        type2 = np.where(valid, code2, type2)
+        if self.exchange_by_group_key:    # the reference's literal behaviour: the group key's own atom arrives (see __init__)
+            type1 = np.where(valid, self.key_adsorbate[code1], type1)
+            type2 = np.where(valid, self.key_adsorbate[code2], type2)
+        else:
+            type1 = np.where(valid, code1, type1)
+            type2 = np.where(valid, code2, type2)
         after = self.apply(self.apply(before, site1, type2), site2, type1)
         moved = np.flatnonzero(valid)
         after.energy = before.energy.copy()

@@ -478,6 +478,35 @@ def test_canonical_exchange_conserves_composition_with_shared_first_atom_keys():
     assert moved > n                                                     # T = 50: nearly every exchange is accepted
 
 
+def test_exchange_by_group_key_reproduces_the_reference_to_the_letter():
+    """``exchange_by_group_key=True``: the reference's Exchange event hands the GROUP KEYS to ``change_site``
+    (``mcmc/slab.py:168-232`` -> ``mcmc/events/event.py:138-151``), so an exchanged "HO" arrives as the plain atom "O": hydrogens
+    are lost, the number of adsorbates is not.  The default (above) conserves the composition instead -- the documented
+    divergence (advisor r3)."""
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[1.5 * s, 0.0, 2.0] for s in range(7)], float)
+    calc = LatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02, Z["H"]: 0.01}, J=0.0)
+    n = 64
+    ens = mc.ChainEnsemble(base, coords, ("HO", "O", "Sr"), n, calc, seed=3, relax=False, temperature=50.0,
+                           reference_groupby=True, exchange_by_group_key=True)
+    HO, O, SR, E = 0, 1, 2, ens.n_ads
+    assert ens.key_adsorbate.tolist() == [O, O, SR, E]                    # "HO" and "O" both arrive as "O"
+    sp = np.tile(np.array([[SR, O, E, SR, E, HO, O]], np.int16), (n, 1))
+    order = np.where(sp != E, np.cumsum(sp != E, axis=1), 0).astype(np.int64)
+    ens.state = mc.ChainState(sp, order, np.full(n, 6, np.int64))
+    ens.initialize()
+    filled0 = ens.num_adsorbates().copy()
+    for _ in range(12):
+        ens.step_canonical()
+        assert np.array_equal(ens.num_adsorbates(), filled0)              # sites stay filled ...
+    lost = (ens.state.species == HO).sum(axis=1) == 0
+    assert lost.any()                                                     # ... but groups have turned into plain atoms
+    with pytest.raises(ValueError):                                       # a key outside the adsorbate list cannot be represented
+        mc.ChainEnsemble(base, coords, ("HO", "Sr"), 2, calc, relax=False, reference_groupby=True, exchange_by_group_key=True)
+
+
 def test_boltzmann_and_distance_decay_weights_match_the_reference_numbers():
     """``compute_boltzmann_weights`` on the reference's fixture (tests/test_slab.py:90-113): per-atom energies
     [1.0, 0.5, 1.0, 0.6], T = 1 -> As 0.1850956, Ga 0.30517106, empty 1; ``compute_distance_weight_matrix``

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--relax-steps", type=int, default=20)
     ap.add_argument("--optimizer", default="BFGS")
+    ap.add_argument("--no-relax", action="store_true", help="single-point acceptance energies (the reference's relax_atoms: false)")
     args = ap.parse_args()
     from surface_sampling_amd import mc, structures
     from surface_sampling_amd.calculators import EnsembleNFFSurface
@@ -71,7 +72,7 @@ def main():
     fixed = np.flatnonzero(base.positions[:, 2] < ztop - 4.0)
     calc = EnsembleNFFSurface(blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV", offset_units="atomic")
     calc.set(offset=True, offset_data=offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0})
-    ens = mc.ChainEnsemble(base, np.array(coords), ("Sr", "O"), args.chains, calc, seed=1, relax=True,
+    ens = mc.ChainEnsemble(base, np.array(coords), ("Sr", "O"), args.chains, calc, seed=1, relax=not args.no_relax,
                            relax_steps=args.relax_steps, fmax=0.01, fixed_indices=fixed, temperature=0.1,
                            optimizer=args.optimizer)
     # pre-populate so that chains look like mid-run states (8..32 adsorbates)
@@ -86,9 +87,8 @@ def main():
                         ("download", "download"), ("set_positions", "upload"), ("run", "device_relax")):
         if hasattr(eng, name):
             ph.wrap(eng, name, phase)
-    for name, phase in (("relax_positions", "device_relax"),):
-        if hasattr(eng, name):
-            ph.wrap(eng, name, phase)
+    ph.wrap(eng, "evaluate", "device_relax")     # (relax=False: one lock-step evaluation; upload / download inside are exclusive)
+    ph.wrap(calc, "calculate_batch", "host_results")
     ph.wrap(ens, "structure", "host_structures")
     ph.wrap(calc, "relax_batch", "host_results")
     ph.wrap(ens, "surface_energy_fn", "host_energy")
@@ -109,7 +109,7 @@ def main():
     host = sum(v for k, v in split.items() if k.startswith("host_"))
     line = {"metric": "batched semigrand MC steps/s (all chains advance one Change event incl. the lock-step relaxation)",
             "chains": args.chains, "atoms_per_chain": int(len(base) + ens.num_adsorbates().mean()),
-            "optimizer": args.optimizer, "relax_steps": args.relax_steps, "mc_steps": args.steps,
+            "optimizer": args.optimizer if not args.no_relax else None, "relax_steps": args.relax_steps if not args.no_relax else 0, "mc_steps": args.steps,
             "s_per_lockstep": dt / args.steps, "proposals_per_s": args.chains * args.steps / dt,
             "acceptance": float(np.mean(acc)),
             "split_s_per_lockstep": {k: round(v, 5) for k, v in sorted(split.items())},

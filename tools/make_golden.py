@@ -226,6 +226,9 @@ def write_pourbaix_fixtures(R, out):
                     c.atoms = slab
                     cases.append({"atom_set": si, "temperature": temp, "formula": formula, "energy": energy,
                                   "adsorbate_corrections": corr,
+                                  # False: the case went through _GeneratorFormula, a stand-in for ase.formula.Formula written
+                                  # by the author of the code under test (advisor r3) -- to be regenerated with real ASE
+                                  "independent": not corr,
                                   "delta_G1": float(c.get_delta_G1(atoms=slab)), "delta_G2": float(c.get_delta_G2(atoms=slab)),
                                   "pourbaix_potential": float(c.get_pourbaix_potential(atoms=slab))})
     with open(os.path.join(out, "pourbaix_kat.json"), "w") as fh:
