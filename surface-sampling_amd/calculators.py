@@ -428,6 +428,42 @@ class EnsembleNFFSurface(_Base):
     ENERGY_THRESHOLD = 1000.0
     MAX_FORCE_THRESHOLD = 1000.0
 
+    def evaluate_packed(self, n_atoms, Z, pos, cell, pbc, relax: bool = False, fixed_mask=None, relax_steps: int = 20,
+                        fmax: float = 0.01, optimizer=None) -> dict:
+        """Arrays in, arrays out: the batched evaluation (``relax=False``: ``calculate_batch``) or lock-step relaxation
+        (``relax=True``: ``relax_batch`` with a device optimizer, "BFGS" / "FIRE") of B slabs given as the ABI's packed arrays
+        (``n_atoms [B]``, ``Z [sum N]``, ``pos [sum N, 3]``, ``cell [B, 9]``, ``pbc [B, 3]``; ``fixed_mask [sum N]`` = FixAtoms).
+        No per-slab Python objects on either side -- what ``mc.ChainEnsemble`` calls every MC step.  Returns ``energy [B]``
+        (float32, the TRUE energies of the final geometries), ``energy_std``, ``forces``, ``energy_atoms``, ``positions``
+        (relaxed, or the input), ``cfg_start``, ``saturated [B]``, ``oob [B]`` (the reference's +-1000 guard,
+        ``mcmc/dynamics.py:159-168``; a saturated evaluation counts), and for relaxations ``n_steps`` / ``converged``."""
+        eng = self._get_engine()
+        eng.upload_arrays(n_atoms, Z, pos, cell, pbc)
+        info = None
+        if relax:
+            if optimizer is None:
+                optimizer = self.parameters.get("optimizer", "FIRE")
+            info = eng.relax(optimizer, fixed=fixed_mask, max_steps=relax_steps, fmax=fmax)   # (raises for host-driven optimizers)
+        else:
+            eng.run()
+        res = eng.download()
+        start = np.asarray(res["cfg_start"], dtype=np.int64)
+        fabs = np.abs(res["forces"]).max(axis=1) if len(res["forces"]) else np.zeros(0, np.float32)
+        nonempty = start[1:] > start[:-1]
+        max_force = np.zeros(len(start) - 1, np.float32)
+        if nonempty.any():
+            max_force[nonempty] = np.maximum.reduceat(fabs, start[:-1][nonempty])
+        energy = res["energy"]
+        with np.errstate(invalid="ignore"):
+            oob = (~np.isfinite(energy)) | (~np.isfinite(max_force)) | (np.abs(energy) > self.ENERGY_THRESHOLD) \
+                | (max_force > self.MAX_FORCE_THRESHOLD) | np.asarray(res["saturated"], dtype=bool)
+        out = {"energy": energy, "energy_std": res["energy_std"], "forces": res["forces"], "energy_atoms": res["energy_atoms"],
+               "positions": info["positions"] if info is not None else np.asarray(pos, dtype=np.float64).reshape(-1, 3),
+               "cfg_start": start, "saturated": np.asarray(res["saturated"], dtype=bool), "oob": oob}
+        if info is not None:
+            out["n_steps"], out["converged"] = info["n_steps"], info["converged"]
+        return out
+
     def relax_batch(self, atoms_list, fixed_indices=None, relax_steps: int = 20, fmax: float = 0.01, optimizer=None,
                     save_traj: bool = False, record_interval: int = 5):
         """Relax B independent slabs at once on the device — the batched counterpart of
@@ -541,6 +577,28 @@ class EnsembleNFFSurface(_Base):
                 r["converged"] = bool((ff ** 2).sum(axis=1).max() < fmax ** 2) if len(ff) else True
             out.append((relaxed, traj, energy, oob, r))
         return out
+
+
+def surface_energy_from_counts(energy, counts: dict, chem_pots: dict, offset_data: dict, offset_units: str = "atomic"):
+    """:func:`surface_energy_from_energy` for MANY slabs at once: ``energy`` ``[B]`` and ``counts`` = element symbol ->
+    ``[B]`` atom counts, the dict's key order being the order in which the elements first appear in the slabs' atom lists
+    (the scalar function walks a ``Counter`` in that order).  Same operations in the same order per slab, so every entry
+    equals the scalar result bit for bit (``tests/test_mc.py``)."""
+    energy = np.asarray(energy, dtype=np.float64)
+    bulk_energies, stoics = offset_data["bulk_energies"], offset_data["stoics"]
+    ref_formula, ref_element = offset_data["ref_formula"], offset_data["ref_element"]
+    n = {k: np.asarray(v, dtype=np.float64) for k, v in counts.items()}
+    n_ref = n.get(ref_element, np.zeros_like(energy))
+    bulk_ref_en = n_ref * bulk_energies[ref_formula]
+    for ele, n_e in n.items():
+        if ele != ref_element:
+            bulk_ref_en = bulk_ref_en + (n_e - stoics[ele] / stoics[ref_element] * n_ref) * bulk_energies[ele]
+    surface_energy = energy - (bulk_ref_en * HARTREE_TO_EV if offset_units == "atomic" else bulk_ref_en)
+    pot = np.zeros_like(energy)
+    for ele, n_e in n.items():
+        if ele != ref_element:
+            pot = pot + (n_e - stoics[ele] / stoics[ref_element] * n_ref) * chem_pots[ele]
+    return surface_energy - pot
 
 
 def _traj_of_chain(traj, b, a0, a1, atoms):

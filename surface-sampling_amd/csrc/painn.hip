@@ -777,8 +777,9 @@ int painn_run(vssr_handle *h, uint32_t want) {
     }
     P.begin(KC_FINALIZE, st);
     if (want & VSSR_WANT_FORCES) {
-#ifdef ABL_LDS_FORCE
-        if (false) {
+#ifdef ABL_LDS_FORCE   // ablation build (profiles/r04/NOTES_force_accum.md): no per-slot partial records, nothing to reduce (results incomplete)
+        if (compact) {   // (skipped)
+        } else if (false) {
 #else
         if (compact) {
 #endif

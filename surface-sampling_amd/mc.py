@@ -206,6 +206,63 @@ def create_anneal_schedule(start_temp: float = 1.0, total_sweeps: int = 1000, al
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Slabs of many chains as packed arrays (no per-chain Python objects on the MC hot path)
+# ---------------------------------------------------------------------------------------------------------------------
+class SlabBatch:
+    """B slabs of one base cell as the ABI's packed arrays; ``batch[b]`` builds the ``Structure`` of chain b on demand."""
+
+    def __init__(self, n_atoms, numbers, positions, cell, pbc):
+        self.n_atoms = np.asarray(n_atoms, dtype=np.int64)
+        self.start = np.concatenate([[0], np.cumsum(self.n_atoms)]).astype(np.int64)
+        self.numbers, self.positions, self.cell, self.pbc = numbers, positions, cell, pbc
+
+    def __len__(self):
+        return len(self.n_atoms)
+
+    def __getitem__(self, b):
+        a0, a1 = int(self.start[b]), int(self.start[b + 1])
+        return structures.Structure(self.numbers[a0:a1].copy(), self.positions[a0:a1].copy(), self.cell, self.pbc)
+
+
+class SlabRefs:
+    """A list of slabs whose entries are either ``Structure`` objects or ``(SlabBatch, index)`` references that turn into a
+    ``Structure`` when they are looked at: the accept / restore bookkeeping of an MC step shuffles 256 references instead of
+    building 256 structures nobody reads."""
+
+    def __init__(self, items):
+        self.items = list(items)
+
+    @classmethod
+    def of_batch(cls, batch: SlabBatch):
+        return cls([(batch, b) for b in range(len(batch))])
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, b):
+        if isinstance(b, slice):
+            return [self[i] for i in range(*b.indices(len(self.items)))]
+        it = self.items[b]
+        if isinstance(it, tuple):
+            it = self.items[b] = it[0][it[1]]
+        return it
+
+    def __setitem__(self, b, value):
+        self.items[b] = value
+
+    def __iter__(self):
+        return (self[b] for b in range(len(self.items)))
+
+    def raw(self, b):
+        """The entry as stored (a reference stays a reference)."""
+        return self.items[b]
+
+
+def _raw_items(seq):
+    return seq.items if isinstance(seq, SlabRefs) else list(seq)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # B chains
 # ---------------------------------------------------------------------------------------------------------------------
 @dataclass
@@ -253,6 +310,13 @@ class ChainEnsemble:
         self.n_ads = len(self.adsorbates)
         self.ads_atoms = [adsorbate_atoms(a) for a in self.adsorbates]          # (numbers [k], offsets [k, 3]) per adsorbate
         self.ads_sizes = np.array([len(z) for z, _ in self.ads_atoms] + [0], np.int64)   # (+ the "None" code)
+        kmax = max(1, int(self.ads_sizes.max()))
+        self._ads_Z = np.zeros((self.n_ads + 1, kmax), np.int32)          # atoms of every adsorbate, padded (batch_arrays)
+        self._ads_off = np.zeros((self.n_ads + 1, kmax, 3))
+        for c, (z, offs) in enumerate(self.ads_atoms):
+            self._ads_Z[c, :len(z)] = z
+            self._ads_off[c, :len(z)] = offs
+        self.fast_path = True     # packed-array evaluation when the calculator offers it (evaluate_packed); False: per-slab objects
         # switch-proposal options of the reference's SwitchProposal (mcmc/events/proposal.py:112-160)
         self.reference_groupby = bool(reference_groupby)
         self.require_per_atom_energies = bool(require_per_atom_energies)
@@ -283,12 +347,13 @@ class ChainEnsemble:
         self.optimizer = optimizer   # reference SrTiO3 configuration: BFGS (scripts/configs/sample_config_painn.json:26)
         self.fixed_indices = None if fixed_indices is None else np.asarray(fixed_indices, np.int64)
         self.temp = float(temperature)
+        self._default_se = surface_energy_fn is None
         self.surface_energy_fn = surface_energy_fn or self._default_surface_energy
         B, S = int(n_chains), len(self.ads_coords)
         self.chain_ids = np.arange(self.first_chain, self.first_chain + B, dtype=np.int64)
         self.state = ChainState(np.full((B, S), self.n_ads, np.int16), np.zeros((B, S), np.int64), np.ones(B, np.int64))
         self.step_count = 0
-        self.relaxed = [None] * B           # relaxed Structure of the current state of every chain
+        self.relaxed = SlabRefs([None] * B)   # relaxed Structure of the current state of every chain (built on demand)
         self.oob = np.zeros(B, bool)        # out-of-bounds flag of the last evaluation of every chain (reference: energy_oob)
         self.per_atom_energies = [None] * B  # of the current state (filled when the backend returns them)
         self.n_evaluations = 0
@@ -442,7 +507,93 @@ class ChainEnsemble:
             xs.append(self.ads_coords[site][None] + offs)
         return structures.Structure(np.concatenate(zs).astype(np.int32), np.vstack(xs), self.base.cell, self.base.pbc)
 
+    def batch_arrays(self, state: ChainState | None = None, which=None):
+        """The unrelaxed slabs of the chains ``which`` (default all) as packed arrays -- ``structure(b)`` for every b without
+        a Python loop: ``(n_atoms [b], numbers [sum], positions [sum, 3], ads_chain [n_ads_atoms], ads_numbers)`` where the last
+        two name the chain (position in ``which``) and the atomic number of every adsorbate atom (element counts)."""
+        st = state or self.state
+        sp = st.species if which is None else st.species[np.asarray(which)]
+        od = st.order if which is None else st.order[np.asarray(which)]
+        b, S = sp.shape
+        nb = len(self.base)
+        filled = sp != self.n_ads
+        key = np.where(filled, od, np.iinfo(np.int64).max)
+        by_order = np.argsort(key, axis=1, kind="stable")                    # sites in adsorption order, empty ones last
+        cnt = filled.sum(axis=1)
+        rows, ranks = np.nonzero(np.arange(S)[None, :] < cnt[:, None])       # adsorbates, chain-major, in adsorption order
+        sites = by_order[rows, ranks]
+        codes = sp[rows, sites].astype(np.int64)
+        sizes = self.ads_sizes[codes]
+        tot = int(sizes.sum())
+        ent = np.repeat(np.arange(len(rows)), sizes)                         # adsorbate of every adsorbate ATOM
+        within = np.arange(tot) - (np.cumsum(sizes) - sizes)[ent]            # its index inside the adsorbate
+        z_ads = self._ads_Z[codes[ent], within]
+        x_ads = self.ads_coords[sites[ent]] + self._ads_off[codes[ent], within]
+        ads_chain = rows[ent]
+        n_ads_atoms = np.bincount(ads_chain, minlength=b).astype(np.int64)
+        n_atoms = nb + n_ads_atoms
+        start = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
+        numbers = np.empty(int(start[-1]), np.int32)
+        positions = np.empty((int(start[-1]), 3))
+        base_idx = (start[:-1, None] + np.arange(nb)[None, :]).ravel()
+        numbers[base_idx] = np.tile(self.base.numbers, b)
+        positions[base_idx] = np.tile(self.base.positions, (b, 1))
+        dst = start[ads_chain] + nb + (np.arange(tot) - (np.cumsum(n_ads_atoms) - n_ads_atoms)[ads_chain])
+        numbers[dst] = z_ads
+        positions[dst] = x_ads
+        return n_atoms, numbers, positions, ads_chain, z_ads
+
     # ---- energies --------------------------------------------------------------------------------------------------
+    def _packed_surface_energy(self):
+        """How the fast path turns energies into acceptance energies, or None when only the per-slab function can:
+        ``("plain",)`` or ``("chem", element order)`` -- the calculator's chemical-potential arithmetic on element counts, valid
+        when every adsorbate element already occurs in the base slab (then all chains walk the elements in the base slab's
+        order of first appearance, like the scalar function's Counter)."""
+        if not self._default_se:      # a user-supplied (energy, structure) -> float function needs the structures
+            return None
+        if hasattr(self.calc, "surface_energy_of") and getattr(self.calc, "pourbaix_atoms", None):
+            return None
+        chem_pots, offset_data = getattr(self.calc, "chem_pots", None), getattr(self.calc, "offset_data", None)
+        if not (chem_pots and offset_data):
+            return ("plain",)
+        order = list(dict.fromkeys(int(z) for z in self.base.numbers))
+        ads_elements = {int(z) for zs, _ in self.ads_atoms for z in zs}
+        if not ads_elements <= set(order):
+            return None
+        return ("chem", order)
+
+    def _evaluate_packed(self, state: ChainState, idx, mode):
+        n_atoms, numbers, positions, ads_chain, z_ads = self.batch_arrays(state, idx)
+        b, nb = len(idx), len(self.base)
+        start = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
+        cell = np.tile(np.asarray(self.base.cell, float).reshape(1, 9), (b, 1))
+        pbc = np.tile(np.asarray(self.base.pbc).astype(np.uint8).reshape(1, 3), (b, 1))
+        fixed = None
+        if self.relax and self.fixed_indices is not None and len(self.fixed_indices):
+            fixed = np.zeros(int(start[-1]), np.uint8)
+            fixed[(start[:-1, None] + self.fixed_indices[None, :]).ravel()] = 1
+        out = self.calc.evaluate_packed(n_atoms, numbers, positions, cell, pbc, relax=self.relax, fixed_mask=fixed,
+                                        relax_steps=self.relax_steps, fmax=self.fmax, optimizer=self.optimizer)
+        if self.relax:
+            self.oob[idx] = out["oob"]
+        ea = out["energy_atoms"]
+        self._last_pae = [ea[start[k]:start[k + 1]] for k in range(b)]
+        raw = np.asarray(out["energy"], dtype=np.float64)
+        if mode[0] == "plain":
+            energies = raw
+        else:
+            from .calculators import surface_energy_from_counts
+
+            counts = {}
+            for z in mode[1]:
+                n_base = int(np.count_nonzero(self.base.numbers == z))
+                counts[structures.SYMBOLS[z]] = n_base + np.bincount(ads_chain[z_ads == z], minlength=b)
+            energies = surface_energy_from_counts(raw, counts, self.calc.chem_pots, self.calc.offset_data,
+                                                  getattr(self.calc, "offset_units", "atomic"))
+        self.n_evaluations += b
+        relaxed = SlabRefs.of_batch(SlabBatch(n_atoms, numbers, out["positions"], self.base.cell, self.base.pbc))
+        return np.asarray(energies, float), relaxed
+
     def _default_surface_energy(self, energy, struct):
         if hasattr(self.calc, "surface_energy_of") and (getattr(self.calc, "pourbaix_atoms", None)):
             return float(self.calc.surface_energy_of(energy, struct))
@@ -458,6 +609,12 @@ class ChainEnsemble:
         """Surface energies of the chains ``which`` (default all) in ``state``: one lock-step batched relaxation
         (or single-point evaluation) of their unrelaxed slabs.  Returns ``(energies, relaxed_structures)``."""
         idx = np.arange(len(state.species)) if which is None else np.asarray(which)
+        if self.fast_path and hasattr(self.calc, "evaluate_packed") and len(idx) \
+                and not (self.relax and (not isinstance(self.optimizer, str)
+                                         or any(k in self.optimizer for k in ("CG", "LAMMPS", "BFGSLineSearch")))):
+            mode = self._packed_surface_energy()
+            if mode is not None:
+                return self._evaluate_packed(state, idx, mode)
         slabs = [self.structure(int(b), state) for b in idx]
         if self.relax:
             fixed = None if self.fixed_indices is None else [self.fixed_indices] * len(slabs)
@@ -503,7 +660,8 @@ class ChainEnsemble:
 
     def initialize(self):
         """Surface energy of the starting states (the reference evaluates the start state before the first sweep)."""
-        self.state.energy, self.relaxed = self.evaluate(self.state)
+        self.state.energy, relaxed = self.evaluate(self.state)
+        self.relaxed = relaxed if isinstance(relaxed, SlabRefs) else SlabRefs(relaxed)
         self.per_atom_energies = list(self._last_pae)
         return self.state.energy
 
@@ -525,7 +683,7 @@ class ChainEnsemble:
         self.state = ChainState(np.where(a2, after.species, before.species), np.where(a2, after.order, before.order),
                                 np.where(accept, after.counter, before.counter),
                                 np.where(accept, after.energy, before.energy))
-        self.relaxed = [ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, self.relaxed)]
+        self.relaxed = SlabRefs([ra if acc else rb for acc, ra, rb in zip(accept, _raw_items(relaxed_after), _raw_items(self.relaxed))])
         self.per_atom_energies = [pa if acc else pb for acc, pa, pb in zip(accept, pae_after, self.per_atom_energies)]
         return accept
 
@@ -555,12 +713,12 @@ class ChainEnsemble:
         after = self.apply(self.apply(before, site1, type2), site2, type1)
         moved = np.flatnonzero(valid)
         after.energy = before.energy.copy()
-        relaxed_after = list(self.relaxed)
+        relaxed_after = _raw_items(self.relaxed)
         pae_after = list(self.per_atom_energies)
         if len(moved):
             e, r = self.evaluate(after, moved)
             after.energy[moved] = e
-            for b, rb, pb in zip(moved, r, self._last_pae):
+            for b, rb, pb in zip(moved, _raw_items(r), self._last_pae):
                 relaxed_after[int(b)] = rb
                 pae_after[int(b)] = pb
         accept = metropolis_accept(before.energy, after.energy, temp, u_acc) & valid
@@ -568,7 +726,7 @@ class ChainEnsemble:
         self.state = ChainState(np.where(a2, after.species, before.species), np.where(a2, after.order, before.order),
                                 np.where(accept, after.counter, before.counter),
                                 np.where(accept, after.energy, before.energy))
-        self.relaxed = [ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, self.relaxed)]
+        self.relaxed = SlabRefs([ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, _raw_items(self.relaxed))])
         self.per_atom_energies = [pa if acc else pb for acc, pa, pb in zip(accept, pae_after, self.per_atom_energies)]
         return accept
 

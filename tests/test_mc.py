@@ -552,3 +552,97 @@ def test_weighted_switch_proposals_follow_their_weights():
     part = s2[sr_first & (s1 == 0)]
     assert set(part.tolist()) <= {1, 2}
     assert abs((part == 1).mean() - np.exp(-1) / (np.exp(-1) + np.exp(-2))) < 0.04
+
+
+# ---- packed-array fast path (no per-slab Python objects on the MC hot path) --------------------------------------------------
+class PackedLatticeGasCalc(LatticeGasCalc):
+    """The toy backend with the calculators' packed interface (``EnsembleNFFSurface.evaluate_packed``): same energies as the
+    per-slab methods, computed from the packed arrays."""
+
+    chem_pots: dict = {}
+    offset_data: dict = {}
+
+    def evaluate_packed(self, n_atoms, Z, pos, cell, pbc, relax=False, fixed_mask=None, relax_steps=20, fmax=0.01, optimizer=None):
+        self.calls += 1
+        self.packed_calls = getattr(self, "packed_calls", 0) + 1
+        start = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
+        e = np.array([self._energy(structures.Structure(Z[a0:a1], pos[a0:a1], np.reshape(cell[k], (3, 3))))
+                      for k, (a0, a1) in enumerate(zip(start[:-1], start[1:]))], np.float64)
+        return {"energy": e, "energy_std": np.zeros_like(e), "forces": np.zeros((len(Z), 3), np.float32),
+                "energy_atoms": np.arange(len(Z), dtype=np.float32), "positions": np.array(pos, float), "cfg_start": start,
+                "saturated": np.zeros(len(e), bool), "oob": np.zeros(len(e), bool),
+                "n_steps": np.zeros(len(e), np.int32), "converged": np.ones(len(e), bool)}
+
+
+def test_batch_arrays_equal_the_per_chain_structures():
+    """``batch_arrays`` builds what ``structure(b)`` builds for every chain -- atoms, groups ("HO", "H2O"), adsorption order."""
+    ens, _ = _group_ensemble(48)
+    state = ens.state
+    for s in range(1, 30):
+        site, end, _, _ = ens.propose(s, state)
+        state = ens.apply(state, site, end)
+    for which in (None, np.array([5, 0, 17, 40])):
+        n_atoms, numbers, positions, ads_chain, z_ads = ens.batch_arrays(state, which)
+        idx = np.arange(48) if which is None else which
+        start = np.concatenate([[0], np.cumsum(n_atoms)])
+        for k, b in enumerate(idx):
+            ref = ens.structure(int(b), state)
+            assert np.array_equal(numbers[start[k]:start[k + 1]], ref.numbers)
+            assert np.array_equal(positions[start[k]:start[k + 1]], ref.positions)
+            assert np.array_equal(np.sort(z_ads[ads_chain == k]), np.sort(ref.numbers[len(ens.base):]))
+    assert ens.num_adsorbates(state).max() > 3 and (ens.num_adsorbate_atoms(state) > ens.num_adsorbates(state)).any()
+
+
+def test_surface_energy_from_counts_equals_the_scalar_function_bit_for_bit(golden):
+    from surface_sampling_amd import calculators as calcs
+
+    rng = np.random.default_rng(5)
+    chem = {"Sr": -2.0, "Ti": 0.3, "O": -0.7}
+    base = ["Sr"] * 48 + ["Ti"] * 48 + ["O"] * 144
+    energies, counts, want = [], {"Sr": [], "Ti": [], "O": []}, []
+    for _ in range(64):
+        extra = list(rng.choice(["Sr", "Ti", "O"], size=int(rng.integers(0, 30))))
+        sym = base + extra
+        e = float(np.float32(-1800.0 + rng.normal() * 40))
+        energies.append(e)
+        for k in counts:
+            counts[k].append(sym.count(k))
+        want.append(calcs.surface_energy_from_energy(e, sym, chem, golden.offset_data, "atomic"))
+    got = calcs.surface_energy_from_counts(np.array(energies), {k: np.array(v) for k, v in counts.items()}, chem,
+                                           golden.offset_data, "atomic")
+    assert np.array_equal(got, np.array(want))
+
+
+def test_packed_fast_path_gives_the_trajectories_of_the_per_slab_path():
+    """Same seed, same toy energies: the packed path (arrays in, arrays out, lazy slabs) and the per-slab path accept the
+    same proposals and end in the same states; the relaxed slabs are built only when somebody looks."""
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[1.0 * s, 0.0, 2.0] for s in range(6)], float)
+    runs = []
+    for fast in (True, False):
+        for relax in (False, True):
+            calc = PackedLatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02, Z["H"]: 0.01}, J=0.03)
+            ens = mc.ChainEnsemble(base, coords, ("Sr", "O", "HO"), 32, calc, seed=4, relax=relax, temperature=0.05,
+                                   fixed_indices=np.array([0]))
+            ens.fast_path = fast
+            acc = np.stack([ens.step_semigrand() for _ in range(8)] + [ens.step_canonical() for _ in range(4)])
+            assert (getattr(calc, "packed_calls", 0) > 0) == fast
+            runs.append((fast, relax, acc, ens.state.species.copy(), ens.state.energy.copy(), ens))
+    for relax in (False, True):
+        a = next(r for r in runs if r[0] and r[1] == relax)
+        b = next(r for r in runs if not r[0] and r[1] == relax)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+        assert a[2].any() and not a[2].all()
+        fast_ens, slow_ens = a[5], b[5]
+        assert isinstance(fast_ens.relaxed, mc.SlabRefs) and any(isinstance(fast_ens.relaxed.raw(k), tuple) for k in range(32))
+        for k in range(32):
+            assert np.array_equal(fast_ens.relaxed[k].numbers, slow_ens.relaxed[k].numbers)
+            assert np.array_equal(fast_ens.relaxed[k].positions, slow_ens.relaxed[k].positions)
+        assert not isinstance(fast_ens.relaxed.raw(0), tuple)        # looked at: now a Structure
+    # a user-supplied energy function needs the structures: the per-slab path serves it
+    calc = PackedLatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.0)
+    ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 4, calc, relax=False, surface_energy_fn=lambda e, s: float(e) + len(s))
+    ens.initialize()
+    assert getattr(calc, "packed_calls", 0) == 0

@@ -78,3 +78,35 @@ def test_mc_state_energies_match_the_oracle(golden, oracle_mod):
         want = surface_energy_from_energy(ref["energy"], slab.get_chemical_symbols(), chem, golden.offset_data, "atomic")
         worst = max(worst, abs(want - float(ens.state.energy[b])))
     assert worst <= 2e-4, worst
+
+
+@pytest.mark.parametrize("relax", [True, False])
+def test_packed_fast_path_equals_the_per_slab_path_on_the_device(golden, relax):
+    """``ChainEnsemble`` talks to the calculator in packed arrays (``evaluate_packed``; no per-slab objects, surface energies
+    from element counts, relaxed slabs built on demand).  Same seed through the per-slab path (``relax_batch`` /
+    ``calculate_batch`` + ``surface_energy_from_energy`` per slab): identical accept masks, species, energies (bit for bit),
+    out-of-bounds flags and relaxed geometries."""
+    from surface_sampling_amd import mc
+    from surface_sampling_amd.calculators import EnsembleNFFSurface
+
+    base = golden.structure("SrTiO3_2x2_pristine")
+    coords = _site_grid(base)
+    fixed = np.flatnonzero(base.positions[:, 2] < base.positions[:, 2].max() - 4.0)
+    runs = []
+    for fast in (True, False):
+        calc = EnsembleNFFSurface(golden.blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV", offset_units="atomic")
+        calc.set(offset=True, offset_data=golden.offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0})
+        ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 7, calc, seed=21, relax=relax, relax_steps=4, fmax=0.05,
+                               fixed_indices=fixed, temperature=0.5)
+        ens.fast_path = fast
+        ens.initialize()
+        acc = np.stack([ens.step_semigrand() for _ in range(3)] + [ens.step_canonical() for _ in range(2)])
+        runs.append((acc, ens.state.species.copy(), ens.state.energy.copy(), ens.oob.copy(), ens))
+    a, b = runs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    assert np.array_equal(a[2], b[2])                                      # bit for bit
+    for k in range(7):
+        ra, rb = a[4].relaxed[k], b[4].relaxed[k]
+        assert np.array_equal(ra.numbers, rb.numbers) and np.array_equal(ra.positions, rb.positions)
+        assert np.array_equal(a[4].per_atom_energies[k], b[4].per_atom_energies[k])
+    assert a[0].any() or not relax      # (unrelaxed adsorbates 1.5 A above the surface are rarely accepted at T = 0.5 eV)
