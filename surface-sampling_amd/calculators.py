@@ -296,6 +296,8 @@ class EnsembleNFFSurface(_Base):
         for k, v in self.__dict__.items():
             if k in ("_engine", "_engine_key"):
                 setattr(new, k, None)
+            elif k in ("_extra_engines", "_extra_key"):
+                continue
             elif k in ("models", "logger"):
                 setattr(new, k, v)  # weights are immutable: share
             else:
@@ -306,6 +308,8 @@ class EnsembleNFFSurface(_Base):
         state = dict(self.__dict__)
         state["_engine"] = None
         state["_engine_key"] = None
+        state.pop("_extra_engines", None)
+        state.pop("_extra_key", None)
         state["logger"] = None
         return state
 
@@ -427,6 +431,27 @@ class EnsembleNFFSurface(_Base):
     # thresholds of the reference's out-of-bounds guard (mcmc/dynamics.py:17-18,159-168)
     ENERGY_THRESHOLD = 1000.0
     MAX_FORCE_THRESHOLD = 1000.0
+    # evaluate_packed: engines (HIP streams) the chains of a batch are split over, and the smallest part worth a stream
+    streams = 2
+    MIN_CHAINS_PER_STREAM = 32
+
+    def _get_engines(self, n: int):
+        """``n`` engines with this calculator's configuration: the first is the calculator's own, the others are created on
+        first use (weights are shared on the host, every engine holds its own device copy and workspaces)."""
+        first = self._get_engine()
+        extra = self.__dict__.setdefault("_extra_engines", [])
+        if self.__dict__.get("_extra_key") != self._engine_key:
+            for e in extra:
+                e.close()
+            extra.clear()
+            self.__dict__["_extra_key"] = self._engine_key
+        table, const = self._offset_config()
+        while len(extra) < n - 1:
+            extra.append(backend.PainnEngine(
+                self.models, device=_device_index(self.device), cutoff=self.cutoff,
+                model_units_per_ev=_units_per_ev(self.model_units, self.prediction_units),
+                offset_per_z=table, offset_const=const, hparams=self.hparams))
+        return [first] + extra[: n - 1]
 
     def evaluate_packed(self, n_atoms, Z, pos, cell, pbc, relax: bool = False, fixed_mask=None, relax_steps: int = 20,
                         fmax: float = 0.01, optimizer=None) -> dict:
@@ -437,16 +462,45 @@ class EnsembleNFFSurface(_Base):
         (float32, the TRUE energies of the final geometries), ``energy_std``, ``forces``, ``energy_atoms``, ``positions``
         (relaxed, or the input), ``cfg_start``, ``saturated [B]``, ``oob [B]`` (the reference's +-1000 guard,
         ``mcmc/dynamics.py:159-168``; a saturated evaluation counts), and for relaxations ``n_steps`` / ``converged``."""
-        eng = self._get_engine()
-        eng.upload_arrays(n_atoms, Z, pos, cell, pbc)
-        info = None
-        if relax:
-            if optimizer is None:
-                optimizer = self.parameters.get("optimizer", "FIRE")
-            info = eng.relax(optimizer, fixed=fixed_mask, max_steps=relax_steps, fmax=fmax)   # (raises for host-driven optimizers)
+        if relax and optimizer is None:
+            optimizer = self.parameters.get("optimizer", "FIRE")
+        n_atoms = np.ascontiguousarray(n_atoms, dtype=np.int64)
+        Z = np.asarray(Z)
+        B = len(n_atoms)
+
+        def one(eng, c0, c1, a0, a1):
+            eng.upload_arrays(n_atoms[c0:c1], Z[a0:a1], pos[a0:a1], cell[c0:c1], pbc[c0:c1])
+            inf = None
+            if relax:
+                inf = eng.relax(optimizer, fixed=None if fixed_mask is None else fixed_mask[a0:a1], max_steps=relax_steps,
+                                fmax=fmax)   # (raises for host-driven optimizers)
+            else:
+                eng.run()
+            return eng.download(), inf
+
+        pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
+        cell, pbc = np.asarray(cell, dtype=np.float64).reshape(B, 9), np.asarray(pbc).reshape(B, 3)
+        # (a single lock-step evaluation is too short to pay for the second host thread: measured 15.4 vs 15.0 ms per MC step)
+        n_str = self.streams if (relax and B >= 2 * self.MIN_CHAINS_PER_STREAM) else 1
+        if n_str <= 1:
+            res, info = one(self._get_engine(), 0, B, 0, int(n_atoms.sum()))
         else:
-            eng.run()
-        res = eng.download()
+            # the chains split over n_str engines (own HIP streams) that run concurrently: the latency-bound node kernels of one
+            # part fill issue slots under the neighbor-sum kernels of the other (+3 % on 256 chains, DESIGN.md section 5).  ctypes
+            # releases the GIL inside the C calls, one host thread per engine drives its relaxation; a chain's results do not
+            # depend on the split (bit-identical, tests/test_mc_gpu.py).
+            from concurrent.futures import ThreadPoolExecutor
+
+            cb = [(k * B) // n_str for k in range(n_str + 1)]
+            ab = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
+            engines = self._get_engines(n_str)
+            with ThreadPoolExecutor(max_workers=n_str) as pool:
+                parts = list(pool.map(lambda k: one(engines[k], cb[k], cb[k + 1], int(ab[cb[k]]), int(ab[cb[k + 1]])), range(n_str)))
+            res = {k: np.concatenate([p[0][k] for p in parts]) for k in parts[0][0] if k != "cfg_start"}
+            res["cfg_start"] = ab
+            info = None
+            if relax:
+                info = {k: np.concatenate([p[1][k] for p in parts]) for k in ("positions", "n_steps", "converged")}
         start = np.asarray(res["cfg_start"], dtype=np.int64)
         fabs = np.abs(res["forces"]).max(axis=1) if len(res["forces"]) else np.zeros(0, np.float32)
         nonempty = start[1:] > start[:-1]

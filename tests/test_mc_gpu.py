@@ -83,7 +83,7 @@ def test_mc_state_energies_match_the_oracle(golden, oracle_mod):
 @pytest.mark.parametrize("relax", [True, False])
 def test_packed_fast_path_equals_the_per_slab_path_on_the_device(golden, relax):
     """``ChainEnsemble`` talks to the calculator in packed arrays (``evaluate_packed``; no per-slab objects, surface energies
-    from element counts, relaxed slabs built on demand).  Same seed through the per-slab path (``relax_batch`` /
+    from element counts, relaxed slabs built on demand, the chains split over two concurrent engines).  Same seed through the per-slab path (``relax_batch`` /
     ``calculate_batch`` + ``surface_energy_from_energy`` per slab): identical accept masks, species, energies (bit for bit),
     out-of-bounds flags and relaxed geometries."""
     from surface_sampling_amd import mc
@@ -99,8 +99,10 @@ def test_packed_fast_path_equals_the_per_slab_path_on_the_device(golden, relax):
         ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 7, calc, seed=21, relax=relax, relax_steps=4, fmax=0.05,
                                fixed_indices=fixed, temperature=0.5)
         ens.fast_path = fast
+        calc.MIN_CHAINS_PER_STREAM = 2      # the packed path splits these 7 chains over two engines (two HIP streams, two host threads)
         ens.initialize()
         acc = np.stack([ens.step_semigrand() for _ in range(3)] + [ens.step_canonical() for _ in range(2)])
+        assert len(calc.__dict__.get("_extra_engines", [])) == (1 if fast and relax else 0)
         runs.append((acc, ens.state.species.copy(), ens.state.energy.copy(), ens.oob.copy(), ens))
     a, b = runs
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
