@@ -63,6 +63,7 @@ class ChainGather:
         self._full = None if self.even else [torch.empty(self.n_chains, self.width, **kw) for _ in range(2)]
         self._flip = 0
         self.n_staging_copies = 0        # (tests: stays 0 on the even, device-resident path)
+        self.force_collective = False    # (tests: a one-rank group still goes through the collective, RCCL sees the real buffers)
 
     def __call__(self, local):
         """``local``: float32 ``[count, width]`` -- numpy array or torch tensor.  Returns the gathered ``[n_chains, width]``
@@ -77,7 +78,7 @@ class ChainGather:
             raise ValueError("local block does not match this rank's chain range")
         self._flip ^= 1
         out = self._out[self._flip]
-        if self.world == 1:
+        if self.world == 1 and not (self.force_collective and self.dist is not None and self.dist.is_initialized()):
             out.copy_(t, non_blocking=True)
             return out
         direct = self.even and t.dtype == torch.float32 and t.device == self.device and t.is_contiguous()

@@ -264,6 +264,23 @@ def test_device_results_reach_torch_and_rccl_without_a_host_copy():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
+        # the step path itself through RCCL: the staging tensor goes to all_gather_into_tensor as it is (even blocks), the
+        # collective's output buffer is the result -- with an engine group (two engines, two streams) as in the default bench
+        grp = sharding.EngineGroup([eng, backend.PainnEngine(blobs, device=0, offset_per_z=table, offset_const=const)])
+        sh2 = sharding.ShardedEnsemble(grp, len(chains), dist, dev)
+        assert sh2.result_path == "device"
+        sh2.upload(local_chains=packs)
+        sh2.step(want, gather=True)
+        sh2._gather.force_collective = True
+        g1, g2 = sh2.step(want, gather=True), sh2.step(want, gather=True)
+        torch.cuda.synchronize()
+        assert sh2._gather.n_staging_copies == 0 and g1.data_ptr() != g2.data_ptr()
+        for g in (g1, g2):
+            assert np.array_equal(g[:, 0].cpu().numpy(), res["energy"]) and np.array_equal(g[:, 1].cpu().numpy(), res["energy_std"])
+        assert sh2.check() is False
+        grp.engines[1].close()
+        sh.upload(local_chains=packs)                       # (the group re-uploaded parts of the list to the first engine)
+        sh.step(want, gather=True)
         local = sh._local_scalars(want).reshape(-1).contiguous()
         out = torch.empty_like(local)
         dist.all_gather_into_tensor(out, local)
