@@ -353,8 +353,7 @@ k_reduce_gpart(int M, int n_groups, int layer_sets, GraphView G, const int *__re
     } else {                // grid (chains, blocks per chain)
         const int b = blockIdx.x;
         if (!G.act.chain(b)) return;
-        const int cls = G.chain_class[b];
-        slices = cls == EDGE_BCLASS_FS16 ? 8 : cls == EDGE_BCLASS_FS8 ? 16 : 1;
+        slices = edge_bclass_slices(G.chain_class[b]);
         if (slices == 1) return;   // gather-class chains accumulate in the final buffer directly
         s0 = G.row_start[G.cfg_start[b]]; s1 = G.row_start[G.cfg_start[b + 1]];
     }
@@ -394,8 +393,7 @@ k_reduce_gbar_groups(int M, int n_groups, int layer_sets, GraphView G, const int
     if (counters[2]) return;
     const int b = blockIdx.x;   // (x: no 65 535 limit on the chain count)
     if (!G.act.chain(b)) return;
-    const int cls = G.chain_class[b];
-    const int slices = cls == EDGE_BCLASS_FS16 ? 8 : cls == EDGE_BCLASS_FS8 ? 16 : 1;   // buffers the chain's reverse kernels wrote per layer set
+    const int slices = edge_bclass_slices(G.chain_class[b]);   // buffers the chain's reverse kernels wrote per layer set
     if (slices == 1) return;
     const int per_set = n_groups / layer_sets;   // group index of layer set k, slice f: k * per_set + f
     const int s0 = G.row_start[G.cfg_start[b]], s1 = G.row_start[G.cfg_start[b + 1]];
@@ -559,8 +557,9 @@ k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const 
 static int gbar_layer_sets(const vssr_handle *h) { return h->gbar_mode == 2 ? h->num_conv - 1 : h->gbar_mode == 1 && h->num_conv > 2 ? h->num_conv - 1 : 1; }
 int painn_gbar_groups(const vssr_handle *h) {
     if (h->num_conv < 2) return 1;
-    const int per_set = h->n_bclass[EDGE_BCLASS_FS8] ? edge_class_groups(EDGE_BCLASS_FS8)
-                                                     : h->n_bclass[EDGE_BCLASS_FS16] ? edge_class_groups(EDGE_BCLASS_FS16) : 1;
+    const int per_set = h->n_bclass[EDGE_BCLASS_FS4] ? edge_class_groups(EDGE_BCLASS_FS4)
+                        : h->n_bclass[EDGE_BCLASS_FS8] ? edge_class_groups(EDGE_BCLASS_FS8)
+                        : h->n_bclass[EDGE_BCLASS_FS16] ? edge_class_groups(EDGE_BCLASS_FS16) : 1;
     return per_set > 1 ? per_set * gbar_layer_sets(h) : 1;
 }
 
@@ -654,11 +653,11 @@ int painn_run(vssr_handle *h, uint32_t want) {
     const bool compact = h->gbar_mode == 2 && n_groups > 1;   // 12-byte partial records in d_gpart, final float4 buffer per model
     const int fin_groups = compact ? 1 : n_groups;             // buffers between two models in the final float4 array
     const int *cls_list[EDGE_MFMA_CLASSES];
-    const int *bcls_list[2];
+    const int *bcls_list[EDGE_MFMA_BCLASSES];
     {
         int o = 0;
         for (int c = 0; c < EDGE_MFMA_CLASSES; o += h->n_class[c], ++c) cls_list[c] = h->d_class_list.as<int>() + o;
-        for (int c = 0; c < 2; o += h->n_bclass[c], ++c) bcls_list[c] = h->d_class_list.as<int>() + o;
+        for (int c = 0; c < EDGE_MFMA_BCLASSES; o += h->n_bclass[c], ++c) bcls_list[c] = h->d_class_list.as<int>() + o;
     }
     const int n_gather = h->n_class[EDGE_CLASS_GATHER];
     // forward intermediates of the update blocks for the reverse pass (fused reverse kernels and forces wanted only)
@@ -755,7 +754,7 @@ int painn_run(vssr_handle *h, uint32_t want) {
                                    sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
                                    (long long)h->slot_cap * fin_groups, -1, (int)compact);
             else {
-                for (int cls = 0; cls < 2; ++cls)
+                for (int cls = 0; cls < EDGE_MFMA_BCLASSES; ++cls)
                     launch_edge_bwd_mfma(st, cls, N, bcls_list[cls], h->n_bclass[cls], M, l, (int)(l == L - 1 || layer_sets > 1),
                                          h->max_bclass_atoms[cls], MW, G, counters, (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l],
                                          sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar,
@@ -783,13 +782,15 @@ int painn_run(vssr_handle *h, uint32_t want) {
 #else
         if (compact) {
 #endif
-            const int uni = h->active_mask ? 0 : h->n_bclass[EDGE_BCLASS_FS16] == h->n_cfg ? 8 : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? 16 : 0;
+            const int uni = h->active_mask ? 0 : h->n_bclass[EDGE_BCLASS_FS16] == h->n_cfg ? 8 : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? 16
+                            : h->n_bclass[EDGE_BCLASS_FS4] == h->n_cfg ? 32 : 0;
             const dim3 grid = uni ? dim3((unsigned)((h->slot_cap + 255) / 256), 1) : dim3(h->n_cfg, 12);
             hipLaunchKernelGGL(k_reduce_gpart, grid, dim3(256), 0, st, M, n_groups, layer_sets, G, counters, h->d_gpart.as<float>(),
                                sv.gbar, (long long)h->slot_cap, uni);
         } else if (n_groups > 1) {
             const int cls_only = h->n_bclass[EDGE_BCLASS_FS16] == h->n_cfg ? EDGE_BCLASS_FS16
-                                 : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? EDGE_BCLASS_FS8 : -1;
+                                 : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? EDGE_BCLASS_FS8
+                                 : h->n_bclass[EDGE_BCLASS_FS4] == h->n_cfg ? EDGE_BCLASS_FS4 : -1;
             if (cls_only >= 0 && !h->active_mask && (layer_sets == 1 || n_gather == 0))   // (switched-off chains keep their reduced gradients: the per-chain form skips them)
                 hipLaunchKernelGGL(k_reduce_gbar_groups_uniform, dim3((unsigned)((h->slot_cap + 255) / 256)), dim3(256), 0, st, M,
                                    n_groups, counters, sv.gbar, (long long)h->slot_cap);

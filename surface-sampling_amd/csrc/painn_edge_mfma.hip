@@ -129,6 +129,25 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 acc) {
 template <int NT>
 __device__ __forceinline__ void filter_tiles_sel(const u32x4 (*const (&w)[NT])[2], const u32x4 (*const (&r)[NT])[2], f32x4 (&acc)[NT],
                                                  const u32x4 &sel, const u32x4 (&rs)[2], f32x4 &accsel) {
+    if constexpr (NT == 1) {
+        // One filter tile (4-feature slices, forward): five matrix instructions in three chains -- (Wh rl, Wl rh) | Wh rh | selector
+        // (l, h) -- ordered so that every product's predecessor in its chain is three instructions back; the two filter partial sums
+        // are added on the vector unit.
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 a = mfma_f16((*w[0])[0], (*r[0])[1], z);
+        __builtin_amdgcn_sched_barrier(0);
+        accsel = mfma_f16(sel, rs[1], z);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 b = mfma_f16((*w[0])[0], (*r[0])[0], z);
+        __builtin_amdgcn_sched_barrier(0);
+        a = mfma_f16((*w[0])[1], (*r[0])[0], a);
+        __builtin_amdgcn_sched_barrier(0);
+        accsel = mfma_f16(sel, rs[0], accsel);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("; mfma operands live" : : "v"((*r[0])[0]), "v"((*r[0])[1]), "v"(rs[0]), "v"(rs[1]));   // (see below)
+        acc[0] = a + b;
+        return;
+    }
     constexpr int wi[3] = {0, 1, 0}, ri[3] = {1, 0, 0};   // Wh rl, Wl rh, Wh rh
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -153,6 +172,14 @@ __device__ __forceinline__ void filter_tiles_sel(const u32x4 (*const (&w)[NT])[2
             accsel = mfma_f16(sel, rs[ri[k]], accsel);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if constexpr (NT == 2) {
+        // The B operands stay live past the block: with few tiles the register allocator otherwise places the destination of a chain's
+        // LAST product over its (dying) B operand while the accumulator input is another register -- the pattern that produced
+        // run-to-run differences in round 3 (lint rule 4, tools/check_mfma_loads.py; seen again in the 4-feature reverse kernel).
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("; mfma operands live" : : "v"((*r[t])[0]), "v"((*r[t])[1]));
+        asm volatile("; mfma operands live" : : "v"(rs[0]), "v"(rs[1]));
     }
 }
 
@@ -197,26 +224,38 @@ void build_wd16(const float *Wd, const float *bd, unsigned *dst) {
 // chain's slice fills the LDS (measured on 260-atom chains: 512 threads -> 2.54, 768 -> 2.17, 1024 -> 2.03 ms / step), two of 8
 // or four of 4 waves when two / four slices fit (small chains: a 74-atom chain has 19 bundles, which 16 waves share badly).
 
+// the NF features of a lane as one register vector (NF = 1: a struct that indexes like one)
+template <int N> struct FeatVec { typedef float type __attribute__((ext_vector_type(N))); };
+struct FeatVec1 {
+    float v;
+    __device__ __forceinline__ float operator[](int) const { return v; }
+};
+template <> struct FeatVec<1> { typedef FeatVec1 type; };
+
 // LDS slice layout: tile[atom][feature f][NSEG] with NSEG = {a, b, c, v_x, v_y, v_z}: the values a lane needs for its NF
 // features of one neighbor are NF * 24 contiguous bytes.  (Layer 0 never comes here: it is either
 // factorised by species, painn_l0.hip, or -- more than 8 species / VSSR_L0_FACTORISE=0 -- runs the gather kernels.)
 template <int NF>
 struct EdgeGeo {
-    static_assert(NF == 4 || NF == 2, "16- or 8-feature slices");
+    static_assert(NF == 4 || NF == 2 || NF == 1, "16-, 8- or 4-feature slices");
     static constexpr int FS = 4 * NF;                // features per slice
     static constexpr int NSLICE = F / FS;            // 8 or 16
     static constexpr int NSEC = 3;                   // filter sections a, b, c
-    static constexpr int NT = NF == 4 ? 3 : 2;       // filter tiles per table (rho; the reverse kernel adds as many for d rho)
+    static constexpr int NT = NF == 4 ? 3 : NF == 2 ? 2 : 1;   // filter tiles per table (rho; the reverse kernel adds as many for d rho)
     static constexpr int NSEG = 6;                   // values staged per (atom, feature): phi a, b, c and v x, y, z
     static constexpr int ROW = NSEG * FS + 4;        // forward LDS row stride (floats); rows stay 16-B aligned
     static constexpr int ROWB = FS * 4 + 4;          // reverse LDS row: [feature][sbar, vbar_x, vbar_y, vbar_z] + pad
     // filter section and slice feature carried by row i of tile T (-1: the row is empty)
-    __host__ __device__ static constexpr int row_section(int T, int i) { return NF == 4 ? T : (2 * T + ((i & 3) >> 1) < 3 ? 2 * T + ((i & 3) >> 1) : -1); }
-    __host__ __device__ static constexpr int row_feature(int i) { return NF == 4 ? i : 2 * (i >> 2) + (i & 1); }
+    // (NF = 1, a 4-feature slice: ONE tile, row 4 q + j = feature q of section j, j = 3 empty -- lane (slot, fq) finds a, b, c of its
+    // feature in accumulator registers 0, 1, 2)
+    __host__ __device__ static constexpr int row_section(int T, int i) {
+        return NF == 4 ? T : NF == 1 ? ((i & 3) < 3 ? (i & 3) : -1) : (2 * T + ((i & 3) >> 1) < 3 ? 2 * T + ((i & 3) >> 1) : -1);
+    }
+    __host__ __device__ static constexpr int row_feature(int i) { return NF == 4 ? i : NF == 1 ? (i >> 2) : 2 * (i >> 2) + (i & 1); }
 };
 // accumulator register r' of tile T that holds the filter of section sec for the lane's feature r (r < NF)
-template <int NF> __device__ __forceinline__ constexpr int sec_tile(int sec) { return NF == 4 ? sec : sec >> 1; }
-template <int NF> __device__ __forceinline__ constexpr int sec_reg(int sec, int r) { return NF == 4 ? r : 2 * (sec & 1) + r; }
+template <int NF> __device__ __forceinline__ constexpr int sec_tile(int sec) { return NF == 4 ? sec : NF == 1 ? 0 : sec >> 1; }
+template <int NF> __device__ __forceinline__ constexpr int sec_reg(int sec, int r) { return NF == 4 ? r : NF == 1 ? sec : 2 * (sec & 1) + r; }
 
 // LDS carve-up: tile [max_atoms][ROW] | SLDS: s slice [max_atoms][FS].  The scalar residual of a centre (its own s slice, which
 // no gather ever touches) either sits in LDS next to the tile (SLDS = true: 468 B per atom with 16-feature slices, <= 350
@@ -244,13 +283,15 @@ __device__ __forceinline__ void quad_sum_n(float (&x)[NF]) {
 #pragma unroll
     for (int r = 0; r < NF; ++r) x[r] = quad_sum(x[r]);
     if constexpr (NF == 4) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-    else asm volatile("" : "+v"(x[0]), "+v"(x[1]));
+    else if constexpr (NF == 2) asm volatile("" : "+v"(x[0]), "+v"(x[1]));
+    else asm volatile("" : "+v"(x[0]));
 }
 // the NF values of a lane to NF consecutive floats (one 16- or 8-byte store)
 template <int NF>
 __device__ __forceinline__ void store_feat(float *dst, const float (&v)[NF]) {
     if constexpr (NF == 4) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-    else *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[1]);
+    else if constexpr (NF == 2) *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[1]);
+    else *dst = v[0];
 }
 
 // sum over the four 16-lane rows (lanes l, l^16, l^32, l^48), result in every lane: the gfx950 row-swap instructions
@@ -432,7 +473,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int fcol = fs * FS + NF * fq;            // first of this lane's NF global feature columns
     // scalar residual of this stream's centre: requested when the wave switches to a bundle (for the bundle after it), used
     // when that bundle completes -- always a load (clamped row for streams without a centre), like the bundle entries
-    typedef float fres __attribute__((ext_vector_type(NF)));
+    typedef typename FeatVec<NF>::type fres;
     fres sres_cur, sres_nxt;
     auto load_residual = [&](int cc) {
         return *reinterpret_cast<const fres *>(s_in + (mN + a0 + min(max(cc, 0), Nc - 1)) * F + fcol);
@@ -520,11 +561,20 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             // gather this slot's neighbor row: NF features x NSEG values, contiguous in LDS
             float tv[NF * LY::NSEG];
             {
-                const float4 *row = reinterpret_cast<const float4 *>(trow + jn * LY::ROW);
+                if constexpr ((NF * LY::NSEG) % 4 == 0) {
+                    const float4 *row = reinterpret_cast<const float4 *>(trow + jn * LY::ROW);
 #pragma unroll
-                for (int q = 0; q < NF * LY::NSEG / 4; ++q) {
-                    const float4 t4 = row[q];
-                    tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
+                    for (int q = 0; q < NF * LY::NSEG / 4; ++q) {
+                        const float4 t4 = row[q];
+                        tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
+                    }
+                } else {   // 4-feature slices: the lane's six values start 24 fq bytes into the row (8-byte aligned)
+                    const float2 *row = reinterpret_cast<const float2 *>(trow + jn * LY::ROW);
+#pragma unroll
+                    for (int q = 0; q < NF * LY::NSEG / 2; ++q) {
+                        const float2 t2 = row[q];
+                        tv[2 * q] = t2.x; tv[2 * q + 1] = t2.y;
+                    }
                 }
             }
             mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
@@ -603,6 +653,9 @@ size_t edge_bwd_lds_bytes_t(int max_atoms) { return sizeof(float) * ((size_t)max
 #endif
 
 // FIRST: the launch writes the partial edge-gradient buffers for the first time (last layer): nothing to add to.
+// (The narrow slices need fewer registers -- 145 / 110 with 8- / 4-feature slices -- but wider workgroups, 12 resp. 16 waves when one
+// workgroup owns the CU, changed nothing: 9.08 vs 9.01 .. 9.22 ms at 700 atoms, 37.1 vs 36.9 at 1 400, profiles/r04/ab_bwd_wide.txt;
+// these launches are bound by the L2 -> L1 stream of the per-slot tables, which every slice re-reads, not by latency.)
 template <int NF, bool FIRST, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 2 waves per SIMD either way: use the 256 VGPRs
 k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
@@ -613,7 +666,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 float *__restrict__ gbar, long long gbar_stride, int n_groups, int group_off, int rec) {
     using LY = EdgeGeo<NF>;
     constexpr int FS = LY::FS, NSG = LY::NSLICE, NT = LY::NT, ROWB = LY::ROWB, BWD_THREADS = 64 * WAVES;
-    typedef float fvx __attribute__((ext_vector_type(NF)));   // the lane's NF features (ext vectors: arrays of HIP float4 stay in scratch memory)
+    typedef typename FeatVec<NF>::type fvx;   // the lane's NF features (ext vectors: arrays of HIP float4 stay in scratch memory)
     extern __shared__ __attribute__((aligned(16))) float tile[];
     if (counters[2]) return;
     int t;
@@ -944,7 +997,9 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 int edge_mfma_init(vssr_handle *h) {
 #define SET_LDS(K) VSSR_HIP(h, hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     SET_LDS((k_edge_fwd_mfma<4, true, 16>)); SET_LDS((k_edge_fwd_mfma<4, false, 16>)); SET_LDS((k_edge_fwd_mfma<2, false, 16>));
-    SET_LDS((k_edge_fwd_mfma<4, true, 8>)); SET_LDS((k_edge_fwd_mfma<4, true, 4>));
+    SET_LDS((k_edge_fwd_mfma<4, true, 8>)); SET_LDS((k_edge_fwd_mfma<4, true, 4>)); SET_LDS((k_edge_fwd_mfma<1, false, 16>));
+    SET_LDS((k_edge_bwd_mfma<1, true, 4>)); SET_LDS((k_edge_bwd_mfma<1, false, 4>));
+    SET_LDS((k_edge_bwd_mfma<1, true, 8>)); SET_LDS((k_edge_bwd_mfma<1, false, 8>));
     SET_LDS((k_edge_bwd_mfma<4, true, 4>)); SET_LDS((k_edge_bwd_mfma<4, false, 4>));
     SET_LDS((k_edge_bwd_mfma<2, true, 4>)); SET_LDS((k_edge_bwd_mfma<2, false, 4>));
     SET_LDS((k_edge_bwd_mfma<4, true, 8>)); SET_LDS((k_edge_bwd_mfma<4, false, 8>));
@@ -959,6 +1014,7 @@ int edge_class_of(int n_atoms) {
     if (edge_fwd_lds_bytes_t<4, true>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS16;
     if (edge_fwd_lds_bytes_t<4, false>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS16M;
     if (edge_fwd_lds_bytes_t<2, false>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS8;
+    if (edge_fwd_lds_bytes_t<1, false>(n_atoms) <= 160 * 1024) return EDGE_CLASS_FS4;   // 112 B per atom: <= 1 462 atoms
     return EDGE_CLASS_GATHER;
 }
 // reverse path of a chain: 16-feature slices while the reverse tile fits LDS (8-wave workgroup), 8-feature slices for the rest
@@ -967,9 +1023,12 @@ int edge_bclass_of(int n_atoms) {
     const int fwd = edge_class_of(n_atoms);
     if (fwd == EDGE_CLASS_GATHER) return EDGE_BCLASS_GATHER;
     if (edge_bwd_lds_bytes_t<4, 8>(n_atoms) <= 160 * 1024) return EDGE_BCLASS_FS16;
-    return EDGE_BCLASS_FS8;
+    if (edge_bwd_lds_bytes_t<2, 8>(n_atoms) <= 160 * 1024) return EDGE_BCLASS_FS8;     // 144 B per atom: <= 1 127 atoms
+    return EDGE_BCLASS_FS4;
 }
-int edge_class_groups(int bcls) { return bcls == EDGE_BCLASS_FS16 ? EdgeGeo<4>::NSLICE : bcls == EDGE_BCLASS_FS8 ? EdgeGeo<2>::NSLICE : 1; }
+int edge_class_groups(int bcls) { return edge_bclass_slices(bcls); }
+static_assert(edge_bclass_slices(EDGE_BCLASS_FS16) == EdgeGeo<4>::NSLICE && edge_bclass_slices(EDGE_BCLASS_FS8) == EdgeGeo<2>::NSLICE &&
+              edge_bclass_slices(EDGE_BCLASS_FS4) == EdgeGeo<1>::NSLICE, "slices per reverse class");
 
 // layers >= 1 only (layer 0: painn_l0.hip or the gather kernels, see painn_run).  cls: EDGE_BCLASS_FS16 / _FS8 (reverse) resp.
 // EDGE_CLASS_FS16 / _FS16M / _FS8 (forward); list / n_list: the chains of that class; max_atoms: the largest of them.
@@ -992,7 +1051,8 @@ void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
         const bool many = (long long)n_list * EdgeGeo<NF>::NSLICE * M > 256;                                                     \
         if (two_fit && many) LAUNCH_BWD(NF, FIRST, 4); else LAUNCH_BWD(NF, FIRST, 8);                                            \
     } while (0)
-    if (cls == EDGE_BCLASS_FS8) { if (layer_first) LAUNCH_BWD_W(2, true); else LAUNCH_BWD_W(2, false); }
+    if (cls == EDGE_BCLASS_FS4) { if (layer_first) LAUNCH_BWD_W(1, true); else LAUNCH_BWD_W(1, false); }
+    else if (cls == EDGE_BCLASS_FS8) { if (layer_first) LAUNCH_BWD_W(2, true); else LAUNCH_BWD_W(2, false); }
     else { if (layer_first) LAUNCH_BWD_W(4, true); else LAUNCH_BWD_W(4, false); }
 #undef LAUNCH_BWD_W
 #undef LAUNCH_BWD
@@ -1014,7 +1074,8 @@ void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
         else if (2 * lds <= 160 * 1024 && wgs > 2 * 256) LAUNCH_FWD(4, true, 8);
         else LAUNCH_FWD(4, true, 16);
     } else if (cls == EDGE_CLASS_FS16M) LAUNCH_FWD(4, false, 16);
-    else LAUNCH_FWD(2, false, 16);
+    else if (cls == EDGE_CLASS_FS8) LAUNCH_FWD(2, false, 16);
+    else LAUNCH_FWD(1, false, 16);
 #undef LAUNCH_FWD
 }
 

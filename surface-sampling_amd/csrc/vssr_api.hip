@@ -319,6 +319,7 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     // test knobs: send chains above these atom counts to the next class (8-feature slices / gather kernels) although they fit
     if (const char *e = getenv("VSSR_EDGE_FS16_MAX")) h->fs16_max_atoms = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_FS8_MAX")) h->fs8_max_atoms = atoi(e);
+    if (const char *e = getenv("VSSR_EDGE_FS4_MAX")) h->fs4_max_atoms = atoi(e);
     if (!rc && cfg->offset_per_z) {
         h->has_offset = true;
         h->offset_const = cfg->offset_const;
@@ -540,11 +541,11 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
     for (int b = 0; b < n_cfg; ++b) h->max_cfg_atoms = n_atoms[b] > h->max_cfg_atoms ? n_atoms[b] : h->max_cfg_atoms;
     if (h->kind == 1) {
         // Neighbor-sum path of every chain, from its OWN atom count (so a chain's results do not depend on its batch):
-        // 16-feature slices, 8-feature slices, or the gather kernels.  (A batch whose largest chain exceeds what the bundle
+        // 16-, 8- or 4-feature slices, or the gather kernels.  (A batch whose largest chain exceeds what the bundle
         // sort stages in LDS has no bundle tables at all: every chain gathers.)
         const bool bundles = (size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024;
         std::vector<unsigned char> bcls(n_cfg);
-        std::vector<int> lists[EDGE_MFMA_CLASSES], blists[2];
+        std::vector<int> lists[EDGE_MFMA_CLASSES], blists[EDGE_MFMA_BCLASSES];
         for (int c = 0; c < EDGE_CLASSES; ++c) { h->n_class[c] = 0; h->max_class_atoms[c] = 0; }
         for (int c = 0; c < EDGE_BCLASSES; ++c) { h->n_bclass[c] = 0; h->max_bclass_atoms[c] = 0; }
         for (int b = 0; b < n_cfg; ++b) {
@@ -552,7 +553,8 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
             int bc = (h->edge_impl && bundles) ? edge_bclass_of(n_atoms[b]) : EDGE_BCLASS_GATHER;
             if (c <= EDGE_CLASS_FS16M && h->fs16_max_atoms >= 0 && n_atoms[b] > h->fs16_max_atoms) c = EDGE_CLASS_FS8;
             if (bc == EDGE_BCLASS_FS16 && h->fs16_max_atoms >= 0 && n_atoms[b] > h->fs16_max_atoms) bc = EDGE_BCLASS_FS8;
-            if (c == EDGE_CLASS_FS8 && h->fs8_max_atoms >= 0 && n_atoms[b] > h->fs8_max_atoms) { c = EDGE_CLASS_GATHER; bc = EDGE_BCLASS_GATHER; }
+            if (c == EDGE_CLASS_FS8 && h->fs8_max_atoms >= 0 && n_atoms[b] > h->fs8_max_atoms) { c = EDGE_CLASS_FS4; bc = EDGE_BCLASS_FS4; }
+            if (c == EDGE_CLASS_FS4 && h->fs4_max_atoms >= 0 && n_atoms[b] > h->fs4_max_atoms) { c = EDGE_CLASS_GATHER; bc = EDGE_BCLASS_GATHER; }
             bcls[b] = (unsigned char)bc;
             h->n_class[c] += 1;
             h->n_bclass[bc] += 1;
@@ -563,7 +565,7 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
         }
         std::vector<int> cat;
         for (int c = 0; c < EDGE_MFMA_CLASSES; ++c) cat.insert(cat.end(), lists[c].begin(), lists[c].end());
-        for (int c = 0; c < 2; ++c) cat.insert(cat.end(), blists[c].begin(), blists[c].end());
+        for (int c = 0; c < EDGE_MFMA_BCLASSES; ++c) cat.insert(cat.end(), blists[c].begin(), blists[c].end());
         cat.push_back(0);
         const std::vector<unsigned char> &cls = bcls;
         if (h->d_chain_class.ensure((size_t)n_cfg) || h->d_class_list.ensure(sizeof(int) * cat.size()))

@@ -245,9 +245,9 @@ struct vssr_handle {
     // chains by neighbor-sum path (EDGE_CLASS_*), fixed at upload from every chain's own atom count: class of every chain,
     // the chain lists of the matrix-pipe classes (concatenated in class order), counts and largest chain per class
     vssr::DevBuf d_chain_class, d_class_list;
-    int n_class[4] = {0, 0, 0, 0}, max_class_atoms[4] = {0, 0, 0, 0};      // forward classes (EDGE_CLASS_*)
-    int n_bclass[3] = {0, 0, 0}, max_bclass_atoms[3] = {0, 0, 0};          // reverse classes (EDGE_BCLASS_*); lists follow the forward lists
-    int fs16_max_atoms = -1, fs8_max_atoms = -1;   // test knobs (VSSR_EDGE_FS16_MAX / VSSR_EDGE_FS8_MAX): lower the class limits
+    int n_class[5] = {0, 0, 0, 0, 0}, max_class_atoms[5] = {0, 0, 0, 0, 0};   // forward classes (EDGE_CLASS_*)
+    int n_bclass[4] = {0, 0, 0, 0}, max_bclass_atoms[4] = {0, 0, 0, 0};       // reverse classes (EDGE_BCLASS_*); lists follow the forward lists
+    int fs16_max_atoms = -1, fs8_max_atoms = -1, fs4_max_atoms = -1;   // test knobs (VSSR_EDGE_FS16_MAX / _FS8_MAX / _FS4_MAX): lower the class limits
     int max_images = 0;          // largest number of periodic images any configuration of the batch scans per pair
 
     // configuration
@@ -384,10 +384,13 @@ int l0_run_reverse(vssr_handle *h, const GraphView &G, int first_write, int fres
                    float4 *gbar, long long gbar_stride, int n_groups);
 // LDS-slice + MFMA edge stages (painn_edge_mfma.hip)
 int edge_mfma_init(vssr_handle *h);
-// forward neighbor-sum paths: 16-feature slices with / without the scalar residual in LDS, 8-feature slices, gather kernels
-enum { EDGE_CLASS_FS16 = 0, EDGE_CLASS_FS16M = 1, EDGE_CLASS_FS8 = 2, EDGE_CLASS_GATHER = 3, EDGE_CLASSES = 4, EDGE_MFMA_CLASSES = 3 };
+// forward neighbor-sum paths: 16-feature slices with / without the scalar residual in LDS, 8- and 4-feature slices, gather kernels
+enum { EDGE_CLASS_FS16 = 0, EDGE_CLASS_FS16M = 1, EDGE_CLASS_FS8 = 2, EDGE_CLASS_FS4 = 3, EDGE_CLASS_GATHER = 4, EDGE_CLASSES = 5,
+       EDGE_MFMA_CLASSES = 4 };
 // reverse paths (the reverse tile is smaller: 16-feature slices serve chains up to 557 atoms): what GraphView::chain_class holds
-enum { EDGE_BCLASS_FS16 = 0, EDGE_BCLASS_FS8 = 1, EDGE_BCLASS_GATHER = 2, EDGE_BCLASSES = 3 };
+enum { EDGE_BCLASS_FS16 = 0, EDGE_BCLASS_FS8 = 1, EDGE_BCLASS_FS4 = 2, EDGE_BCLASS_GATHER = 3, EDGE_BCLASSES = 4, EDGE_MFMA_BCLASSES = 3 };
+// partial edge-gradient buffers (feature slices) a chain of reverse class c writes per layer set and model
+__host__ __device__ constexpr int edge_bclass_slices(int c) { return c == EDGE_BCLASS_FS16 ? 8 : c == EDGE_BCLASS_FS8 ? 16 : c == EDGE_BCLASS_FS4 ? 32 : 1; }
 int edge_bclass_of(int n_atoms);
 int edge_class_of(int n_atoms);       // path of a chain by its own atom count
 int edge_class_groups(int cls);       // partial edge-gradient buffers a chain of that class writes per model

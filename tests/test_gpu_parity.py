@@ -676,11 +676,12 @@ def _sized_chains(golden):
 def test_mixed_chain_sizes_take_their_own_path(golden, oracle_mod, engine):
     """One batch with chains of 260 / 370 / 495 / 735 / 975 atoms: every chain is served by the kernels its own size selects
     (16-feature slices up to 350 atoms, the same with the scalar residual read from memory up to 405, 8-feature slices up to
-    787, gather kernels beyond), within the stated tolerances of the fp64 oracle, and BIT-IDENTICAL to the same chain evaluated
+    787, 4-feature slices up to 1 462 -- the 975-atom chain: forward 4-feature, reverse 8-feature slices -- gather kernels beyond),
+    within the stated tolerances of the fp64 oracle, and BIT-IDENTICAL to the same chain evaluated
     alone or in another order -- one large chain no longer sends its whole batch to the slow path."""
     chains = _sized_chains(golden)
     sizes = [len(c) for c in chains]
-    assert sizes[0] <= 350 < sizes[1] <= 405 < sizes[2] < sizes[3] <= 787 < sizes[4], sizes
+    assert sizes[0] <= 350 < sizes[1] <= 405 < sizes[2] < sizes[3] <= 787 < sizes[4] <= 1127, sizes
     res = engine.evaluate([_arrays(c) for c in chains])
     assert not res["saturated"].any()
     cs = res["cfg_start"]
@@ -698,16 +699,21 @@ def test_mixed_chain_sizes_take_their_own_path(golden, oracle_mod, engine):
     assert np.array_equal(rev["energy"][::-1], res["energy"])
 
 
-def test_eight_feature_slices_match_the_oracle_on_the_small_structures(golden, oracle_mod, monkeypatch):
-    """The 8-feature-slice kernels on inputs every other test sends through the 16-feature ones (VSSR_EDGE_FS16_MAX=0 moves
-    every chain to the next class): reference KAT structure, per-layer intermediates, a ragged batch; results agree with the
+@pytest.mark.parametrize("knobs", [{"VSSR_EDGE_FS16_MAX": "0"}, {"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0"}],
+                         ids=["8-feature", "4-feature"])
+def test_narrow_feature_slices_match_the_oracle_on_the_small_structures(golden, oracle_mod, monkeypatch, knobs):
+    """The 8- and the 4-feature-slice kernels on inputs every other test sends through the 16-feature ones (VSSR_EDGE_FS16_MAX=0
+    moves every chain to the next class, VSSR_EDGE_FS8_MAX=0 one further: 4-feature slices in both directions -- the class of
+    788 .. 1 462-atom chains): reference KAT structure, per-layer intermediates, a ragged batch; results agree with the
     default path to fp32 rounding (different summation tree inside a slot quad is NOT involved: same order, other slices)."""
     from surface_sampling_amd import backend, structures
 
-    monkeypatch.setenv("VSSR_EDGE_FS16_MAX", "0")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
     table, const = golden.offset_table()
     eng8 = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
-    monkeypatch.delenv("VSSR_EDGE_FS16_MAX")
+    for k in knobs:
+        monkeypatch.delenv(k)
     eng16 = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
     big = golden.structure("SrTiO3_2x2_pristine").repeat((2, 2, 1))
     chains = [golden.structure("O44Sr12Ti16"), structures.synth_chain(big, 3), structures.synth_chain(big, 17),
@@ -762,7 +768,7 @@ def test_stored_forward_intermediates_give_identical_results(golden, monkeypatch
 
 
 def test_repeatability_of_every_neighbor_sum_path():
-    """Short form of tools/gpu_stress_classes.py (the builder-run soak: 6 configurations x 450 evaluations, 0 mismatches,
+    """Short form of tools/gpu_stress_classes.py (the builder-run soak: 8 configurations incl. the 4-feature slices of round 4,
     profiles/r03/NOTES_soak.md): every slice width / workgroup width of the edge kernels, three fresh engines each, every
     evaluation bit-identical to the first (MFMA operand hazards show up as isolated run-to-run differences)."""
     import subprocess
@@ -773,4 +779,4 @@ def test_repeatability_of_every_neighbor_sum_path():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_stress_classes.py")], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("mismatches 0") == 6, r.stdout
+    assert r.stdout.count("mismatches 0") == 8, r.stdout
