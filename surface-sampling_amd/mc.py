@@ -173,6 +173,46 @@ def metropolis_accept(prev_energy, curr_energy, temperature: float, u) -> np.nda
     return np.asarray(u, float) < prob
 
 
+def mic_distance_matrix(xa, xb, cell, pbc) -> np.ndarray:
+    """Minimum-image distances ``[len(xa), len(xb)]`` (``ase.Atoms.get_all_distances(mic=True)``): fractional differences are
+    wrapped into [-1/2, 1/2) along the periodic axes, then the shortest of the 3^p neighbouring images is taken (exact for cells
+    that are not extremely skewed: every slab cell of the reference; orthorhombic cells need only the wrap)."""
+    cell = np.asarray(cell, float).reshape(3, 3)
+    pbc = np.asarray(pbc, bool).reshape(3)
+    d = np.asarray(xb, float)[None, :, :] - np.asarray(xa, float)[:, None, :]
+    frac = d @ np.linalg.inv(cell)
+    frac = np.where(pbc[None, None, :], frac - np.round(frac), frac)
+    d = frac @ cell
+    ortho = np.allclose(cell - np.diag(np.diag(cell)), 0.0)
+    if ortho or not pbc.any():
+        return np.sqrt((d * d).sum(axis=2))
+    rng = [(-1, 0, 1) if p else (0,) for p in pbc]
+    best = None
+    for i in rng[0]:
+        for j in rng[1]:
+            for k in rng[2]:
+                dd = d + (i * cell[0] + j * cell[1] + k * cell[2])[None, None, :]
+                r2 = (dd * dd).sum(axis=2)
+                best = r2 if best is None else np.minimum(best, r2)
+    return np.sqrt(best)
+
+
+def filter_distances(slab, ads=("O",), cutoff_distance: float = 1.5) -> bool:
+    """``filter_distances`` of the reference (``mcmc/utils/misc.py:118-135``): True when no two atoms whose symbol is in ``ads``
+    -- slab atoms of those species included -- are closer than ``cutoff_distance`` under the minimum-image convention (pairs at
+    exactly zero distance pass, as there).  ``slab``: anything with ``numbers`` / ``positions`` / ``cell`` / ``pbc``
+    (``structures.Structure``) or the ASE accessors."""
+    num, pos, cell, pbc = structures.as_arrays(slab)
+    ads = [ads] if isinstance(ads, str) else list(ads)
+    sel = np.isin(num, [structures.ATOMIC_NUMBERS[a] for a in ads])
+    if sel.sum() < 2:
+        return True
+    d = mic_distance_matrix(pos[sel], pos[sel], cell, pbc)
+    iu = np.triu_indices(int(sel.sum()), k=1)
+    dd = d[iu]
+    return not bool(np.any((dd > 0) & (dd <= cutoff_distance)))
+
+
 def geometric_schedule(start_temp: float, total_sweeps: int, alpha: float) -> list:
     """Simulated-annealing temperatures ``T_i = start_temp * alpha**i`` for ``total_sweeps`` sweeps."""
     return (float(start_temp) * np.power(float(alpha), np.arange(int(total_sweeps)))).tolist()
@@ -303,7 +343,8 @@ class ChainEnsemble:
                  surface_energy_fn=None, temperature: float = 1.0, optimizer: str = "BFGS",
                  reference_groupby: bool = False, require_per_atom_energies: bool = False,
                  require_distance_decay: bool = False, distance_decay_factor: float = 1.0,
-                 exchange_by_group_key: bool = False):
+                 exchange_by_group_key: bool = False, filter_distance: float = 0.0,
+                 distance_adsorbate_types=("Sr", "Ti"), testing: bool = False):
         self.base = base
         self.ads_coords = np.asarray(ads_coords, float).reshape(-1, 3)
         self.adsorbates = list(adsorbates)
@@ -341,6 +382,14 @@ class ChainEnsemble:
                     raise ValueError(f'exchange_by_group_key: the reference would adsorb the plain atom "{sym}" (group key of '
                                      f'"{self.adsorbates[c]}"), which is not in the adsorbate list {self.adsorbates}')
                 self.key_adsorbate[c] = self.adsorbates.index(sym)
+        # Acceptance criterion, chosen like MCMC.step_semigrand / step_canonical choose it (mcmc/mcmc.py:218-227,253-262):
+        # filter_distance > 0 -> DistanceCriterion (mcmc/events/criterion.py:74-114: accept iff filter_distances() holds for the
+        # proposed UNRELAXED slab; adsorbate_types keeps the criterion's default ("Sr", "Ti") -- the reference calls it without
+        # arguments -- and no energy enters), elif testing -> TestingCriterion (always accept), else Metropolis.
+        self.filter_distance = float(filter_distance)
+        self.distance_adsorbate_types = tuple(distance_adsorbate_types)
+        self.testing = bool(testing)
+        self.criterion = "distance" if self.filter_distance > 0 else "testing" if self.testing else "metropolis"
         self.calc = calc
         self.seed, self.first_chain = int(seed), int(first_chain)
         self.relax, self.relax_steps, self.fmax = bool(relax), int(relax_steps), float(fmax)
@@ -357,6 +406,7 @@ class ChainEnsemble:
         self.oob = np.zeros(B, bool)        # out-of-bounds flag of the last evaluation of every chain (reference: energy_oob)
         self.per_atom_energies = [None] * B  # of the current state (filled when the backend returns them)
         self.n_evaluations = 0
+        self.energy_stale = np.zeros(B, bool)   # criteria without energies: state energies are brought up to date per sweep
 
     # ---- proposal: vectorised ChangeProposal.get_action ------------------------------------------------------------
     def propose(self, step: int, state: ChainState | None = None):
@@ -665,10 +715,81 @@ class ChainEnsemble:
         self.per_atom_energies = list(self._last_pae)
         return self.state.energy
 
+    # ---- acceptance criteria without energies (DistanceCriterion, TestingCriterion) ---------------------------------------------
+    def distance_accept(self, state: ChainState, which=None) -> np.ndarray:
+        """``DistanceCriterion`` for the proposed states of the chains ``which``: ``filter_distances`` on the unrelaxed slab
+        (``system.real_atoms``) with ``ads = distance_adsorbate_types``.  The base slab's own pairs never change (checked
+        once); per chain only the pairs that involve an adsorbate atom are measured."""
+        idx = np.arange(len(state.species)) if which is None else np.asarray(which)
+        zsel = np.array([structures.ATOMIC_NUMBERS[a] for a in self.distance_adsorbate_types], np.int64)
+        if not hasattr(self, "_base_pairs_ok"):
+            self._base_pairs_ok = filter_distances(self.base, self.distance_adsorbate_types, self.filter_distance)
+            self._base_sel = self.base.positions[np.isin(self.base.numbers, zsel)]
+        if not self._base_pairs_ok:
+            return np.zeros(len(idx), bool)
+        n_atoms, numbers, positions, ads_chain, z_ads = self.batch_arrays(state, idx)
+        start = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
+        nb = len(self.base)
+        ok = np.ones(len(idx), bool)
+        for k in range(len(idx)):
+            za = numbers[start[k] + nb:start[k + 1]]
+            xa = positions[start[k] + nb:start[k + 1]][np.isin(za, zsel)]
+            if len(xa) == 0:
+                continue
+            cut = self.filter_distance
+            d1 = mic_distance_matrix(xa, self._base_sel, self.base.cell, self.base.pbc) if len(self._base_sel) else np.zeros((len(xa), 0))
+            bad = np.any((d1 > 0) & (d1 <= cut))
+            if not bad and len(xa) > 1:
+                d2 = mic_distance_matrix(xa, xa, self.base.cell, self.base.pbc)[np.triu_indices(len(xa), k=1)]
+                bad = np.any((d2 > 0) & (d2 <= cut))
+            ok[k] = not bad
+        return ok
+
+    def _accept_without_energy(self, before: ChainState, after: ChainState, valid=None) -> np.ndarray:
+        """Distance / testing criterion: the accept mask; accepted chains take the proposed occupations, their energies are
+        marked stale (the reference evaluates ``get_surface_energy`` once per sweep in these modes, ``mcmc/mcmc.py:290-296``)."""
+        B = len(before.species)
+        cand = np.ones(B, bool) if valid is None else np.asarray(valid, bool)
+        accept = np.zeros(B, bool)
+        if self.criterion == "testing":
+            accept = cand.copy()
+        elif cand.any():
+            w = np.flatnonzero(cand)
+            accept[w] = self.distance_accept(after, w)
+        a2 = accept[:, None]
+        energy = None if before.energy is None else before.energy.copy()
+        self.state = ChainState(np.where(a2, after.species, before.species), np.where(a2, after.order, before.order),
+                                np.where(accept, after.counter, before.counter), energy)
+        self.energy_stale |= accept
+        return accept
+
+    def refresh_energies(self):
+        """Evaluate the chains whose state changed under a criterion that needs no energies (one batched evaluation)."""
+        if self.state.energy is None:
+            self.initialize()
+            self.energy_stale[:] = False
+            return self.state.energy
+        w = np.flatnonzero(self.energy_stale)
+        if len(w):
+            e, r = self.evaluate(self.state, w)
+            self.state.energy[w] = e
+            raw = _raw_items(self.relaxed)
+            for b, rb, pb in zip(w, _raw_items(r), self._last_pae):
+                raw[int(b)] = rb
+                self.per_atom_energies[int(b)] = pb
+            self.relaxed = SlabRefs(raw)
+            self.energy_stale[:] = False
+        return self.state.energy
+
     # ---- one Change event + Metropolis for every chain --------------------------------------------------------------
     def step_semigrand(self, temperature: float | None = None) -> np.ndarray:
         """``MCMC.step_semigrand`` (``mcmc/mcmc.py:233-266``) for all chains at once; returns the accept mask."""
         temp = self.temp if temperature is None else float(temperature)
+        if self.criterion != "metropolis":
+            self.step_count += 1
+            before = self.state
+            site, end, _, _ = self.propose(self.step_count, before)
+            return self._accept_without_energy(before, self.apply(before, site, end))
         if self.state.energy is None:
             self.initialize()
         self.step_count += 1
@@ -693,7 +814,7 @@ class ChainEnsemble:
         different type are exchanged (two ``change_site`` calls, ``mcmc/events/event.py:138-156``), the composition is
         conserved.  Chains without two different types keep their state.  Returns the accept mask."""
         temp = self.temp if temperature is None else float(temperature)
-        if self.state.energy is None:
+        if self.state.energy is None and self.criterion == "metropolis":
             self.initialize()
         self.step_count += 1
         before = self.state
@@ -711,6 +832,8 @@ class ChainEnsemble:
             type1 = np.where(valid, code1, type1)
             type2 = np.where(valid, code2, type2)
         after = self.apply(self.apply(before, site1, type2), site2, type1)
+        if self.criterion != "metropolis":
+            return self._accept_without_energy(before, after, valid)
         moved = np.flatnonzero(valid)
         after.energy = before.energy.copy()
         relaxed_after = _raw_items(self.relaxed)
@@ -736,6 +859,8 @@ class ChainEnsemble:
         n_acc = np.zeros(len(self.chain_ids), np.int64)
         for _ in range(sweep_size):
             n_acc += self.step_canonical(temperature) if canonical else self.step_semigrand(temperature)
+        if self.criterion != "metropolis":
+            self.refresh_energies()          # (the reference's sweep ends with surface.get_surface_energy())
         return {"energy": self.state.energy.copy(), "adsorption_count": self.num_adsorbates(),
                 "acceptance_rate": n_acc / float(sweep_size), "species": self.state.species.copy()}
 

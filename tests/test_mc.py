@@ -646,3 +646,86 @@ def test_packed_fast_path_gives_the_trajectories_of_the_per_slab_path():
     ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 4, calc, relax=False, surface_energy_fn=lambda e, s: float(e) + len(s))
     ens.initialize()
     assert getattr(calc, "packed_calls", 0) == 0
+
+
+# ---- DistanceCriterion / filter_distances (reference tests/test_filter_distance.py, tests/events/test_criterion.py:8-11) ---------
+def _filter_fixture():
+    import os
+
+    F = np.load(os.path.join(os.path.dirname(__file__), "golden", "filter_distance.npz"))
+    unit = structures.Structure(F["unit_numbers"], F["unit_positions"], F["unit_cell"], F["unit_pbc"])
+    failed = structures.Structure(F["failed_numbers"], F["failed_positions"], F["failed_cell"], F["failed_pbc"])
+    return unit.repeat((2, 2, 1)), failed, {k: F[k] for k in ("ase_bridge", "ase_top1", "ase_top2")}
+
+
+def _with_adsorbed(slab, coords, element="O"):
+    s = slab.copy()
+    for x in coords:
+        s.numbers = np.append(s.numbers, structures.ATOMIC_NUMBERS[element]).astype(np.int32)
+        s.positions = np.vstack([s.positions, np.asarray(x, float)[None]])
+    return s
+
+
+def test_filter_distances_reference_cases():
+    """The five cases of the reference's tests/test_filter_distance.py on its own fixtures (the 2 x 2 tiling of its unit-cell
+    slab with O adsorbed at the bridge / top coordinates the test file defines; the 'distance failed' CIF)."""
+    pristine, failed, c = _filter_fixture()
+    assert not mc.filter_distances(_with_adsorbed(pristine, [c["ase_bridge"]]), ads=["O"], cutoff_distance=1.5)       # test_one_O_fail
+    assert mc.filter_distances(_with_adsorbed(pristine, [c["ase_top1"]]), ads=["O"], cutoff_distance=1.5)             # test_one_O_pass
+    assert not mc.filter_distances(_with_adsorbed(pristine, [c["ase_bridge"], c["ase_top1"]]), ads=["O"], cutoff_distance=1.5)   # two_O_fail
+    assert mc.filter_distances(_with_adsorbed(pristine, [c["ase_top1"], c["ase_top2"]]), ads=["O"], cutoff_distance=1.5)         # two_O_pass
+    assert not mc.filter_distances(failed, ads=["O"], cutoff_distance=1.5)                                             # cell_distance_failed
+    # the reference's DistanceCriterion fixture (tests/events/test_fixtures.py:12-24): Ga atoms sqrt(3) apart pass at 1.5
+    Z = structures.ATOMIC_NUMBERS
+    gaas = structures.Structure(np.array([Z["Ga"], Z["As"], Z["Ga"], Z["As"]], np.int32),
+                                np.array([[0, 0, 0], [0, 0, 3], [1, 1, 1], [1, 1, 4]], float), np.eye(3) * 30, np.array([False] * 3))
+    assert mc.filter_distances(gaas, ["Ga"], 1.5) is True and mc.filter_distances(gaas, ["Ga"], 1.8) is False
+    # minimum image in a skewed (hexagonal) cell: two atoms 0.9 A apart across the periodic boundary
+    hexc = np.array([[3.0, 0, 0], [-1.5, 1.5 * np.sqrt(3.0), 0], [0, 0, 20.0]])
+    a, b = np.array([0.05, 0.05, 5.0]) @ hexc, (np.array([0.95, 0.95, 5.0]) @ hexc)
+    d = mc.mic_distance_matrix(a[None], b[None], hexc, [True, True, False])[0, 0]
+    brute = min(np.linalg.norm(b - a + i * hexc[0] + j * hexc[1]) for i in (-2, -1, 0, 1, 2) for j in (-2, -1, 0, 1, 2))
+    assert d == pytest.approx(brute, abs=1e-12) and d < 1.0
+
+
+def test_distance_and_testing_criteria_replace_the_energy_test():
+    """``filter_distance > 0`` selects the reference's DistanceCriterion (mcmc/mcmc.py:218-227,253-262): acceptance = the
+    proposed unrelaxed slab passes ``filter_distances`` for the criterion's atom types, no energy enters, state energies are
+    brought up to date once per sweep; ``testing=True`` accepts everything."""
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[1.0 * s, 0.0, 2.0] for s in range(6)], float)       # sites 1 A apart: neighbouring Sr adsorbates collide
+    calc = PackedLatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.03)
+    ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 64, calc, seed=2, relax=False, temperature=0.05, filter_distance=1.5)
+    assert ens.criterion == "distance"
+    n_acc = np.zeros(64, int)
+    for _ in range(30):
+        before = ens.state.copy()
+        acc = ens.step_semigrand()
+        n_acc += acc
+        for b in range(64):
+            s = ens.structure(b)
+            assert mc.filter_distances(s, ("Sr", "Ti"), 1.5)                  # every kept state passes the filter ...
+            if not acc[b]:
+                assert np.array_equal(ens.state.species[b], before.species[b])
+    assert calc.calls == 0                                                    # ... and no energy was asked for
+    assert n_acc.min() < 30 and n_acc.sum() > 0                               # some proposals collide, some do not
+    SR = 0
+    sr = ens.state.species == SR
+    assert not (sr[:, 1:] & sr[:, :-1]).any()                                 # never two Sr on neighbouring sites (1 A apart)
+    out = ens.sweep(0, sweep_size=5)
+    assert calc.calls >= 1 and not ens.energy_stale.any() and np.isfinite(out["energy"]).all()
+    for b in range(64):
+        assert out["energy"][b] == pytest.approx(calc._energy(ens.structure(b)), abs=1e-12)
+    # O is not among the criterion's default types: O adsorbates may sit on neighbouring sites
+    o = ens.state.species == 1
+    assert (o[:, 1:] & o[:, :-1]).any()
+    # exchange moves under the same criterion
+    acc = np.stack([ens.step_canonical() for _ in range(10)])
+    assert acc.any()
+    for b in range(64):
+        assert mc.filter_distances(ens.structure(b), ("Sr", "Ti"), 1.5)
+    # testing criterion: always accept
+    ens2 = mc.ChainEnsemble(base, coords, ("Sr", "O"), 16, calc, seed=2, relax=False, testing=True)
+    assert ens2.criterion == "testing" and all(ens2.step_semigrand().all() for _ in range(5))

@@ -109,6 +109,25 @@ def write_eam_fixtures(R, out):
     print("eam fixtures written")
 
 
+def write_filter_distance_fixture(R, out):
+    """Inputs of the reference's tests/test_filter_distance.py as plain arrays: its unit-cell slab pickle, the slab of its
+    'distance failed' CIF and the three adsorption coordinates the test file defines (tests/test_filter_distance.py:17-19)."""
+    import ast
+
+    unit = structures.read_slab_pickle(os.path.join(R, "tests/data/SrTiO3_001/SrTiO3_unit_cell.pkl"))
+    failed = structures.read_cif(os.path.join(R, "tests/data/SrTiO3_001/SrTiO3_001_distance_failed.cif"))
+    src = open(os.path.join(R, "tests/test_filter_distance.py")).read()
+    coords = {}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) and node.targets[0].id.startswith("ase_"):
+            coords[node.targets[0].id] = np.array(ast.literal_eval(node.value), float)
+    np.savez_compressed(os.path.join(out, "filter_distance.npz"),
+                        unit_numbers=unit.numbers, unit_positions=unit.positions, unit_cell=unit.cell, unit_pbc=unit.pbc,
+                        failed_numbers=failed.numbers, failed_positions=failed.positions, failed_cell=failed.cell, failed_pbc=failed.pbc,
+                        **coords)
+    print("filter_distance fixture:", len(unit), "+", len(failed), "atoms,", sorted(coords))
+
+
 def reference_pourbaix_atoms(R):
     """The PourbaixAtom fields the reference's own test asserts (tests/pourbaix/test_pourbaix_atoms.py:41-152): one set per
     test function, i.e. per (phi, pH) the atoms were generated for."""
@@ -243,14 +262,18 @@ def write_pourbaix_fixtures(R, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
-    ap.add_argument("--only", default="", help="'traces' / 'eam' / 'pourbaix': rewrite only the small trace, EAM and Pourbaix fixtures")
+    ap.add_argument("--only", default="", help="'traces' / 'eam' / 'pourbaix' / 'filter': rewrite only the small trace, EAM, Pourbaix and filter-distance fixtures")
     args = ap.parse_args()
     R = args.reference
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(os.path.join(out, "weights"), exist_ok=True)
+    if args.only == "filter":
+        write_filter_distance_fixture(R, out)
+        return
     write_bfgs_traces(R, out)
     write_eam_fixtures(R, out)
     write_pourbaix_fixtures(R, out)
+    write_filter_distance_fixture(R, out)
     if args.only in ("traces", "eam", "pourbaix"):
         return
 
