@@ -409,7 +409,7 @@ class ChainEnsemble:
         self.energy_stale = np.zeros(B, bool)   # criteria without energies: state energies are brought up to date per sweep
 
     # ---- proposal: vectorised ChangeProposal.get_action ------------------------------------------------------------
-    def propose(self, step: int, state: ChainState | None = None):
+    def propose(self, step: int, state: ChainState | None = None, site_idx=None):
         """Per chain: a uniformly random site, and a uniformly random entry of ``adsorbates + ["None"]`` minus what
         is on the site now (``proposal.py:82-106``).  Returns ``(site_idx [B], end_code [B], start_code [B], u_acc [B])``
         where ``u_acc`` is the uniform reserved for the acceptance test of this step."""
@@ -417,6 +417,10 @@ class ChainEnsemble:
         u = chain_uniforms(self.seed, self.chain_ids, step)
         S = st.species.shape[1]
         site = np.minimum((u[:, 0] * S).astype(np.int64), S - 1)
+        if site_idx is not None:       # ChangeProposal(site_idx=...): the site is given, the new adsorbate is still drawn
+            site = np.broadcast_to(np.asarray(site_idx, dtype=np.int64), site.shape).copy()
+            if site.min() < 0 or site.max() >= S:
+                raise IndexError("site index out of range")
         start = st.species[np.arange(len(site)), site].astype(np.int64)
         k = np.minimum((u[:, 1] * self.n_ads).astype(np.int64), self.n_ads - 1)   # n_ads + 1 choices minus the current one
         end = np.where(k < start, k, k + 1)
@@ -782,31 +786,89 @@ class ChainEnsemble:
         return self.state.energy
 
     # ---- one Change event + Metropolis for every chain --------------------------------------------------------------
-    def step_semigrand(self, temperature: float | None = None) -> np.ndarray:
-        """``MCMC.step_semigrand`` (``mcmc/mcmc.py:233-266``) for all chains at once; returns the accept mask."""
+    def step_semigrand(self, temperature: float | None = None, site_idx=None, which=None) -> np.ndarray:
+        """``MCMC.step_semigrand`` (``mcmc/mcmc.py:233-266``) for all chains at once; returns the accept mask.
+        ``site_idx``: an int or ``[B]`` array fixes the site of the change (``ChangeProposal(site_idx=...)``,
+        ``mcmc/events/proposal.py:81-84``) instead of drawing it.  ``which``: bool ``[B]``, only these chains take part (the
+        others keep their state and are not evaluated) -- how ``prepare_canonical`` stops a chain at its target."""
         temp = self.temp if temperature is None else float(temperature)
+        B = len(self.chain_ids)
+        part = np.ones(B, bool) if which is None else np.asarray(which, bool)
         if self.criterion != "metropolis":
             self.step_count += 1
             before = self.state
-            site, end, _, _ = self.propose(self.step_count, before)
-            return self._accept_without_energy(before, self.apply(before, site, end))
+            site, end, start, _ = self.propose(self.step_count, before, site_idx)
+            end = np.where(part, end, start)                      # (a chain outside `which` "changes" its site into what is there)
+            return self._accept_without_energy(before, self.apply_masked(before, site, end, part), part)
         if self.state.energy is None:
             self.initialize()
         self.step_count += 1
         before = self.state                                   # save_state("before")
-        site, end, _, u_acc = self.propose(self.step_count, before)
-        after = self.apply(before, site, end)                 # change_site + save_state("after")
-        after.energy, relaxed_after = self.evaluate(after)    # get_surface_energy(recalculate=True)
-        pae_after = list(self._last_pae)
-        accept = metropolis_accept(before.energy, after.energy, temp, u_acc)
+        site, end, _, u_acc = self.propose(self.step_count, before, site_idx)
+        after = self.apply_masked(before, site, end, part)    # change_site + save_state("after")
+        after.energy = before.energy.copy()
+        relaxed_after, pae_after = _raw_items(self.relaxed), list(self.per_atom_energies)
+        moved = np.flatnonzero(part)
+        if len(moved):
+            e, r = self.evaluate(after, None if len(moved) == B else moved)    # get_surface_energy(recalculate=True)
+            after.energy[moved] = e
+            for b, rb, pb in zip(moved, _raw_items(r), self._last_pae):
+                relaxed_after[int(b)] = rb
+                pae_after[int(b)] = pb
+        accept = metropolis_accept(before.energy, after.energy, temp, u_acc) & part
         # accepted chains keep "after", the others are restored to "before" (Event.backward)
         a2 = accept[:, None]
         self.state = ChainState(np.where(a2, after.species, before.species), np.where(a2, after.order, before.order),
                                 np.where(accept, after.counter, before.counter),
                                 np.where(accept, after.energy, before.energy))
-        self.relaxed = SlabRefs([ra if acc else rb for acc, ra, rb in zip(accept, _raw_items(relaxed_after), _raw_items(self.relaxed))])
+        self.relaxed = SlabRefs([ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, _raw_items(self.relaxed))])
         self.per_atom_energies = [pa if acc else pb for acc, pa, pb in zip(accept, pae_after, self.per_atom_energies)]
         return accept
+
+    def apply_masked(self, state: ChainState, site, end_code, part) -> ChainState:
+        """:meth:`apply` for the chains of the bool mask ``part``; the others are copied unchanged."""
+        new = self.apply(state, site, end_code)
+        if part.all():
+            return new
+        p2 = part[:, None]
+        return ChainState(np.where(p2, new.species, state.species), np.where(p2, new.order, state.order),
+                          np.where(part, new.counter, state.counter), None)
+
+    # ---- MCMC.prepare_canonical (mcmc/mcmc.py:148-188) -----------------------------------------------------------------------
+    def even_adsorption_sites(self, n: int) -> np.ndarray:
+        """The reference's even seeding (``get_cluster_centers`` + ``find_closest_points_indices``, ``mcmc/utils/clustering.py:160-233``):
+        Ward clustering of the in-plane site coordinates into ``n`` clusters, of each the site closest to its centre."""
+        from scipy.cluster.hierarchy import fcluster, linkage
+
+        pts = self.ads_coords[:, :2]
+        labels = fcluster(linkage(pts, "ward"), int(n), criterion="maxclust")
+        out = []
+        for i in range(1, int(n) + 1):
+            members = np.where(labels == i)[0]
+            centre = pts[members].mean(axis=0)
+            out.append(members[np.argmin(np.linalg.norm(pts[members] - centre, axis=1))])
+        return np.array(out, dtype=np.int64)
+
+    def prepare_canonical(self, num_ads_atoms: int, even_adsorption_sites: bool = False, max_steps: int = 10_000) -> np.ndarray:
+        """Bring every chain to the composition a canonical run starts from: semigrand steps (with this ensemble's criterion)
+        until a chain holds ``num_ads_atoms`` adsorbates -- it then stops while the others go on -- or, with
+        ``even_adsorption_sites``, one semigrand step on each of the evenly spread sites.  Returns the adsorbate counts."""
+        if int(num_ads_atoms) <= 0:
+            raise ValueError("for canonical runs, need number of adsorbed atoms greater than 0")
+        if even_adsorption_sites:
+            for site in self.even_adsorption_sites(num_ads_atoms):
+                self.step_semigrand(site_idx=int(site))
+        else:
+            for _ in range(int(max_steps)):
+                need = self.num_adsorbates() < int(num_ads_atoms)
+                if not need.any():
+                    break
+                self.step_semigrand(which=need)
+            else:
+                raise RuntimeError("prepare_canonical: some chains did not reach the requested number of adsorbates")
+        if self.criterion != "metropolis":
+            self.refresh_energies()
+        return self.num_adsorbates()
 
     # ---- one Exchange event + Metropolis for every chain ------------------------------------------------------------
     def step_canonical(self, temperature: float | None = None) -> np.ndarray:

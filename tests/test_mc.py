@@ -729,3 +729,51 @@ def test_distance_and_testing_criteria_replace_the_energy_test():
     # testing criterion: always accept
     ens2 = mc.ChainEnsemble(base, coords, ("Sr", "O"), 16, calc, seed=2, relax=False, testing=True)
     assert ens2.criterion == "testing" and all(ens2.step_semigrand().all() for _ in range(5))
+
+
+def test_prepare_canonical_and_fixed_site_steps():
+    """``MCMC.prepare_canonical`` (mcmc/mcmc.py:148-188): semigrand steps until every chain holds the requested number of
+    adsorbates -- a chain that has reached it stops while the others go on -- or one step on each of the evenly spread sites
+    (Ward clustering of the in-plane site coordinates, the site closest to each cluster centre); ``step_semigrand(site_idx=...)``
+    changes the given site (``ChangeProposal(site_idx=...)``)."""
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[2.0 * i, 2.0 * j, 2.0] for i in range(4) for j in range(3)], float)
+    calc = PackedLatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.0)
+    ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 24, calc, seed=6, relax=False, temperature=5.0)
+    ens.initialize()
+    hist = []
+    orig = ens.step_semigrand
+
+    def spy(*a, **k):
+        hist.append(None if k.get("which") is None else k["which"].copy())
+        return orig(*a, **k)
+
+    ens.step_semigrand = spy
+    counts = ens.prepare_canonical(4)
+    assert (counts >= 4).all() and (counts == 4).all()          # a change adds at most one adsorbate, finished chains are frozen
+    assert len(hist) >= 4 and hist[-1].sum() < 24               # ... the last steps ran for the stragglers only
+    frozen = ens.state.species.copy()
+    ens.step_semigrand = orig
+    acc = ens.step_semigrand(which=np.zeros(24, bool))
+    assert not acc.any() and np.array_equal(ens.state.species, frozen)
+    # fixed site: only that site may differ afterwards
+    before = ens.state.species.copy()
+    ens.step_semigrand(site_idx=7)
+    changed = np.argwhere(ens.state.species != before)
+    assert set(changed[:, 1].tolist()) <= {7}
+    with pytest.raises(IndexError):
+        ens.step_semigrand(site_idx=99)
+    # even seeding: n well separated sites, one per cluster, the same for every chain
+    ens2 = mc.ChainEnsemble(base, coords, ("Sr", "O"), 8, calc, seed=6, relax=False, testing=True)
+    sites = ens2.even_adsorption_sites(4)
+    assert len(set(sites.tolist())) == 4
+    from scipy.cluster.hierarchy import fcluster, linkage
+    labels = fcluster(linkage(coords[:, :2], "ward"), 4, criterion="maxclust")
+    assert sorted(labels[sites].tolist()) == [1, 2, 3, 4]
+    n = ens2.prepare_canonical(4, even_adsorption_sites=True)
+    filled = ens2.state.species != ens2.n_ads
+    assert (n == 4).all() and all(set(np.flatnonzero(f).tolist()) == set(sites.tolist()) for f in filled)   # testing criterion: every step accepted
+    with pytest.raises(ValueError):
+        ens2.prepare_canonical(0)
