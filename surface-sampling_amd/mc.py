@@ -299,7 +299,8 @@ class SlabRefs:
 
 
 def _raw_items(seq):
-    return seq.items if isinstance(seq, SlabRefs) else list(seq)
+    """The entries as stored (references stay references), in a NEW list."""
+    return list(seq.items) if isinstance(seq, SlabRefs) else list(seq)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

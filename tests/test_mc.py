@@ -640,6 +640,10 @@ def test_packed_fast_path_gives_the_trajectories_of_the_per_slab_path():
         for k in range(32):
             assert np.array_equal(fast_ens.relaxed[k].numbers, slow_ens.relaxed[k].numbers)
             assert np.array_equal(fast_ens.relaxed[k].positions, slow_ens.relaxed[k].positions)
+            # the stored slab is the slab of the KEPT state (the toy backend does not move atoms): a rejected chain must not
+            # end up with the slab of its rejected proposal
+            kept = fast_ens.structure(k)
+            assert np.array_equal(fast_ens.relaxed[k].numbers, kept.numbers) and np.array_equal(fast_ens.relaxed[k].positions, kept.positions)
         assert not isinstance(fast_ens.relaxed.raw(0), tuple)        # looked at: now a Structure
     # a user-supplied energy function needs the structures: the per-slab path serves it
     calc = PackedLatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.0)
