@@ -297,6 +297,26 @@ class SlabRefs:
         """The entry as stored (a reference stays a reference)."""
         return self.items[b]
 
+    def consolidate(self, max_batches: int = 16):
+        """A reference keeps its whole ``SlabBatch`` (the packed slabs of ALL chains of one MC step) alive; a chain that has not
+        been accepted for a long time pins an old one.  When more than ``max_batches`` distinct batches are referenced, the
+        referenced slabs are copied into ONE fresh batch (still no ``Structure`` objects), bounding the memory at about
+        ``max_batches`` steps' worth of positions."""
+        batches = {id(it[0]): it[0] for it in self.items if isinstance(it, tuple)}
+        if len(batches) <= max_batches:
+            return self
+        ref_idx = [k for k, it in enumerate(self.items) if isinstance(it, tuple)]
+        first = self.items[ref_idx[0]][0]
+        n_atoms = np.array([int(self.items[k][0].n_atoms[self.items[k][1]]) for k in ref_idx], np.int64)
+        numbers = np.concatenate([self.items[k][0].numbers[self.items[k][0].start[self.items[k][1]]:self.items[k][0].start[self.items[k][1] + 1]]
+                                  for k in ref_idx])
+        positions = np.concatenate([self.items[k][0].positions[self.items[k][0].start[self.items[k][1]]:self.items[k][0].start[self.items[k][1] + 1]]
+                                    for k in ref_idx])
+        merged = SlabBatch(n_atoms, numbers, positions, first.cell, first.pbc)
+        for j, k in enumerate(ref_idx):
+            self.items[k] = (merged, j)
+        return self
+
 
 def _raw_items(seq):
     """The entries as stored (references stay references), in a NEW list."""
@@ -822,7 +842,7 @@ class ChainEnsemble:
         self.state = ChainState(np.where(a2, after.species, before.species), np.where(a2, after.order, before.order),
                                 np.where(accept, after.counter, before.counter),
                                 np.where(accept, after.energy, before.energy))
-        self.relaxed = SlabRefs([ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, _raw_items(self.relaxed))])
+        self.relaxed = SlabRefs([ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, _raw_items(self.relaxed))]).consolidate()
         self.per_atom_energies = [pa if acc else pb for acc, pa, pb in zip(accept, pae_after, self.per_atom_energies)]
         return accept
 
@@ -912,7 +932,7 @@ class ChainEnsemble:
         self.state = ChainState(np.where(a2, after.species, before.species), np.where(a2, after.order, before.order),
                                 np.where(accept, after.counter, before.counter),
                                 np.where(accept, after.energy, before.energy))
-        self.relaxed = SlabRefs([ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, _raw_items(self.relaxed))])
+        self.relaxed = SlabRefs([ra if acc else rb for acc, ra, rb in zip(accept, relaxed_after, _raw_items(self.relaxed))]).consolidate()
         self.per_atom_energies = [pa if acc else pb for acc, pa, pb in zip(accept, pae_after, self.per_atom_energies)]
         return accept
 

@@ -61,6 +61,13 @@ def test_vssr_eval_and_eval_batch_through_raw_ctypes(golden):
         assert rc == 0, lib.vssr_last_error(h)
         assert np.array_equal(Eb, ref["energy"]) and np.array_equal(Fb, ref["forces"]) and np.array_equal(Fsb, ref["forces_std"])
         assert np.allclose(Em.mean(axis=1), Eb, atol=2e-4) and Em.std() > 0
+        # ---- vssr_batch_stress: the virial of the evaluation that has just run (two chains), raw pointers -------------------------
+        st, sd = np.zeros((2, 6)), np.zeros((2, 6))
+        rc = lib.vssr_batch_stress(h, st.ctypes.data_as(C.POINTER(C.c_double)), sd.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == 0, lib.vssr_last_error(h)
+        want_st, want_sd = engine.stress()                      # the helper class on the same resident batch
+        assert np.array_equal(st, want_st) and np.array_equal(sd, want_sd) and np.isfinite(st).all() and np.abs(st).max() > 0
+        assert lib.vssr_batch_stress(h, None, None) == 0        # both outputs optional
         # ---- error reporting: bad argument -> negative status + message ---------------------------------------------------------
         rc = lib.vssr_eval(h, -1, Z.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_double)),
                            cell.ctypes.data_as(C.POINTER(C.c_double)), pbc.ctypes.data_as(C.POINTER(C.c_uint8)), want,

@@ -781,3 +781,25 @@ def test_prepare_canonical_and_fixed_site_steps():
     assert (n == 4).all() and all(set(np.flatnonzero(f).tolist()) == set(sites.tolist()) for f in filled)   # testing criterion: every step accepted
     with pytest.raises(ValueError):
         ens2.prepare_canonical(0)
+
+
+def test_slab_references_do_not_pin_an_unbounded_number_of_batches():
+    """A chain that is never accepted keeps referencing the packed batch of an old step; beyond 16 distinct batches the
+    referenced slabs are copied into one (``SlabRefs.consolidate``) -- the slabs themselves are unchanged."""
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[1.0 * s, 0.0, 2.0] for s in range(6)], float)
+    calc = PackedLatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.03)
+    ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 48, calc, seed=8, relax=False, temperature=0.02)
+    ens.initialize()
+    seen = 0
+    for _ in range(60):
+        ens.step_semigrand()
+        n = len({id(it[0]) for it in ens.relaxed.items if isinstance(it, tuple)})
+        seen = max(seen, n)
+        assert n <= 17
+    assert seen > 4                                                # (references to several steps do coexist)
+    for b in range(48):
+        kept = ens.structure(b)
+        assert np.array_equal(ens.relaxed[b].numbers, kept.numbers) and np.array_equal(ens.relaxed[b].positions, kept.positions)
