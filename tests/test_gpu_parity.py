@@ -780,3 +780,26 @@ def test_repeatability_of_every_neighbor_sum_path():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("mismatches 0") == 8, r.stdout
+
+
+def test_large_chain_takes_four_feature_slices_in_both_directions(golden, oracle_mod, engine):
+    """A 1 2xx-atom chain (5 x 3 tiling of the 80-atom slab + adsorbates) is beyond the 8-feature reverse kernel (1 127 atoms):
+    forward AND reverse pass run on 4-feature slices by its own size.  Forces within the stated 2e-4 eV/A of the fp64 oracle;
+    the energy (-9.4 keV) is returned as float32, whose spacing there is 9.8e-4 eV -- tolerance 1.5e-3 eV; bit-identical when
+    evaluated again and next to a small chain."""
+    from surface_sampling_amd import structures
+
+    s80 = golden.structure("SrTiO3_2x2x4_pristine")
+    big = structures.synth_chain(s80.repeat((5, 3, 1)), 3, grid=(20, 12))
+    small = structures.synth_chain(golden.structure("SrTiO3_2x2_pristine").repeat((2, 2, 1)), 8)
+    assert 1127 < len(big) <= 1462
+    res = engine.evaluate([_arrays(big)])
+    ref = _oracle(golden, oracle_mod, big)
+    assert abs(float(res["energy"][0]) - ref["energy"]) <= 1.5e-3, (float(res["energy"][0]), ref["energy"])
+    assert np.abs(res["forces"] - ref["forces"]).max() <= F_TOL
+    assert np.abs(res["forces_std"] - ref["forces_std"]).max() <= STD_TOL and not res["saturated"].any()
+    both = engine.evaluate([_arrays(small), _arrays(big)])
+    cs = both["cfg_start"]
+    assert float(both["energy"][1]) == float(res["energy"][0]) and np.array_equal(both["forces"][cs[1]:cs[2]], res["forces"])
+    st, _ = engine.stress()
+    assert np.isfinite(st).all()
