@@ -21,7 +21,9 @@ from __future__ import annotations
 
 import copy
 import dataclasses
+import json
 import logging
+import os
 import re
 from collections import Counter
 
@@ -733,14 +735,10 @@ def _formula_counts(formula: str) -> Counter:
     return out
 
 
-def pourbaix_potential_from_energy(energy: float, symbols, pourbaix_atoms: dict, temp: float = 0.0257, phi: float = 0.0,
-                                   pH: float = 7.0, adsorbate_corrections: dict | None = None) -> float:
-    """Pourbaix ("grand") potential of a slab with known potential energy — the arithmetic of the reference's
-    ``NFFPourbaix`` (``calculators.py:197-305``):
-    ``dG1 = sum_atoms E_std(atom) - (E_slab + adsorbate corrections)`` (``get_delta_G1``),
-    ``dG2 = sum_atoms [dG2_std - n_e phi - ln(10) n_H kT pH + kT ln(conc)]`` (``get_delta_G2``), result ``-(dG1 + dG2)``.
-    Adsorbate corrections count how many times the adsorbate formula fits into the slab formula; for O-H adsorbates the
-    hydrogens in excess of the oxygens are first attributed to water and removed (``calculators.py:254-268``)."""
+def pourbaix_delta_G1(energy: float, symbols, pourbaix_atoms: dict, adsorbate_corrections: dict | None = None) -> float:
+    """``NFFPourbaix.get_delta_G1`` (reference ``calculators.py:235-272``): ``sum_atoms E_std(atom) - (E_slab + adsorbate
+    corrections)``.  Adsorbate corrections count how many times the adsorbate formula fits into the slab formula; for O-H
+    adsorbates the hydrogens in excess of the oxygens are first attributed to water and removed (``:254-268``)."""
     counts = Counter(symbols)
     sum_std = sum(n * pourbaix_atoms[a].atom_std_state_energy for a, n in counts.items())
     slab_energy = float(np.ravel(energy)[0])
@@ -753,12 +751,25 @@ def pourbaix_potential_from_energy(energy: float, symbols, pourbaix_atoms: dict,
         ads = _formula_counts(adsorbate)
         div = min(formula[k] // n for k, n in ads.items()) if ads else 0
         slab_energy += div * correction
-    dg1 = sum_std - slab_energy
+    return sum_std - slab_energy
+
+
+def pourbaix_delta_G2(symbols, pourbaix_atoms: dict, temp: float = 0.0257, phi: float = 0.0, pH: float = 7.0) -> float:
+    """``NFFPourbaix.get_delta_G2`` (reference ``calculators.py:197-233``): ``sum_atoms [dG2_std - n_e phi - ln(10) n_H kT pH +
+    kT ln(conc)]``."""
     dg2 = 0.0
-    for a, n in counts.items():
+    for a, n in Counter(symbols).items():
         pa = pourbaix_atoms[a]
         dg2 += n * (pa.delta_G2_std - pa.num_e * phi - np.log(10) * pa.num_H * temp * pH + temp * np.log(pa.species_conc))
-    return -(dg1 + dg2)
+    return dg2
+
+
+def pourbaix_potential_from_energy(energy: float, symbols, pourbaix_atoms: dict, temp: float = 0.0257, phi: float = 0.0,
+                                   pH: float = 7.0, adsorbate_corrections: dict | None = None) -> float:
+    """Pourbaix ("grand") potential of a slab with known potential energy — the arithmetic of the reference's
+    ``NFFPourbaix`` (``calculators.py:197-305``): ``-(dG1 + dG2)`` with :func:`pourbaix_delta_G1` and :func:`pourbaix_delta_G2`."""
+    return -(pourbaix_delta_G1(energy, symbols, pourbaix_atoms, adsorbate_corrections)
+             + pourbaix_delta_G2(symbols, pourbaix_atoms, temp, phi, pH))
 
 
 class NFFPourbaix(EnsembleNFFSurface):
@@ -792,6 +803,12 @@ class NFFPourbaix(EnsembleNFFSurface):
     def get_delta_G2(self, atoms=None) -> float:
         atoms = self.atoms if atoms is None else atoms
         return sum(self.get_delta_G2_individual(a) for a in atoms.get_chemical_symbols())
+
+    def get_delta_G1(self, atoms=None) -> float:
+        """Dissociation energy of all atoms incl. the adsorbate corrections (reference ``calculators.py:235-272``)."""
+        atoms = self.atoms if atoms is None else atoms
+        return pourbaix_delta_G1(self.get_potential_energy(atoms=atoms), atoms.get_chemical_symbols(),
+                                 self._require(self.pourbaix_atoms, "Pourbaix atoms"), self.adsorbate_corrections)
 
     def surface_energy_of(self, energy, atoms):
         return pourbaix_potential_from_energy(energy, atoms.get_chemical_symbols(),
@@ -882,6 +899,13 @@ class _AnalyticSurfCalc(_Base):
             self.results["per_atom_energies"] = ea_rel
         if "surface_energy" in properties:
             self.results["surface_energy"] = self.results["energy"]
+
+    def run_lammps_energy(self, slab, run_dir=None, **kwargs):
+        """``LAMMMPSCalc.run_lammps_energy`` (reference ``calculators.py:621-640``: the static energy through the run
+        directory's ``lammps_energy_template.txt``): one device evaluation; returns the reference's tuple
+        ``(slab, energy, per_atom_energies)``."""
+        e, ea, _ = self._get_engine().evaluate_f64([self._pack(slab)])
+        return slab, float(e[0]), ea
 
     def run_lammps_opt(self, slab, run_dir=None, fixed_indices=None, optimizer="CG", **kwargs):
         """Relaxation counterpart of ``LAMMMPSCalc.run_lammps_opt`` (reference ``calculators.py:600-619``: LAMMPS
@@ -1030,3 +1054,135 @@ class EAMSurfCalc(_AnalyticSurfCalc):
 
 
 LAMMPSRunSurfCalc = EAMSurfCalc   # the reference's class name for this role
+
+
+class LAMMPSSurfCalc(_AnalyticSurfCalc):
+    """Drop-in for the reference's ``LAMMPSSurfCalc`` / ``LAMMMPSCalc`` (``calculators.py:492-752``) the way its GaN tutorial
+    uses them: constructed WITHOUT arguments and configured through ``set(run_dir=..., relax_steps=..., optimizer="LAMMPS",
+    ...)`` (``tutorials/GaN_0001.ipynb``: ``lammps_surf_calc = LAMMPSSurfCalc(); lammps_surf_calc.set(**calc_settings)``).
+    Instead of writing ``lammps.in`` / ``lammps.data`` and calling LAMMPS, the run directory's own files say what to evaluate:
+
+    * ``lammps_config.json``: ``potential_file``, ``atoms`` (species in LAMMPS type order), ``bulk_index`` (atoms with id <=
+      bulk_index form the group the relaxation template holds with ``fix ... setforce 0``);
+    * ``lammps_energy_template.txt`` / ``lammps_opt_template.txt``: the ``pair_style`` line selects the potential -- ``tersoff``
+      (multi-element file) or ``eam`` (one funcfl element) are evaluated on the device, anything else raises.
+
+    The potential file is looked up like LAMMPS does (as given, in the run directory, in the working directory, in
+    ``$LAMMPS_POTENTIALS``) and additionally in ``potential_dirs`` and in the reference's ``mcmc/potentials`` when that package
+    is importable.  ``boundary p p p`` of the templates = periodic in all directions."""
+
+    name = "lammps_surf_mi355x"
+
+    def __init__(self, device="cuda", potential_dirs=(), logger=None, **kwargs):
+        self.potential_dirs = [str(d) for d in potential_dirs]
+        self.species = []
+        self.bulk_index = 0
+        self.pair_style = None
+        self._cfg_key = None
+        self._init_common(device, True, logger)
+        self.run_dir = os.getcwd()        # the reference's default (calculators.py:502)
+        super().__init__(**kwargs)
+
+    # -- configuration from the run directory ----------------------------------------------------------------------------------
+    def _find_potential(self, name, run_dir):
+        cands = [name] if os.path.isabs(name) else [os.path.join(d, name) for d in
+                                                    [str(run_dir), os.getcwd(),
+                                                     *[x for x in os.environ.get("LAMMPS_POTENTIALS", "").split(os.pathsep) if x],
+                                                     *self.potential_dirs]]
+        if not os.path.isabs(name):
+            try:
+                import importlib.util
+
+                spec = importlib.util.find_spec("mcmc")
+                for loc in (spec.submodule_search_locations or []) if spec else []:
+                    cands.append(os.path.join(loc, "potentials", name))
+            except (ImportError, ValueError):
+                pass
+        for c in cands:
+            if os.path.isfile(c):
+                return c
+        raise FileNotFoundError(f"potential file {name!r} not found; looked in: " + ", ".join(cands))
+
+    def _configure(self):
+        run_dir = str(self.run_dir)
+        cfg_path = os.path.join(run_dir, "lammps_config.json")
+        if not os.path.isfile(cfg_path):
+            raise FileNotFoundError(f"{cfg_path}: the run directory needs the reference's lammps_config.json "
+                                    "(potential_file, atoms, bulk_index)")
+        with open(cfg_path, encoding="utf-8") as fh:
+            cfg = json.load(fh)
+        style = None
+        for tmpl in ("lammps_energy_template.txt", "lammps_opt_template.txt"):
+            tp = os.path.join(run_dir, tmpl)
+            if os.path.isfile(tp):
+                with open(tp, encoding="utf-8") as fh:
+                    m = re.search(r"^\s*pair_style\s+(\S+)", fh.read(), re.M)
+                if m:
+                    style = m.group(1)
+                    break
+        if style is None:
+            raise FileNotFoundError(f"{run_dir}: no lammps_energy_template.txt / lammps_opt_template.txt with a pair_style line")
+        if self.parameters.get("kim_potential") or style.startswith("kim"):
+            raise backend.BackendError("KIM potentials are not provided by this backend (tersoff and eam/funcfl are)")
+        pot = self._find_potential(cfg["potential_file"], run_dir)
+        key = (cfg_path, os.path.getmtime(cfg_path), pot, style)
+        if key == self._cfg_key:
+            return
+        self.species = list(cfg["atoms"])
+        self.bulk_index = int(cfg.get("bulk_index", 0))
+        self.pair_style = style
+        with open(pot, encoding="utf-8") as fh:
+            text = fh.read()
+        if style == "tersoff":
+            self.params = tersoff_io.parse_tersoff(text, self.species)
+            self.funcfl = None
+        elif style == "eam":
+            from . import eam as eam_io
+
+            self.funcfl = eam_io.parse_funcfl(text)
+            self.params = None
+            if self.species != [structures.SYMBOLS[self.funcfl.atomic_number]]:
+                raise ValueError(f"pair_style eam (funcfl) holds one element, lammps_config.json lists {self.species}")
+        else:
+            raise backend.BackendError(f"pair_style {style!r} is not provided by this backend (tersoff and eam are)")
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        self._cfg_key = key
+
+    def _make_engine(self):
+        if self.pair_style == "tersoff":
+            return backend.TersoffEngine(self.params, device=_device_index(self.device))
+        return backend.EAMEngine(self.funcfl, device=_device_index(self.device))
+
+    def _get_engine(self):
+        self._configure()
+        return super()._get_engine()
+
+    def _pack(self, atoms):
+        self._configure()
+        return super()._pack(atoms)
+
+    def run_lammps_opt(self, slab, run_dir=None, fixed_indices=None, optimizer="CG", **kwargs):
+        """As the base class; without ``fixed_indices`` the template's ``group bulk id <= bulk_index`` + ``setforce 0`` applies:
+        the first ``bulk_index`` atoms are held."""
+        if run_dir is not None and str(run_dir) != str(self.run_dir):
+            self.run_dir = run_dir
+        self._configure()
+        if fixed_indices is None and self.bulk_index > 0:
+            fixed_indices = np.arange(min(self.bulk_index, len(slab)))
+        return super().run_lammps_opt(slab, run_dir=run_dir, fixed_indices=fixed_indices, optimizer=optimizer, **kwargs)
+
+    def run_lammps_energy(self, slab, run_dir=None, **kwargs):
+        if run_dir is not None and str(run_dir) != str(self.run_dir):
+            self.run_dir = run_dir
+        return super().run_lammps_energy(slab, run_dir=run_dir, **kwargs)
+
+    def relax_batch(self, atoms_list, fixed_indices=None, **kwargs):
+        self._configure()
+        if fixed_indices is None and self.bulk_index > 0:
+            fixed_indices = [np.arange(min(self.bulk_index, len(a))) for a in atoms_list]
+        return super().relax_batch(atoms_list, fixed_indices=fixed_indices, **kwargs)
+
+
+LAMMMPSCalc = LAMMPSSurfCalc      # (the reference's base class name, spelled as there)

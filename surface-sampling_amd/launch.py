@@ -25,6 +25,8 @@ REPLACEMENTS = {
     "EnsembleNFFSurface": "EnsembleNFFSurface",        # mcmc/calculators/calculators.py:366-489
     "NFFPourbaix": "NFFPourbaix",                      # :137-357
     "LAMMPSRunSurfCalc": "LAMMPSRunSurfCalc",          # :755-811 (pair_style eam)
+    "LAMMPSSurfCalc": "LAMMPSSurfCalc",                # :696-752 (run_dir with lammps_config.json + templates: tersoff / eam)
+    "LAMMMPSCalc": "LAMMMPSCalc",                      # :492-693
     "get_results_single": "get_results_single",        # :34-47
     "get_embeddings_single": "get_embeddings_single",  # :67-93
     "get_embeddings": "get_embeddings",

@@ -803,3 +803,35 @@ def test_large_chain_takes_four_feature_slices_in_both_directions(golden, oracle
     assert float(both["energy"][1]) == float(res["energy"][0]) and np.array_equal(both["forces"][cs[1]:cs[2]], res["forces"])
     st, _ = engine.stress()
     assert np.isfinite(st).all()
+
+
+def test_lammps_surf_calc_runs_the_gan_tutorial_flow(tmp_path, golden, oracle_mod):
+    """BASELINE configs[1] through the reference's own front end (tutorials/GaN_0001.ipynb): ``LAMMPSSurfCalc()`` configured
+    with ``set(**calc_settings)`` (run directory with lammps_config.json + templates), static energy -144.059 eV
+    (``tutorials/GaN_0001.ipynb:228``), ``run_lammps_energy`` / ``run_lammps_opt`` tuples, the template's bulk group held."""
+    from test_host_logic import _gan_run_dir
+    from surface_sampling_amd import calculators as calcs
+
+    rd = _gan_run_dir(tmp_path, golden)
+    calc = calcs.LAMMPSSurfCalc(device="cuda:0")
+    calc.set(calc_name="LAMMPS", optimizer="LAMMPS", chem_pots={"Ga": 5}, relax_atoms=True, relax_steps=100, run_dir=rd)
+    s = golden.structure("GaN_3x3_pristine")
+    e = calc.get_potential_energy(s)
+    assert abs(e - golden.kat["tersoff"]["energy"]) <= golden.kat["tolerance"]["tersoff_energy_abs"]
+    same, e2, pe = calc.run_lammps_energy(s, run_dir=rd)
+    assert same is s and e2 == e and pe.shape == (36,) and abs(pe.sum() - e) <= 1e-9
+    assert calc.get_surface_energy(s) == e and calc.get_property("per_atom_energies", s).shape == (36,)
+    # 12 Ga adatoms on top (the tutorial's canonical composition), relaxed with the template's minimiser: ids <= bulk_index held
+    rng = np.random.default_rng(3)
+    ads = s.copy()
+    ads.numbers = np.r_[s.numbers, np.full(12, 31)].astype(np.int32)
+    ads.positions = np.r_[s.positions, s.positions[18:30] + [0.3, 0.2, 1.9] + rng.normal(0, 0.03, (12, 3))]
+    e_static = calc.get_potential_energy(ads)
+    relaxed, e_rel, pe_rel = calc.run_lammps_opt(ads, run_dir=calc.run_dir)
+    assert np.array_equal(relaxed.positions[:36], ads.positions[:36])           # group bulk id <= 36, setforce 0
+    assert np.abs(relaxed.positions[36:] - ads.positions[36:]).max() > 1e-3 and e_rel < e_static - 1e-3
+    assert pe_rel.shape == (48,) and calc.last_opt["optimizer"] == "CG"
+    types = np.array([0 if z == 31 else 1 for z in relaxed.numbers], np.int32)
+    E0, _, _ = oracle_mod.tersoff(golden.tersoff_params, types, relaxed.positions, relaxed.cell, [1, 1, 1])
+    assert abs(e_rel - E0) <= 1e-9 * abs(E0)
+    assert calc.get_property("relaxed_energy", ads) == pytest.approx(e_rel, abs=1e-9)

@@ -327,3 +327,82 @@ def test_embedding_and_uncertainty_helpers_mirror_the_reference_functions():
 
     with pytest.raises(KeyError):
         calcs.get_embeddings_single(s, NoEmbedding(1))
+
+
+def _gan_run_dir(tmp_path, golden, style="tersoff"):
+    """A run directory the way the reference's GaN tutorial prepares one (tutorials/GaN_0001.ipynb: lammps_config.json,
+    lammps_energy_template.txt, lammps_opt_template.txt next to the potential file) -- written here from the committed parameter
+    fixture; only the lines this backend reads are meaningful."""
+    sp = golden.tersoff["species"]
+    lines = [" ".join([a, b, c] + [repr(float(x)) for x in golden.tersoff["params_ijk"][i][j][k]])
+             for i, a in enumerate(sp) for j, b in enumerate(sp) for k, c in enumerate(sp)]
+    (tmp_path / "GaN.tersoff").write_text("# GaN (test copy written from tests/golden/GaN_tersoff_params.json)\n" + "\n".join(lines) + "\n")
+    (tmp_path / "lammps_config.json").write_text(json.dumps({"potential_file": "GaN.tersoff", "atoms": ["Ga", "N"],
+                                                              "atomic_numbers_dict": {"1": 31, "2": 7}, "bulk_index": 36}))
+    body = "units metal\nboundary p p p\nread_data {}\ngroup bulk id <= {}\npair_style %s\npair_coeff * * {} {} {}\n" % style
+    (tmp_path / "lammps_energy_template.txt").write_text(body + "run 0\nwrite_data {}\n")
+    (tmp_path / "lammps_opt_template.txt").write_text(body + "fix 2 bulk setforce 0.0 0.0 0.0\nmin_style cg\nminimize 1e-5 1e-5 {} 10000\nwrite_data {}\n")
+    return tmp_path
+
+
+def test_lammps_surf_calc_configures_itself_from_the_run_directory(tmp_path, golden):
+    """``LAMMPSSurfCalc()`` + ``set(run_dir=...)`` as in the reference's GaN tutorial: potential file, species order, bulk
+    group and pair style come from the run directory's lammps_config.json / templates (reference calculators.py:507-598)."""
+    rd = _gan_run_dir(tmp_path, golden)
+    calc = calcs.LAMMPSSurfCalc()
+    assert calc.relax_steps == 100 and os.path.isdir(calc.run_dir)             # the reference's defaults (:499-505)
+    changed = calc.set(calc_name="LAMMPS", optimizer="LAMMPS", chem_pots={"Ga": 5}, relax_atoms=True, relax_steps=100, run_dir=rd)
+    assert "run_dir" in changed and str(calc.run_dir) == str(rd)
+    calc._configure()
+    assert calc.pair_style == "tersoff" and calc.species == ["Ga", "N"] and calc.bulk_index == 36
+    assert np.array_equal(calc.params, golden.tersoff_params)
+    s = golden.structure("GaN_3x3_pristine")
+    types, pos, cell, pbc = calc._pack(s)
+    assert set(types.tolist()) == {0, 1} and pbc.tolist() == [1, 1, 1]         # boundary p p p
+    twin = copy.deepcopy(calc)
+    twin._configure()
+    assert twin.params is calc.params and twin._engine is None
+    assert {"energy", "relaxed_energy", "forces", "per_atom_energies", "surface_energy"} <= set(calc.implemented_properties)
+    assert calcs.LAMMMPSCalc is calcs.LAMMPSSurfCalc
+    # what the backend does not provide fails loudly
+    lj = tmp_path / "lj"
+    lj.mkdir()
+    bad = calcs.LAMMPSSurfCalc()
+    bad.set(run_dir=_gan_run_dir(lj, golden, style="lj/cut"))
+    with pytest.raises(backend.BackendError):
+        bad._configure()
+    none = calcs.LAMMPSSurfCalc()
+    none.set(run_dir=tmp_path / "missing")
+    with pytest.raises(FileNotFoundError):
+        none._configure()
+    (tmp_path / "nopot").mkdir()
+    (tmp_path / "nopot" / "lammps_config.json").write_text(json.dumps({"potential_file": "Nowhere.tersoff", "atoms": ["Ga", "N"], "bulk_index": 1}))
+    (tmp_path / "nopot" / "lammps_energy_template.txt").write_text("pair_style tersoff\n")
+    lost = calcs.LAMMPSSurfCalc()
+    lost.set(run_dir=tmp_path / "nopot")
+    with pytest.raises(FileNotFoundError, match="looked in"):
+        lost._configure()
+
+
+def test_pourbaix_delta_g1_method_and_decomposition():
+    """``NFFPourbaix.get_delta_G1`` (reference calculators.py:235-272) and ``-(dG1 + dG2)`` on the reference-generated vectors."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pourbaix_kat.json")) as fh:
+        kat = json.load(fh)
+    for case in kat["cases"]:
+        aset = kat["atom_sets"][case["atom_set"]]
+        atoms = {k: calcs.PourbaixAtom(**v) for k, v in aset["atoms"].items()}
+        symbols = [s for s, n in case["formula"].items() for _ in range(n)]
+        assert calcs.pourbaix_delta_G1(case["energy"], symbols, atoms, case["adsorbate_corrections"]) == pytest.approx(case["delta_G1"], abs=1e-10)
+        assert calcs.pourbaix_delta_G2(symbols, atoms, case["temperature"], aset["phi"], aset["pH"]) == pytest.approx(case["delta_G2"], abs=1e-10)
+    case = kat["cases"][1]
+    aset = kat["atom_sets"][case["atom_set"]]
+    calc = calcs.NFFPourbaix.__new__(calcs.NFFPourbaix)
+    calc.pourbaix_atoms = {k: calcs.PourbaixAtom(**v) for k, v in aset["atoms"].items()}
+    calc.adsorbate_corrections = case["adsorbate_corrections"]
+    calc.get_potential_energy = lambda atoms=None: case["energy"]
+
+    class _Slab:
+        def get_chemical_symbols(self):
+            return [s for s, n in case["formula"].items() for _ in range(n)]
+
+    assert calc.get_delta_G1(_Slab()) == pytest.approx(case["delta_G1"], abs=1e-10)

@@ -17,20 +17,20 @@ def test_launcher_patches_the_reference_namespace_and_runs_the_script_unchanged(
     (pkg / "calculators.py").write_text(textwrap.dedent("""
         class EnsembleNFFSurface:          # stands for the reference class (torch / nff behind it)
             origin = "reference"
-        class LAMMPSSurfCalc:
+        class CHGNetSurfCalc:
             origin = "reference"
         def get_std_devs_single(a, c):
             return "reference"
     """))
-    (pkg / "__init__.py").write_text("from .calculators import EnsembleNFFSurface, LAMMPSSurfCalc, get_std_devs_single\n")
+    (pkg / "__init__.py").write_text("from .calculators import EnsembleNFFSurface, CHGNetSurfCalc, get_std_devs_single\n")
     script = tmp_path / "sample_surface.py"
     script.write_text(textwrap.dedent("""
         import sys
-        from mcmc.calculators import EnsembleNFFSurface, LAMMPSSurfCalc, get_std_devs_single
+        from mcmc.calculators import EnsembleNFFSurface, CHGNetSurfCalc, get_std_devs_single
         import mcmc.calculators.calculators as inner
         print("argv", sys.argv[1:])
         print("class", EnsembleNFFSurface.__module__, inner.EnsembleNFFSurface.__module__)
-        print("kept", LAMMPSSurfCalc.origin, get_std_devs_single.__module__)
+        print("kept", CHGNetSurfCalc.origin, get_std_devs_single.__module__)
         if __name__ == "__main__":
             print("main-ok")
     """))
