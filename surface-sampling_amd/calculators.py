@@ -233,6 +233,11 @@ class EnsembleNFFSurface(_Base):
 
     def __init__(self, models, device="cuda", model_units="kcal/mol", prediction_units="eV",
                  offset_units="atomic", cutoff=5.0, hparams=None, logger=None, properties=("energy", "forces"), **kwargs):
+        # a single model is accepted as well: the reference's NFFPourbaix is a NeuralFF and is constructed with ONE module,
+        # NFFPourbaix(models[0], device=..., model_units=..., prediction_units="eV") (scripts/sample_pourbaix_surface.py:253-258)
+        if isinstance(models, (str, bytes)) or hasattr(models, "__fspath__") or hasattr(models, "state_dict") \
+                or (isinstance(models, np.ndarray) and models.ndim == 1):
+            models = [models]
         self.models = [self._load_model(m, hparams) for m in models]
         # like NeuralFF(properties=[...]) in the reference's clustering script (scripts/clustering.py:150-158): "embedding" in
         # this list makes every calculate() also return the latent features
