@@ -159,16 +159,18 @@ def _units_per_ev(model_units: str, prediction_units: str) -> float:
     raise ValueError(f"unknown model_units {model_units!r}")
 
 
-def stoich_offset_table(offset_data: dict, n_embed: int = 100):
-    """``stoidict`` (Hartree) -> per-species eV table + constant, as EnsembleNFF adds it to every
-    prediction when ``offset_data`` is configured."""
+def stoich_offset_table(offset_data: dict, n_embed: int = 100, offset_units: str = "atomic"):
+    """``stoidict`` -> per-species eV table + constant, as EnsembleNFF adds it to every prediction when ``offset_data`` is
+    configured.  ``offset_units="atomic"`` (the PaiNN configuration,
+    ``scripts/sample_surface.py:173``): the entries are Hartree; any other unit string ("eV"): taken as eV."""
     stoidict = offset_data["stoidict"]
+    factor = HARTREE_TO_EV if offset_units == "atomic" else 1.0
     table = np.zeros(n_embed)
     for sym, val in stoidict.items():
         if sym == "offset":
             continue
-        table[structures.ATOMIC_NUMBERS[sym]] = float(val) * HARTREE_TO_EV
-    return table, float(stoidict.get("offset", 0.0)) * HARTREE_TO_EV
+        table[structures.ATOMIC_NUMBERS[sym]] = float(val) * factor
+    return table, float(stoidict.get("offset", 0.0)) * factor
 
 
 def surface_energy_from_energy(energy: float, symbols, chem_pots: dict, offset_data: dict,
@@ -280,7 +282,7 @@ class EnsembleNFFSurface(_Base):
     # -- engine lifetime (lazy: created on first use, re-created when the offset config changes) ----
     def _offset_config(self):
         if self.parameters.get("offset", False) and self.offset_data and "stoidict" in self.offset_data:
-            table, const = stoich_offset_table(self.offset_data)
+            table, const = stoich_offset_table(self.offset_data, offset_units=self.offset_units)
             return table, const
         return None, 0.0
 

@@ -68,6 +68,8 @@ def test_stoich_offset_table(golden):
     sd = golden.offset_data["stoidict"]
     assert abs(table[38] - sd["Sr"] * 27.2114) < 1e-12 and abs(const - sd["offset"] * 27.2114) < 1e-12
     assert table[1] == 0
+    tev, cev = calcs.stoich_offset_table(golden.offset_data, offset_units="eV")      # non-"atomic": the entries are eV already
+    assert tev[38] == sd["Sr"] and cev == sd["offset"]
 
 
 def test_calculator_surface_without_gpu(golden):
