@@ -29,27 +29,35 @@
 namespace vssr {
 
 // ---- shared block reductions (fp64) ---------------------------------------------------------------------------------------
+// Wave-level butterflies (fixed order, every lane ends with the wave's result) + one exchange of the per-wave results through LDS:
+// two barriers per reduction instead of ten (the optimizer kernels run ~15 .. 250 of them per step).  `red` holds >= 16 doubles.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
 __device__ inline double block_sum(double v, double *red) {
-    const int tid = threadIdx.x;
-    red[tid] = v;
+    const int tid = threadIdx.x, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum_f64(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
     double r = red[0];
+    for (int w = 1; w < nw; ++w) r += red[w];
     __syncthreads();
     return r;
 }
 __device__ inline double block_max(double v, double *red) {
-    const int tid = threadIdx.x;
-    red[tid] = v;
+    const int tid = threadIdx.x, nw = (blockDim.x + 63) >> 6;
+    v = wave_max_f64(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
-        __syncthreads();
-    }
     double r = red[0];
+    for (int w = 1; w < nw; ++w) r = fmax(r, red[w]);
     __syncthreads();
     return r;
 }
@@ -250,6 +258,7 @@ k_bfgs_step(const int *__restrict__ cfg_start, const int *__restrict__ counters,
     extern __shared__ double lds[];
     __shared__ double red[256];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
     if (counters[2]) return;
     const int a0 = cfg_start[b], a1 = cfg_start[b + 1];
     const int n = 3 * (a1 - a0);
@@ -289,11 +298,11 @@ k_bfgs_step(const int *__restrict__ cfg_start, const int *__restrict__ counters,
             double a = 0.0;
             for (int k = tid; k < n; k += nt) a += (x[k] - xr0[k]) * (F(k) - xf0[k]);
             a = block_sum(a, red);
-            for (int j = 0; j < m; ++j) {
+            for (int j = wave; j < m; j += nwaves) {   // one wave per basis vector: no block barrier per dot product
                 double d = 0.0;
-                for (int k = tid; k < n; k += nt) d += Q[(size_t)j * n + k] * (x[k] - xr0[k]);
-                d = block_sum(d, red);
-                if (tid == 0) c1[j] = d;
+                for (int k = lane; k < n; k += 64) d += Q[(size_t)j * n + k] * (x[k] - xr0[k]);
+                d = wave_sum_f64(d);
+                if (lane == 0) c1[j] = d;
             }
             __syncthreads();
             // tv = B c1 ; dg = alpha dr + Q tv -> w ; b = dr.dg
@@ -326,15 +335,25 @@ k_bfgs_step(const int *__restrict__ cfg_start, const int *__restrict__ counters,
                 nrm0 = block_sum(nrm0, red);
                 for (int j = tid; j < mmax; j += nt) cc[j] = 0.0;
                 __syncthreads();
-                for (int pass = 0; pass < 2; ++pass)
-                    for (int j = 0; j < m; ++j) {
+                // classical Gram-Schmidt, twice ("twice is enough"): all m projections of a pass at once (a wave per basis vector),
+                // then one sweep over the candidate -- 2 x 2 barriers instead of 2 m block reductions (it was the modified form,
+                // sequential in j: ~170 of the kernel's ~250 reductions at m = 42)
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int j = wave; j < m; j += nwaves) {
                         double d = 0.0;
-                        for (int k = tid; k < n; k += nt) d += Q[(size_t)j * n + k] * qn[k];
-                        d = block_sum(d, red);
-                        for (int k = tid; k < n; k += nt) qn[k] -= d * Q[(size_t)j * n + k];
-                        if (tid == 0) cc[j] += d;
-                        __syncthreads();
+                        for (int k = lane; k < n; k += 64) d += Q[(size_t)j * n + k] * qn[k];
+                        d = wave_sum_f64(d);
+                        if (lane == 0) tv[j] = d;
                     }
+                    __syncthreads();
+                    for (int k = tid; k < n; k += nt) {
+                        double v = qn[k];
+                        for (int j = 0; j < m; ++j) v -= tv[j] * Q[(size_t)j * n + k];
+                        qn[k] = v;
+                    }
+                    for (int j = tid; j < m; j += nt) cc[j] += tv[j];
+                    __syncthreads();
+                }
                 double nrm = 0.0;
                 for (int k = tid; k < n; k += nt) nrm += qn[k] * qn[k];
                 nrm = block_sum(nrm, red);
@@ -363,11 +382,11 @@ k_bfgs_step(const int *__restrict__ cfg_start, const int *__restrict__ counters,
     }
     __syncthreads();
     jacobi_eigh(A, Y, m, ld, cs, red);
-    for (int j = 0; j < m; ++j) {   // cf = Q^T f
+    for (int j = wave; j < m; j += nwaves) {   // cf = Q^T f, a wave per basis vector
         double d = 0.0;
-        for (int k = tid; k < n; k += nt) d += Q[(size_t)j * n + k] * F(k);
-        d = block_sum(d, red);
-        if (tid == 0) cf[j] = d;
+        for (int k = lane; k < n; k += 64) d += Q[(size_t)j * n + k] * F(k);
+        d = wave_sum_f64(d);
+        if (lane == 0) cf[j] = d;
     }
     __syncthreads();
     for (int j = tid; j < m; j += nt) {   // tv = |L|^-1 Y^T cf
