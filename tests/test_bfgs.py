@@ -220,3 +220,36 @@ def test_relaxation_survives_neighbor_capacity_overflows(golden, optimizer):
     assert g0 == 0 and g1 >= 1
     assert np.array_equal(i0["n_steps"], i1["n_steps"]) and np.array_equal(i0["positions"], i1["positions"])
     assert np.array_equal(r0["energy"], r1["energy"]) and np.array_equal(r0["forces"], r1["forces"])
+
+
+@pytest.mark.gpu
+def test_chains_that_converge_at_different_steps_equal_their_own_relaxations(golden):
+    """Lock-step drop-out: four slabs that converge after different numbers of BFGS steps (one at once, one never within the
+    budget) relaxed in one batch -- the activity mask reaches the evaluation kernels only at the first poll after a chain has
+    converged, so a converged chain is evaluated a few more times at its final positions -- give, chain for chain, the step
+    counts, positions, energies and forces of the same slab relaxed alone, bit for bit."""
+    from surface_sampling_amd import backend, structures
+
+    table, const = golden.offset_table()
+    base = golden.structure("SrTiO3_2x2_pristine")
+    slabs = [base, golden.structure("O44Sr12Ti16"), structures.synth_chain(base, 3, grid=(4, 4)), golden.structure("O40Sr16Ti12")]
+    packs = [(s.numbers, s.positions, s.cell, s.pbc) for s in slabs]
+    fixed = np.concatenate([(s.positions[:, 2] < s.positions[:, 2].max() - 4.0).astype(np.uint8) for s in slabs])
+    eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+    eng.upload(packs)
+    info = eng.relax_bfgs(fixed=fixed, max_steps=12, fmax=0.25)
+    res = eng.download()
+    assert len(set(info["n_steps"].tolist())) >= 3 and info["converged"].any() and not info["converged"].all(), info
+    o = 0
+    for b, s in enumerate(slabs):
+        n = len(s.numbers)
+        one = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+        one.upload([packs[b]])
+        i1 = one.relax_bfgs(fixed=fixed[o:o + n], max_steps=12, fmax=0.25)
+        r1 = one.download()
+        assert int(i1["n_steps"][0]) == int(info["n_steps"][b]) and bool(i1["converged"][0]) == bool(info["converged"][b])
+        assert np.array_equal(i1["positions"], info["positions"][o:o + n])
+        assert float(r1["energy"][0]) == float(res["energy"][b]) and np.array_equal(r1["forces"], res["forces"][o:o + n])
+        one.close()
+        o += n
+    eng.close()
