@@ -948,17 +948,33 @@ class ChainEnsemble:
                 "acceptance_rate": n_acc / float(sweep_size), "species": self.state.species.copy()}
 
     def run(self, total_sweeps: int = 10, sweep_size: int = 20, start_temp: float = 1.0, perform_annealing: bool = True,
-            alpha: float = 0.99, multiple_anneal: bool = False, anneal_schedule=None, canonical: bool = False) -> dict:
-        """``MCMC.run`` (``mcmc/mcmc.py:301-420``) without the file outputs: temperature schedule + sweeps."""
+            alpha: float = 0.99, multiple_anneal: bool = False, anneal_schedule=None, canonical: bool = False,
+            starting_iteration: int = 0, keep_structures: bool = False) -> dict:
+        """``MCMC.run`` (``mcmc/mcmc.py:301-392``) without the file outputs: temperature schedule + sweeps
+        ``starting_iteration .. total_sweeps - 1``.  The result carries the reference's keys, one entry per sweep, each entry
+        an array over the chains: ``energy_hist``, ``frac_accept_hist``, ``adsorption_count_hist``; ``history`` holds the
+        ``ChainState`` after the sweep (occupation table, adsorption order and energies of every chain -- ``structure(b, state)``
+        turns a row back into the unrelaxed slab) and, with ``keep_structures``, ``trajectories`` the relaxed slabs (``SlabRefs``, one per
+        sweep; off by default: B slabs per sweep are the bulk of the memory of a long run).  ``energy`` /
+        ``adsorption_count`` / ``acceptance_rate`` are the same lists under this module's own names."""
         if anneal_schedule is not None:
             temps = list(anneal_schedule)
         elif perform_annealing:
             temps = create_anneal_schedule(start_temp, total_sweeps, alpha, multiple_anneal)
         else:
             temps = [start_temp] * total_sweeps
-        hist = {"energy": [], "adsorption_count": [], "acceptance_rate": [], "temperature": temps}
-        for i in range(total_sweeps):
+        hist = {"energy": [], "adsorption_count": [], "acceptance_rate": [], "history": [], "temperature": temps}
+        if keep_structures:
+            hist["trajectories"] = []
+        for i in range(starting_iteration, total_sweeps):
+            self.temp = float(temps[i])        # (mcmc/mcmc.py:382: the sweep's temperature is the sampler's, also for the proposal weights)
             r = self.sweep(i, sweep_size, temps[i], canonical=canonical)
             for k in ("energy", "adsorption_count", "acceptance_rate"):
                 hist[k].append(r[k])
+            hist["history"].append(self.state.copy())
+            if keep_structures:
+                hist["trajectories"].append(self.relaxed)
+        hist["energy_hist"] = hist["energy"]
+        hist["frac_accept_hist"] = hist["acceptance_rate"]
+        hist["adsorption_count_hist"] = hist["adsorption_count"]
         return hist

@@ -268,6 +268,18 @@ def test_run_with_annealing_returns_per_chain_history():
     assert len(hist["energy"]) == 3 and hist["energy"][0].shape == (6,)
     assert ((hist["acceptance_rate"][0] >= 0) & (hist["acceptance_rate"][0] <= 1)).all()
     assert ens.step_count == 15
+    # the reference's result keys (mcmc/mcmc.py:383-390), one entry per sweep
+    for ref_key, own in (("energy_hist", "energy"), ("frac_accept_hist", "acceptance_rate"), ("adsorption_count_hist", "adsorption_count")):
+        assert hist[ref_key] is hist[own] and len(hist[ref_key]) == 3
+    assert len(hist["history"]) == 3 and np.array_equal(hist["history"][-1].species, ens.state.species)
+    assert np.array_equal(hist["history"][-1].energy, hist["energy_hist"][-1]) and "trajectories" not in hist
+    slab = ens.structure(2, hist["history"][0])                      # a history row turns back into its slab
+    assert len(slab) == len(ens.base) + int(hist["adsorption_count_hist"][0][2])
+    # resuming at sweep 2 runs only the last sweep, at that sweep's temperature; relaxed slabs are kept on request
+    ens2, _ = _toy(6)
+    h2 = ens2.run(total_sweeps=3, sweep_size=5, start_temp=0.1, alpha=0.5, starting_iteration=2, keep_structures=True)
+    assert len(h2["energy_hist"]) == 1 and ens2.step_count == 5 and ens2.temp == 0.025
+    assert len(h2["trajectories"]) == 1 and len(h2["trajectories"][0]) == 6
 
 
 # ---- canonical (switch) moves: mirrors tests/events/test_proposal.py:79-110, tests/test_slab.py:153-183, ----------------
