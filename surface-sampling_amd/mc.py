@@ -978,3 +978,95 @@ class ChainEnsemble:
         hist["frac_accept_hist"] = hist["acceptance_rate"]
         hist["adsorption_count_hist"] = hist["adsorption_count"]
         return hist
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Chain groups that advance independently: the host work of one group runs while the device evaluates another
+# ---------------------------------------------------------------------------------------------------------------------
+class ConcurrentChains:
+    """Several ``ChainEnsemble`` objects over DISJOINT chains, each with its own calculator (its own engine = its own HIP
+    stream), every one advanced by its own host thread.
+
+    Chains never interact and their random numbers are a function of (seed, global chain id, step) only, so a group steps
+    through exactly the trajectory its chains have inside one big ensemble (``tests/test_mc.py``: bit for bit).  What the
+    grouping buys is overlap ACROSS MC steps: a step is host work (proposal, packing, acceptance: numpy under the GIL) followed
+    by a blocking wait on the device (the C ABI call releases the GIL), so while one group waits the other one proposes /
+    packs / accepts, and the two engines share the GPU like ``bench.py --streams 2``.  With single-point acceptance energies
+    (``relax=False``) the host work is ~30 % of a step of one 256-chain ensemble and is hidden this way (``profiles/r04/bench_mc_groups.txt``:
+    17.0 k -> 23.0 k proposals/s with three groups); with relaxations it is 2 % and nothing is gained.
+
+    ``build`` cuts ``n_chains`` into ``len(calcs)`` contiguous ranges of global chain ids."""
+
+    def __init__(self, ensembles):
+        self.groups = list(ensembles)
+        if not self.groups:
+            raise ValueError("no chain groups")
+        ids = np.concatenate([g.chain_ids for g in self.groups])
+        if len(np.unique(ids)) != len(ids):
+            raise ValueError("chain groups overlap: a global chain id may belong to one group only")
+        if len({id(g.calc) for g in self.groups}) != len(self.groups):
+            raise ValueError("every chain group needs its own calculator (its own engine and HIP stream)")
+        self.chain_ids = ids
+
+    @classmethod
+    def build(cls, base, ads_coords, adsorbates, n_chains: int, calcs, *, first_chain: int = 0, **kwargs):
+        calcs = list(calcs)
+        bounds = np.linspace(0, int(n_chains), len(calcs) + 1).astype(int)
+        return cls([ChainEnsemble(base, ads_coords, adsorbates, int(bounds[k + 1] - bounds[k]), calc,
+                                  first_chain=first_chain + int(bounds[k]), **kwargs)
+                    for k, calc in enumerate(calcs) if bounds[k + 1] > bounds[k]])
+
+    def __len__(self):
+        return len(self.chain_ids)
+
+    def _each(self, fn):
+        """``fn(group)`` for every group, one thread per group; the first exception is raised here."""
+        if len(self.groups) == 1:
+            return [fn(self.groups[0])]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(len(self.groups)) as pool:
+            return [f.result() for f in [pool.submit(fn, g) for g in self.groups]]
+
+    @property
+    def energy(self) -> np.ndarray:
+        return np.concatenate([g.state.energy for g in self.groups])
+
+    @property
+    def species(self) -> np.ndarray:
+        return np.concatenate([g.state.species for g in self.groups])
+
+    @property
+    def n_evaluations(self) -> int:
+        return sum(g.n_evaluations for g in self.groups)
+
+    def num_adsorbates(self) -> np.ndarray:
+        return np.concatenate([g.num_adsorbates() for g in self.groups])
+
+    def initialize(self) -> np.ndarray:
+        return np.concatenate(self._each(lambda g: g.initialize()))
+
+    def steps(self, n: int, temperature: float | None = None, canonical: bool = False) -> np.ndarray:
+        """``n`` MC steps of every group (each group runs its n steps without waiting for the others); accept counts ``[B]``."""
+        def go(g):
+            acc = np.zeros(len(g.chain_ids), np.int64)
+            for _ in range(n):
+                acc += g.step_canonical(temperature) if canonical else g.step_semigrand(temperature)
+            return acc
+        return np.concatenate(self._each(go))
+
+    def run(self, **kwargs) -> dict:
+        """``ChainEnsemble.run`` of every group concurrently; the per-sweep entries are joined along the chain axis."""
+        parts = self._each(lambda g: g.run(**kwargs))
+        out = {"temperature": parts[0]["temperature"]}
+        n_sweeps = len(parts[0]["energy"])
+        for k in ("energy", "adsorption_count", "acceptance_rate"):
+            out[k] = [np.concatenate([p[k][i] for p in parts]) for i in range(n_sweeps)]
+        out["history"] = [ChainState(np.concatenate([p["history"][i].species for p in parts]),
+                                     np.concatenate([p["history"][i].order for p in parts]),
+                                     np.concatenate([p["history"][i].counter for p in parts]),
+                                     np.concatenate([p["history"][i].energy for p in parts])) for i in range(n_sweeps)]
+        if "trajectories" in parts[0]:
+            out["trajectories"] = [SlabRefs(sum((_raw_items(p["trajectories"][i]) for p in parts), [])) for i in range(n_sweeps)]
+        out["energy_hist"], out["frac_accept_hist"] = out["energy"], out["acceptance_rate"]
+        out["adsorption_count_hist"] = out["adsorption_count"]
+        return out

@@ -815,3 +815,49 @@ def test_slab_references_do_not_pin_an_unbounded_number_of_batches():
     for b in range(48):
         kept = ens.structure(b)
         assert np.array_equal(ens.relaxed[b].numbers, kept.numbers) and np.array_equal(ens.relaxed[b].positions, kept.positions)
+
+
+def test_concurrent_chain_groups_walk_the_trajectories_of_one_ensemble():
+    """``ConcurrentChains``: 3 groups of chains (own calculators, own host threads) step through exactly what the same 10
+    chains do inside one ensemble -- accept counts, energies, occupations, every sweep of the history."""
+    Z = structures.ATOMIC_NUMBERS
+    whole, _ = _toy(10)
+    want = whole.run(total_sweeps=3, sweep_size=4, start_temp=0.1, alpha=0.5, keep_structures=True)
+    calcs = [LatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.03) for _ in range(3)]
+    groups = mc.ConcurrentChains.build(whole.base, whole.ads_coords, ("Sr", "O"), 10, calcs, seed=3, relax=False, temperature=0.05)
+    assert [len(g.chain_ids) for g in groups.groups] == [3, 3, 4] and np.array_equal(groups.chain_ids, np.arange(10))
+    got = groups.run(total_sweeps=3, sweep_size=4, start_temp=0.1, alpha=0.5, keep_structures=True)
+    for k in ("energy_hist", "frac_accept_hist", "adsorption_count_hist"):
+        assert len(got[k]) == 3
+        for a, b in zip(got[k], want[k]):
+            assert np.array_equal(a, b), k
+    for a, b in zip(got["history"], want["history"]):
+        assert np.array_equal(a.species, b.species) and np.array_equal(a.order, b.order) and np.array_equal(a.counter, b.counter)
+    for a, b in zip(got["trajectories"], want["trajectories"]):
+        assert len(a) == len(b) == 10
+        assert all(np.array_equal(x.numbers, y.numbers) and np.array_equal(x.positions, y.positions) for x, y in zip(a, b))
+    assert np.array_equal(groups.energy, whole.state.energy) and np.array_equal(groups.species, whole.state.species)
+    assert groups.n_evaluations == whole.n_evaluations
+    # steps(): the same again, continuing both
+    acc = groups.steps(5)
+    ref = np.zeros(10, np.int64)
+    for _ in range(5):
+        ref += whole.step_semigrand()
+    assert np.array_equal(acc, ref) and np.array_equal(groups.energy, whole.state.energy)
+    # guards: overlapping chains, a shared calculator; an exception inside a group's thread surfaces
+    a, ca = _toy(4)
+    b, cb = _toy(4, first_chain=2)
+    with pytest.raises(ValueError, match="overlap"):
+        mc.ConcurrentChains([a, b])
+    c = mc.ChainEnsemble(a.base, a.ads_coords, ("Sr", "O"), 4, ca, seed=3, first_chain=10, relax=False)
+    with pytest.raises(ValueError, match="own calculator"):
+        mc.ConcurrentChains([a, c])
+
+    class Broken(LatticeGasCalc):
+        def calculate_batch(self, *args, **kw):
+            raise RuntimeError("device lost")
+    bad = mc.ConcurrentChains.build(whole.base, whole.ads_coords, ("Sr", "O"), 4,
+                                    [LatticeGasCalc(2, {Z["Sr"]: -0.05}, J=0.0), Broken(2, {Z["Sr"]: -0.05}, J=0.0)],
+                                    seed=3, relax=False)
+    with pytest.raises(RuntimeError, match="device lost"):
+        bad.initialize()

@@ -112,3 +112,33 @@ def test_packed_fast_path_equals_the_per_slab_path_on_the_device(golden, relax):
         assert np.array_equal(ra.numbers, rb.numbers) and np.array_equal(ra.positions, rb.positions)
         assert np.array_equal(a[4].per_atom_energies[k], b[4].per_atom_energies[k])
     assert a[0].any() or not relax      # (unrelaxed adsorbates 1.5 A above the surface are rarely accepted at T = 0.5 eV)
+
+
+@pytest.mark.parametrize("relax", [False, True])
+def test_concurrent_chain_groups_on_the_device(golden, relax):
+    """``mc.ConcurrentChains``: two groups of chains with their own calculators (own engines / HIP streams), advanced by their
+    own host threads -- the device work of one overlaps the host work of the other -- end in the states of ONE ensemble over
+    the same chains: accept counts, occupations and energies bit for bit."""
+    from surface_sampling_amd import mc
+    from surface_sampling_amd.calculators import EnsembleNFFSurface
+
+    base = golden.structure("SrTiO3_2x2_pristine")
+    coords = _site_grid(base)
+    fixed = np.flatnonzero(base.positions[:, 2] < base.positions[:, 2].max() - 4.0)
+
+    def new_calc():
+        c = EnsembleNFFSurface(golden.blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV", offset_units="atomic")
+        c.set(offset=True, offset_data=golden.offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0})
+        return c
+    kw = dict(seed=9, relax=relax, relax_steps=3, fmax=0.05, fixed_indices=fixed, temperature=0.5)
+    whole = mc.ChainEnsemble(base, coords, ("Sr", "O"), 9, new_calc(), **kw)
+    whole.initialize()
+    want = np.zeros(9, np.int64)
+    for _ in range(4):
+        want += whole.step_semigrand()
+    groups = mc.ConcurrentChains.build(base, coords, ("Sr", "O"), 9, [new_calc(), new_calc()], **kw)
+    groups.initialize()
+    got = groups.steps(4)
+    assert np.array_equal(got, want) and np.array_equal(groups.species, whole.state.species)
+    assert np.array_equal(groups.energy, whole.state.energy)
+    assert groups.n_evaluations == whole.n_evaluations

@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--relax-steps", type=int, default=20)
     ap.add_argument("--optimizer", default="BFGS")
     ap.add_argument("--no-relax", action="store_true", help="single-point acceptance energies (the reference's relax_atoms: false)")
+    ap.add_argument("--groups", type=int, default=1, help="> 1: mc.ConcurrentChains -- the chains in this many groups, each with its own "
+                    "calculator / engine / host thread (no phase split: the phases of different groups overlap)")
     args = ap.parse_args()
     from surface_sampling_amd import mc, structures
     from surface_sampling_amd.calculators import EnsembleNFFSurface
@@ -70,8 +72,13 @@ def main():
             p = (i + 0.5) / n * base.cell[0] + (j + 0.5) / n * base.cell[1]
             coords.append([p[0], p[1], ztop + 1.5])
     fixed = np.flatnonzero(base.positions[:, 2] < ztop - 4.0)
-    calc = EnsembleNFFSurface(blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV", offset_units="atomic")
-    calc.set(offset=True, offset_data=offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0})
+    def new_calc():
+        c = EnsembleNFFSurface(blobs, device="cuda:0", model_units="kcal/mol", prediction_units="eV", offset_units="atomic")
+        c.set(offset=True, offset_data=offset_data, chem_pots={"Sr": -2, "Ti": 0, "O": 0})
+        return c
+    if args.groups > 1:
+        return grouped(args, base, np.array(coords), fixed, new_calc)
+    calc = new_calc()
     ens = mc.ChainEnsemble(base, np.array(coords), ("Sr", "O"), args.chains, calc, seed=1, relax=not args.no_relax,
                            relax_steps=args.relax_steps, fmax=0.01, fixed_indices=fixed, temperature=0.1,
                            optimizer=args.optimizer)
@@ -115,6 +122,35 @@ def main():
             "split_s_per_lockstep": {k: round(v, 5) for k, v in sorted(split.items())},
             "device_share": dev / (dt / args.steps), "transfer_share": (split.get("upload", 0) + split.get("download", 0)) / (dt / args.steps),
             "host_share": host / (dt / args.steps),
+            "reference": {"s_per_proposal": 606.0 / 50, "where": "tutorials/SrTiO3_001.ipynb:1558 (one 72-atom chain, RTX 2080 Ti, nff)"}}
+    line["speedup_vs_reference_per_proposal"] = line["proposals_per_s"] * line["reference"]["s_per_proposal"]
+    print(json.dumps(line))
+
+
+def grouped(args, base, coords, fixed, new_calc):
+    from surface_sampling_amd import mc
+    calcs = [new_calc() for _ in range(args.groups)]
+    for c in calcs:
+        c.streams = 1                        # one engine per group: the groups are the streams
+    cc = mc.ConcurrentChains.build(base, coords, ("Sr", "O"), args.chains, calcs, seed=1, relax=not args.no_relax,
+                                   relax_steps=args.relax_steps, fmax=0.01, fixed_indices=fixed, temperature=0.1,
+                                   optimizer=args.optimizer)
+    for g in cc.groups:                      # the same mid-run starting states as the single-ensemble measurement
+        state = g.state
+        for s in range(1, 21):
+            site, end, _, _ = g.propose(10_000 + s, state)
+            state = g.apply(state, site, end)
+        g.state = state
+    cc.initialize()
+    cc.steps(2)                              # warm-up (engine capacities settle)
+    t0 = time.perf_counter()
+    acc = cc.steps(args.steps)
+    dt = time.perf_counter() - t0
+    line = {"metric": "batched semigrand MC steps/s, chains in concurrent groups (mc.ConcurrentChains)", "chains": args.chains,
+            "groups": len(cc.groups), "atoms_per_chain": int(len(base) + cc.num_adsorbates().mean()),
+            "optimizer": args.optimizer if not args.no_relax else None, "relax_steps": args.relax_steps if not args.no_relax else 0,
+            "mc_steps": args.steps, "s_per_lockstep": dt / args.steps, "proposals_per_s": args.chains * args.steps / dt,
+            "acceptance": float(acc.mean() / args.steps), "energy_checksum": float(np.sum(cc.energy)),
             "reference": {"s_per_proposal": 606.0 / 50, "where": "tutorials/SrTiO3_001.ipynb:1558 (one 72-atom chain, RTX 2080 Ti, nff)"}}
     line["speedup_vs_reference_per_proposal"] = line["proposals_per_s"] * line["reference"]["s_per_proposal"]
     print(json.dumps(line))
