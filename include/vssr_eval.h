@@ -30,7 +30,8 @@
  *   - Status codes: 0 ok, <0 error (see VSSR_E_*); vssr_last_error() gives the message.
  *     Non-finite energies are returned, not raised (the +-1000 clamp is the caller's job,
  *     mcmc/dynamics.py:159-168).
- *   - A handle is not re-entrant; distinct handles are independent (one per GPU / stream).
+ *   - A handle is not re-entrant; distinct handles are independent (one per GPU / stream) and may be driven from
+ *     different host threads at the same time (mc.ConcurrentChains does).
  *     Calls are synchronous unless stated.
  *
  * Weight blob layout (float32, little endian), F=feat_dim, R=n_rbf, H=readout_hidden:
@@ -117,7 +118,7 @@ int vssr_abi_version(void);
  *   VSSR_DEBUG_KEEP=1        materialise buffers that only vssr_debug_read consumes (the last block's vector output) */
 int vssr_create(const vssr_painn_config *cfg, vssr_handle **out);
 void vssr_destroy(vssr_handle *h);
-const char *vssr_last_error(const vssr_handle *h); /* h may be NULL: last create() error */
+const char *vssr_last_error(const vssr_handle *h); /* h may be NULL: last create() error of the calling thread */
 
 /* One configuration (what one ASE calculate() call is). */
 int vssr_eval(vssr_handle *h, int32_t n_atoms, const int32_t *Z, const double *pos,

@@ -11,7 +11,7 @@ const char *const kKernelClassNames[KC_COUNT] = {
     "update_bwd", "edge_message_bwd", "message_mlp_bwd", "finalize", "tersoff", "layer0_factorised_fwd",
     "layer0_factorised_bwd"};
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;   // per thread: handles may be created concurrently (one host thread per engine)
 
 int set_err(vssr_handle *h, int code, const char *fmt, ...) {
     char buf[512];

@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--no-relax", action="store_true", help="single-point acceptance energies (the reference's relax_atoms: false)")
     ap.add_argument("--groups", type=int, default=1, help="> 1: mc.ConcurrentChains -- the chains in this many groups, each with its own "
                     "calculator / engine / host thread (no phase split: the phases of different groups overlap)")
+    ap.add_argument("--verify", action="store_true", help="with --groups: walk the same steps with ONE ensemble afterwards and "
+                    "require identical accept counts, occupations and energies")
     args = ap.parse_args()
     from surface_sampling_amd import mc, structures
     from surface_sampling_amd.calculators import EnsembleNFFSurface
@@ -153,6 +155,26 @@ def grouped(args, base, coords, fixed, new_calc):
             "acceptance": float(acc.mean() / args.steps), "energy_checksum": float(np.sum(cc.energy)),
             "reference": {"s_per_proposal": 606.0 / 50, "where": "tutorials/SrTiO3_001.ipynb:1558 (one 72-atom chain, RTX 2080 Ti, nff)"}}
     line["speedup_vs_reference_per_proposal"] = line["proposals_per_s"] * line["reference"]["s_per_proposal"]
+    if args.verify:
+        one = mc.ChainEnsemble(base, coords, ("Sr", "O"), args.chains, new_calc(), seed=1, relax=not args.no_relax,
+                               relax_steps=args.relax_steps, fmax=0.01, fixed_indices=fixed, temperature=0.1, optimizer=args.optimizer)
+        state = one.state
+        for s in range(1, 21):
+            site, end, _, _ = one.propose(10_000 + s, state)
+            state = one.apply(state, site, end)
+        one.state = state
+        one.initialize()
+        ref = np.zeros(args.chains, np.int64)
+        for k in range(2 + args.steps):
+            a = one.step_semigrand()
+            if k >= 2:
+                ref += a
+        same = bool(np.array_equal(ref, acc) and np.array_equal(one.state.species, cc.species)
+                    and np.array_equal(one.state.energy, cc.energy))
+        line["identical_to_one_ensemble"] = same
+        if not same:
+            print(json.dumps(line))
+            raise SystemExit("grouped chains diverged from the single ensemble")
     print(json.dumps(line))
 
 
