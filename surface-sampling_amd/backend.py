@@ -484,22 +484,25 @@ class _AnalyticEngine(_Handle):
     def relax_f64(self, structs, fixed=None, max_steps=100, fmax=0.01, optimizer="FIRE"):
         """Relax (types, positions, cell, pbc) structures with FIRE / BFGS; returns (energy [B], e_atom [N], forces [N,3],
         positions [N,3], n_steps [B], converged [B]) with fp64 energies/forces of the relaxed structures."""
-        self.upload(structs)
+        return self.relax_arrays_f64(*pack_batch(structs), fixed=fixed, max_steps=max_steps, fmax=fmax, optimizer=optimizer)
+
+    def relax_arrays_f64(self, n_atoms, T, pos, cell, pbc, fixed=None, max_steps=100, fmax=0.01, optimizer="FIRE"):
+        """``relax_f64`` on the ABI's packed arrays (no per-structure objects)."""
+        self.upload_arrays(n_atoms, T, pos, cell, pbc)
         info = self.relax(optimizer, fixed=fixed, max_steps=max_steps, fmax=fmax,
                           want=WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM)
-        packs = []
-        o = 0
-        for t, p, c, b in structs:
-            n = len(t)
-            packs.append((t, info["positions"][o:o + n], c, b))
-            o += n
-        e, ea, f = self.evaluate_f64(packs)
+        e, ea, f = self.evaluate_arrays_f64(n_atoms, T, info["positions"], cell, pbc)
         return e, ea, f, info["positions"], info["n_steps"], info["converged"]
 
     def relax_cg_f64(self, structs, fixed=None, max_iter=100, max_eval=10000, etol=1e-5, ftol=1e-5):
         """LAMMPS ``min_style cg`` / ``minimize etol ftol max_iter max_eval`` on the device (vssr_batch_relax_cg).  Returns
         (energy [B], e_atom [N], forces [N,3], positions [N,3], n_iter [B], n_eval [B], stop_reason [B])."""
-        self.upload(structs)
+        return self.relax_cg_arrays_f64(*pack_batch(structs), fixed=fixed, max_iter=max_iter, max_eval=max_eval, etol=etol, ftol=ftol)
+
+    def relax_cg_arrays_f64(self, n_atoms, T, pos, cell, pbc, fixed=None, max_iter=100, max_eval=10000, etol=1e-5, ftol=1e-5):
+        """``relax_cg_f64`` on the ABI's packed arrays: the minimisation, then the static evaluation of the minimised geometries
+        (the reference's ``run_lammps_opt`` followed by ``run_lammps_energy``)."""
+        self.upload_arrays(n_atoms, T, pos, cell, pbc)
         N, B = self._n_atoms, self._n_cfg
         fx = None
         if fixed is not None:
@@ -507,23 +510,28 @@ class _AnalyticEngine(_Handle):
             if fx.size != N:
                 raise ValueError("fixed mask does not match the resident batch")
         p = CgParams.default(max_iter, max_eval, etol, ftol)
-        pos = np.zeros((N, 3), np.float64)
+        out = np.zeros((N, 3), np.float64)
         it, ev, why = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
         self._check(self._lib.vssr_batch_relax_cg(self._h, C.byref(p), _ptr(fx, C.c_uint8),
-                                                  WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM, _ptr(pos, C.c_double),
+                                                  WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM, _ptr(out, C.c_double),
                                                   _ptr(it, C.c_int32), _ptr(ev, C.c_int32), _ptr(why, C.c_int32)))
-        packs, o = [], 0
-        for t, _, c, b in structs:
-            n = len(t)
-            packs.append((t, pos[o:o + n], c, b))
-            o += n
-        e, ea, f = self.evaluate_f64(packs)
-        return e, ea, f, pos, it, ev, why
+        e, ea, f = self.evaluate_arrays_f64(n_atoms, T, out, cell, pbc)
+        return e, ea, f, out, it, ev, why
 
     def evaluate_f64(self, structs, want=WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM):
         """structs: list of (types, positions, cell, pbc). Returns fp64 energy [B], e_atom [N], forces [N,3]."""
-        n_atoms, T, pos, cell, pbc = pack_batch(structs)
+        return self.evaluate_arrays_f64(*pack_batch(structs), want=want)
+
+    def evaluate_arrays_f64(self, n_atoms, T, pos, cell, pbc, want=WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM):
+        """``evaluate_f64`` on the ABI's packed arrays."""
+        n_atoms = np.ascontiguousarray(n_atoms, dtype=np.int32)
+        T = np.ascontiguousarray(T, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        cell = np.ascontiguousarray(cell, dtype=np.float64)
+        pbc = np.ascontiguousarray(pbc, dtype=np.uint8)
         B, N = len(n_atoms), len(T)
+        if N != int(n_atoms.sum()) or pos.size != 3 * N or cell.size != 9 * B or pbc.size != 3 * B:
+            raise ValueError("inconsistent batch arrays")
         e = np.zeros(B); ea = np.zeros(N); f = np.zeros((N, 3))
         self._check(self._lib.vssr_tersoff_eval_batch(
             self._h, B, _ptr(n_atoms, C.c_int32), _ptr(T, C.c_int32), _ptr(pos, C.c_double),

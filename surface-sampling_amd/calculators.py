@@ -462,6 +462,13 @@ class EnsembleNFFSurface(_Base):
                 offset_per_z=table, offset_const=const, hparams=self.hparams))
         return [first] + extra[: n - 1]
 
+    @staticmethod
+    def packed_supported(relax: bool, optimizer) -> bool:
+        """Whether ``evaluate_packed`` serves this request: everything but relaxations with a host-driven optimizer (an optimizer
+        class, "BFGSLineSearch", the LAMMPS-style "CG")."""
+        return not relax or optimizer is None or (isinstance(optimizer, str)
+                                                  and not any(k in optimizer for k in ("CG", "LAMMPS", "BFGSLineSearch")))
+
     def evaluate_packed(self, n_atoms, Z, pos, cell, pbc, relax: bool = False, fixed_mask=None, relax_steps: int = 20,
                         fmax: float = 0.01, optimizer=None) -> dict:
         """Arrays in, arrays out: the batched evaluation (``relax=False``: ``calculate_batch``) or lock-step relaxation
@@ -1000,6 +1007,70 @@ class _AnalyticSurfCalc(_Base):
         return out
 
 
+    @staticmethod
+    def packed_supported(relax: bool, optimizer) -> bool:
+        """``evaluate_packed`` relaxes with the device optimizers only: "LAMMPS" / "CG" (the default), "FIRE", "BFGS"."""
+        return not relax or optimizer is None or (isinstance(optimizer, str)
+                                                  and optimizer.upper() in ("CG", "LAMMPS", "FIRE", "BFGS"))
+
+    def _types_of(self, Z) -> np.ndarray:
+        """LAMMPS types of atomic numbers (the order of ``species``), vectorised."""
+        table = np.full(len(structures.SYMBOLS) + 1, -1, np.int32)
+        for t, sym in enumerate(self.species):
+            table[structures.ATOMIC_NUMBERS[sym]] = t
+        Z = np.asarray(Z, dtype=np.int64)
+        types = table[np.clip(Z, 0, len(table) - 1)]
+        if len(types) and types.min() < 0:
+            raise ValueError(f"element Z={int(Z[np.argmin(types)])} is not covered by the potential {self.species}")
+        return types
+
+    def evaluate_packed(self, n_atoms, Z, pos, cell, pbc, relax: bool = False, fixed_mask=None, relax_steps: int | None = None,
+                        fmax: float = 0.01, optimizer=None, **kwargs) -> dict:
+        """``calculate_batch`` (``relax=False``) / ``relax_batch`` (``relax=True``) with the ABI's packed arrays on both sides
+        (``n_atoms [B]``, atomic numbers ``Z [sum N]``, ``pos [sum N, 3]``, ``cell [B, 9]``, ``pbc [B, 3]``, ``fixed_mask
+        [sum N]``): what ``mc.ChainEnsemble`` calls every MC step -- no per-slab objects (4 096 GaN chains: the per-slab
+        bookkeeping was 41 % of an MC step, ``profiles/r04/bench_gan.jsonl``).  Returns fp64 ``energy [B]`` (the static energies of
+        the final geometries), ``forces``, ``energy_atoms``, ``positions``, ``cfg_start``, ``oob [B]`` (the +-1000 guard of
+        ``mcmc/dynamics.py:159-168``), ``energy_std`` / ``saturated`` (zeros: one deterministic fp64 potential), and for
+        relaxations ``iterations`` / ``evaluations`` / ``stop`` (CG) or ``n_steps`` / ``converged`` (FIRE, BFGS)."""
+        if optimizer is None:
+            optimizer = self.parameters.get("optimizer", "LAMMPS")
+        if relax and not self.packed_supported(True, optimizer):
+            raise backend.BackendError(f"evaluate_packed relaxes on the device only (CG / LAMMPS, FIRE, BFGS), not with {optimizer!r}")
+        n_atoms = np.ascontiguousarray(n_atoms, dtype=np.int32)
+        B = len(n_atoms)
+        types = self._types_of(Z)
+        pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
+        cell = np.asarray(cell, dtype=np.float64).reshape(B, 9)
+        pbc = np.ones((B, 3), np.uint8) if self.all_periodic else np.asarray(pbc).astype(np.uint8).reshape(B, 3)
+        eng = self._get_engine()
+        extra = {}
+        if not relax:
+            e, ea, f = eng.evaluate_arrays_f64(n_atoms, types, pos, cell, pbc)
+            new_pos = pos
+        elif str(optimizer).upper() in ("CG", "LAMMPS"):
+            steps = int(self.relax_steps if relax_steps is None else relax_steps)
+            e, ea, f, new_pos, it, ev, why = eng.relax_cg_arrays_f64(n_atoms, types, pos, cell, pbc, fixed=fixed_mask, max_iter=steps,
+                                                                     etol=kwargs.get("etol", 1e-5), ftol=kwargs.get("ftol", 1e-5))
+            extra = {"iterations": it, "evaluations": ev, "stop": why}
+        else:
+            steps = int(self.relax_steps if relax_steps is None else relax_steps)
+            e, ea, f, new_pos, nst, conv = eng.relax_arrays_f64(n_atoms, types, pos, cell, pbc, fixed=fixed_mask, max_steps=steps,
+                                                                fmax=fmax, optimizer=optimizer)
+            extra = {"n_steps": nst, "converged": conv}
+        start = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
+        fabs = np.abs(f).max(axis=1) if len(f) else np.zeros(0)
+        nonempty = start[1:] > start[:-1]
+        max_force = np.zeros(B)
+        if nonempty.any():
+            max_force[nonempty] = np.maximum.reduceat(fabs, start[:-1][nonempty])
+        with np.errstate(invalid="ignore"):
+            oob = (~np.isfinite(e)) | (~np.isfinite(max_force)) | (np.abs(e) > self.ENERGY_THRESHOLD) \
+                | (max_force > self.MAX_FORCE_THRESHOLD)
+        return {"energy": e, "energy_std": np.zeros(B), "forces": f, "energy_atoms": ea, "positions": new_pos, "cfg_start": start,
+                "saturated": np.zeros(B, bool), "oob": oob, **extra}
+
+
 class TersoffSurfCalc(_AnalyticSurfCalc):
     """Tersoff energy / per-atom energies / forces on MI355X (drop-in for ``LAMMPSSurfCalc`` with
     ``pair_style tersoff``, reference ``calculators.py:492-752``): ``energy`` is the static energy,
@@ -1190,6 +1261,16 @@ class LAMMPSSurfCalc(_AnalyticSurfCalc):
         if fixed_indices is None and self.bulk_index > 0:
             fixed_indices = [np.arange(min(self.bulk_index, len(a))) for a in atoms_list]
         return super().relax_batch(atoms_list, fixed_indices=fixed_indices, **kwargs)
+
+    def evaluate_packed(self, n_atoms, Z, pos, cell, pbc, relax: bool = False, fixed_mask=None, **kwargs) -> dict:
+        """As the base class; relaxations without a mask hold the template's bulk group (the first ``bulk_index`` atoms of every slab)."""
+        self._configure()
+        if relax and fixed_mask is None and self.bulk_index > 0:
+            n_atoms = np.asarray(n_atoms, dtype=np.int64)
+            start = np.concatenate([[0], np.cumsum(n_atoms)])
+            local = np.arange(int(start[-1])) - np.repeat(start[:-1], n_atoms)
+            fixed_mask = (local < self.bulk_index).astype(np.uint8)
+        return super().evaluate_packed(n_atoms, Z, pos, cell, pbc, relax=relax, fixed_mask=fixed_mask, **kwargs)
 
 
 LAMMMPSCalc = LAMMPSSurfCalc      # (the reference's base class name, spelled as there)

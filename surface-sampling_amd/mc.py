@@ -637,6 +637,15 @@ class ChainEnsemble:
             return None
         return ("chem", order)
 
+    def _packed_supported(self) -> bool:
+        """Whether the calculator's ``evaluate_packed`` serves this ensemble's request (``calc.packed_supported(relax,
+        optimizer)``; calculators without the method: everything but relaxations with a host-driven optimizer)."""
+        ask = getattr(self.calc, "packed_supported", None)
+        if ask is not None:
+            return bool(ask(self.relax, self.optimizer))
+        return not (self.relax and (not isinstance(self.optimizer, str)
+                                    or any(k in self.optimizer for k in ("CG", "LAMMPS", "BFGSLineSearch"))))
+
     def _evaluate_packed(self, state: ChainState, idx, mode):
         n_atoms, numbers, positions, ads_chain, z_ads = self.batch_arrays(state, idx)
         b, nb = len(idx), len(self.base)
@@ -684,9 +693,7 @@ class ChainEnsemble:
         """Surface energies of the chains ``which`` (default all) in ``state``: one lock-step batched relaxation
         (or single-point evaluation) of their unrelaxed slabs.  Returns ``(energies, relaxed_structures)``."""
         idx = np.arange(len(state.species)) if which is None else np.asarray(which)
-        if self.fast_path and hasattr(self.calc, "evaluate_packed") and len(idx) \
-                and not (self.relax and (not isinstance(self.optimizer, str)
-                                         or any(k in self.optimizer for k in ("CG", "LAMMPS", "BFGSLineSearch")))):
+        if self.fast_path and hasattr(self.calc, "evaluate_packed") and len(idx) and self._packed_supported():
             mode = self._packed_surface_energy()
             if mode is not None:
                 return self._evaluate_packed(state, idx, mode)

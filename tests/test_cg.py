@@ -159,3 +159,47 @@ def test_gan_batched_mc_with_lammps_style_relaxation(golden, oracle_mod):
             assert np.array_equal(r.positions[fixed], g.positions[fixed])
         runs.append((ens.state.species.copy(), ens.state.energy.copy()))
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("relax,optimizer", [(True, "LAMMPS"), (True, "FIRE"), (False, "LAMMPS")])
+def test_gan_packed_mc_path_equals_the_per_slab_path(golden, relax, optimizer):
+    """``TersoffSurfCalc.evaluate_packed`` (packed arrays in and out, what ``ChainEnsemble`` calls every step) against the
+    per-slab path (``relax_batch`` / ``calculate_batch`` with one object per slab): same seed, identical accept masks,
+    occupations, energies (bit for bit), per-atom energies and relaxed geometries -- semigrand and canonical steps."""
+    from surface_sampling_amd import mc
+    from surface_sampling_amd.calculators import TersoffSurfCalc
+
+    g = golden.structure("GaN_3x3_pristine")
+    ztop = g.positions[:, 2].max()
+    coords = np.array([(i + 0.5) / 3 * g.cell[0] + (j + 0.5) / 3 * g.cell[1] for i in range(3) for j in range(3)], float)
+    coords[:, 2] = ztop + 1.8
+    fixed = np.flatnonzero(g.positions[:, 2] < ztop - 3.0)
+    runs = []
+    for fast in (True, False):
+        calc = TersoffSurfCalc(golden.tersoff_params, ["Ga", "N"], device="cuda:0")
+        calc.set(relax_steps=25)
+        ens = mc.ChainEnsemble(g, coords, ("Ga", "N"), 7, calc, seed=6, relax=relax, relax_steps=25, fmax=0.05,
+                               fixed_indices=fixed, temperature=0.4, optimizer=optimizer)
+        ens.fast_path = fast
+        assert ens._packed_supported()
+        ens.initialize()
+        acc = np.stack([ens.step_semigrand() for _ in range(4)] + [ens.step_canonical() for _ in range(2)])
+        runs.append((acc, ens))
+    (a, ea), (b, eb) = runs
+    assert np.array_equal(a, b) and np.array_equal(ea.state.species, eb.state.species)
+    assert np.array_equal(ea.state.energy, eb.state.energy) and np.array_equal(ea.oob, eb.oob)
+    for k in range(7):
+        assert np.array_equal(ea.relaxed[k].numbers, eb.relaxed[k].numbers)
+        assert np.array_equal(ea.relaxed[k].positions, eb.relaxed[k].positions)
+        assert np.array_equal(ea.per_atom_energies[k], eb.per_atom_energies[k])
+    assert a.any()
+    # a host-driven optimizer is not served by the packed path, and asking for it directly fails loudly
+    from surface_sampling_amd import backend
+    assert not calc.packed_supported(True, "BFGSLineSearch") and calc.packed_supported(False, "BFGSLineSearch")
+    n_atoms, numbers, positions, _, _ = ea.batch_arrays(ea.state, np.arange(2))
+    with pytest.raises(backend.BackendError, match="on the device only"):
+        calc.evaluate_packed(n_atoms, numbers, positions, np.tile(np.ravel(g.cell), (2, 1)), np.ones((2, 3), np.uint8),
+                             relax=True, optimizer="BFGSLineSearch")
+    with pytest.raises(ValueError, match="not covered"):
+        calc.evaluate_packed([1], [38], [[0.0, 0.0, 0.0]], np.ravel(g.cell)[None], np.ones((1, 3), np.uint8))

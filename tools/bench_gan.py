@@ -1,0 +1,63 @@
+"""Secondary measurement (not the BASELINE metric): the reference's GaN(0001) configuration -- BASELINE configs[1], Tersoff, canonical
+sampling with 12 Ga adatoms on the 3 x 3 slab (36 + 12 atoms), every proposal relaxed with the LAMMPS-style CG minimiser (<= 100
+iterations) before the Metropolis test -- as batched MC over B chains on one GPU (`mc.ChainEnsemble` + `TersoffSurfCalc`, fp64).
+Prints one JSON line per chain count.  The reference's own figure for the same loop: 32.667 s for 1 040 proposals of ONE chain =
+31 ms per proposal (/root/reference/tutorials/GaN_0001.ipynb:6356, CPU, in-process LAMMPS).
+Usage: python tools/bench_gan.py [--chains 256,1024,4096] [--steps 5] [--relax-steps 100]"""
+import argparse, json, os, sys, time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chains", default="256,1024,4096")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--relax-steps", type=int, default=100)
+    ap.add_argument("--sites", type=int, default=6, help="n x n adsorption-site grid above the slab")
+    args = ap.parse_args()
+    from surface_sampling_amd import mc, structures
+    from surface_sampling_amd.calculators import TersoffSurfCalc
+
+    g = os.path.join(ROOT, "tests", "golden")
+    S = np.load(os.path.join(g, "structures.npz"))
+    with open(os.path.join(g, "GaN_tersoff_params.json")) as fh:
+        params = np.array(json.load(fh)["params_ijk"], dtype=np.float64)
+    k = "GaN_3x3_pristine"
+    base = structures.Structure(S[f"{k}.numbers"], S[f"{k}.positions"], S[f"{k}.cell"], S[f"{k}.pbc"])
+    ztop = base.positions[:, 2].max()
+    n = args.sites
+    coords = np.array([(i + 0.5) / n * base.cell[0] + (j + 0.5) / n * base.cell[1] for i in range(n) for j in range(n)], float)
+    coords[:, 2] = ztop + 1.8
+    fixed = np.flatnonzero(base.positions[:, 2] < ztop - 3.0)
+    for B in [int(x) for x in args.chains.split(",")]:
+        calc = TersoffSurfCalc(params, ["Ga", "N"], device="cuda:0")
+        calc.set(relax_steps=args.relax_steps)
+        ens = mc.ChainEnsemble(base, coords, ("Ga",), B, calc, seed=4, relax=True, relax_steps=args.relax_steps,
+                               fixed_indices=fixed, temperature=0.3, optimizer="LAMMPS")
+        state = ens.state                                           # the tutorial's composition: 12 Ga adatoms per chain, evenly spread
+        for site in ens.even_adsorption_sites(12):
+            state = ens.apply(state, np.full(B, int(site), np.int64), np.zeros(B, np.int64))
+        ens.state = state
+        assert (ens.num_adsorbates() == 12).all()
+        ens.initialize()
+        ens.step_canonical()                                        # warm-up (engine capacities settle)
+        n0 = ens.n_evaluations
+        t0 = time.perf_counter()
+        acc = [ens.step_canonical().mean() for _ in range(args.steps)]
+        dt = time.perf_counter() - t0
+        line = {"metric": "batched canonical MC proposals/s, GaN(0001) 3x3 Tersoff, every proposal CG-relaxed (<= %d iterations)" % args.relax_steps,
+                "chains": B, "atoms_per_chain": int(len(base) + 12), "sites": n * n, "mc_steps": args.steps,
+                "s_per_lockstep": dt / args.steps, "proposals_per_s": B * args.steps / dt, "acceptance": float(np.mean(acc)),
+                "mean_energy_eV": float(np.mean(ens.state.energy)), "relaxations": int(ens.n_evaluations - n0),
+                "reference": {"s_per_proposal": 32.667 / 1040, "where": "tutorials/GaN_0001.ipynb:6356 (one chain, CPU, in-process LAMMPS)"}}
+        line["speedup_vs_reference_per_proposal"] = line["proposals_per_s"] * line["reference"]["s_per_proposal"]
+        print(json.dumps(line), flush=True)
+        del ens, calc
+
+
+if __name__ == "__main__":
+    main()
