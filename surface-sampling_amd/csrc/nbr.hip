@@ -179,54 +179,91 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
     }
 }
 
-// exclusive scan of padded degrees -> row_start ; counters[0] = slots, [1] = real edges.  One workgroup walks the array in
-// tiles of 4096 (4 consecutive atoms per thread, int4 loads): wave-level shuffles + one LDS exchange per tile, running
-// prefix carried in registers.
+// exclusive scan of padded degrees -> row_start ; counters[0] = slots, [1] = real edges.  Tiles of 4096 atoms (4 consecutive
+// atoms per thread, int4 loads; wave-level DPP scans + one LDS exchange), one workgroup per tile, two launches: k_scan_tiles
+// writes every tile's (padded, real) sums, k_scan_rows adds up the sums of the tiles in front of its own (a few hundred
+// values at most) and scans its tile.  (One workgroup walking all tiles took 72 us for the 197 k atoms of 4 096 GaN chains,
+// 27 us for the 66 k atoms of the PaiNN bench: 1.5 us of exposed load latency + two barriers per tile.)
+struct ScanTile {
+    int d[4], pd[4], p, real;
+};
+__device__ __forceinline__ ScanTile scan_tile_load(int n, const int *__restrict__ deg, int i0) {
+    ScanTile s;
+    if (i0 + 3 < n) {
+        const int4 v = *reinterpret_cast<const int4 *>(deg + i0);   // (deg is 256-byte aligned, i0 a multiple of 4)
+        s.d[0] = v.x; s.d[1] = v.y; s.d[2] = v.z; s.d[3] = v.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s.d[u] = i0 + u < n ? deg[i0 + u] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s.pd[u] = i0 + u < n ? max((s.d[u] + 3) & ~3, 8) : 0;
+    s.p = s.pd[0] + s.pd[1] + s.pd[2] + s.pd[3];
+    s.real = s.d[0] + s.d[1] + s.d[2] + s.d[3];
+    return s;
+}
+
 __global__ void __launch_bounds__(1024)
-k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int *__restrict__ counters,
-            long long slot_cap) {
+k_scan_tiles(int n, const int *__restrict__ deg, int *__restrict__ tile_sums /*[tiles][2]*/) {
     __shared__ int wsum[16], wreal[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    long long run = 0, run_real = 0;
-    for (int base = 0; base < n; base += 4096) {
-        const int i0 = base + 4 * t;
-        int d[4], pd[4];
-        if (i0 + 3 < n) {
-            const int4 v = *reinterpret_cast<const int4 *>(deg + i0);   // (deg is 256-byte aligned, i0 a multiple of 4)
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) d[u] = i0 + u < n ? deg[i0 + u] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pd[u] = i0 + u < n ? max((d[u] + 3) & ~3, 8) : 0;
-        const int p = pd[0] + pd[1] + pd[2] + pd[3];
-        const int x = wave_incl_scan_i32(p), xr = wave_incl_scan_i32(d[0] + d[1] + d[2] + d[3]);   // inclusive scans of the thread sums inside the wave
-        if (lane == 63) { wsum[w] = x; wreal[w] = xr; }
-        __syncthreads();
-        int woff = 0, tile = 0, tile_real = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int v = wsum[k];
-            if (k < w) woff += v;
-            tile += v;
-            tile_real += wreal[k];
-        }
-        int o = (int)(run + woff + x - p);   // first slot of this thread's first atom
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i0 + u < n) row_start[i0 + u] = o;
-            o += pd[u];
-        }
-        run += tile;
-        run_real += tile_real;
-        __syncthreads();
-    }
+    const ScanTile s = scan_tile_load(n, deg, blockIdx.x * 4096 + 4 * t);
+    const int x = wave_incl_scan_i32(s.p), xr = wave_incl_scan_i32(s.real);
+    if (lane == 63) { wsum[w] = x; wreal[w] = xr; }
+    __syncthreads();
     if (t == 0) {
-        row_start[n] = (int)run;
-        counters[0] = (int)run;
-        counters[1] = (int)run_real;
-        counters[2] = (run > slot_cap - 64 || run > 2147483000LL) ? 1 : 0;
+        int a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a += wsum[k]; b += wreal[k]; }
+        tile_sums[2 * blockIdx.x] = a;
+        tile_sums[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int *__restrict__ counters,
+            long long slot_cap, const int *__restrict__ tile_sums) {
+    __shared__ int wsum[16];
+    __shared__ long long wrun[16], wrun_real[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, tile = blockIdx.x;
+    const bool last = tile == (int)gridDim.x - 1;
+    // slots (and, in the last workgroup, real edges) in front of this tile
+    long long run = 0, run_real = 0;
+    for (int k = t; k < tile; k += 1024) {
+        run += tile_sums[2 * k];
+        if (last) run_real += tile_sums[2 * k + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        run += __shfl_xor(run, o);
+        run_real += __shfl_xor(run_real, o);
+    }
+    if (lane == 0) { wrun[w] = run; wrun_real[w] = run_real; }
+    const ScanTile s = scan_tile_load(n, deg, tile * 4096 + 4 * t);
+    const int x = wave_incl_scan_i32(s.p);   // inclusive scan of the thread sums inside the wave
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    run = 0; run_real = 0;
+    int woff = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        run += wrun[k];
+        run_real += wrun_real[k];
+        if (k < w) woff += wsum[k];
+    }
+    const int i0 = tile * 4096 + 4 * t;
+    int o = (int)(run + woff + x - s.p);   // first slot of this thread's first atom
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (i0 + u < n) row_start[i0 + u] = o;
+        o += s.pd[u];
+    }
+    if (last && t == 0) {
+        const long long total = run + tile_sums[2 * tile], total_real = run_real + tile_sums[2 * tile + 1];
+        row_start[n] = (int)total;
+        counters[0] = (int)total;
+        counters[1] = (int)total_real;
+        counters[2] = (total > slot_cap - 64 || total > 2147483000LL) ? 1 : 0;
     }
 }
 
@@ -471,7 +508,7 @@ int build_neighbors(vssr_handle *h, double cutoff) {
     hipStream_t st = h->stream;
     if (h->d_wpos.ensure(sizeof(double) * 3 * n) || h->d_wrap.ensure(sizeof(int) * 3 * n) ||
         h->d_deg.ensure(sizeof(int) * n) || h->d_row_start.ensure(sizeof(int) * (n + 1)) ||
-        h->d_counters.ensure(sizeof(int) * 4))
+        h->d_counters.ensure(sizeof(int) * 4) || h->d_tile_sums.ensure(sizeof(int) * 2 * ((size_t)n / 4096 + 1)))
         return set_err(h, VSSR_E_NOMEM, "neighbor buffers: out of device memory");
     if (h->slot_cap < (int64_t)n * h->cap_per_atom + 64) h->slot_cap = (int64_t)n * h->cap_per_atom + 64;
     if (h->d_edge.ensure(sizeof(float4) * h->slot_cap) || h->d_edge_S.ensure(sizeof(int) * h->slot_cap) ||
@@ -493,8 +530,10 @@ int build_neighbors(vssr_handle *h, double cutoff) {
                        h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_nimg.as<int>(),
                        cutoff * cutoff, h->d_deg.as<int>(), (const int *)nullptr, (float4 *)nullptr,
                        (int *)nullptr, (long long)0, hits_buf, hits_stride, h->active_mask);
-    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, n, h->d_deg.as<int>(),
-                       h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap);
+    const int n_tiles = n > 0 ? (n + 4095) / 4096 : 1;   // (an empty batch still writes its counters)
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, st, n, h->d_deg.as<int>(), h->d_tile_sums.as<int>());
+    hipLaunchKernelGGL(k_scan_rows, dim3(n_tiles), dim3(1024), 0, st, n, h->d_deg.as<int>(),
+                       h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap, h->d_tile_sums.as<int>());
     hipLaunchKernelGGL(k_nbr<true>, wgrd, wblk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_nimg.as<int>(),
                        cutoff * cutoff, h->d_deg.as<int>(), h->d_row_start.as<int>(),

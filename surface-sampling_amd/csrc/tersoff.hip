@@ -8,31 +8,81 @@
 // three-body terms and fc(r_ik) from (i,j,k); b_ij with the LAMMPS asymptotic branches;
 // pe/atom splits every directed pair term half/half between i and j.
 //
-// The site energy E_i depends only on the vectors r_ij from i to its neighbors, so one thread owns
-// one centre: it writes G_slot = dE_i/d r_ij for its own slots, and the force on atom c is
-// gathered as sum_{slots of c} (G[slot] - G[rev[slot]]) — no atomics, deterministic.
+// The site energy E_i depends only on the vectors r_ij from i to its neighbors, so a centre is self-contained:
+// G_slot = dE_i/d r_ij is written for its own slots, and the force on atom c is gathered as
+// sum_{slots of c} (G[slot] - G[rev[slot]]) — no atomics, deterministic.
+//
+// k_tersoff_site4 (rows of <= TS_MAXD slots, <= 4 species: every row of the GaN workloads): FOUR lanes per centre.  The
+// neighborhood (unit vectors, distances, types) is written to LDS once, the parameter entries sit in LDS next to it, and
+// every loop of the three-body sums runs from LDS -- the first form of this kernel (k_tersoff_site, one thread per centre,
+// kept for longer rows / more species) chased edge -> type -> parameters -> position through global memory for every (j, k)
+// and accumulated dE/dr_ik with global read-modify-writes: 882 us per evaluation of 4 096 x 48 atoms, all of it latency
+// (profiles/r04/NOTES_tersoff.md).  A lane owns the slots n = q, q + 4, ... of its centre in both passes:
+//   pass 1 (slot as j):  zeta_ij over all k, b_ij, the pair energy, dV/dr_ij and pref_j = 1/2 fc fA db/dzeta -> LDS
+//   pass 2 (slot n):     G_n = dV/dr_n rhat_n + sum_m [ pref_n dzeta_nm/dr_n + pref_m dzeta_mn/dr_n ]   (n as j, then n as k)
+// so every G is produced by one lane in registers and stored once.
 #include "vssr_internal.h"
 
 namespace vssr {
 
 struct TersP { double m, gamma, lam3, c, d, h, n, beta, lam2, B, R, D, lam1, A; };
 
+// sin and cos of an argument in [-pi/2, pi/2] (the cutoff shell maps onto exactly that interval): Taylor series to x^21 / x^22,
+// truncation error < 2e-18.  The library's fp64 sin() + cos() were ~300 instructions per three-body term once any lane of a
+// wave sat in a cutoff shell -- together with exp() most of what k_tersoff_site4 executed (profiles/r04/NOTES_tersoff.md).
+__device__ __forceinline__ void t_sincos_half_pi(double x, double &sn, double &cs) {
+    const double z = x * x;
+    double ps = -1.0 / 51090942171709440000.0;                 // -1/21!
+    ps = fma(ps, z, 1.0 / 121645100408832000.0);               //  1/19!
+    ps = fma(ps, z, -1.0 / 355687428096000.0);                 // -1/17!
+    ps = fma(ps, z, 1.0 / 1307674368000.0);                    //  1/15!
+    ps = fma(ps, z, -1.0 / 6227020800.0);                      // -1/13!
+    ps = fma(ps, z, 1.0 / 39916800.0);                         //  1/11!
+    ps = fma(ps, z, -1.0 / 362880.0);                          // -1/9!
+    ps = fma(ps, z, 1.0 / 5040.0);                             //  1/7!
+    ps = fma(ps, z, -1.0 / 120.0);                             // -1/5!
+    ps = fma(ps, z, 1.0 / 6.0);                                //  1/3!
+    sn = fma(-x * z, ps, x);
+    double pc = 1.0 / 1124000727777607680000.0;                //  1/22!
+    pc = fma(pc, z, -1.0 / 2432902008176640000.0);             // -1/20!
+    pc = fma(pc, z, 1.0 / 6402373705728000.0);                 //  1/18!
+    pc = fma(pc, z, -1.0 / 20922789888000.0);                  // -1/16!
+    pc = fma(pc, z, 1.0 / 87178291200.0);                      //  1/14!
+    pc = fma(pc, z, -1.0 / 479001600.0);                       // -1/12!
+    pc = fma(pc, z, 1.0 / 3628800.0);                          //  1/10!
+    pc = fma(pc, z, -1.0 / 40320.0);                           // -1/8!
+    pc = fma(pc, z, 1.0 / 720.0);                              //  1/6!
+    pc = fma(pc, z, -1.0 / 24.0);                              // -1/4!
+    pc = fma(pc, z, 0.5);                                      //  1/2!
+    cs = fma(-z, pc, 1.0);
+}
+// cutoff function and its derivative (LAMMPS ters_fc / ters_fc_d)
+__device__ inline void t_fc_both(double r, const TersP &p, double &fc, double &dfc) {
+    if (r < p.R - p.D) { fc = 1.0; dfc = 0.0; return; }
+    if (r > p.R + p.D) { fc = 0.0; dfc = 0.0; return; }
+    double sn, cs;
+    t_sincos_half_pi(M_PI_2 * (r - p.R) / p.D, sn, cs);
+    fc = 0.5 * (1.0 - sn);
+    dfc = -(M_PI_4 / p.D) * cs;
+}
 __device__ inline double t_fc(double r, const TersP &p) {
-    if (r < p.R - p.D) return 1.0;
-    if (r > p.R + p.D) return 0.0;
-    return 0.5 * (1.0 - sin(M_PI_2 * (r - p.R) / p.D));
+    double fc, dfc;
+    t_fc_both(r, p, fc, dfc);
+    return fc;
 }
 __device__ inline double t_fc_d(double r, const TersP &p) {
-    if (r < p.R - p.D || r > p.R + p.D) return 0.0;
-    return -(M_PI_4 / p.D) * cos(M_PI_2 * (r - p.R) / p.D);
+    double fc, dfc;
+    t_fc_both(r, p, fc, dfc);
+    return dfc;
 }
 __device__ inline void t_gijk(double cs, const TersP &p, double &g, double &dg) {
     double c2 = p.c * p.c, d2 = p.d * p.d, hc = p.h - cs;
-    double den = d2 + hc * hc;
-    g = p.gamma * (1.0 + c2 / d2 - c2 / den);
-    dg = p.gamma * (-2.0 * c2 * hc) / (den * den);
+    double inv = 1.0 / (d2 + hc * hc);
+    g = p.gamma * (1.0 + c2 / d2 - c2 * inv);
+    dg = p.gamma * (-2.0 * c2 * hc) * (inv * inv);
 }
 __device__ inline void t_ex(double rij, double rik, const TersP &p, double &ex, double &dex) {
+    if (p.lam3 == 0.0) { ex = 1.0; dex = 0.0; return; }   // exp(0) = 1, derivative lam3 (or 3 lam3 arg^2) = 0: the same values, no exp()
     double arg = p.lam3 * (rij - rik), darg = p.lam3;
     if ((int)p.m == 3) {
         darg = 3.0 * p.lam3 * arg * arg;
@@ -42,9 +92,14 @@ __device__ inline void t_ex(double rij, double rik, const TersP &p, double &ex, 
     else if (arg < -69.0776) { ex = 0.0; dex = 0.0; }
     else { ex = exp(arg); dex = ex * darg; }
 }
-__device__ inline void t_bij(double zeta, const TersP &p, double &b, double &db) {
+// thresholds of the asymptotic branches of b_ij (LAMMPS pair_tersoff.cpp ters_bij): functions of the entry's n only
+__device__ inline void t_bij_limits(double n, double &c1, double &c2) {
+    if (n == 1.0) { c1 = 1.0 / 2.0e-16; c2 = 1.0 / 2.0e-8; return; }
+    c1 = pow(2.0 * n * 1.0e-16, -1.0 / n);
+    c2 = pow(2.0 * n * 1.0e-8, -1.0 / n);
+}
+__device__ inline void t_bij(double zeta, const TersP &p, double c1, double c2, double &b, double &db) {
     double tmp = p.beta * zeta, n = p.n;
-    double c1 = pow(2.0 * n * 1.0e-16, -1.0 / n), c2 = pow(2.0 * n * 1.0e-8, -1.0 / n);
     double c3 = 1.0 / c2, c4 = 1.0 / c1;
     if (tmp > c1) { b = 1.0 / sqrt(tmp); db = p.beta * -0.5 * pow(tmp, -1.5); return; }
     if (tmp > c2) {
@@ -54,9 +109,20 @@ __device__ inline void t_bij(double zeta, const TersP &p, double &b, double &db)
     }
     if (tmp < c4) { b = 1.0; db = 0.0; return; }
     if (tmp < c3) { b = 1.0 - pow(tmp, n) / (2.0 * n); db = -0.5 * p.beta * pow(tmp, n - 1.0); return; }
+    if (n == 1.0) {   // (1 + x)^(-1/2) and (1 + x)^(-3/2) without pow(): the GaN entries, and every potential with n = 1
+        const double s1 = 1.0 + tmp;
+        b = 1.0 / sqrt(s1);
+        db = -0.5 * (b / s1) * tmp / zeta;
+        return;
+    }
     double tn = pow(tmp, n);
     b = pow(1.0 + tn, -1.0 / (2.0 * n));
-    db = -0.5 * pow(1.0 + tn, -1.0 - 1.0 / (2.0 * n)) * tn / zeta;
+    db = -0.5 * (b / (1.0 + tn)) * tn / zeta;   // (1 + tn)^(-1 - 1/(2n)) = b / (1 + tn)
+}
+__device__ inline void t_bij(double zeta, const TersP &p, double &b, double &db) {
+    double c1, c2;
+    t_bij_limits(p.n, c1, c2);
+    t_bij(zeta, p, c1, c2, b, db);
 }
 
 __device__ inline void edge_vec(const double *__restrict__ wpos, const double *C, int i, int j, int packedS,
@@ -66,17 +132,18 @@ __device__ inline void edge_vec(const double *__restrict__ wpos, const double *C
         r[x] = wpos[3 * j + x] - wpos[3 * i + x] + s0 * C[x] + s1 * C[3 + x] + s2 * C[6 + x];
 }
 
-__global__ void k_tersoff_site(int N, int nt, const TersP *__restrict__ P, const int *__restrict__ type,
+__global__ void __launch_bounds__(64) k_tersoff_site(int N, int nt, const TersP *__restrict__ P, const int *__restrict__ type,
                                const int *__restrict__ atom_cfg, const double *__restrict__ cell,
                                const double *__restrict__ wpos, const int *__restrict__ row_start,
                                const float4 *__restrict__ edge, const int *__restrict__ edge_S,
                                const int *__restrict__ counters, double *__restrict__ eps /*[slots]*/,
-                               double *__restrict__ gslot /*[slots][3]*/, ActiveView av) {
+                               double *__restrict__ gslot /*[slots][3]*/, ActiveView av, int longer_than) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N || counters[2] || !av.atom(i)) return;
     const double *C = cell + 9 * atom_cfg[i];
     const int ti = type[i];
     const int e0 = row_start[i], e1 = row_start[i + 1];
+    if (e1 - e0 <= longer_than) return;   // rows k_tersoff_site4 has done (-1: every row)
     for (int e = e0; e < e1; ++e) {
         eps[e] = 0.0;
         gslot[3 * e] = 0.0; gslot[3 * e + 1] = 0.0; gslot[3 * e + 2] = 0.0;
@@ -141,6 +208,145 @@ __global__ void k_tersoff_site(int N, int nt, const TersP *__restrict__ P, const
     }
 }
 
+
+constexpr int TS_MAXD = 16, TS_CENTRES = 64, TS_LANES = 4, TS_MAXP = 64;   // slots per row in LDS; centres / workgroup; lanes / centre; 4^3 entries
+
+struct TersTri { double g, dg, ex, dex, fc, dfc; };
+// three-body factors of (i, j, k) with parameter entry p: false when k is outside the entry's cutoff
+__device__ __forceinline__ bool t_tri(const TersP &p, double rj, double rk, double cs, TersTri &o) {
+    if (rk > p.R + p.D) return false;
+    t_gijk(cs, p, o.g, o.dg);
+    t_ex(rj, rk, p, o.ex, o.dex);
+    t_fc_both(rk, p, o.fc, o.dfc);
+    return true;
+}
+
+__global__ void __launch_bounds__(TS_CENTRES * TS_LANES)
+k_tersoff_site4(int N, int nt, const TersP *__restrict__ P, const int *__restrict__ type,
+                const int *__restrict__ atom_cfg, const double *__restrict__ cell,
+                const double *__restrict__ wpos, const int *__restrict__ row_start,
+                const float4 *__restrict__ edge, const int *__restrict__ edge_S,
+                const int *__restrict__ counters, double *__restrict__ eps /*[slots]*/,
+                double *__restrict__ gslot /*[slots][3]*/, ActiveView av) {
+    __shared__ double s_ux[TS_MAXD][TS_CENTRES], s_uy[TS_MAXD][TS_CENTRES], s_uz[TS_MAXD][TS_CENTRES];   // unit vectors i -> n
+    __shared__ double s_r[TS_MAXD][TS_CENTRES], s_pref[TS_MAXD][TS_CENTRES];
+    __shared__ signed char s_tp[TS_MAXD][TS_CENTRES];                                                     // type of n, -1: padding slot
+    __shared__ TersP s_P[TS_MAXP];
+    __shared__ double s_lim[TS_MAXP][2];   // b_ij branch thresholds of every entry
+    if (counters[2]) return;   // (uniform)
+    const int tid = threadIdx.x, cb = tid >> 2, q = tid & 3;
+    const int i = blockIdx.x * TS_CENTRES + cb;
+    for (int t = tid; t < nt * nt * nt; t += TS_CENTRES * TS_LANES) {
+        s_P[t] = P[t];
+        t_bij_limits(P[t].n, s_lim[t][0], s_lim[t][1]);
+    }
+    int e0 = 0, deg = 0, ti = 0;
+    bool mine = i < N && av.atom(i);
+    if (mine) {
+        e0 = row_start[i];
+        deg = row_start[i + 1] - e0;
+        mine = deg <= TS_MAXD;   // longer rows: k_tersoff_site
+        ti = type[i];
+    }
+    if (!mine) deg = 0;
+    // ---- neighborhood -> LDS -----------------------------------------------------------------------------------
+    if (deg > 0) {
+        const double *C = cell + 9 * atom_cfg[i];
+        for (int n = q; n < deg; n += TS_LANES) {
+            const int j = __float_as_int(edge[e0 + n].w);
+            signed char tp = -1;
+            double u[3] = {0.0, 0.0, 0.0}, r = 0.0;
+            if (j >= 0) {
+                edge_vec(wpos, C, i, j, edge_S[e0 + n], u);
+                r = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+                const double inv = 1.0 / r;
+                u[0] *= inv; u[1] *= inv; u[2] *= inv;
+                tp = (signed char)type[j];
+            }
+            s_ux[n][cb] = u[0]; s_uy[n][cb] = u[1]; s_uz[n][cb] = u[2];
+            s_r[n][cb] = r; s_tp[n][cb] = tp;
+        }
+    }
+    __syncthreads();
+    // ---- pass 1: the lane's slots as j ---------------------------------------------------------------------------
+    // (rolled loops: the body holds inlined fp64 exp / sin / cos / pow; four unrolled copies of both passes were 140 KB of code,
+    // more than the instruction cache two CUs share)
+#pragma unroll 1
+    for (int n = q; n < deg; n += TS_LANES) {
+        const int tj = s_tp[n][cb];
+        double e_pair = 0.0, pref = 0.0, dVdr = 0.0;
+        if (tj >= 0) {
+            const int eij = (ti * nt + tj) * nt + tj;
+            const TersP &pij = s_P[eij];
+            const double r = s_r[n][cb];
+            if (r <= pij.R + pij.D) {
+                const double ux = s_ux[n][cb], uy = s_uy[n][cb], uz = s_uz[n][cb];
+                double zeta = 0.0;
+#pragma unroll 1
+                for (int m = 0; m < deg; ++m) {
+                    const int tk = s_tp[m][cb];
+                    if (m == n || tk < 0) continue;
+                    const double rk = s_r[m][cb];
+                    const double cs = ux * s_ux[m][cb] + uy * s_uy[m][cb] + uz * s_uz[m][cb];
+                    TersTri t;
+                    if (t_tri(s_P[(ti * nt + tj) * nt + tk], r, rk, cs, t)) zeta += t.fc * t.g * t.ex;
+                }
+                double fc, dfc;
+                t_fc_both(r, pij, fc, dfc);
+                const double fR = pij.A * exp(-pij.lam1 * r), fA = -pij.B * exp(-pij.lam2 * r);
+                double bij, dbij;
+                t_bij(zeta, pij, s_lim[eij][0], s_lim[eij][1], bij, dbij);
+                e_pair = 0.5 * fc * (fR + bij * fA);
+                dVdr = 0.5 * (dfc * (fR + bij * fA) + fc * (-pij.lam1 * fR - pij.lam2 * bij * fA));
+                pref = 0.5 * fc * fA * dbij;
+            }
+        }
+        eps[e0 + n] = e_pair;
+        gslot[3 * (e0 + n)] = dVdr;   // parked for pass 2 (the same lane reads it back and overwrites the slot's record)
+        s_pref[n][cb] = pref;
+    }
+    __syncthreads();
+    // ---- pass 2: G of the lane's slots -----------------------------------------------------------------------------
+#pragma unroll 1
+    for (int n = q; n < deg; n += TS_LANES) {
+        const int tn = s_tp[n][cb];
+        double gx = 0.0, gy = 0.0, gz = 0.0;
+        if (tn >= 0) {
+            const double dVdr = gslot[3 * (e0 + n)];
+            const double ux = s_ux[n][cb], uy = s_uy[n][cb], uz = s_uz[n][cb], r = s_r[n][cb], inv_r = 1.0 / r;
+            const double pref_n = s_pref[n][cb];
+            double su = 0.0;   // coefficient of u collected over all terms
+#pragma unroll 1
+            for (int m = 0; m < deg; ++m) {
+                const int tm = s_tp[m][cb];
+                if (m == n || tm < 0) continue;
+                const double pref_m = s_pref[m][cb];
+                if (pref_n == 0.0 && pref_m == 0.0) continue;
+                const double vx = s_ux[m][cb], vy = s_uy[m][cb], vz = s_uz[m][cb], rm = s_r[m][cb];
+                const double cs = ux * vx + uy * vy + uz * vz;
+                double a = 0.0;   // coefficient of (v - cs u) / r
+                // o = 0: n as j, m as k (d zeta_n / d r_n);  o = 1: m as j, n as k (d zeta_m / d r_n)
+#pragma unroll 1
+                for (int o = 0; o < 2; ++o) {
+                    const double pf = o ? pref_m : pref_n;
+                    if (pf == 0.0) continue;
+                    TersTri t;
+                    if (!t_tri(s_P[(ti * nt + (o ? tm : tn)) * nt + (o ? tn : tm)], o ? rm : r, o ? r : rm, cs, t)) continue;
+                    a += pf * t.fc * t.dg * t.ex;
+                    su += o ? pf * (t.dfc * t.g * t.ex - t.fc * t.g * t.dex) : pf * t.fc * t.g * t.dex;
+                }
+                a *= inv_r;
+                gx += a * (vx - cs * ux);
+                gy += a * (vy - cs * uy);
+                gz += a * (vz - cs * uz);
+            }
+            su += dVdr;
+            gx += su * ux; gy += su * uy; gz += su * uz;
+        }
+        gslot[3 * (e0 + n)] = gx; gslot[3 * (e0 + n) + 1] = gy; gslot[3 * (e0 + n) + 2] = gz;
+    }
+}
+
 __global__ void k_tersoff_gather(int N, const int *__restrict__ row_start, const int *__restrict__ rev,
                                  const int *__restrict__ counters, const double *__restrict__ eps,
                                  const double *__restrict__ gslot, double *__restrict__ e_atom,
@@ -191,10 +397,19 @@ int tersoff_run(vssr_handle *h, uint32_t want) {
     h->prof.begin(KC_TERSOFF, st);
     dim3 blk(64), grd((N + 63) / 64);
     const ActiveView av{h->active_mask, h->d_atom_cfg.as<int>()};
+    // rows of <= TS_MAXD slots: four lanes per centre from LDS; longer rows (and potentials of more than 4 species): one thread per
+    // centre.  VSSR_TERSOFF_SITE=1 forces the one-thread form for every row (A/B, tests).
+    static const bool one_thread = [] { const char *e = getenv("VSSR_TERSOFF_SITE"); return e && atoi(e) == 1; }();
+    const bool fast = !one_thread && h->n_types * h->n_types * h->n_types <= TS_MAXP;
+    if (fast)
+        hipLaunchKernelGGL(k_tersoff_site4, dim3((N + TS_CENTRES - 1) / TS_CENTRES), dim3(TS_CENTRES * TS_LANES), 0, st, N, h->n_types,
+                           h->ters_params.as<TersP>(), h->d_Z.as<int>(), h->d_atom_cfg.as<int>(), h->d_cell.as<double>(),
+                           h->d_wpos.as<double>(), h->d_row_start.as<int>(), h->d_edge.as<float4>(), h->d_edge_S.as<int>(),
+                           h->d_counters.as<int>(), eps, gslot, av);
     hipLaunchKernelGGL(k_tersoff_site, grd, blk, 0, st, N, h->n_types, h->ters_params.as<TersP>(), h->d_Z.as<int>(),
                        h->d_atom_cfg.as<int>(), h->d_cell.as<double>(), h->d_wpos.as<double>(),
                        h->d_row_start.as<int>(), h->d_edge.as<float4>(), h->d_edge_S.as<int>(),
-                       h->d_counters.as<int>(), eps, gslot, av);
+                       h->d_counters.as<int>(), eps, gslot, av, fast ? TS_MAXD : -1);
     hipLaunchKernelGGL(k_tersoff_gather, grd, blk, 0, st, N, h->d_row_start.as<int>(), h->d_rev.as<int>(),
                        h->d_counters.as<int>(), eps, gslot, h->d_ters_ea.as<double>(), h->d_ters_f.as<double>(), av);
     hipLaunchKernelGGL(k_tersoff_energy, dim3(h->n_cfg), dim3(256), 0, st, h->d_cfg_start.as<int>(),

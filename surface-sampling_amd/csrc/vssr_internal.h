@@ -276,7 +276,7 @@ struct vssr_handle {
     int n_cfg = 0, n_atoms = 0;
     std::vector<int> h_n_atoms, h_cfg_start;
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
-    vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters;
+    vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters, d_tile_sums;
     vssr::DevBuf d_erec, d_rho, d_dist, d_rho16, d_drho16, d_zslot, d_bundle, d_excl;
     vssr::DevBuf d_hits;         // neighbor search: per (centre, candidate) 64-bit hit masks of the counting pass
     // layer-0 species factorisation (painn_l0.hip)

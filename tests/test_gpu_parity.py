@@ -293,6 +293,60 @@ def test_tersoff_gpu_vs_oracle(golden, oracle_mod):
     eng.close()
 
 
+def _synthetic_tersoff(nt, seed):
+    """Random but physical-looking entries [nt, nt, nt, 14] (field order of include/vssr_eval.h: m gamma lam3 c d h n beta lam2 B R D
+    lam1 A) covering what GaN.tersoff does not: m = 3, lam3 != 0 everywhere, n != 1, tiny / huge beta (the asymptotic b_ij branches)."""
+    rng = np.random.default_rng(seed)
+    P = np.zeros((nt, nt, nt, 14))
+    for i in range(nt):
+        for j in range(nt):
+            for k in range(nt):
+                P[i, j, k] = [rng.choice([1.0, 3.0]), rng.uniform(0.05, 1.0), rng.choice([0.0, 0.4, 1.3]), rng.uniform(0.5, 4.0),
+                              rng.uniform(0.5, 3.0), rng.uniform(-0.8, 0.2), rng.choice([1.0, 0.78734, 2.5]),
+                              rng.choice([1.0, 1e-9, 1e-3, 3e9]), rng.uniform(1.2, 2.6), rng.uniform(100.0, 500.0),
+                              rng.uniform(2.5, 3.3), rng.uniform(0.15, 0.3), rng.uniform(2.0, 3.5), rng.uniform(500.0, 2000.0)]
+    return P
+
+
+def test_tersoff_synthetic_parameter_sets_and_long_rows(oracle_mod):
+    """Tersoff beyond GaN.tersoff: three species with m = 3 / lam3 != 0 / n != 1 / extreme beta entries, dense random
+    configurations whose rows run from a few to > 16 slots (the four-lanes-per-centre kernel takes rows of <= 16 slots, the
+    one-thread form the longer ones -- both in one launch), a sparse one (every row short) and an isolated atom.  Energies,
+    per-atom energies and forces against the fp64 oracle."""
+    from surface_sampling_amd import backend
+
+    def random_box(n, box, dmin, seed, nt):
+        rng = np.random.default_rng(seed)
+        pts = []
+        while len(pts) < n:
+            x = rng.uniform(0, box, 3)
+            if all(np.linalg.norm((x - y + box / 2) % box - box / 2) >= dmin for y in pts):
+                pts.append(x)
+        return rng.integers(0, nt, n).astype(np.int32), np.array(pts), np.eye(3) * box
+
+    for nt, seed in ((3, 1), (2, 2), (4, 3)):
+        P = _synthetic_tersoff(nt, seed)
+        eng = backend.TersoffEngine(P, device=0)
+        batch = []
+        for n, box, dmin, sd in ((60, 8.0, 1.7, 10 + seed), (24, 9.0, 2.0, 20 + seed), (90, 8.5, 1.55, 30 + seed)):
+            t, x, c = random_box(n, box, dmin, sd, nt)
+            batch.append((t, x, c, [1, 1, 1] if n != 24 else [1, 1, 0]))
+        batch.append((np.zeros(1, np.int32), np.zeros((1, 3)), np.eye(3) * 20.0, [0, 0, 0]))
+        e, ea, F = eng.evaluate_f64(batch)
+        st = eng.stats()
+        o, longest = 0, 0
+        for b, (t, x, c, pbc) in enumerate(batch):
+            E0, ea0, F0 = oracle_mod.tersoff(P, t, x, c, pbc)
+            n = len(t)
+            scale = max(1.0, np.abs(ea0).max())
+            assert abs(e[b] - E0) <= 1e-9 * max(1.0, abs(E0)), (nt, b, e[b], E0)
+            assert np.abs(ea[o:o + n] - ea0).max() <= 1e-9 * scale
+            assert np.abs(F[o:o + n] - F0).max() <= 1e-8 * max(1.0, np.abs(F0).max())
+            o += n
+        assert st["edges"] / st["atoms"] > 8        # dense: rows well beyond the 16-slot limit exist next to short ones
+        eng.close()
+
+
 def test_calculator_front_end_end_to_end(golden, oracle_mod):
     """The reference-shaped calculator on plain Atoms-like objects (scripts/sample_surface.py:168-183)."""
     import copy
