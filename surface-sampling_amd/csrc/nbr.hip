@@ -46,26 +46,39 @@ __global__ void k_wrap(int n, const double *__restrict__ pos, const int *__restr
     wpos[3 * i + 2] = q[2];
 }
 
-// One WAVE per centre atom: lane L tests candidate atom j = a0 + 64*chunk + L against all periodic images.
+// LPC lanes per centre atom -- a 16-lane row of a wave (the default: four centres per wave), half a wave or a whole wave:
+// lane L tests candidate atom j = a0 + LPC*chunk + L against all periodic images.
 // FILL = false counts, FILL = true writes the slots.  Slot order inside a centre is (j ascending, image shift
 // lexicographic), reproduced exactly by an exclusive wave scan of the per-lane hit counts, so the CSR is
 // identical however the work is spread over lanes.
-__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
-    const int x = wave_incl_scan_i32(v);   // DPP network (vssr_internal.h): the neighbor kernels run 5 of these per centre and are latency-bound
-    total = __builtin_amdgcn_readlane(x, 63);
-    (void)lane;
-    return x - v;
+template <int LPC>
+__device__ __forceinline__ int group_excl_scan(int v, int &total) {
+    if constexpr (LPC == 64) {
+        const int x = wave_incl_scan_i32(v);   // DPP network (vssr_internal.h): the neighbor kernels run 5 of these per centre and are latency-bound
+        total = __builtin_amdgcn_readlane(x, 63);
+        return x - v;
+    } else {   // 16 lanes per centre = one DPP row: the first four steps of the same network (32 lanes: five); the group's last lane holds the total
+        static_assert(LPC == 16 || LPC == 32, "a wave, half a wave or one 16-lane row per centre");
+        int x = v;
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);    // row_shr:1
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);    // row_shr:2
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);    // row_shr:4
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);    // row_shr:8
+        if constexpr (LPC == 32) x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+        total = __shfl(x, (threadIdx.x & 63) | (LPC - 1));
+        return x - v;
+    }
 }
 
-template <bool FILL>
+template <bool FILL, int LPC>
 __global__ void __launch_bounds__(256)
 k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
       const int *__restrict__ cfg_start, const double *__restrict__ cell, const double *__restrict__ invcell,
       const int *__restrict__ nimg, double rc2, int *__restrict__ deg, const int *__restrict__ row_start, float4 *__restrict__ edge,
       int *__restrict__ edge_S, long long slot_cap, unsigned long long *__restrict__ hits_buf, int hits_stride,
       const unsigned char *__restrict__ active) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & (LPC - 1);
+    const int i = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     if (i >= n) return;
     const int c = atom_cfg[i];
     if (active && !active[c]) {   // chain switched off by the relaxation driver: an empty row (its 8 pad slots are never read)
@@ -89,7 +102,7 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
     const double wd2 = rcut * sqrt(I6 * I6 + I7 * I7 + I8 * I8) * (1.0 + 1e-9) + 1e-9;
     long long base = FILL ? (long long)row_start[i] : 0;
     int run = 0;
-    for (int j0 = a0; j0 < a1; j0 += 64) {
+    for (int j0 = a0; j0 < a1; j0 += LPC) {
         const int j = j0 + lane;
         const bool have = j < a1;
         double bx = 0, by = 0, bz = 0;
@@ -129,7 +142,7 @@ k_nbr(int n, const double *__restrict__ wpos, const int *__restrict__ atom_cfg,
             if (!FILL && hslot) *hslot = hits;
         }
         int total;
-        const int off = wave_excl_scan(cnt, lane, total);
+        const int off = group_excl_scan<LPC>(cnt, total);
         if (FILL && cnt > 0) {
             long long slot = base + run + off;
             const int w1 = 2 * n1 + 1, w2 = 2 * n2 + 1;
@@ -268,13 +281,14 @@ k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int
 }
 
 // reverse-edge slot: for slot (i -> j, S') find (j -> i, -S') in j's row.  One wave per centre, lane per slot.
+template <int LPC>
 __global__ void __launch_bounds__(256)
 k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
       const int *__restrict__ edge_S, int *__restrict__ rev, const int *__restrict__ counters, ActiveView av) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & (LPC - 1);
+    const int i = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     if (i >= n || counters[2] || !av.atom(i)) return;
-    for (int e = row_start[i] + lane; e < row_start[i + 1]; e += 64) {
+    for (int e = row_start[i] + lane; e < row_start[i + 1]; e += LPC) {
         int j = __float_as_int(edge[e].w);
         int found = -1;
         if (j >= 0) {
@@ -522,26 +536,41 @@ int build_neighbors(vssr_handle *h, double cutoff) {
         hits_buf = h->d_hits.as<unsigned long long>();
     h->prof.begin(KC_NBR, st);
     dim3 blk(128), grd((n + 127) / 128);
-    dim3 wblk(256), wgrd((n + 3) / 4);   // one wave per centre
+    // lanes per centre.  Measured on the PaiNN bench (profiles/r04/ab_nbr_lanes_per_centre.txt) and the GaN workload: 16-lane rows
+    // beat one wave per centre in the search at every chain size (260-atom chains: 4 full chunks of 64 + one with 4 lanes; 48-atom
+    // chains: 48 of 64 lanes, once), the reverse-slot search likes 32 lanes on PaiNN rows (~41 slots) and 16 on the 8-slot rows of
+    // the analytic potentials.  VSSR_NBR_LPC / VSSR_REV_LPC = 16 | 32 | 64 force a form (tests run the suite with each).
+    static const int lpc_env = [] { const char *e = getenv("VSSR_NBR_LPC"); return e ? atoi(e) : 0; }();
+    static const int rev_env = [] { const char *e = getenv("VSSR_REV_LPC"); return e ? atoi(e) : 0; }();
+    const int lpc_nbr = lpc_env ? lpc_env : 16;
+    const int lpc_rev = rev_env ? rev_env : lpc_env ? lpc_env : (h->kind != 1 ? 16 : 32);
+    dim3 wblk(256);
+    auto grid_for = [&](int lpc) { return dim3((n + 256 / lpc - 1) / (256 / lpc)); };
+#define NBR_ARGS(FILLING) n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(), h->d_cfg_start.as<int>(), h->d_cell.as<double>(),          \
+        h->d_invcell.as<double>(), h->d_nimg.as<int>(), cutoff * cutoff, h->d_deg.as<int>(),                                            \
+        (FILLING) ? h->d_row_start.as<int>() : (const int *)nullptr, (FILLING) ? h->d_edge.as<float4>() : (float4 *)nullptr,            \
+        (FILLING) ? h->d_edge_S.as<int>() : (int *)nullptr, (FILLING) ? (long long)h->slot_cap : (long long)0, hits_buf, hits_stride,   \
+        h->active_mask
     hipLaunchKernelGGL(k_wrap, grd, blk, 0, st, n, h->d_pos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_pbc.as<uint8_t>(),
                        h->d_wpos.as<double>(), h->d_wrap.as<int>());
-    hipLaunchKernelGGL(k_nbr<false>, wgrd, wblk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
-                       h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_nimg.as<int>(),
-                       cutoff * cutoff, h->d_deg.as<int>(), (const int *)nullptr, (float4 *)nullptr,
-                       (int *)nullptr, (long long)0, hits_buf, hits_stride, h->active_mask);
+    if (lpc_nbr == 16) hipLaunchKernelGGL((k_nbr<false, 16>), grid_for(16), wblk, 0, st, NBR_ARGS(false));
+    else if (lpc_nbr == 32) hipLaunchKernelGGL((k_nbr<false, 32>), grid_for(32), wblk, 0, st, NBR_ARGS(false));
+    else hipLaunchKernelGGL((k_nbr<false, 64>), grid_for(64), wblk, 0, st, NBR_ARGS(false));
     const int n_tiles = n > 0 ? (n + 4095) / 4096 : 1;   // (an empty batch still writes its counters)
     hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, st, n, h->d_deg.as<int>(), h->d_tile_sums.as<int>());
     hipLaunchKernelGGL(k_scan_rows, dim3(n_tiles), dim3(1024), 0, st, n, h->d_deg.as<int>(),
                        h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap, h->d_tile_sums.as<int>());
-    hipLaunchKernelGGL(k_nbr<true>, wgrd, wblk, 0, st, n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(),
-                       h->d_cfg_start.as<int>(), h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_nimg.as<int>(),
-                       cutoff * cutoff, h->d_deg.as<int>(), h->d_row_start.as<int>(),
-                       h->d_edge.as<float4>(), h->d_edge_S.as<int>(), (long long)h->slot_cap, hits_buf, hits_stride,
-                       h->active_mask);
-    hipLaunchKernelGGL(k_rev, wgrd, wblk, 0, st, n, h->d_row_start.as<int>(), h->d_edge.as<float4>(),
-                       h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>(),
-                       ActiveView{h->active_mask, h->d_atom_cfg.as<int>()});
+    if (lpc_nbr == 16) hipLaunchKernelGGL((k_nbr<true, 16>), grid_for(16), wblk, 0, st, NBR_ARGS(true));
+    else if (lpc_nbr == 32) hipLaunchKernelGGL((k_nbr<true, 32>), grid_for(32), wblk, 0, st, NBR_ARGS(true));
+    else hipLaunchKernelGGL((k_nbr<true, 64>), grid_for(64), wblk, 0, st, NBR_ARGS(true));
+#undef NBR_ARGS
+    const ActiveView rev_av{h->active_mask, h->d_atom_cfg.as<int>()};
+#define REV_ARGS n, h->d_row_start.as<int>(), h->d_edge.as<float4>(), h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>(), rev_av
+    if (lpc_rev == 16) hipLaunchKernelGGL(k_rev<16>, grid_for(16), wblk, 0, st, REV_ARGS);
+    else if (lpc_rev == 32) hipLaunchKernelGGL(k_rev<32>, grid_for(32), wblk, 0, st, REV_ARGS);
+    else hipLaunchKernelGGL(k_rev<64>, grid_for(64), wblk, 0, st, REV_ARGS);
+#undef REV_ARGS
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
         // layer-0 factorisation with at most 4 species: its T blocks are accumulated by k_edge_geom (h->l0T_by_geom); with more species
         // a separate kernel builds them from the fp32 table and the per-slot unit vectors, which are only written for it
