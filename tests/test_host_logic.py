@@ -161,14 +161,17 @@ def test_edge_kernel_isa_keeps_loads_out_of_mfma_windows():
 def test_hot_kernels_have_no_register_spills():
     """VERDICT r2 item 1c, kept true: every matrix-pipe kernel of the edge and node files compiles without spilled VGPRs / SGPRs
     -- since round 4 without exception (the unfused MODE 0 reverse update kernel, used with readout widths other than 64, runs
-    the rolled GEMMs).  Reads the code-object metadata of a cross-compile (no GPU needed)."""
+    the rolled GEMMs).  Also the Tersoff kernels: no spilled VECTOR registers and no scratch (the first one-thread-per-centre
+    kernel ran for three rounds with 49 spilled registers because it was compiled for 1 024-thread workgroups; scalar spills go
+    to vector lanes and are allowed there).  Reads the code-object metadata of a cross-compile (no GPU needed)."""
     import re
     import subprocess
     import tempfile
 
     csrc = os.path.join(ROOT, "surface-sampling_amd", "csrc")
     checked = 0
-    for hip, extra in (("painn_node_mfma.hip", []), ("painn_edge_mfma.hip", ["-fno-slp-vectorize"]), ("painn_l0.hip", [])):
+    for hip, extra, scalar_spills_ok in (("painn_node_mfma.hip", [], False), ("painn_edge_mfma.hip", ["-fno-slp-vectorize"], False),
+                                         ("painn_l0.hip", [], False), ("tersoff.hip", [], True)):
         with tempfile.TemporaryDirectory() as tmp:
             out = os.path.join(tmp, "k.s")
             subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", *extra,
@@ -177,11 +180,13 @@ def test_hot_kernels_have_no_register_spills():
         meta = meta[meta.rfind("amdhsa.kernels"):]
         for blk in meta.split("  - .agpr_count")[1:]:
             name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-            spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) + int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1))
+            spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+            if not scalar_spills_ok:
+                spills += int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1))
             scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
             checked += 1
             assert spills == 0 and scratch == 0, (hip, name, spills, scratch)
-    assert checked >= 25
+    assert checked >= 29
 
 
 def test_pourbaix_potential_arithmetic():
@@ -408,3 +413,22 @@ def test_pourbaix_delta_g1_method_and_decomposition():
             return [s for s, n in case["formula"].items() for _ in range(n)]
 
     assert calc.get_delta_G1(_Slab()) == pytest.approx(case["delta_G1"], abs=1e-10)
+
+
+def test_packed_path_helpers_of_the_calculators(golden):
+    """What ``mc.ChainEnsemble`` asks a calculator before it hands over packed arrays: which requests ``evaluate_packed`` serves, and
+    the vectorised atomic-number -> LAMMPS-type map of the analytic calculators (no engine is created)."""
+    E = calcs.EnsembleNFFSurface
+    assert E.packed_supported(False, "CG") and E.packed_supported(True, "BFGS") and E.packed_supported(True, "FIRE")
+    assert E.packed_supported(True, None)
+    assert not E.packed_supported(True, "CG") and not E.packed_supported(True, "LAMMPS")
+    assert not E.packed_supported(True, "BFGSLineSearch") and not E.packed_supported(True, object)
+    t = calcs.TersoffSurfCalc(golden.tersoff_params, ["Ga", "N"], device="cuda:0")
+    assert t.packed_supported(True, "LAMMPS") and t.packed_supported(True, "cg") and t.packed_supported(True, "FIRE")
+    assert t.packed_supported(True, "BFGS") and t.packed_supported(True, None) and t.packed_supported(False, "BFGSLineSearch")
+    assert not t.packed_supported(True, "BFGSLineSearch") and not t.packed_supported(True, object)
+    types = t._types_of([31, 7, 7, 31])
+    assert types.dtype == np.int32 and list(types) == [0, 1, 1, 0] and len(t._types_of([])) == 0
+    with pytest.raises(ValueError, match="Z=38"):
+        t._types_of([31, 38])
+    assert t._engine is None
