@@ -111,11 +111,17 @@ int vssr_abi_version(void);
 /* Environment variables read once by vssr_create -- test / measurement hooks, none is needed in production:
  *   VSSR_EDGE_IMPL=gather    every chain takes the gather neighbor kernels (reference path of the parity tests)
  *   VSSR_L0_FACTORISE=0      layer 0 runs the generic kernels instead of the species factorisation
- *   VSSR_EDGE_FS16_MAX=n, VSSR_EDGE_FS8_MAX=n   largest chain (atoms) served by the 16- / 8-feature-slice kernels (lower = force a path)
+ *   VSSR_EDGE_FS16_MAX=n, VSSR_EDGE_FS8_MAX=n, VSSR_EDGE_FS4_MAX=n   largest chain (atoms) served by the 16- / 8- / 4-feature-slice
+ *                            kernels (lower = force a path)
  *   VSSR_UPD_SAVE=1          update blocks store their forward intermediates for the reverse pass (measured: no gain)
  *   VSSR_GBAR_MODE=0|1|2     partial edge-gradient buffers: 0 shared float4 set with read-modify-write (round 2), 1 one float4 set per
  *                            layer, 2 (default) one compact 12-byte set per layer
- *   VSSR_DEBUG_KEEP=1        materialise buffers that only vssr_debug_read consumes (the last block's vector output) */
+ *   VSSR_DEBUG_KEEP=1        materialise buffers that only vssr_debug_read consumes (the last block's vector output)
+ * Read once per process by the first evaluation (every kind of handle):
+ *   VSSR_NBR_LPC=16|32|64, VSSR_REV_LPC=16|32|64   lanes per centre atom in the neighbor search / the reverse-slot search (default 16;
+ *                            reverse-slot search 32 for PaiNN handles); the neighbor list is the same bit for bit in every form
+ *   VSSR_TERSOFF_SITE=1      Tersoff: the one-thread-per-centre kernel for every row (default: rows of <= 16 slots take the
+ *                            four-lanes-per-centre kernel) */
 int vssr_create(const vssr_painn_config *cfg, vssr_handle **out);
 void vssr_destroy(vssr_handle *h);
 const char *vssr_last_error(const vssr_handle *h); /* h may be NULL: last create() error of the calling thread */
