@@ -889,3 +889,39 @@ def test_lammps_surf_calc_runs_the_gan_tutorial_flow(tmp_path, golden, oracle_mo
     E0, _, _ = oracle_mod.tersoff(golden.tersoff_params, types, relaxed.positions, relaxed.cell, [1, 1, 1])
     assert abs(e_rel - E0) <= 1e-9 * abs(E0)
     assert calc.get_property("relaxed_energy", ads) == pytest.approx(e_rel, abs=1e-9)
+
+
+def test_row_scan_across_tile_boundaries(golden):
+    """The CSR row offsets come from a two-launch scan over tiles of 4 096 atoms (``k_scan_tiles`` + ``k_scan_rows``): batches whose
+    atom count sits on, just below and just above one and two tile boundaries give every chain exactly the energy, per-atom
+    energies and forces it has when evaluated alone, and the batch's edge count is the sum of the chains'."""
+    from surface_sampling_amd import backend
+
+    eng = backend.TersoffEngine(golden.tersoff_params, device=0)
+    s = golden.structure("GaN_3x3_pristine")
+    types = np.array([0 if z == 31 else 1 for z in s.numbers], np.int32)
+    rng = np.random.default_rng(5)
+    slab = (types, s.positions + rng.normal(0, 0.02, s.positions.shape), s.cell, [1, 1, 1])
+    dimer = (np.array([0, 1], np.int32), np.array([[0.0, 0.0, 0.0], [1.9, 0.1, 0.0]]), np.eye(3) * 15.0, [0, 0, 0])
+    lone = (np.zeros(1, np.int32), np.zeros((1, 3)), np.eye(3) * 15.0, [0, 0, 0])
+    alone = {}
+    for name, st in (("slab", slab), ("dimer", dimer), ("lone", lone)):
+        e, ea, f = eng.evaluate_f64([st])
+        alone[name] = (e[0], ea.copy(), f.copy(), eng.stats()["edges"])
+    for total in (4095, 4096, 4097, 8191, 8192, 8193, 12289):
+        n_slab = total // 36 - 1
+        rest = total - 36 * n_slab                    # 36 .. 71 atoms as dimers + single atoms, spread through the batch
+        names = ["slab"] * n_slab + ["dimer"] * (rest // 2) + ["lone"] * (rest % 2)
+        order = rng.permutation(len(names))
+        names = [names[k] for k in order]
+        batch = [{"slab": slab, "dimer": dimer, "lone": lone}[k] for k in names]
+        assert sum(len(b[0]) for b in batch) == total
+        e, ea, f = eng.evaluate_f64(batch)
+        assert eng.stats()["atoms"] == total and eng.stats()["edges"] == sum(alone[k][3] for k in names)
+        o = 0
+        for b, k in enumerate(names):
+            n = len(batch[b][0])
+            assert e[b] == alone[k][0], (total, b, k)
+            assert np.array_equal(ea[o:o + n], alone[k][1]) and np.array_equal(f[o:o + n], alone[k][2])
+            o += n
+    eng.close()
