@@ -236,7 +236,7 @@ k_scan_tiles(int n, const int *__restrict__ deg, int *__restrict__ tile_sums /*[
 __global__ void __launch_bounds__(1024)
 k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int *__restrict__ counters,
             long long slot_cap, const int *__restrict__ tile_sums) {
-    __shared__ int wsum[16];
+    __shared__ int wsum[16], wreal[16];
     __shared__ long long wrun[16], wrun_real[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, tile = blockIdx.x;
     const bool last = tile == (int)gridDim.x - 1;
@@ -255,6 +255,10 @@ k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int
     const ScanTile s = scan_tile_load(n, deg, tile * 4096 + 4 * t);
     const int x = wave_incl_scan_i32(s.p);   // inclusive scan of the thread sums inside the wave
     if (lane == 63) wsum[w] = x;
+    if (!tile_sums) {   // (uniform) single-tile launch: the real edge count comes from here as well
+        const int xr = wave_incl_scan_i32(s.real);
+        if (lane == 63) wreal[w] = xr;
+    }
     __syncthreads();
     run = 0; run_real = 0;
     int woff = 0;
@@ -272,7 +276,13 @@ k_scan_rows(int n, const int *__restrict__ deg, int *__restrict__ row_start, int
         o += s.pd[u];
     }
     if (last && t == 0) {
-        const long long total = run + tile_sums[2 * tile], total_real = run_real + tile_sums[2 * tile + 1];
+        // (a batch of one tile is launched without k_scan_tiles: its sums are this workgroup's own wave sums)
+        long long own = 0, own_real = 0;
+        if (tile_sums) { own = tile_sums[2 * tile]; own_real = tile_sums[2 * tile + 1]; }
+        else {
+            for (int k = 0; k < 16; ++k) { own += wsum[k]; own_real += wreal[k]; }
+        }
+        const long long total = run + own, total_real = run_real + own_real;
         row_start[n] = (int)total;
         counters[0] = (int)total;
         counters[1] = (int)total_real;
@@ -558,9 +568,11 @@ int build_neighbors(vssr_handle *h, double cutoff) {
     else if (lpc_nbr == 32) hipLaunchKernelGGL((k_nbr<false, 32>), grid_for(32), wblk, 0, st, NBR_ARGS(false));
     else hipLaunchKernelGGL((k_nbr<false, 64>), grid_for(64), wblk, 0, st, NBR_ARGS(false));
     const int n_tiles = n > 0 ? (n + 4095) / 4096 : 1;   // (an empty batch still writes its counters)
-    hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, st, n, h->d_deg.as<int>(), h->d_tile_sums.as<int>());
+    if (n_tiles > 1)
+        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, st, n, h->d_deg.as<int>(), h->d_tile_sums.as<int>());
     hipLaunchKernelGGL(k_scan_rows, dim3(n_tiles), dim3(1024), 0, st, n, h->d_deg.as<int>(),
-                       h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap, h->d_tile_sums.as<int>());
+                       h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap,
+                       n_tiles > 1 ? h->d_tile_sums.as<int>() : (const int *)nullptr);
     if (lpc_nbr == 16) hipLaunchKernelGGL((k_nbr<true, 16>), grid_for(16), wblk, 0, st, NBR_ARGS(true));
     else if (lpc_nbr == 32) hipLaunchKernelGGL((k_nbr<true, 32>), grid_for(32), wblk, 0, st, NBR_ARGS(true));
     else hipLaunchKernelGGL((k_nbr<true, 64>), grid_for(64), wblk, 0, st, NBR_ARGS(true));

@@ -799,13 +799,16 @@ int relax_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host
         for (; it < max_launch && !rc; ++it) {
             rc = h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : eam_run(h, want | VSSR_WANT_FORCES);
             if (rc) break;
-            VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
+            // the count of chains still running is read at the polls only: it is cleared and copied back in those iterations (the
+            // step kernels in between add to a value nobody looks at) -- two dispatches less per evaluation, ~15 of them at 48 atoms
+            const bool poll_it = (it + 1) % POLL == 0;
+            if (poll_it) VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
             hipLaunchKernelGGL(k_cg_step, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
                                h->d_ters_e.as<double>(), h->d_ters_f.as<double>(), fixed, cp->max_iter, cp->max_eval, cp->etol,
                                cp->ftol, cp->dmax, h->d_pos.as<double>(), h->d_vel.as<double>(), h->d_vel.as<double>() + 3 * (size_t)N,
                                h->d_vel.as<double>() + 6 * (size_t)N, h->d_fire.as<CgState>(), active, n_active_d);
-            VSSR_HIP(h, hipMemcpyAsync(h->h_counters + 3, n_active_d, sizeof(int), hipMemcpyDeviceToHost, st));
-            if ((it + 1) % POLL == 0) {
+            if (poll_it) {
+                VSSR_HIP(h, hipMemcpyAsync(h->h_counters + 3, n_active_d, sizeof(int), hipMemcpyDeviceToHost, st));
                 VSSR_HIP(h, hipStreamSynchronize(st));
                 if (h->h_counters[2]) {
                     rc = regrow();
