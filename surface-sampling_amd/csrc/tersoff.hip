@@ -211,14 +211,71 @@ __global__ void __launch_bounds__(64) k_tersoff_site(int N, int nt, const TersP 
 
 constexpr int TS_MAXD = 16, TS_CENTRES = 64, TS_LANES = 4, TS_MAXP = 64;   // slots per row in LDS; centres / workgroup; lanes / centre; 4^3 entries
 
+// A parameter entry as k_tersoff_site4 keeps it in LDS: what every three-body term would otherwise recompute from the file's
+// fields is done once per workgroup -- gamma (1 + c^2/d^2), gamma c^2, d^2 (g(theta) is left with ONE fp64 division), the shell
+// bounds R -+ D and pi / (2 D) (no division inside the cutoff function), the b_ij branch thresholds, m == 3 as a flag.
+struct TersL {
+    double Rmax, Rmin, R, piD2, g0, g1, d2, h, lam3;       // three-body use of the entry (i, j, k)
+    double A, lam1, B, lam2, beta, n, c1, c2, c3, c4;      // pair use of the entry (i, j, j); c1..c4: b_ij branch thresholds
+    int m3, pad;
+};
+__device__ inline TersL t_derive(const TersP &p) {
+    TersL l;
+    l.Rmax = p.R + p.D; l.Rmin = p.R - p.D; l.R = p.R; l.piD2 = M_PI_2 / p.D;
+    const double c2 = p.c * p.c, d2 = p.d * p.d;
+    l.g0 = p.gamma * (1.0 + c2 / d2); l.g1 = p.gamma * c2; l.d2 = d2; l.h = p.h; l.lam3 = p.lam3;
+    l.A = p.A; l.lam1 = p.lam1; l.B = p.B; l.lam2 = p.lam2; l.beta = p.beta; l.n = p.n;
+    t_bij_limits(p.n, l.c1, l.c2);
+    l.c3 = 1.0 / l.c2; l.c4 = 1.0 / l.c1;
+    l.m3 = (int)p.m == 3; l.pad = 0;
+    return l;
+}
+__device__ __forceinline__ void t_fc_both(double r, const TersL &p, double &fc, double &dfc) {
+    if (r < p.Rmin) { fc = 1.0; dfc = 0.0; return; }
+    if (r > p.Rmax) { fc = 0.0; dfc = 0.0; return; }
+    double sn, cs;
+    t_sincos_half_pi(p.piD2 * (r - p.R), sn, cs);
+    fc = 0.5 * (1.0 - sn);
+    dfc = -0.5 * p.piD2 * cs;
+}
 struct TersTri { double g, dg, ex, dex, fc, dfc; };
-// three-body factors of (i, j, k) with parameter entry p: false when k is outside the entry's cutoff
-__device__ __forceinline__ bool t_tri(const TersP &p, double rj, double rk, double cs, TersTri &o) {
-    if (rk > p.R + p.D) return false;
-    t_gijk(cs, p, o.g, o.dg);
-    t_ex(rj, rk, p, o.ex, o.dex);
+// three-body factors of (i, j, k) with entry p: false when k is outside the entry's cutoff
+__device__ __forceinline__ bool t_tri(const TersL &p, double rj, double rk, double cs, TersTri &o) {
+    if (rk > p.Rmax) return false;
+    const double hc = p.h - cs, inv = 1.0 / (p.d2 + hc * hc);
+    o.g = p.g0 - p.g1 * inv;
+    o.dg = -2.0 * p.g1 * hc * (inv * inv);
+    if (p.lam3 == 0.0) { o.ex = 1.0; o.dex = 0.0; }   // exp(0) = 1 and a zero derivative: the same values without exp()
+    else {
+        double arg = p.lam3 * (rj - rk), darg = p.lam3;
+        if (p.m3) { darg = 3.0 * p.lam3 * arg * arg; arg = arg * arg * arg; }
+        if (arg > 69.0776) { o.ex = 1.e30; o.dex = 0.0; }
+        else if (arg < -69.0776) { o.ex = 0.0; o.dex = 0.0; }
+        else { o.ex = exp(arg); o.dex = o.ex * darg; }
+    }
     t_fc_both(rk, p, o.fc, o.dfc);
     return true;
+}
+// b_ij and its derivative from the derived entry: the branches of t_bij with the thresholds read instead of recomputed
+__device__ __forceinline__ void t_bij(double zeta, const TersL &l, double &b, double &db) {
+    const double tmp = l.beta * zeta, n = l.n;
+    if (tmp > l.c1) { b = 1.0 / sqrt(tmp); db = l.beta * -0.5 * pow(tmp, -1.5); return; }
+    if (tmp > l.c2) {
+        b = (1.0 - pow(tmp, -n) / (2.0 * n)) / sqrt(tmp);
+        db = l.beta * (-0.5 * pow(tmp, -1.5) * (1.0 - (1.0 + 1.0 / (2.0 * n)) * pow(tmp, -n)));
+        return;
+    }
+    if (tmp < l.c4) { b = 1.0; db = 0.0; return; }
+    if (tmp < l.c3) { b = 1.0 - pow(tmp, n) / (2.0 * n); db = -0.5 * l.beta * pow(tmp, n - 1.0); return; }
+    if (n == 1.0) {
+        const double s1 = 1.0 + tmp, rs = 1.0 / sqrt(s1);
+        b = rs;
+        db = -0.5 * (rs * rs * rs) * l.beta;   // -1/2 (1 + x)^(-3/2) beta  (= -1/2 b / (1 + x) tmp / zeta)
+        return;
+    }
+    const double tn = pow(tmp, n);
+    b = pow(1.0 + tn, -1.0 / (2.0 * n));
+    db = -0.5 * (b / (1.0 + tn)) * tn / zeta;
 }
 
 __global__ void __launch_bounds__(TS_CENTRES * TS_LANES)
@@ -231,14 +288,12 @@ k_tersoff_site4(int N, int nt, const TersP *__restrict__ P, const int *__restric
     __shared__ double s_ux[TS_MAXD][TS_CENTRES], s_uy[TS_MAXD][TS_CENTRES], s_uz[TS_MAXD][TS_CENTRES];   // unit vectors i -> n
     __shared__ double s_r[TS_MAXD][TS_CENTRES], s_pref[TS_MAXD][TS_CENTRES];
     __shared__ signed char s_tp[TS_MAXD][TS_CENTRES];                                                     // type of n, -1: padding slot
-    __shared__ TersP s_P[TS_MAXP];
-    __shared__ double s_lim[TS_MAXP][2];   // b_ij branch thresholds of every entry
+    __shared__ TersL s_P[TS_MAXP];
     if (counters[2]) return;   // (uniform)
     const int tid = threadIdx.x, cb = tid >> 2, q = tid & 3;
     const int i = blockIdx.x * TS_CENTRES + cb;
     for (int t = tid; t < nt * nt * nt; t += TS_CENTRES * TS_LANES) {
-        s_P[t] = P[t];
-        t_bij_limits(P[t].n, s_lim[t][0], s_lim[t][1]);
+        s_P[t] = t_derive(P[t]);
     }
     int e0 = 0, deg = 0, ti = 0;
     bool mine = i < N && av.atom(i);
@@ -277,9 +332,9 @@ k_tersoff_site4(int N, int nt, const TersP *__restrict__ P, const int *__restric
         double e_pair = 0.0, pref = 0.0, dVdr = 0.0;
         if (tj >= 0) {
             const int eij = (ti * nt + tj) * nt + tj;
-            const TersP &pij = s_P[eij];
+            const TersL &pij = s_P[eij];
             const double r = s_r[n][cb];
-            if (r <= pij.R + pij.D) {
+            if (r <= pij.Rmax) {
                 const double ux = s_ux[n][cb], uy = s_uy[n][cb], uz = s_uz[n][cb];
                 double zeta = 0.0;
 #pragma unroll 1
@@ -295,7 +350,7 @@ k_tersoff_site4(int N, int nt, const TersP *__restrict__ P, const int *__restric
                 t_fc_both(r, pij, fc, dfc);
                 const double fR = pij.A * exp(-pij.lam1 * r), fA = -pij.B * exp(-pij.lam2 * r);
                 double bij, dbij;
-                t_bij(zeta, pij, s_lim[eij][0], s_lim[eij][1], bij, dbij);
+                t_bij(zeta, pij, bij, dbij);
                 e_pair = 0.5 * fc * (fR + bij * fA);
                 dVdr = 0.5 * (dfc * (fR + bij * fA) + fc * (-pij.lam1 * fR - pij.lam2 * bij * fA));
                 pref = 0.5 * fc * fA * dbij;
