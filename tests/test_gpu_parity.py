@@ -925,3 +925,35 @@ def test_row_scan_across_tile_boundaries(golden):
             assert np.array_equal(ea[o:o + n], alone[k][1]) and np.array_equal(f[o:o + n], alone[k][2])
             o += n
     eng.close()
+
+
+def test_lammps_surf_calc_packed_path_holds_the_bulk_group(tmp_path, golden):
+    """``LAMMPSSurfCalc.evaluate_packed`` without a mask holds the template's bulk group (ids <= bulk_index) like ``relax_batch``
+    without ``fixed_indices``: batched MC through the packed path and through the per-slab path end in identical states, and the
+    first 36 atoms of every relaxed slab are where the pristine slab has them."""
+    from test_host_logic import _gan_run_dir
+    from surface_sampling_amd import calculators as calcs
+    from surface_sampling_amd import mc
+
+    rd = _gan_run_dir(tmp_path, golden)
+    g = golden.structure("GaN_3x3_pristine")
+    ztop = g.positions[:, 2].max()
+    coords = np.array([(i + 0.5) / 3 * g.cell[0] + (j + 0.5) / 3 * g.cell[1] for i in range(3) for j in range(3)], float)
+    coords[:, 2] = ztop + 1.8
+    runs = []
+    for fast in (True, False):
+        calc = calcs.LAMMPSSurfCalc(device="cuda:0")
+        calc.set(calc_name="LAMMPS", optimizer="LAMMPS", chem_pots={"Ga": 5}, relax_atoms=True, relax_steps=20, run_dir=rd)
+        ens = mc.ChainEnsemble(g, coords, ("Ga", "N"), 5, calc, seed=8, relax=True, relax_steps=20, temperature=0.4, optimizer="LAMMPS")
+        ens.fast_path = fast
+        ens.initialize()
+        acc = np.stack([ens.step_semigrand() for _ in range(4)])
+        runs.append((acc, ens))
+    (a, ea), (b, eb) = runs
+    assert np.array_equal(a, b) and np.array_equal(ea.state.species, eb.state.species) and np.array_equal(ea.state.energy, eb.state.energy)
+    assert a.any() and (ea.num_adsorbates() > 0).any()
+    for k in range(5):
+        assert np.array_equal(ea.relaxed[k].positions, eb.relaxed[k].positions)
+        assert np.array_equal(ea.relaxed[k].positions[:36], g.positions)               # group bulk id <= 36: setforce 0
+        if len(ea.relaxed[k]) > 36:
+            assert np.abs(ea.relaxed[k].positions[36:] - ea.structure(k).positions[36:]).max() > 1e-4   # the adsorbates did move
