@@ -293,19 +293,7 @@ def test_tersoff_gpu_vs_oracle(golden, oracle_mod):
     eng.close()
 
 
-def _synthetic_tersoff(nt, seed):
-    """Random but physical-looking entries [nt, nt, nt, 14] (field order of include/vssr_eval.h: m gamma lam3 c d h n beta lam2 B R D
-    lam1 A) covering what GaN.tersoff does not: m = 3, lam3 != 0 everywhere, n != 1, tiny / huge beta (the asymptotic b_ij branches)."""
-    rng = np.random.default_rng(seed)
-    P = np.zeros((nt, nt, nt, 14))
-    for i in range(nt):
-        for j in range(nt):
-            for k in range(nt):
-                P[i, j, k] = [rng.choice([1.0, 3.0]), rng.uniform(0.05, 1.0), rng.choice([0.0, 0.4, 1.3]), rng.uniform(0.5, 4.0),
-                              rng.uniform(0.5, 3.0), rng.uniform(-0.8, 0.2), rng.choice([1.0, 0.78734, 2.5]),
-                              rng.choice([1.0, 1e-9, 1e-3, 3e9]), rng.uniform(1.2, 2.6), rng.uniform(100.0, 500.0),
-                              rng.uniform(2.5, 3.3), rng.uniform(0.15, 0.3), rng.uniform(2.0, 3.5), rng.uniform(500.0, 2000.0)]
-    return P
+from conftest import synthetic_tersoff as _synthetic_tersoff  # noqa: E402
 
 
 def test_tersoff_synthetic_parameter_sets_and_long_rows(oracle_mod):

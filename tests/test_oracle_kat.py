@@ -80,6 +80,37 @@ def test_tersoff_forces_finite_difference(golden, oracle_mod):
         assert abs(-(Ep - Em) / (2 * h) - F[i, x]) < 1e-7
 
 
+def test_tersoff_oracle_branches_beyond_gan_are_self_consistent(oracle_mod):
+    """GaN.tersoff exercises m = 1, n = 1, lam3 = 0 / 1.846 only, and the reference holds no vector for anything else.  The other
+    branches of the restated LAMMPS formulas (m = 3, n != 1, tiny / huge beta: the asymptotic b_ij forms) are anchored on the
+    oracle's own consistency: forces are the negative finite-difference gradient of its energy, per-atom energies sum to the
+    energy, the net force vanishes -- on synthetic three-species entries and a dense periodic configuration.  The HIP kernels
+    are then compared with this oracle (tests/test_gpu_parity.py)."""
+    from conftest import synthetic_tersoff
+
+    rng = np.random.default_rng(4)
+    box, pts = 7.5, []
+    while len(pts) < 40:
+        x = rng.uniform(0, box, 3)
+        if all(np.linalg.norm((x - y + box / 2) % box - box / 2) >= 1.7 for y in pts):
+            pts.append(x)
+    pos, cell = np.array(pts), np.eye(3) * box
+    for nt, seed in ((3, 1), (2, 2)):
+        P = synthetic_tersoff(nt, seed)
+        assert {1.0, 3.0} <= set(P[..., 0].ravel()) and (P[..., 6] != 1.0).any() and (P[..., 2] != 0.0).any()
+        types = rng.integers(0, nt, len(pos)).astype(np.int32)
+        E, ea, F = oracle_mod.tersoff(P, types, pos, cell, [1, 1, 1])
+        assert abs(ea.sum() - E) <= 1e-9 * max(1.0, abs(E)) and np.abs(F.sum(0)).max() <= 1e-8 * max(1.0, np.abs(F).max())
+        h = 1e-5
+        for i, x in [(0, 0), (11, 2), (29, 1), (39, 0)]:
+            p = pos.copy(); p[i, x] += h
+            Ep, _, _ = oracle_mod.tersoff(P, types, p, cell, [1, 1, 1], False)
+            p[i, x] -= 2 * h
+            Em, _, _ = oracle_mod.tersoff(P, types, p, cell, [1, 1, 1], False)
+            fd = -(Ep - Em) / (2 * h)
+            assert abs(fd - F[i, x]) <= 2e-6 * max(1.0, abs(F[i, x])), (nt, i, x, fd, F[i, x])
+
+
 def test_neighbor_multigraph_properties(golden, oracle_mod):
     """in the 60-atom slab (cell < 2*cutoff) pairs repeat through several images."""
     s = golden.structure("SrTiO3_2x2_pristine")
