@@ -17,10 +17,11 @@ handle each) that run concurrently -- the latency-bound node kernels of one half
 the other; `config.streams_per_gpu` says what ran.
 
 The ONE JSON line carries, besides the contract fields:
-  roofline      dominant kernel = reverse neighbor pass, priced on the pipe it EXECUTES on: `achieved` = matrix-pipe flops
-                executed per launch (static MFMA count x 16x16x32x2) / launch time, `peak` = 2.5 PFLOP/s dense fp16;
-                `views` gives the same launch as fp32-equivalent algorithmic work (2 x 17 408 flop per real
-                directed edge and model; a yardstick, not a ceiling) and against HBM; `binding_resource` is built from the
+  roofline      dominant kernel = reverse neighbor pass: `achieved` = ALGORITHMIC flops per launch (2 x 17 408 flop
+                per real directed edge and model) / launch time, `peak` = 2.5 PFLOP/s dense fp16 (the pipe the contraction
+                executes on); `executed_pipe` = matrix-pipe occupancy (static MFMA count x 16x16x32x2 / launch time: ~4.9 x the
+                algorithmic flops because fp32 operands run as 3 fp16 products + padding -- occupancy, not useful work);
+                `views` gives the same launch against the fp32 vector peak and against HBM; `binding_resource` is built from the
                 committed PMC passes (profiles/r04/pmc_summary.json).  Launch times = HIP events on the engine's stream in a
                 SEPARATE single-stream pass after the timed region (with S > 1 launches of the two engines overlap, so
                 per-kernel durations inside the timed region are not clean);
@@ -236,6 +237,10 @@ def main():
                          "over one stream, DESIGN.md section 5); the per-kernel launch times of `roofline` always come from a "
                          "separate single-stream pass after the timed region")
     ap.add_argument("--profile-steps", type=int, default=20, help="steps of the single-stream per-kernel timing pass")
+    ap.add_argument("--verify-ranks", type=int, default=2,
+                    help="N > 1: rank 0 re-evaluates chains of this many OTHER ranks' blocks and compares them bit-exactly with the "
+                         "gathered rows (0 = off); mismatch = non-zero exit")
+    ap.add_argument("--verify-chains", type=int, default=4, help="chains per verified rank (at least 4)")
     ap.add_argument("--dump-gathered", default=None,
                     help="rank 0 writes the last step's gathered per-chain [n_chains, >= 2] (E, sigma_E) array to this .npy (tests)")
     args = ap.parse_args()
@@ -250,8 +255,12 @@ def main():
     # Rehearsal switches (tests only; the driver never sets them): VSSR_DIST_BACKEND=gloo lets N ranks share ONE GPU (RCCL
     # refuses two ranks on one device), VSSR_LOCAL_DEVICE pins every rank to that GPU.  Everything else -- rank / chain
     # arithmetic, ShardedEnsemble.step, the max-over-ranks clock, barriers -- is the code the 8-GPU run executes.
+    # VSSR_RESULT_PATH=device runs the DEVICE result path under gloo (event-ordered staging, double buffering, overflow column
+    # in every rank; only the transport differs: pinned D2H -> gloo -> H2D, sharding.ChainGather.transport).
     dist_backend = os.environ.get("VSSR_DIST_BACKEND", "nccl")
     device_ordinal = int(os.environ.get("VSSR_LOCAL_DEVICE", local_rank))
+    result_path = os.environ.get("VSSR_RESULT_PATH", "auto")
+    init_timeout_s = float(os.environ.get("VSSR_DIST_TIMEOUT_S", "600"))
 
     import torch
 
@@ -264,12 +273,26 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(device_ordinal)
-        if dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(dist_backend, rank=rank, world_size=world)
+        # a group that cannot form (a rank missing, RCCL refusing the device set) ends the run with the rank named and a
+        # non-zero exit instead of hanging: finite timeout on the rendezvous and on every collective
+        try:
+            torch.cuda.set_device(device_ordinal)
+            kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=init_timeout_s))
+            if dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, **kw)
+            else:
+                dist.init_process_group(dist_backend, **kw)
+            probe = torch.ones(1, device=dev if dist_backend == "nccl" else "cpu")
+            dist.all_reduce(probe)                      # the first collective: communicator set-up failures surface here
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all_reduce probe returned {probe.item()} instead of {world}")
+        except Exception as exc:
+            print(f"bench.py: rank {rank} (device {device_ordinal}) could not join the {dist_backend} group of {world}: "
+                  f"{type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
 
     blobs, S, offset_data = load_golden()
     table, const = stoich_offset_table(offset_data)
@@ -284,7 +307,7 @@ def main():
     n_str = max(1, min(args.streams, count))
     engs = [new_engine() for _ in range(n_str)]
     engine = engs[0] if n_str == 1 else EngineGroup(engs)
-    sharded = ShardedEnsemble(engine, world * B, dist, dev)
+    sharded = ShardedEnsemble(engine, world * B, dist, dev, result_path=result_path)
     assert (sharded.first, sharded.count) == (first, count)
     sharded.upload(local_chains=packs)                    # inputs resident in HBM
     want = backend.WANT_ENERGY | backend.WANT_FORCES | backend.WANT_STD
@@ -314,14 +337,18 @@ def main():
     res = engine.download(want)
     if not (np.isfinite(res["energy"]).all() and np.isfinite(res["forces"]).all()):
         raise SystemExit("non-finite results in the timed region")
+    g = None
     if world > 1:
-        g = gathered.detach().cpu().numpy()
-        if not (np.array_equal(g[first:first + count, 0], res["energy"]) and np.array_equal(g[first:first + count, 1], res["energy_std"])):
-            raise SystemExit("the gathered block of this rank differs from its own results")
+        g = gathered.detach().cpu().numpy()       # float64 [n_chains, 2 or 3]: (E, sigma_E[, overflow flag]) of EVERY rank's chains
+        if not (np.array_equal(g[first:first + count, 0], res["energy_f64"])
+                and np.array_equal(g[first:first + count, 1], res["energy_std_f64"])
+                and np.array_equal(g[first:first + count, 0].astype(np.float32), res["energy"])):
+            print(f"bench.py: rank {rank}: the gathered block of this rank differs from its own results", file=sys.stderr, flush=True)
+            raise SystemExit(4)
         if rank == 0 and args.dump_gathered:
             np.save(args.dump_gathered, g)
     elif args.dump_gathered:
-        np.save(args.dump_gathered, np.stack([res["energy"], res["energy_std"]], axis=1))
+        np.save(args.dump_gathered, np.stack([res["energy_f64"], res["energy_std_f64"]], axis=1))
 
     # ---- per-kernel launch times: a separate single-stream pass over the same resident chains (HIP events on that engine's
     # stream; with S > 1 the launches of the timed region overlap and their durations are not a kernel's own) -----------------
@@ -349,6 +376,39 @@ def main():
     split_identical = bool(np.array_equal(res1["energy"], res["energy"]) and np.array_equal(res1["forces"], res["forces"]))
     if not split_identical:
         raise SystemExit("the engine split changed a chain's results (must be bit-identical)")
+
+    # ---- N > 1: rank 0 re-evaluates chains of OTHER ranks' blocks on its own engine and compares them bit for bit with the
+    # rows the gather delivered (a chain's result does not depend on its batch, so four chains alone = the same four chains
+    # inside their owner's block of 256): the first contact with more than one GPU verifies itself ---------------------------
+    gather_verified = None
+    if world > 1 and rank == 0:
+        others = sorted({1, world // 2, world - 1} - {0})[:max(2, args.verify_ranks)] if args.verify_ranks else []
+        n_checked, bad = 0, []
+        plan = shard_plan(world, B)
+        for r in others:
+            f_r, c_r = plan[r]
+            picks = sorted({0, 1, c_r // 2, c_r - 2, c_r - 1} & set(range(c_r)))[:max(4, args.verify_chains)]
+            ids = [f_r + k for k in picks]
+            theirs = []
+            for cid in ids:
+                theirs.extend(build_chains(S, cid, 1, args.atoms_per_chain))
+            one.upload([(s.numbers, s.positions, s.cell, s.pbc) for s in theirs])
+            one.run(want)
+            mine = one.download(want)
+            for k, cid in enumerate(ids):
+                n_checked += 1
+                if not (g[cid, 0] == mine["energy_f64"][k] and g[cid, 1] == mine["energy_std_f64"][k]):
+                    bad.append({"rank": r, "chain": cid, "gathered": [float(g[cid, 0]), float(g[cid, 1])],
+                                "recomputed": [float(mine["energy_f64"][k]), float(mine["energy_std_f64"][k])]})
+        gather_verified = {"ranks": others, "chains": n_checked, "bit_exact": not bad,
+                           "how": "rank 0 rebuilt these chains of the other ranks' blocks, evaluated them on its own engine and "
+                                  "compared (E, sigma_E) as float64 bit patterns with the gathered rows"}
+        if bad:
+            print("bench.py: gathered rows differ from rank 0's re-evaluation: " + json.dumps(bad[:8]), file=sys.stderr, flush=True)
+            raise SystemExit(5)
+        one.upload(packs)      # (the passes below run on this rank's own block again)
+        one.run(want)
+        one.synchronize()
 
     # ---- the same evaluations with the host round trip the reference's calculate() makes: positions up, E + F down ---------
     pcie = None
@@ -396,7 +456,8 @@ def main():
         bwd_exec, fwd_exec = executed_mfma_flops("bwd", SL, M), executed_mfma_flops("fwd", SL, M)
         bwd_views = view(bwd_flops, bwd_bytes, bwd_exec, bwd_ms)
         fwd_views = view(fwd_flops, fwd_bytes, fwd_exec, fwd_ms)
-        achieved = bwd_exec / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+        achieved = bwd_flops / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0     # algorithmic
+        executed = bwd_exec / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0      # matrix-pipe occupancy
         step_ms = sum(v["total_ms"] for v in prof.values()) / k_prof
         step_flops = 33.0e6 * N     # 33 MFLOP per atom and ensemble evaluation (fp32-equivalent algorithmic work)
         line = {
@@ -415,6 +476,12 @@ def main():
                                         "concurrently; results bit-identical to one engine (checked in this run)"
                                         if n_str > 1 else "one engine, one HIP stream"),
                        "result_path": sharded.result_path, "dist_backend": dist_backend if world > 1 else None,
+                       "gather_transport": (sharded._gather.transport if sharded._gather is not None else None),
+                       "gathered_dtype": "f64 (E, sigma_E as the device forms them; results[\"energy\"] stays float32)" if world > 1 else None,
+                       "timed_region_note": ("K steps, then ONE ShardedEnsemble.check() (device result path: a host read of the "
+                                             "gathered overflow column, returns at once when no rank overflowed) and the closing "
+                                             "fence are inside the timed region") if world > 1 else
+                                            "K steps + the closing fence; check() returns at once without a gather",
                        "parallelism": ("one GPU, no collective" if world == 1 else
                                        f"chains sharded x{world} (rank r owns chains [{count} r, {count} r + {count})), "
                                        + ("RCCL" if dist_backend == "nccl" else dist_backend)
@@ -426,13 +493,19 @@ def main():
                          "pipe": "fp16 matrix pipe (v_mfma_f32_16x16x32_f16, dense peak 2.5 PFLOP/s); what binds is SIMD "
                                  "instruction issue -- see binding_resource",
                          "kernel": "edge_message_bwd (reverse neighbor pass, k_edge_bwd_mfma)",
+                         # the contract's definition: ALGORITHMIC flops (SURVEY 8(d) per-edge figure x edges x models) / launch time
+                         # against the dense peak of the pipe the contraction executes on
                          "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F16_MFMA_PEAK_TFLOPS, "traffic": measured_traffic("k_edge_bwd_mfma"),
-                         "formula": "achieved = executed matrix-pipe flops per launch / avg_launch_ms; executed = models x 8 feature "
-                                    "slices x slots_per_gpu / 16 steps x 20 v_mfma_f32_16x16x32_f16 per 16-slot step (static count "
-                                    "of the ISA) x 16384 flop.  The filter products are exact 3-way fp16 splits of fp32 operands, so "
-                                    "the ALGORITHMIC flops (views.fp32_equivalent / algorithmic_on_matrix_pipe: SURVEY 8(d), "
-                                    "2 x 17408 per real directed edge and model) are ~1/5 of the executed ones",
+                         "formula": "achieved = ALGORITHMIC flops per launch / avg_launch_ms; algorithmic = SURVEY 8(d): reverse = "
+                                    "2 x 17408 flop per real directed edge and model x edges_per_gpu x models.  The kernel executes "
+                                    "~4.9x that on the matrix pipe (exact 3-way fp16 split of fp32 operands, K padding 23/32, selector "
+                                    "and derivative tiles, 3 % slot padding): executed_pipe reports that occupancy separately",
+                         "executed_pipe": {"achieved": executed, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": executed / F16_MFMA_PEAK_TFLOPS,
+                                           "formula": "models x 8 feature slices x slots_per_gpu / 16 steps x 20 "
+                                                      "v_mfma_f32_16x16x32_f16 per 16-slot step (static count of the ISA) x 16384 flop "
+                                                      "/ avg_launch_ms: matrix-pipe occupancy, NOT useful work"},
                          "avg_launch_ms": bwd_ms, "launches": bwd_n,
                          "launch_times_from": f"separate single-stream pass of {k_prof} steps after the timed region "
                                               "(HIP events on the engine's stream)",
@@ -442,9 +515,12 @@ def main():
                          "binding_resource": binding_resource("k_edge_bwd_mfma"),
                          "second_kernel": {"kernel": "edge_message_fwd (neighbor-sum, k_edge_fwd_mfma)",
                                            "avg_launch_ms": fwd_ms, "launches": fwd_n,
-                                           "achieved": fwd_exec / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0,
+                                           "achieved": fwd_flops / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0,
                                            "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": (fwd_exec / (fwd_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS) if fwd_ms > 0 else 0.0,
+                                           "frac": (fwd_flops / (fwd_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS) if fwd_ms > 0 else 0.0,
+                                           "executed_pipe": {"achieved": fwd_exec / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0,
+                                                             "frac": (fwd_exec / (fwd_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS)
+                                                             if fwd_ms > 0 else 0.0},
                                            "executed_matrix_flops_per_launch": fwd_exec,
                                            "algorithmic_flops_per_launch": fwd_flops,
                                            "algorithmic_bytes_per_launch": fwd_bytes,
@@ -467,6 +543,7 @@ def main():
             "single_stream": {"ms_per_step": one_ms, "value": count / (one_ms * 1e-3), "steps": k_prof,
                               "note": "the per-kernel pass: one engine, HIP events around every kernel class"},
             "pcie_inclusive": pcie,
+            "gather_verified": gather_verified,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blobs, chains, table, const)

@@ -220,6 +220,17 @@ int vssr_batch_neighbors(vssr_handle *h, int64_t cap, int32_t *ei, int32_t *ej, 
  * synchronised run): lets the multi-GPU result gather (RCCL all_gather of per-chain scalars) read
  * them in place instead of through the host.  The pointers stay valid until the next vssr_batch_upload. */
 int vssr_batch_device_results(vssr_handle *h, const float **energy, const float **energy_std);
+/* The same values as doubles (the device holds the ensemble mean / spread in fp64 before narrowing them to the float32 result
+ * word): what the result gather of sharding.py moves between GPUs. */
+int vssr_batch_device_results_f64(vssr_handle *h, const double **energy, const double **energy_std);
+/* Energies of the LAST evaluation of the resident batch without the float32 output word (synchronises).  The reference's
+ * results["energy"] is a float32 tensor (EnsembleNFF.calculate, mcmc/calculators/calculators.py:484) and vssr_out keeps that
+ * type; but the per-chain sum over atoms, the unit conversion, the stoichiometric offset and the mean / population spread over
+ * the models are formed in fp64 on the device, and at |E| ~ 2 ... 9 keV the spacing of float32 (1.2e-4 ... 4.9e-4 eV) is as
+ * large as the whole arithmetic error of the evaluation.  energy [B], energy_std [B], energy_models [B][n_models]; any pointer
+ * may be NULL.  Tersoff / EAM handles: energy = energy_models = the fp64 energy, energy_std = 0.  The Metropolis test of the
+ * batched MC loop (mc.py) and relax_batch's returned energy take these values. */
+int vssr_batch_energy_f64(vssr_handle *h, double *energy, double *energy_std, double *energy_models);
 /* Latent-space embedding: the per-atom scalar features after the last update block, [sum N][feat_dim] fp32 per model --
  * what nff's Painn returns as results["embedding"] with requires_embedding=True and the reference's clustering /
  * uncertainty helpers read (get_embeddings_single, mcmc/calculators/calculators.py:67-93; scripts/clustering.py:239).

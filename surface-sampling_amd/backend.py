@@ -29,7 +29,7 @@ EXPORTS = (
     "vssr_batch_device_results", "vssr_eam_create", "vssr_eam_eval_batch",
     "vssr_tersoff_create_from_text", "vssr_batch_relax_cg", "vssr_batch_saturated",
     "vssr_batch_embedding", "vssr_batch_traj_configure", "vssr_batch_traj_read",
-    "vssr_device_context", "vssr_batch_stress",
+    "vssr_device_context", "vssr_batch_stress", "vssr_batch_energy_f64", "vssr_batch_device_results_f64",
 )
 
 
@@ -182,6 +182,10 @@ def load_library():
     L.vssr_batch_relax_bfgs.argtypes = [vp, C.POINTER(BfgsParams), u8p, C.c_uint32, dp, ip, u8p]
     L.vssr_batch_device_results.restype = C.c_int
     L.vssr_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.vssr_batch_device_results_f64.restype = C.c_int
+    L.vssr_batch_device_results_f64.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.vssr_batch_energy_f64.restype = C.c_int
+    L.vssr_batch_energy_f64.argtypes = [vp, dp, dp, dp]
     L.vssr_batch_traj_configure.restype = C.c_int
     L.vssr_batch_traj_configure.argtypes = [vp, C.c_int32]
     L.vssr_batch_traj_read.restype = C.c_int
@@ -295,6 +299,11 @@ class _Handle:
         self._check(self._lib.vssr_batch_download(self._h, int(want), C.byref(out)))
         res["cfg_start"] = self._cfg_start
         res["saturated"] = self.saturated()
+        # the same energies without the float32 output word (vssr_batch_energy_f64): what acceptance tests and relaxation
+        # drivers compare; "energy" keeps the reference's float32 type
+        e64, s64, m64 = np.zeros(B), np.zeros(B), np.zeros((B, M))
+        self._check(self._lib.vssr_batch_energy_f64(self._h, _ptr(e64, C.c_double), _ptr(s64, C.c_double), _ptr(m64, C.c_double)))
+        res["energy_f64"], res["energy_std_f64"], res["energy_models_f64"] = e64, s64, m64
         return res
 
     def embedding(self, model=None):
@@ -329,6 +338,12 @@ class _Handle:
         e, s = C.c_void_p(None), C.c_void_p(None)
         self._check(self._lib.vssr_batch_device_results(self._h, C.byref(e), C.byref(s)))
         return _DeviceArray(e.value, self._n_cfg), _DeviceArray(s.value, self._n_cfg)
+
+    def device_results_f64(self):
+        """``(energy, energy_std)`` as zero-copy float64 device arrays (vssr_batch_device_results_f64)."""
+        e, s = C.c_void_p(None), C.c_void_p(None)
+        self._check(self._lib.vssr_batch_device_results_f64(self._h, C.byref(e), C.byref(s)))
+        return _DeviceArray(e.value, self._n_cfg, "<f8"), _DeviceArray(s.value, self._n_cfg, "<f8")
 
     def device_context(self):
         """``(device ordinal, hipStream_t of the engine as int, device address of the overflow flag or None)``

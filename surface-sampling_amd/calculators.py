@@ -378,6 +378,11 @@ class EnsembleNFFSurface(_Base):
             "per_atom_energies": res["energy_atoms"][a0:a1].copy(),
             # the evaluation left the range of the fp16-split arithmetic (backend.saturated): finite, but not the model's
             "saturated": bool(res["saturated"][b]) if "saturated" in res else False,
+            # the same ensemble mean / spread without the float32 result word (vssr_batch_energy_f64): the reference's
+            # results["energy"] is a float32 tensor (calculators.py:484) and stays one; acceptance tests and relaxation drivers
+            # of this package compare these
+            **({"energy_f64": float(res["energy_f64"][b]), "energy_std_f64": float(res["energy_std_f64"][b])}
+               if "energy_f64" in res else {}),
         }
 
     def calculate(self, atoms=None, properties=implemented_properties, system_changes=all_changes):
@@ -524,12 +529,14 @@ class EnsembleNFFSurface(_Base):
         if nonempty.any():
             max_force[nonempty] = np.maximum.reduceat(fabs, start[:-1][nonempty])
         energy = res["energy"]
+        e64 = np.asarray(res["energy_f64"] if "energy_f64" in res else energy, dtype=np.float64)
         with np.errstate(invalid="ignore"):
             oob = (~np.isfinite(energy)) | (~np.isfinite(max_force)) | (np.abs(energy) > self.ENERGY_THRESHOLD) \
                 | (max_force > self.MAX_FORCE_THRESHOLD) | np.asarray(res["saturated"], dtype=bool)
         out = {"energy": energy, "energy_std": res["energy_std"], "forces": res["forces"], "energy_atoms": res["energy_atoms"],
                "positions": info["positions"] if info is not None else np.asarray(pos, dtype=np.float64).reshape(-1, 3),
-               "cfg_start": start, "saturated": np.asarray(res["saturated"], dtype=bool), "oob": oob}
+               "cfg_start": start, "saturated": np.asarray(res["saturated"], dtype=bool), "oob": oob, "energy_f64": e64,
+               "energy_std_f64": np.asarray(res["energy_std_f64"] if "energy_std_f64" in res else res["energy_std"], dtype=np.float64)}
         if info is not None:
             out["n_steps"], out["converged"] = info["n_steps"], info["converged"]
         return out
@@ -577,7 +584,7 @@ class EnsembleNFFSurface(_Base):
                 eng.set_positions(pos_all)
                 eng.run()
                 r = eng.download()
-                return np.asarray(r["energy"], dtype=np.float64), np.asarray(r["forces"], dtype=np.float64)
+                return np.asarray(r.get("energy_f64", r["energy"]), dtype=np.float64), np.asarray(r["forces"], dtype=np.float64)
 
             cfg = np.concatenate([[0], np.cumsum([len(p[0]) for p in packs])])
             kw = {"logfile": None} if HAVE_ASE and not callable(optimizer) else {}
@@ -599,7 +606,7 @@ class EnsembleNFFSurface(_Base):
                 eng.set_positions(pos_all)
                 eng.run()
                 r = eng.download()
-                return np.asarray(r["energy"], dtype=np.float64), np.asarray(r["forces"], dtype=np.float64)
+                return np.asarray(r.get("energy_f64", r["energy"]), dtype=np.float64), np.asarray(r["forces"], dtype=np.float64)
 
             cfg = np.concatenate([[0], np.cumsum([len(p[0]) for p in packs])])
             pos0 = np.concatenate([np.asarray(p[1], dtype=np.float64).reshape(-1, 3) for p in packs])
@@ -632,7 +639,7 @@ class EnsembleNFFSurface(_Base):
             else:
                 traj = _traj_of_chain(info.get("traj"), b, a0, a1, atoms) if save_traj else None
             r = self._fill_results(res, b)
-            energy = float(r["energy"][0])
+            energy = float(r["energy_f64"]) if "energy_f64" in r else float(r["energy"][0])
             max_force = float(np.abs(r["forces"]).max()) if a1 > a0 else 0.0
             oob = bool(not np.isfinite(energy) or not np.isfinite(max_force) or abs(energy) > self.ENERGY_THRESHOLD
                        or max_force > self.MAX_FORCE_THRESHOLD or r["saturated"])

@@ -501,8 +501,8 @@ __global__ void __launch_bounds__(256)
 k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const int *__restrict__ cfg_start, const int *__restrict__ Z,
                   const float *__restrict__ e_atom, double units_per_ev, const double *__restrict__ offset_per_z,
                   double offset_const, float *__restrict__ energy, float *__restrict__ energy_std,
-                  float *__restrict__ energy_models, float *__restrict__ e_atoms_mean, unsigned *__restrict__ sat,
-                  unsigned *__restrict__ sat_out) {
+                  float *__restrict__ energy_models, double *__restrict__ energy64, float *__restrict__ e_atoms_mean,
+                  unsigned *__restrict__ sat, unsigned *__restrict__ sat_out) {
     __shared__ double red[256];
     __shared__ double em[MAX_MODELS];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -539,6 +539,11 @@ k_finalize_energy(int N, int M, const unsigned char *__restrict__ active, const 
         for (int m = 0; m < M; ++m) var += (em[m] - mu) * (em[m] - mu);
         energy[b] = (float)mu;
         energy_std[b] = (float)sqrt(var / M);
+        // the same values before the narrowing to the reference's float32 result word (vssr_batch_energy_f64): [E | sigma | models]
+        const int B = gridDim.x;
+        energy64[b] = mu;
+        energy64[B + b] = sqrt(var / M);
+        for (int m = 0; m < M; ++m) energy64[(size_t)2 * B + (size_t)b * M + m] = em[m];
         // saturation report of this evaluation (mfma16.h SatTrack): the node kernels' flag, or a non-finite energy; the run
         // flag is cleared for the chain's next evaluation
         sat_out[b] = (sat[b] != 0u || !isfinite((float)mu)) ? 1u : 0u;
@@ -596,7 +601,8 @@ int painn_alloc_state(vssr_handle *h) {
         return set_err(h, VSSR_E_NOMEM, "edge-gradient buffer: out of device memory");
     sv.gbar = h->d_gbar.as<float4>();
     if (h->d_energy.ensure(sizeof(float) * h->n_cfg) || h->d_energy_std.ensure(sizeof(float) * h->n_cfg) ||
-        h->d_energy_models.ensure(sizeof(float) * h->n_cfg * M) || h->d_forces.ensure(sizeof(float) * 3 * N) ||
+        h->d_energy_models.ensure(sizeof(float) * h->n_cfg * M) || h->d_energy64.ensure(sizeof(double) * h->n_cfg * (2 + M)) ||
+        h->d_forces.ensure(sizeof(float) * 3 * N) ||
         h->d_forces_std.ensure(sizeof(float) * 3 * N) || h->d_e_atoms.ensure(sizeof(float) * N))
         return set_err(h, VSSR_E_NOMEM, "result buffers: out of device memory");
     if (h->d_sat.bytes < sizeof(unsigned) * h->n_cfg || h->d_sat_out.bytes < sizeof(unsigned) * h->n_cfg) {
@@ -805,8 +811,8 @@ int painn_run(vssr_handle *h, uint32_t want) {
     hipLaunchKernelGGL(k_finalize_energy, dim3(h->n_cfg), dim3(256), 0, st, N, M, h->active_mask, G.cfg_start, Z, sv.e_atom,
                        h->units_per_ev, h->has_offset ? h->offset_per_z.as<double>() : (const double *)nullptr,
                        h->offset_const, h->d_energy.as<float>(), h->d_energy_std.as<float>(),
-                       h->d_energy_models.as<float>(), h->d_e_atoms.as<float>(), h->d_sat.as<unsigned>(),
-                       h->d_sat_out.as<unsigned>());
+                       h->d_energy_models.as<float>(), h->d_energy64.as<double>(), h->d_e_atoms.as<float>(),
+                       h->d_sat.as<unsigned>(), h->d_sat_out.as<unsigned>());
     P.end(st);
     VSSR_HIP(h, hipGetLastError());
     return VSSR_OK;

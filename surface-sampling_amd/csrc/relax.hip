@@ -595,7 +595,8 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
                 continue;
             }
             if (!last && h->h_counters[3] == 0) break;   // no chain stepped in the last iteration: all converged, results final
-            if (!masked && h->h_counters[3] < B) { h->active_mask = active; masked = true; }
+            // (never at the final poll: the last evaluation above ran unmasked over every chain, the resident graph is complete)
+            if (!last && !masked && h->h_counters[3] < B) { h->active_mask = active; masked = true; }
         }
     }
     h->active_mask = nullptr;

@@ -468,7 +468,7 @@ void vssr_destroy(vssr_handle *h) {
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
                       &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_tile_sums, &h->d_erec, &h->d_rho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->d_zslot, &h->d_bundle, &h->d_excl, &h->d_hits, &h->wd16, &h->node16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv, &h->d_active, &h->d_bfgs_q, &h->d_bfgs_b,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
-                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_stress, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n, &h->d_chain_class, &h->d_class_list, &h->d_upd_save, &h->d_gpart};
+                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_stress, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n, &h->d_chain_class, &h->d_class_list, &h->d_upd_save, &h->d_gpart, &h->d_energy64};
     for (DevBuf *b : bufs) b->release();
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -837,6 +837,34 @@ int vssr_batch_device_results(vssr_handle *h, const float **energy, const float 
     if (!h->ran || h->kind != 1) return set_err(h, VSSR_E_STATE, "no completed PaiNN run");
     if (energy) *energy = h->d_energy.as<float>();
     if (energy_std) *energy_std = h->d_energy_std.as<float>();
+    return VSSR_OK;
+}
+
+int vssr_batch_device_results_f64(vssr_handle *h, const double **energy, const double **energy_std) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->ran || h->kind != 1) return set_err(h, VSSR_E_STATE, "no completed PaiNN run");
+    if (energy) *energy = h->d_energy64.as<double>();
+    if (energy_std) *energy_std = h->d_energy64.as<double>() + h->n_cfg;
+    return VSSR_OK;
+}
+
+int vssr_batch_energy_f64(vssr_handle *h, double *energy, double *energy_std, double *energy_models) {
+    if (!h) return VSSR_E_BADARG;
+    if (!h->ran) return set_err(h, VSSR_E_STATE, "vssr_batch_energy_f64 before a run");
+    VSSR_HIP(h, hipSetDevice(h->device));
+    int rc = sync_and_check(h);
+    if (rc) return rc;
+    const size_t B = h->n_cfg, M = h->n_models;
+    if (h->kind == 2 || h->kind == 3) {   // one analytic potential: no spread, the "model" is the potential
+        if (energy) VSSR_HIP(h, hipMemcpy(energy, h->d_ters_e.p, sizeof(double) * B, hipMemcpyDeviceToHost));
+        if (energy_models) VSSR_HIP(h, hipMemcpy(energy_models, h->d_ters_e.p, sizeof(double) * B, hipMemcpyDeviceToHost));
+        if (energy_std) for (size_t b = 0; b < B; ++b) energy_std[b] = 0.0;
+        return VSSR_OK;
+    }
+    const double *src = h->d_energy64.as<double>();
+    if (energy) VSSR_HIP(h, hipMemcpy(energy, src, sizeof(double) * B, hipMemcpyDeviceToHost));
+    if (energy_std) VSSR_HIP(h, hipMemcpy(energy_std, src + B, sizeof(double) * B, hipMemcpyDeviceToHost));
+    if (energy_models) VSSR_HIP(h, hipMemcpy(energy_models, src + 2 * B, sizeof(double) * B * M, hipMemcpyDeviceToHost));
     return VSSR_OK;
 }
 

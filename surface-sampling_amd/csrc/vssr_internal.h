@@ -319,6 +319,7 @@ struct vssr_handle {
                                  // profiles/r03/NOTES_node_kernels.md)
     // results (device)
     vssr::DevBuf d_energy, d_energy_std, d_energy_models, d_forces, d_forces_std, d_e_atoms;
+    vssr::DevBuf d_energy64;   // double [B] E | [B] sigma_E | [B][M] per model: the results before narrowing to float32
     vssr::DevBuf d_ters_e, d_ters_ea, d_ters_f;  // fp64 Tersoff results
     vssr::DevBuf d_sat, d_sat_out;   // [n_cfg] unsigned: saturation flags raised during a run / reported for the last evaluation of every chain
     std::vector<unsigned> h_sat;     // host copy of d_sat_out taken by vssr_batch_download (vssr_batch_saturated serves it: no second

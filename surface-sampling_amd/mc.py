@@ -173,11 +173,35 @@ def metropolis_accept(prev_energy, curr_energy, temperature: float, u) -> np.nda
     return np.asarray(u, float) < prob
 
 
+def complete_cell(cell) -> np.ndarray:
+    """``ase.geometry.complete_cell``: zero-length cell vectors (the non-periodic axis of a slab given without vacuum) are replaced
+    by unit vectors orthogonal to the others, so the cell can be inverted."""
+    cell = np.array(cell, float).reshape(3, 3)
+    missing = np.nonzero(~cell.any(axis=1))[0]
+    if len(missing) == 3:
+        cell.flat[::4] = 1.0
+    elif len(missing) == 2:
+        i = 3 - int(missing.sum())            # the one vector present
+        _, _, vh = np.linalg.svd(cell[i][None, :])
+        cell[missing] = vh[1:]
+    elif len(missing) == 1:
+        i = int(missing[0])
+        n = np.cross(cell[i - 2], cell[i - 1])
+        nn = np.linalg.norm(n)
+        if nn == 0.0:
+            raise ValueError("cell vectors are linearly dependent")
+        cell[i] = n / nn
+    return cell
+
+
 def mic_distance_matrix(xa, xb, cell, pbc) -> np.ndarray:
     """Minimum-image distances ``[len(xa), len(xb)]`` (``ase.Atoms.get_all_distances(mic=True)``): fractional differences are
-    wrapped into [-1/2, 1/2) along the periodic axes, then the shortest of the 3^p neighbouring images is taken (exact for cells
-    that are not extremely skewed: every slab cell of the reference; orthorhombic cells need only the wrap)."""
-    cell = np.asarray(cell, float).reshape(3, 3)
+    wrapped into [-1/2, 1/2) along the periodic axes, then the shortest image within a search range is taken.  Degenerate
+    (zero-length) vectors of non-periodic axes are completed like ASE does.  The image range per periodic axis is derived from
+    the cell: every lattice vector whose length could beat the wrapped difference is covered (range ``ceil(|d|max / h_i)`` with
+    ``h_i`` the distance between the lattice planes of axis i) -- ASE reaches the same minimum through a Minkowski reduction;
+    1 for every slab cell of the reference, more only for strongly skewed cells."""
+    cell = complete_cell(cell)
     pbc = np.asarray(pbc, bool).reshape(3)
     d = np.asarray(xb, float)[None, :, :] - np.asarray(xa, float)[:, None, :]
     frac = d @ np.linalg.inv(cell)
@@ -186,11 +210,17 @@ def mic_distance_matrix(xa, xb, cell, pbc) -> np.ndarray:
     ortho = np.allclose(cell - np.diag(np.diag(cell)), 0.0)
     if ortho or not pbc.any():
         return np.sqrt((d * d).sum(axis=2))
-    rng = [(-1, 0, 1) if p else (0,) for p in pbc]
+    # an image shifted by n_i along axis i is at least (|n_i| - 1/2) h_i away (h_i: spacing of that axis' lattice planes; the
+    # wrapped difference lies within +- h_i / 2 of its plane): images with (|n_i| - 1/2) h_i > max |d| cannot win
+    dmax = float(np.sqrt((d * d).sum(axis=2)).max()) if d.size else 0.0
+    heights = abs(np.linalg.det(cell)) / np.array([np.linalg.norm(np.cross(cell[(i + 1) % 3], cell[(i + 2) % 3])) for i in range(3)])
+    reach = [max(1, int(np.floor(dmax / heights[i] + 0.5))) if pbc[i] else 0 for i in range(3)]
+    if max(reach) > 64:
+        raise ValueError("cell too skewed for the minimum-image search: reduce it first")
     best = None
-    for i in rng[0]:
-        for j in rng[1]:
-            for k in rng[2]:
+    for i in range(-reach[0], reach[0] + 1):
+        for j in range(-reach[1], reach[1] + 1):
+            for k in range(-reach[2], reach[2] + 1):
                 dd = d + (i * cell[0] + j * cell[1] + k * cell[2])[None, None, :]
                 r2 = (dd * dd).sum(axis=2)
                 best = r2 if best is None else np.minimum(best, r2)
@@ -652,17 +682,22 @@ class ChainEnsemble:
         start = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
         cell = np.tile(np.asarray(self.base.cell, float).reshape(1, 9), (b, 1))
         pbc = np.tile(np.asarray(self.base.pbc).astype(np.uint8).reshape(1, 3), (b, 1))
+        # fixed_indices None = "the calculator's default" (LAMMPSSurfCalc: the template's bulk group); an explicit list --
+        # also an EMPTY one: hold nothing -- always becomes a mask, exactly as the per-slab path passes [indices] * B
         fixed = None
-        if self.relax and self.fixed_indices is not None and len(self.fixed_indices):
+        if self.relax and self.fixed_indices is not None:
             fixed = np.zeros(int(start[-1]), np.uint8)
-            fixed[(start[:-1, None] + self.fixed_indices[None, :]).ravel()] = 1
+            if len(self.fixed_indices):
+                fixed[(start[:-1, None] + np.asarray(self.fixed_indices, dtype=np.int64)[None, :]).ravel()] = 1
         out = self.calc.evaluate_packed(n_atoms, numbers, positions, cell, pbc, relax=self.relax, fixed_mask=fixed,
                                         relax_steps=self.relax_steps, fmax=self.fmax, optimizer=self.optimizer)
         if self.relax:
             self.oob[idx] = out["oob"]
         ea = out["energy_atoms"]
         self._last_pae = [ea[start[k]:start[k + 1]] for k in range(b)]
-        raw = np.asarray(out["energy"], dtype=np.float64)
+        # the acceptance energy is the device's fp64 value where the backend returns it (vssr_batch_energy_f64); "energy"
+        # keeps the reference's float32 result word
+        raw = np.asarray(out["energy_f64"] if "energy_f64" in out else out["energy"], dtype=np.float64)
         if mode[0] == "plain":
             energies = raw
         else:
@@ -712,7 +747,7 @@ class ChainEnsemble:
             self._last_pae = [o[4].get("per_atom_energies") if len(o) > 4 and isinstance(o[4], dict) else None for o in out]
         else:
             out = self.calc.calculate_batch(slabs)
-            raw = [float(np.ravel(o["energy"])[0]) for o in out]
+            raw = [float(o["energy_f64"]) if "energy_f64" in o else float(np.ravel(o["energy"])[0]) for o in out]
             relaxed = slabs
             self._last_pae = [o.get("per_atom_energies") for o in out]
         self.n_evaluations += len(slabs)
@@ -736,6 +771,8 @@ class ChainEnsemble:
         """Energy of the relaxed slab from a ``relax_batch`` tuple: the results of its final evaluation when the backend
         returns them, else the tuple's energy field."""
         res = relax_out[4] if len(relax_out) > 4 else None
+        if isinstance(res, dict) and "energy_f64" in res:
+            return float(res["energy_f64"])
         if isinstance(res, dict) and "energy" in res:
             return float(np.ravel(res["energy"])[0])
         return float(relax_out[2])
@@ -887,6 +924,7 @@ class ChainEnsemble:
             for site in self.even_adsorption_sites(num_ads_atoms):
                 self.step_semigrand(site_idx=int(site))
         else:
+            start = self.step_count
             for _ in range(int(max_steps)):
                 need = self.num_adsorbates() < int(num_ads_atoms)
                 if not need.any():
@@ -894,6 +932,11 @@ class ChainEnsemble:
                 self.step_semigrand(which=need)
             else:
                 raise RuntimeError("prepare_canonical: some chains did not reach the requested number of adsorbates")
+            # A chain consumed the random numbers of steps start + 1 .. start + k_chain, k_chain <= max_steps, whatever the
+            # other chains of this ensemble needed.  The steps AFTER the preparation continue from a fixed index, not from the
+            # slowest chain's count: a chain's trajectory stays independent of which chains share its ensemble / group / rank
+            # (random numbers are keyed by (seed, global chain id, step)).
+            self.step_count = start + int(max_steps)
         if self.criterion != "metropolis":
             self.refresh_energies()
         return self.num_adsorbates()

@@ -46,10 +46,11 @@ class ChainGather:
     copy, no ``cat``, no allocation per step.  Uneven blocks go through a preallocated pad buffer and are compacted into a
     preallocated result.  Two output buffers alternate, so the result of step n stays intact while step n + 1 is gathered."""
 
-    def __init__(self, n_chains: int, width: int, dist, device=None):
+    def __init__(self, n_chains: int, width: int, dist, device=None, dtype=None):
         import torch
 
         self.n_chains, self.width, self.dist = int(n_chains), int(width), dist
+        self.dtype = torch.float32 if dtype is None else dtype
         self.world = _world(dist)
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.ranges = all_ranges(self.n_chains, self.world)
@@ -57,11 +58,23 @@ class ChainGather:
         self.cmax = max(c for _, c in self.ranges) if self.ranges else 0
         self.even = all(c == self.cmax for _, c in self.ranges)
         self.device = torch.device("cpu") if device is None else torch.device(device)
-        kw = dict(dtype=torch.float32, device=self.device)
+        kw = dict(dtype=self.dtype, device=self.device)
         self._pad = torch.zeros(self.cmax, self.width, **kw)
         self._out = [torch.empty(self.world * self.cmax, self.width, **kw) for _ in range(2)]
         self._full = None if self.even else [torch.empty(self.n_chains, self.width, **kw) for _ in range(2)]
         self._flip = 0
+        # Transport.  "direct": the device (or CPU) tensor goes to the collective -- RCCL on the GPU box, gloo on CPU tensors.
+        # "host_bounce": a DEVICE-resident block under a backend that has no device all_gather (gloo: the one-GPU rehearsal of
+        # the N > 1 path, RCCL refuses two ranks on one device): pinned staging D2H -> gloo -> H2D into the same device result
+        # buffers.  Everything before and after the transport (event-ordered staging, double buffering, overflow column, the
+        # result tensors) is the code of the RCCL path.
+        self.transport = "direct"
+        if self.world > 1 and self.device.type == "cuda" and dist.get_backend() != "nccl":
+            self.transport = "host_bounce"
+            pin = dict(dtype=self.dtype, device="cpu", pin_memory=True)
+            self._h_in = torch.zeros(self.cmax, self.width, **pin)
+            self._h_out = torch.empty(self.world * self.cmax, self.width, **pin)
+        self.n_bounces = 0
         self.n_staging_copies = 0        # (tests: stays 0 on the even, device-resident path)
         self.force_collective = False    # (tests: a one-rank group still goes through the collective, RCCL sees the real buffers)
 
@@ -73,7 +86,7 @@ class ChainGather:
         if isinstance(local, torch.Tensor):
             t = local
         else:
-            t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
+            t = torch.from_numpy(np.ascontiguousarray(local)).to(self.dtype)
         if tuple(t.shape) != (self.count, self.width):
             raise ValueError("local block does not match this rank's chain range")
         self._flip ^= 1
@@ -81,12 +94,20 @@ class ChainGather:
         if self.world == 1 and not (self.force_collective and self.dist is not None and self.dist.is_initialized()):
             out.copy_(t, non_blocking=True)
             return out
-        direct = self.even and t.dtype == torch.float32 and t.device == self.device and t.is_contiguous()
-        if not direct:
-            self._pad[: self.count].copy_(t, non_blocking=True)
-            self.n_staging_copies += 1
-            t = self._pad
-        self.dist.all_gather_into_tensor(out, t)
+        if self.transport == "host_bounce":
+            # (rehearsal transport: the host waits for the producer's stream here -- the RCCL path never does)
+            self._h_in[: self.count].copy_(t, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            self.dist.all_gather_into_tensor(self._h_out, self._h_in)
+            out.copy_(self._h_out, non_blocking=True)
+            self.n_bounces += 1
+        else:
+            direct = self.even and t.dtype == self.dtype and t.device == self.device and t.is_contiguous()
+            if not direct:
+                self._pad[: self.count].copy_(t, non_blocking=True)
+                self.n_staging_copies += 1
+                t = self._pad
+            self.dist.all_gather_into_tensor(out, t)
         if self.even:
             return out
         full = self._full[self._flip]
@@ -99,21 +120,24 @@ class ChainGather:
 def gather_chain_scalars(local, n_chains: int, dist=None, device=None, keep_on_device: bool = False):
     """One-shot form of :class:`ChainGather` (allocates; the per-step path of ``ShardedEnsemble`` keeps a ``ChainGather``).
 
-    ``local``: float32 ``[count, k]`` (or ``[count]``) for this rank's block — a numpy array, or a torch tensor that may
-    already live on the GPU (then nothing passes through the host before the collective).  Returns a numpy array, or with
-    ``keep_on_device`` the gathered torch tensor ``[n_chains, k]``."""
+    ``local``: float32 / float64 ``[count, k]`` (or ``[count]``) for this rank's block — a numpy array, or a torch tensor that
+    may already live on the GPU (then nothing passes through the host before the collective); the gathered array keeps the
+    floating type.  Returns a numpy array, or with ``keep_on_device`` the gathered torch tensor ``[n_chains, k]``."""
     import torch
 
     is_tensor = isinstance(local, torch.Tensor)
     shape_tail = tuple(local.shape[1:])
     width = int(np.prod(shape_tail)) if shape_tail else 1
     if is_tensor:
-        flat = local.to(dtype=torch.float32).reshape(int(local.shape[0]), width)
+        dtype = torch.float64 if local.dtype == torch.float64 else torch.float32
+        flat = local.to(dtype=dtype).reshape(int(local.shape[0]), width)
         dev = flat.device if device is None else device
     else:
-        flat = np.ascontiguousarray(local, dtype=np.float32).reshape(int(local.shape[0]), width)
+        local = np.asarray(local)
+        dtype = torch.float64 if local.dtype == np.float64 else torch.float32
+        flat = np.ascontiguousarray(local, dtype=np.float64 if dtype == torch.float64 else np.float32).reshape(int(local.shape[0]), width)
         dev = device
-    full = ChainGather(n_chains, width, dist, dev)(flat).reshape((n_chains,) + shape_tail)
+    full = ChainGather(n_chains, width, dist, dev, dtype)(flat).reshape((n_chains,) + shape_tail)
     return full if keep_on_device else full.cpu().numpy()
 
 
@@ -195,7 +219,13 @@ class ShardedEnsemble:
     is enqueued while the gather of step n is still in flight (two staging buffers).  A neighbor-capacity overflow of a
     run cannot be seen without the host: its flag travels with the results (third column) and :meth:`check` repairs it.
     ``"host"`` -- ``download`` + numpy (the CPU stand-in of the tests; ``gloo`` groups; fp64 engines without device results).
-    ``"auto"``: device for an ``nccl`` group or a single rank when the engine can, host otherwise."""
+    ``"auto"``: device for an ``nccl`` group or a single rank when the engine can, host otherwise.  ``"device"`` under a
+    ``gloo`` group is the one-GPU rehearsal of the RCCL path: everything is the device path except the transport
+    (``ChainGather.transport == "host_bounce"``).
+
+    The gathered values are float64: the ensemble mean / spread as the device forms them, before the narrowing to the
+    reference's float32 result word (``vssr_batch_device_results_f64`` / ``energy_f64``; an engine without them contributes
+    its float32 energies widened)."""
 
     def __init__(self, engine, n_chains: int, dist=None, device=None, result_path: str = "auto"):
         self.engine, self.n_chains, self.dist, self.device = engine, n_chains, dist, device
@@ -233,7 +263,7 @@ class ShardedEnsemble:
         self._staging = None
 
     def _device_scalars(self):
-        """This rank's per-chain (E, sigma_E, overflow flag) as a ``[count, 3]`` tensor on the ENGINE's device, ordered
+        """This rank's per-chain (E, sigma_E, overflow flag) as a float64 ``[count, 3]`` tensor on the ENGINE's device, ordered
         behind the engine's stream(s) by events only.  Errors of the engine propagate (no fallback, see ``__init__``).
         An ``EngineGroup`` contributes one row range per engine."""
         import torch
@@ -242,7 +272,7 @@ class ShardedEnsemble:
         ordinal = parts[0][0].device_context()[0]
         dev = torch.device("cuda", ordinal)     # the engine's device, whatever torch's current device is
         if self._staging is None or self._staging[0].shape[0] != self.count or self._staging[0].device != dev:
-            self._staging = [torch.zeros(self.count, 3, dtype=torch.float32, device=dev) for _ in range(2)]
+            self._staging = [torch.zeros(self.count, 3, dtype=torch.float64, device=dev) for _ in range(2)]
             self._views = {}
         self._flip ^= 1
         buf = self._staging[self._flip]
@@ -250,7 +280,7 @@ class ShardedEnsemble:
         exts = []
         for k, (eng, lo, hi) in enumerate(parts):
             _, stream_ptr, flag_ptr = eng.device_context()
-            e, s = eng.device_results()
+            e, s = eng.device_results_f64() if hasattr(eng, "device_results_f64") else eng.device_results()
             ptrs = (e.__cuda_array_interface__["data"][0], s.__cuda_array_interface__["data"][0], flag_ptr, stream_ptr)
             v = self._views.get(k)
             if v is None or v[0] != ptrs:      # zero-copy views, made once per resident batch (again after a capacity regrow)
@@ -264,7 +294,7 @@ class ShardedEnsemble:
                 buf[lo:hi, 0].copy_(ve, non_blocking=True)
                 buf[lo:hi, 1].copy_(vs, non_blocking=True)
                 if vf is not None:
-                    buf[lo:hi, 2].copy_(vf.expand(hi - lo), non_blocking=True)     # int32 -> float32 inside the copy
+                    buf[lo:hi, 2].copy_(vf.expand(hi - lo), non_blocking=True)     # int32 -> float64 inside the copy
             exts.append(ext)
         for ext in exts:
             ext.wait_stream(cur)                 # an engine's next run overwrites its result buffers only after these copies
@@ -275,7 +305,8 @@ class ShardedEnsemble:
         if self.result_path == "device":
             return self._device_scalars()
         res = self.engine.download(want_energy_flags)   # synchronises, repairs a capacity overflow
-        return np.stack([res["energy"], res["energy_std"]], axis=1)
+        return np.stack([np.asarray(res.get("energy_f64", res["energy"]), dtype=np.float64),
+                         np.asarray(res.get("energy_std_f64", res["energy_std"]), dtype=np.float64)], axis=1)
 
     def _gather_local(self, scal):
         width = int(scal.shape[1])
@@ -285,7 +316,9 @@ class ShardedEnsemble:
             dev = self.device if (self.world > 1 and self.dist.get_backend() == "nccl") else None
         g = self._gather
         if g is None or g.width != width or g.count != self.count or str(g.device) != str("cpu" if dev is None else dev):
-            g = self._gather = ChainGather(self.n_chains, width, self.dist, dev)
+            import torch
+
+            g = self._gather = ChainGather(self.n_chains, width, self.dist, dev, torch.float64)
         return g(scal)
 
     def step(self, want, gather: bool | None = None):
@@ -333,7 +366,8 @@ class ShardedEnsemble:
         """``all_chains``: the global list (every rank passes the same list; only its block is evaluated).
         Returns global per-chain ``energy`` / ``energy_std`` on every rank and this rank's ``forces``."""
         res = self.engine.evaluate(self.local_slice(all_chains))
-        scal = np.stack([res["energy"], res["energy_std"]], axis=1)
+        scal = np.stack([np.asarray(res.get("energy_f64", res["energy"]), dtype=np.float64),
+                         np.asarray(res.get("energy_std_f64", res["energy_std"]), dtype=np.float64)], axis=1)
         full = gather_chain_scalars(scal, self.n_chains, self.dist, self.device)
         return {"energy": full[:, 0], "energy_std": full[:, 1], "forces_local": res["forces"],
                 "cfg_start_local": res["cfg_start"], "first": self.first, "count": self.count}

@@ -61,6 +61,17 @@ def test_vssr_eval_and_eval_batch_through_raw_ctypes(golden):
         assert rc == 0, lib.vssr_last_error(h)
         assert np.array_equal(Eb, ref["energy"]) and np.array_equal(Fb, ref["forces"]) and np.array_equal(Fsb, ref["forces_std"])
         assert np.allclose(Em.mean(axis=1), Eb, atol=2e-4) and Em.std() > 0
+        # ---- vssr_batch_energy_f64: the same energies without the float32 result word, raw pointers -------------------------------
+        e64, s64, m64 = np.zeros(2), np.zeros(2), np.zeros((2, len(blobs)))
+        dp = C.POINTER(C.c_double)
+        rc = lib.vssr_batch_energy_f64(h, e64.ctypes.data_as(dp), s64.ctypes.data_as(dp), m64.ctypes.data_as(dp))
+        assert rc == 0, lib.vssr_last_error(h)
+        assert np.array_equal(e64.astype(np.float32), Eb) and np.array_equal(s64.astype(np.float32), Esb)
+        assert np.array_equal(m64.astype(np.float32), Em) and (e64 != Eb.astype(np.float64)).any()     # more digits than float32 holds
+        assert np.allclose(m64.mean(axis=1), e64, rtol=0, atol=1e-9) and np.allclose(m64.std(axis=1), s64, rtol=0, atol=1e-9)
+        assert lib.vssr_batch_energy_f64(h, None, None, None) == 0        # every output optional
+        d_e, d_s = C.c_void_p(), C.c_void_p()
+        assert lib.vssr_batch_device_results_f64(h, C.byref(d_e), C.byref(d_s)) == 0 and d_e.value and d_s.value == d_e.value + 16
         # ---- vssr_batch_stress: the virial of the evaluation that has just run (two chains), raw pointers -------------------------
         st, sd = np.zeros((2, 6)), np.zeros((2, 6))
         rc = lib.vssr_batch_stress(h, st.ctypes.data_as(C.POINTER(C.c_double)), sd.ctypes.data_as(C.POINTER(C.c_double)))

@@ -15,6 +15,7 @@ from conftest import top_layer
 pytestmark = pytest.mark.gpu
 
 E_TOL = 1e-4      # eV, GPU fp32 vs fp64 oracle
+E_TOL_LARGE = 2e-4   # eV, chains of 300 .. 1 462 atoms (beyond the survey's range; |E| up to 9.4 keV), on the fp64 output word
 F_TOL = 2e-4      # eV/A
 STD_TOL = 2e-4
 
@@ -444,7 +445,8 @@ def test_fallback_paths_large_chain_many_species_and_forced_gather(golden, oracl
     for b, s in enumerate((big, small)):
         ref = _oracle(golden, oracle_mod, s)
         a0, a1 = res["cfg_start"][b], res["cfg_start"][b + 1]
-        assert abs(float(res["energy"][b]) - ref["energy"]) <= (4e-4 if len(s) > 500 else E_TOL), (b, res["energy"][b], ref["energy"])
+        assert abs(float(res["energy_f64"][b]) - ref["energy"]) <= (E_TOL_LARGE if len(s) > 300 else E_TOL), (b, res["energy_f64"][b], ref["energy"])
+        assert float(np.float32(res["energy_f64"][b])) == float(res["energy"][b])      # the float32 word = the same value, narrowed
         assert np.abs(res["forces"][a0:a1] - ref["forces"]).max() <= F_TOL
     # (2) nine species: the embedding rows of the extra species are untrained but perfectly valid inputs
     many = small.copy()
@@ -729,8 +731,10 @@ def test_mixed_chain_sizes_take_their_own_path(golden, oracle_mod, engine):
     cs = res["cfg_start"]
     for b, c in enumerate(chains):
         ref = _oracle(golden, oracle_mod, c)
-        tol_e = E_TOL if len(c) <= 300 else 4e-4 if len(c) <= 800 else 6e-4   # (fp32 summation noise grows with |E|: -1.9e3 .. -7.5e3 eV here)
-        assert abs(float(res["energy"][b]) - ref["energy"]) <= tol_e, (b, len(c), float(res["energy"][b]), ref["energy"])
+        # on the fp64 output word (vssr_batch_energy_f64): the float32 word alone is good for 1.2e-4 (-1.9 keV) .. 4.9e-4 eV (-7.5 keV)
+        tol_e = E_TOL if len(c) <= 300 else E_TOL_LARGE
+        assert abs(float(res["energy_f64"][b]) - ref["energy"]) <= tol_e, (b, len(c), float(res["energy_f64"][b]), ref["energy"])
+        assert float(np.float32(res["energy_f64"][b])) == float(res["energy"][b])
         assert np.abs(res["forces"][cs[b]:cs[b + 1]] - ref["forces"]).max() <= F_TOL, (b, len(c))
         assert abs(float(res["energy_std"][b]) - ref["energy_std"]) <= STD_TOL
         alone = engine.evaluate([_arrays(c)])
@@ -827,8 +831,8 @@ def test_repeatability_of_every_neighbor_sum_path():
 def test_large_chain_takes_four_feature_slices_in_both_directions(golden, oracle_mod, engine):
     """A 1 2xx-atom chain (5 x 3 tiling of the 80-atom slab + adsorbates) is beyond the 8-feature reverse kernel (1 127 atoms):
     forward AND reverse pass run on 4-feature slices by its own size.  Forces within the stated 2e-4 eV/A of the fp64 oracle;
-    the energy (-9.4 keV) is returned as float32, whose spacing there is 9.8e-4 eV -- tolerance 1.5e-3 eV; bit-identical when
-    evaluated again and next to a small chain."""
+    the energy (-9.4 keV) within 2e-4 eV on the fp64 output word (the float32 word's spacing there is 9.8e-4 eV: it is the
+    same value narrowed, at most half a spacing away); bit-identical when evaluated again and next to a small chain."""
     from surface_sampling_amd import structures
 
     s80 = golden.structure("SrTiO3_2x2x4_pristine")
@@ -837,7 +841,8 @@ def test_large_chain_takes_four_feature_slices_in_both_directions(golden, oracle
     assert 1127 < len(big) <= 1462
     res = engine.evaluate([_arrays(big)])
     ref = _oracle(golden, oracle_mod, big)
-    assert abs(float(res["energy"][0]) - ref["energy"]) <= 1.5e-3, (float(res["energy"][0]), ref["energy"])
+    assert abs(float(res["energy_f64"][0]) - ref["energy"]) <= E_TOL_LARGE, (float(res["energy_f64"][0]), ref["energy"])
+    assert float(np.float32(res["energy_f64"][0])) == float(res["energy"][0]) and abs(float(res["energy"][0]) - ref["energy"]) <= 5e-4 + E_TOL_LARGE
     assert np.abs(res["forces"] - ref["forces"]).max() <= F_TOL
     assert np.abs(res["forces_std"] - ref["forces_std"]).max() <= STD_TOL and not res["saturated"].any()
     both = engine.evaluate([_arrays(small), _arrays(big)])

@@ -861,3 +861,92 @@ def test_concurrent_chain_groups_walk_the_trajectories_of_one_ensemble():
                                     seed=3, relax=False)
     with pytest.raises(RuntimeError, match="device lost"):
         bad.initialize()
+
+
+# ---- advisor findings, round 4 ----------------------------------------------------------------------------------------------
+def test_explicit_empty_fixed_indices_hold_nothing_on_both_paths():
+    """``fixed_indices=[]`` means "hold nothing" on the packed path as on the per-slab path (a mask of zeros reaches the
+    calculator); only ``None`` means "the calculator's default group" (``fixed_mask=None``)."""
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[1.0 * s, 0.0, 2.0] for s in range(6)], float)
+    seen = {}
+
+    class Spy(PackedLatticeGasCalc):
+        def evaluate_packed(self, *a, fixed_mask=None, **k):
+            seen["packed"] = None if fixed_mask is None else np.array(fixed_mask, copy=True)
+            return super().evaluate_packed(*a, fixed_mask=fixed_mask, **k)
+
+        def relax_batch(self, slabs, fixed_indices=None, relax_steps=20, fmax=0.01):
+            seen["slab"] = fixed_indices
+            return super().relax_batch(slabs, fixed_indices, relax_steps, fmax)
+
+    for fixed, packed_is_none in ((np.array([], np.int64), False), (None, True), (np.array([1]), False)):
+        for fast in (True, False):
+            calc = Spy(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.03)
+            ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 5, calc, seed=4, relax=True, temperature=0.05, fixed_indices=fixed)
+            ens.fast_path = fast
+            ens.initialize()
+            if fast:
+                assert (seen["packed"] is None) == packed_is_none
+                if fixed is not None:
+                    assert seen["packed"].dtype == np.uint8 and int(seen["packed"].sum()) == 5 * len(fixed)
+            else:
+                assert (seen["slab"] is None) == (fixed is None)
+                if fixed is not None:
+                    assert all(len(f) == len(fixed) for f in seen["slab"])
+
+
+def test_steps_after_prepare_canonical_do_not_depend_on_the_other_chains():
+    """The random numbers are keyed by (seed, global chain id, step): after ``prepare_canonical`` every ensemble continues from
+    the SAME step index whatever its slowest chain needed, so chains prepared together walk exactly the trajectories they
+    walk when prepared in two separate ensembles (grouping / sharding independence holds through the preparation)."""
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[2.0 * i, 2.0 * j, 2.0] for i in range(4) for j in range(3)], float)
+
+    def run(n, first):
+        calc = PackedLatticeGasCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.0)
+        ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), n, calc, seed=6, first_chain=first, relax=False, temperature=5.0)
+        ens.initialize()
+        counts = ens.prepare_canonical(4, max_steps=500)
+        prepared = ens.state.species.copy()
+        after_prepare = ens.step_count
+        acc = np.stack([ens.step_canonical() for _ in range(6)] + [ens.step_semigrand() for _ in range(3)])
+        return counts, prepared, after_prepare, acc, ens.state.species.copy(), ens.state.energy.copy()
+
+    whole = run(24, 0)
+    parts = [run(10, 0), run(14, 10)]
+    assert whole[2] == parts[0][2] == parts[1][2] == 500           # a fixed continuation index
+    assert np.array_equal(whole[1], np.concatenate([p[1] for p in parts]))
+    assert np.array_equal(whole[3], np.concatenate([p[3] for p in parts], axis=1)) and whole[3].any()
+    assert np.array_equal(whole[4], np.concatenate([p[4] for p in parts]))
+    assert np.array_equal(whole[5], np.concatenate([p[5] for p in parts]))
+
+
+def test_minimum_image_distances_in_skewed_and_degenerate_cells():
+    """``mic_distance_matrix`` = brute force over many images for strongly skewed cells (ASE gets there by a Minkowski
+    reduction), and a zero-length vector on a non-periodic axis is completed instead of raising (``ase.geometry.complete_cell``)."""
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        cell = np.array([[4, 0, 0], [rng.uniform(-9, 9), 3, 0], [rng.uniform(-3, 3), rng.uniform(-3, 3), 10]])
+        pbc = [True, True, trial % 2 == 0]
+        xa, xb = rng.uniform(0, 4, (5, 3)), rng.uniform(0, 4, (6, 3))
+        got = mc.mic_distance_matrix(xa, xb, cell, pbc)
+        best = np.full((5, 6), np.inf)
+        span = range(-14, 15)
+        for i in span:
+            for j in span:
+                for k in (span if pbc[2] else [0]):
+                    dd = xb[None] - xa[:, None] + i * cell[0] + j * cell[1] + k * cell[2]
+                    best = np.minimum(best, np.sqrt((dd * dd).sum(2)))
+        assert np.allclose(got, best, atol=1e-12)
+    flat = np.array([[4.0, 0, 0], [1.0, 3.0, 0], [0, 0, 0]])
+    d = mc.mic_distance_matrix(np.zeros((1, 3)), np.array([[3.9, 0.0, 1.0]]), flat, [True, True, False])
+    assert d[0, 0] == pytest.approx(np.hypot(0.1, 1.0))
+    assert np.allclose(mc.complete_cell(flat)[2], [0, 0, 1])
+    assert np.allclose(mc.complete_cell(np.zeros((3, 3))), np.eye(3))
+    one = mc.complete_cell(np.array([[0, 0, 0], [0, 2.0, 0], [0, 0, 0]]))
+    assert abs(np.linalg.det(one)) == pytest.approx(2.0)

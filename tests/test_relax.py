@@ -135,17 +135,35 @@ def test_relax_batch_records_the_trajectory_like_the_reference_observer(golden, 
 
 @pytest.mark.gpu
 def test_stats_after_a_relaxation_need_a_full_run(golden):
-    """After a lock-step relaxation the resident graph covers only the chains of its last iteration: the introspection calls
-    say so instead of returning partial data (advisor finding, round 2); one full run makes them valid again."""
+    """A lock-step relaxation in which a chain converged EARLY leaves a resident graph that covers only the chains of its last
+    iteration: the introspection calls say so instead of returning partial data (advisor finding, round 2); one full run makes
+    them valid again.  A relaxation that uses its whole step budget with every chain running -- the normal case with the
+    reference's settings -- ends on a complete, unmasked evaluation and leaves everything valid (advisor finding, round 4)."""
     from surface_sampling_amd import backend
 
     table, const = golden.offset_table()
     eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
     s = golden.structure("O36Sr12Ti12")
-    eng.upload([(s.numbers, s.positions, s.cell, s.pbc)] * 2)
+    rattled = s.positions + np.random.default_rng(5).normal(0, 0.08, s.positions.shape)
+    packs = [(s.numbers, s.positions, s.cell, s.pbc), (s.numbers, rattled, s.cell, s.pbc)]
+    eng.upload(packs)
     eng.run()
     before = eng.stats()
-    eng.relax("BFGS", max_steps=3)
+    f = np.linalg.norm(eng.download()["forces"].astype(np.float64), axis=1)
+    f_a, f_b = f[:len(s.numbers)].max(), f[len(s.numbers):].max()
+    assert f_b > 3 * f_a
+    # (i) nobody converges within the budget: complete graph, introspection valid without another run
+    info = eng.relax("BFGS", max_steps=3, fmax=1e-4)
+    assert not info["converged"].any() and (info["n_steps"] == 3).all()
+    assert np.isfinite(eng.download()["energy"]).all()
+    assert eng.stats()["atoms"] == before["atoms"] and len(eng.neighbors()[0]) > 0
+    assert eng.debug_read("e_atom", 0).size == before["atoms"]
+    st, _ = eng.stress()
+    assert np.isfinite(st).all()
+    # (ii) chain 0 is converged from the start, chain 1 keeps stepping: the mask goes in at the first poll
+    eng.upload(packs)
+    info = eng.relax("FIRE", max_steps=8, fmax=1.5 * f_a)
+    assert info["converged"][0] and info["n_steps"][0] == 0 and info["n_steps"][1] >= 4
     res = eng.download()                                                      # results stay available
     assert np.isfinite(res["energy"]).all()
     for call in (eng.stats, eng.neighbors, lambda: eng.debug_read("e_atom", 0)):

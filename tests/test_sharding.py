@@ -121,6 +121,29 @@ def test_bench_step_function_world_size_2_gloo(tmp_path):
     assert all(np.load(tmp_path / f"ok{r}.npy")[0] == 1 for r in (0, 1))
 
 
+def test_bench_step_function_world_size_8_gloo_at_2048_chains(tmp_path):
+    """BASELINE configs[4] at its real shape on CPU: 8 ranks x 256 chains over gloo, `bench.shard_plan` / `ShardedEnsemble.step`
+    / `ChainGather` with a stand-in engine -- every rank sees all 2 048 rows in global chain order, three steps in a row."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_bench_worker, args=(8, port, 256, str(tmp_path)), nprocs=8, join=True)
+    assert all(np.load(tmp_path / f"ok{r}.npy")[0] == 1 for r in range(8))
+
+
+def test_chain_gather_world_size_8_uneven_blocks(tmp_path):
+    """2 045 chains on 8 ranks (blocks of 256 and 255): the padded path of `ChainGather`, float64 rows."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gather_worker, args=(8, port, 2045, str(tmp_path), "float64"), nprocs=8, join=True)
+    assert all(np.load(tmp_path / f"ok{r}.npy")[0] == 1 for r in range(8))
+
+
 def test_single_rank_step_has_no_collective():
     import bench
     from surface_sampling_amd.sharding import ShardedEnsemble
@@ -131,7 +154,7 @@ def test_single_rank_step_has_no_collective():
     assert bench.make_step(sh, 7)() is None and eng.runs == 1
 
 
-def _gather_worker(rank, world, port, n_chains, out_dir):
+def _gather_worker(rank, world, port, n_chains, out_dir, dtype="float32"):
     """ChainGather over gloo: buffers allocated once, the even case hands the caller's tensor straight to the collective."""
     sys.path.insert(0, ROOT)
     import torch
@@ -143,14 +166,15 @@ def _gather_worker(rank, world, port, n_chains, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     first, count = all_ranges(n_chains, world)[rank]
-    g = ChainGather(n_chains, 3, dist)
-    ok = g.even == (n_chains % world == 0)
+    dt = getattr(torch, dtype)
+    g = ChainGather(n_chains, 3, dist, dtype=dt)
+    ok = g.even == (n_chains % world == 0) and g.transport == "direct"
     seen = set()
     for k in range(6):
-        local = torch.arange(first, first + count, dtype=torch.float32)[:, None] * torch.tensor([1.0, 10.0, 100.0]) + k
+        local = torch.arange(first, first + count, dtype=dt)[:, None] * torch.tensor([1.0, 10.0, 100.0], dtype=dt) + k
         full = g(local)
-        want = torch.arange(n_chains, dtype=torch.float32)[:, None] * torch.tensor([1.0, 10.0, 100.0]) + k
-        ok = ok and torch.equal(full, want)
+        want = torch.arange(n_chains, dtype=dt)[:, None] * torch.tensor([1.0, 10.0, 100.0], dtype=dt) + k
+        ok = ok and torch.equal(full, want) and full.dtype == dt
         seen.add(full.data_ptr())
         if k:
             ok = ok and torch.equal(prev, want - 1.0)      # the previous result is still intact (two buffers alternate)
@@ -245,8 +269,13 @@ def test_device_results_reach_torch_and_rccl_without_a_host_copy():
     got = sh.step(want, gather=True)                     # world 1: the local block, taken from the device buffers
     res = eng.download(want)
     assert sh.result_path == "device"
-    assert got.is_cuda and got.shape == (len(chains), 3)     # E, sigma_E and the run's capacity-overflow flag
-    assert np.array_equal(got[:, 0].cpu().numpy(), res["energy"]) and np.array_equal(got[:, 1].cpu().numpy(), res["energy_std"])
+    assert got.is_cuda and got.shape == (len(chains), 3) and got.dtype == torch.float64     # E, sigma_E, capacity-overflow flag
+    assert np.array_equal(got[:, 0].cpu().numpy(), res["energy_f64"]) and np.array_equal(got[:, 1].cpu().numpy(), res["energy_std_f64"])
+    # the float32 result word of the ABI is the narrowing of the same device value
+    assert np.array_equal(res["energy_f64"].astype(np.float32), res["energy"])
+    assert np.array_equal(res["energy_std_f64"].astype(np.float32), res["energy_std"])
+    assert np.array_equal(res["energy_models_f64"].astype(np.float32), res["energy_models"])
+    assert np.allclose(res["energy_models_f64"].mean(axis=1), res["energy_f64"], rtol=0, atol=1e-9)
     assert not got[:, 2].any() and sh.check() is False
     # step n + 1 is enqueued behind the staging copy of step n without a host synchronisation: ten back-to-back steps, results
     # of every one identical (the same resident positions), the two staging buffers alternate
@@ -257,7 +286,7 @@ def test_device_results_reach_torch_and_rccl_without_a_host_copy():
         seen.append(sh._staging[sh._flip].data_ptr())
     assert len(set(seen)) == 2 and seen[0] != seen[1] and seen[0] == seen[2]
     torch.cuda.synchronize()
-    assert np.array_equal(outs[-1][:, 0].cpu().numpy(), res["energy"]) and np.array_equal(outs[-2][:, 0].cpu().numpy(), res["energy"])
+    assert np.array_equal(outs[-1][:, 0].cpu().numpy(), res["energy_f64"]) and np.array_equal(outs[-2][:, 0].cpu().numpy(), res["energy_f64"])
     with _socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -276,7 +305,7 @@ def test_device_results_reach_torch_and_rccl_without_a_host_copy():
         torch.cuda.synchronize()
         assert sh2._gather.n_staging_copies == 0 and g1.data_ptr() != g2.data_ptr()
         for g in (g1, g2):
-            assert np.array_equal(g[:, 0].cpu().numpy(), res["energy"]) and np.array_equal(g[:, 1].cpu().numpy(), res["energy_std"])
+            assert np.array_equal(g[:, 0].cpu().numpy(), res["energy_f64"]) and np.array_equal(g[:, 1].cpu().numpy(), res["energy_std_f64"])
         assert sh2.check() is False
         grp.engines[1].close()
         sh.upload(local_chains=packs)                       # (the group re-uploaded parts of the list to the first engine)
@@ -294,51 +323,86 @@ def test_device_results_reach_torch_and_rccl_without_a_host_copy():
         eng.close()
 
 
-@pytest.mark.gpu
-def test_bench_entry_point_two_ranks_on_one_gpu(tmp_path):
-    """BASELINE configs[4]'s entry point, rehearsed end to end on the one GPU there is: ``python -m torch.distributed.run
-    --nproc-per-node 2 bench.py --gpus 2 ...`` as a FRESH subprocess (torchrun starts the ranks before anything touches the
-    GPU; this process never re-execs).  RCCL refuses two ranks on one device, so the rehearsal switches select gloo and pin
-    both ranks to device 0 (``VSSR_DIST_BACKEND`` / ``VSSR_LOCAL_DEVICE``, read by bench.py only); rank / chain arithmetic,
-    ``ShardedEnsemble.step``, the max-over-ranks clock, barriers and the JSON line are the code the 8-GPU run executes."""
+def _run_bench_ranks(tmp_path, world, chains_per_gpu, result_path, steps=3):
+    """`python -m torch.distributed.run --nproc-per-node <world> bench.py --gpus <world> ...` as a FRESH subprocess (torchrun
+    starts the ranks before anything touches the GPU; this process never re-execs), all ranks on device 0 over gloo."""
     import json
     import subprocess
-
-    import bench
-    from surface_sampling_amd import backend
-    from surface_sampling_amd.calculators import stoich_offset_table
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     dump = tmp_path / "gathered.npy"
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VSSR_DIST_BACKEND="gloo", VSSR_LOCAL_DEVICE="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VSSR_DIST_BACKEND="gloo", VSSR_LOCAL_DEVICE="0",
+               VSSR_RESULT_PATH=result_path)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--chains-per-gpu", "16", "--no-cpu-baseline", "--dump-gathered", str(dump)]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps),
+           "--warmup", "1", "--chains-per-gpu", str(chains_per_gpu), "--no-cpu-baseline", "--dump-gathered", str(dump)]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout                      # rank 0 prints ONE line
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
-    assert line["config"]["chains_per_gpu"] == 16 and "sharded x2" in line["config"]["parallelism"]
-    assert "gloo" in line["config"]["parallelism"] and line["config"]["dist_backend"] == "gloo"
-    assert np.isfinite(line["value"]) and line["value"] > 0
-    assert abs(line["value"] - 2 * 16 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]     # whole-job aggregate
-    assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["second_kernel"]["frac"] <= 1.0
-    gathered = np.load(dump)
-    assert gathered.shape[0] == 32 and gathered.shape[1] >= 2
-    # one engine, all 32 global chains, in THIS process (after the ranks have gone)
+    return json.loads(lines[0]), np.load(dump)
+
+
+def _one_engine_reference(n_chains):
+    import bench
+    from surface_sampling_amd import backend
+    from surface_sampling_amd.calculators import stoich_offset_table
+
     blobs, S, offset_data = bench.load_golden()
     table, const = stoich_offset_table(offset_data)
-    chains = bench.build_chains(S, 0, 32)
+    chains = bench.build_chains(S, 0, n_chains)
     eng = backend.PainnEngine(blobs, device=0, offset_per_z=table, offset_const=const)
     full = eng.evaluate([(c.numbers, c.positions, c.cell, c.pbc) for c in chains])
     eng.close()
-    assert np.array_equal(gathered[:, 0], full["energy"]) and np.array_equal(gathered[:, 1], full["energy_std"])
+    return full
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("result_path", ["host", "device"])
+def test_bench_entry_point_two_ranks_on_one_gpu(tmp_path, result_path):
+    """BASELINE configs[4]'s entry point, rehearsed end to end on the one GPU there is.  RCCL refuses two ranks on one device,
+    so the rehearsal switches select gloo and pin both ranks to device 0 (``VSSR_DIST_BACKEND`` / ``VSSR_LOCAL_DEVICE``, read
+    by bench.py only); rank / chain arithmetic, ``ShardedEnsemble.step``, the max-over-ranks clock, barriers, the cross-rank
+    check and the JSON line are the code the 8-GPU run executes.  ``result_path="device"``: the DEVICE result path with two
+    ranks -- ``_device_scalars`` (events, ``ExternalStream``, double-buffered staging, overflow column) runs in both ranks,
+    only the transport is swapped (pinned D2H -> gloo -> H2D, ``ChainGather.transport == "host_bounce"``)."""
+    line, gathered = _run_bench_ranks(tmp_path, 2, 16, result_path)
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["chains_per_gpu"] == 16 and "sharded x2" in line["config"]["parallelism"]
+    assert "gloo" in line["config"]["parallelism"] and line["config"]["dist_backend"] == "gloo"
+    assert line["config"]["result_path"] == result_path
+    assert line["config"]["gather_transport"] == ("host_bounce" if result_path == "device" else "direct")
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    assert abs(line["value"] - 2 * 16 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]     # whole-job aggregate
+    assert 0 < line["roofline"]["frac"] <= line["roofline"]["executed_pipe"]["frac"] <= 1.0
+    assert line["roofline"]["second_kernel"]["executed_pipe"]["frac"] <= 1.0
+    gv = line["gather_verified"]
+    assert gv["bit_exact"] and gv["ranks"] == [1] and gv["chains"] >= 4
+    assert gathered.shape[0] == 32 and gathered.shape[1] == (3 if result_path == "device" else 2) and gathered.dtype == np.float64
+    full = _one_engine_reference(32)      # one engine, all 32 global chains, in THIS process (after the ranks have gone)
+    assert np.array_equal(gathered[:, 0], full["energy_f64"]) and np.array_equal(gathered[:, 1], full["energy_std_f64"])
+    assert np.array_equal(gathered[:, 0].astype(np.float32), full["energy"])
+
+
+@pytest.mark.gpu
+def test_bench_entry_point_eight_ranks_on_one_gpu(tmp_path):
+    """configs[4]'s world size: ``torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 --chains-per-gpu 8`` on one GPU
+    (gloo, every rank on device 0, device result path in every rank): one JSON line, ``n_gpus == 8``, rank 0's bit-exact
+    re-evaluation of chains of two OTHER ranks' blocks (``gather_verified``), and the gathered ``[64, 3]`` equal to one engine
+    bit for bit."""
+    line, gathered = _run_bench_ranks(tmp_path, 8, 8, "device", steps=2)
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["config"]["chains_per_gpu"] == 8
+    assert "sharded x8" in line["config"]["parallelism"] and line["config"]["result_path"] == "device"
+    assert abs(line["value"] - 8 * 8 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    gv = line["gather_verified"]
+    assert gv["bit_exact"] and len(gv["ranks"]) == 2 and 0 not in gv["ranks"] and gv["chains"] >= 8
+    assert gathered.shape == (64, 3) and not gathered[:, 2].any()
+    full = _one_engine_reference(64)
+    assert np.array_equal(gathered[:, 0], full["energy_f64"]) and np.array_equal(gathered[:, 1], full["energy_std_f64"])
 
 
 @pytest.mark.gpu
@@ -367,7 +431,7 @@ def test_engine_group_device_path_gathers_what_one_engine_computes():
     full = one.evaluate(packs, want)
     for o in outs[-2:]:
         assert o.shape == (7, 3) and not o[:, 2].any()
-        assert np.array_equal(o[:, 0].cpu().numpy(), full["energy"]) and np.array_equal(o[:, 1].cpu().numpy(), full["energy_std"])
+        assert np.array_equal(o[:, 0].cpu().numpy(), full["energy_f64"]) and np.array_equal(o[:, 1].cpu().numpy(), full["energy_std_f64"])
     res = grp.download(want)
     assert np.array_equal(res["forces"], full["forces"]) and np.array_equal(res["cfg_start"], full["cfg_start"])
     assert sh.check() is False and sh._gather.n_staging_copies == 0
@@ -409,8 +473,8 @@ def test_two_ranks_share_one_gpu(tmp_path, golden):
     eng.close()
     for r in (r0, r1):
         assert r["gathered"].shape == (6, 2)
-        assert np.array_equal(r["gathered"][:, 0], full["energy"]) and np.array_equal(r["gathered"][:, 1], full["energy_std"])
-        assert np.array_equal(r["one_shot_energy"], full["energy"])
+        assert np.array_equal(r["gathered"][:, 0], full["energy_f64"]) and np.array_equal(r["gathered"][:, 1], full["energy_std_f64"])
+        assert np.array_equal(r["one_shot_energy"], full["energy_f64"])
     # (ii) world-1 trajectories of global chains 0..5
     acc, species, energy = run_mc(golden, 6, 0)
     assert np.array_equal(np.concatenate([r0["acc"], r1["acc"]], axis=1), acc)
