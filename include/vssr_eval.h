@@ -121,7 +121,11 @@ int vssr_abi_version(void);
  *   VSSR_NBR_LPC=16|32|64, VSSR_REV_LPC=16|32|64   lanes per centre atom in the neighbor search / the reverse-slot search (default 16;
  *                            reverse-slot search 32 for PaiNN handles); the neighbor list is the same bit for bit in every form
  *   VSSR_TERSOFF_SITE=1      Tersoff: the one-thread-per-centre kernel for every row (default: rows of <= 16 slots take the
- *                            four-lanes-per-centre kernel) */
+ *                            four-lanes-per-centre kernel)
+ * Read by every vssr_batch_relax_cg call:
+ *   VSSR_RELAX_COMPACT=0     no live-chain compaction of the resident batch (default on for resident batches of >= 65 536 atoms: once
+ *                            at most 3/4 of the chains are still minimising, the batch continues as a smaller one; same trajectories
+ *                            bit for bit); n > 1: compact batches of >= n atoms (tests: 2 = always) */
 int vssr_create(const vssr_painn_config *cfg, vssr_handle **out);
 void vssr_destroy(vssr_handle *h);
 const char *vssr_last_error(const vssr_handle *h); /* h may be NULL: last create() error of the calling thread */
@@ -261,6 +265,11 @@ int vssr_device_context(vssr_handle *h, int32_t *device, void **stream, const in
  * regrow to the exact need only (every later growth of the edge count overflows again), tight < 0: unchanged;
  * n_regrows (may be NULL) receives the number of regrows of the last relaxation. */
 int vssr_debug_capacity(vssr_handle *h, int32_t slots_per_atom, int32_t tight, int32_t *n_regrows);
+/* Work counters of the LAST relaxation of this handle (vssr_batch_relax_fire / _bfgs / _cg): lockstep_evaluations = evaluations of
+ * the batch the driver launched (the final static evaluation included); chain_evaluations = chain-evaluations those launches
+ * dispatched (a launch over all B chains counts B even when converged chains leave their kernels at once).  Together with the
+ * per-chain counts the relaxation returns (n_steps / n_eval) they give the lock-step waste: dispatched / needed. */
+int vssr_batch_relax_counts(vssr_handle *h, int64_t *lockstep_evaluations, int64_t *chain_evaluations);
 /* Copy a named device intermediate of model m (fp32) to host; for parity debugging.
  * Names: "phi<l>", "s_msg<l>", "v_msg<l>", "s_upd<l>", "v_upd<l>", "sbar_msg<l>", "vbar_msg<l>",
  * "e_atom".  Layouts: s [N][F], v [N][3][F], phi [N][3F]. */

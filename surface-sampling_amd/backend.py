@@ -30,6 +30,7 @@ EXPORTS = (
     "vssr_tersoff_create_from_text", "vssr_batch_relax_cg", "vssr_batch_saturated",
     "vssr_batch_embedding", "vssr_batch_traj_configure", "vssr_batch_traj_read",
     "vssr_device_context", "vssr_batch_stress", "vssr_batch_energy_f64", "vssr_batch_device_results_f64",
+    "vssr_batch_relax_counts",
 )
 
 
@@ -184,6 +185,8 @@ def load_library():
     L.vssr_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.vssr_batch_device_results_f64.restype = C.c_int
     L.vssr_batch_device_results_f64.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.vssr_batch_relax_counts.restype = C.c_int
+    L.vssr_batch_relax_counts.argtypes = [vp, i64p, i64p]
     L.vssr_batch_energy_f64.restype = C.c_int
     L.vssr_batch_energy_f64.argtypes = [vp, dp, dp, dp]
     L.vssr_batch_traj_configure.restype = C.c_int
@@ -382,6 +385,12 @@ class _Handle:
         p = params or FireParams.default(max_steps, fmax)
         return self._relax_call(self._lib.vssr_batch_relax_fire, p, fixed, want, record_interval)
 
+    def relax_counts(self):
+        """``(lock-step evaluations, dispatched chain-evaluations)`` of the last relaxation (vssr_batch_relax_counts)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.vssr_batch_relax_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def debug_capacity(self, slots_per_atom=0, tight=-1):
         """Test hook (vssr_debug_capacity); returns the regrow count of the last relaxation."""
         n = C.c_int32(0)
@@ -402,6 +411,7 @@ class _Handle:
         self._check(fn(self._h, C.byref(p), _ptr(fx, C.c_uint8), int(want), _ptr(pos, C.c_double),
                        _ptr(steps, C.c_int32), _ptr(conv, C.c_uint8)))
         out = {"positions": pos, "n_steps": steps, "converged": conv.astype(bool)}
+        self.last_relax_counts = self.relax_counts()
         if record_interval:
             R = C.c_int32(0)
             self._check(self._lib.vssr_batch_traj_read(self._h, 0, None, None, None, None, C.byref(R)))
@@ -530,6 +540,7 @@ class _AnalyticEngine(_Handle):
         self._check(self._lib.vssr_batch_relax_cg(self._h, C.byref(p), _ptr(fx, C.c_uint8),
                                                   WANT_ENERGY | WANT_FORCES | WANT_PER_ATOM, _ptr(out, C.c_double),
                                                   _ptr(it, C.c_int32), _ptr(ev, C.c_int32), _ptr(why, C.c_int32)))
+        self.last_relax_counts = self.relax_counts()
         e, ea, f = self.evaluate_arrays_f64(n_atoms, T, out, cell, pbc)
         return e, ea, f, out, it, ev, why
 

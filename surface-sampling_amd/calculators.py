@@ -1059,7 +1059,8 @@ class _AnalyticSurfCalc(_Base):
             steps = int(self.relax_steps if relax_steps is None else relax_steps)
             e, ea, f, new_pos, it, ev, why = eng.relax_cg_arrays_f64(n_atoms, types, pos, cell, pbc, fixed=fixed_mask, max_iter=steps,
                                                                      etol=kwargs.get("etol", 1e-5), ftol=kwargs.get("ftol", 1e-5))
-            extra = {"iterations": it, "evaluations": ev, "stop": why}
+            ls, ce = getattr(eng, "last_relax_counts", (0, 0))
+            extra = {"iterations": it, "evaluations": ev, "stop": why, "lockstep_evaluations": ls, "dispatched_chain_evaluations": ce}
         else:
             steps = int(self.relax_steps if relax_steps is None else relax_steps)
             e, ea, f, new_pos, nst, conv = eng.relax_arrays_f64(n_atoms, types, pos, cell, pbc, fixed=fixed_mask, max_steps=steps,

@@ -1189,10 +1189,31 @@ void launch_update_bwd_mfma(hipStream_t st, int N, int M, int l, int mode, int v
                             const float *s_msg, const float *v_msg, const float *sbar_src, const float *vbar,
                             const float *s_next, const float *phibar, const float *e_excl, float *e_atom,
                             float *sbar_msg, float *vbar_msg, const void *save) {
-    const dim3 grid((N + TA - 1) / TA, M), blk(NTHREADS);
-    const size_t lds = node_mfma_lds_bytes(3);
     const f32x4 *sv = reinterpret_cast<const f32x4 *>(save);
     if (mode == 1) vbar_is_zero = 1;
+#if defined(UPD_BWD_RT) && UPD_BWD_RT == 1
+    // A/B build only (tools/build_variant.sh rt1 -DUPD_BWD_RT=1 [-DUPD_PF=0], profiles/r05/NOTES_node_occupancy.md): 16-atom tiles,
+    // 8 waves at 128 registers, two workgroups per CU.  Never shipped: it spills, and the saturation watch attributes rows modulo 32.
+    if (!sv && mode != 0) {
+        const dim3 grid1((N + 15) / 16, M), blk1(NTHREADS);
+        const size_t lds1 = sizeof(_Float16) * UpdLds<1>::HALVES + sizeof(float) * 3 * 16 * FT;
+        static bool once = [] {
+            (void)hipFuncSetAttribute((const void *)k_update_bwd_mfma<1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_update_bwd_mfma<2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            return true;
+        }();
+        (void)once;
+        if (mode == 1)
+            hipLaunchKernelGGL((k_update_bwd_mfma<1, 1, false>), grid1, blk1, lds1, st, N, l, vbar_is_zero, av, MW, s_msg, v_msg, sbar_src,
+                               vbar, s_next, phibar, e_excl, e_atom, sbar_msg, vbar_msg, sv);
+        else
+            hipLaunchKernelGGL((k_update_bwd_mfma<2, 1, false>), grid1, blk1, lds1, st, N, l, vbar_is_zero, av, MW, s_msg, v_msg, sbar_src,
+                               vbar, s_next, phibar, e_excl, e_atom, sbar_msg, vbar_msg, sv);
+        return;
+    }
+#endif
+    const dim3 grid((N + TA - 1) / TA, M), blk(NTHREADS);
+    const size_t lds = node_mfma_lds_bytes(3);
 #define LAUNCH_UPD(MODE, SAVED)                                                                                             \
     hipLaunchKernelGGL((k_update_bwd_mfma<MODE, 2, SAVED>), grid, blk, lds, st, N, l, vbar_is_zero, av, MW, s_msg, v_msg, sbar_src, \
                        vbar, s_next, phibar, e_excl, e_atom, sbar_msg, vbar_msg, sv)

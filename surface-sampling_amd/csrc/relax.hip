@@ -543,9 +543,13 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
         return h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES)
                             : h->kind == 3 ? eam_run(h, want | VSSR_WANT_FORCES) : painn_run(h, want | VSSR_WANT_FORCES);
     };
+    h->relax_lockstep = 0;
+    h->relax_chain_evals = 0;
     for (int it = 0; it <= max_steps && !rc; ++it) {
         rc = evaluate();
         if (rc) break;
+        ++h->relax_lockstep;
+        h->relax_chain_evals += B;
         const bool last = it == max_steps;
         {   // (last iteration: every unconverged chain has taken relax_steps steps -- the kernel only tests convergence, like the
             // final check of ASE's run loop)
@@ -760,6 +764,97 @@ k_cg_step(const int *__restrict__ cfg_start, const int *__restrict__ counters, c
     start_linesearch();
 }
 
+
+// ---- live-chain compaction of the resident batch (fp64 analytic potentials) ---------------------------------------------------
+// The CG minimiser stops every chain by its own criteria; with the activity mask alone a finished chain still costs its share of
+// every later launch (grids are sized for the whole batch, its workgroups leave at once).  At a poll with at most 3/4 of the
+// resident chains still running the batch is PHYSICALLY compacted: the live chains' inputs (positions, types, cells) and optimizer
+// state are gathered into a smaller resident batch, the finished chains' final positions / states are parked in full-size
+// arrays, and every kernel of the path (neighbor build, potential, CG step) runs unchanged on the smaller batch -- a chain's
+// results do not depend on its batch, so the trajectories are the same bit for bit (tests/test_cg.py).  The original batch is
+// restored before the final static evaluation.
+struct CmpView {   // device pointers of one layout of the per-chain / per-atom arrays
+    int *cfg_start, *Z, *atom_cfg, *nimg;
+    double *pos, *cell, *inv, *x0, *hh, *gg;
+    uint8_t *pbc, *fixed;
+    CgState *st;
+};
+
+__global__ void __launch_bounds__(1024)
+k_cmp_plan(int B, const int *__restrict__ cfg_start, const unsigned char *__restrict__ active, const int *__restrict__ live,
+           int *__restrict__ live_new, int *__restrict__ src, int *__restrict__ start_new, int *__restrict__ totals) {
+    __shared__ int sc[1024], sa[1024];
+    const int t = threadIdx.x, per = (B + 1023) / 1024, c0 = min(B, t * per), c1 = min(B, c0 + per);
+    int nc = 0, na = 0;
+    for (int c = c0; c < c1; ++c)
+        if (active[c]) { nc += 1; na += cfg_start[c + 1] - cfg_start[c]; }
+    sc[t] = nc; sa[t] = na;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {   // inclusive scans
+        const int vc = t >= d ? sc[t - d] : 0, va = t >= d ? sa[t - d] : 0;
+        __syncthreads();
+        sc[t] += vc; sa[t] += va;
+        __syncthreads();
+    }
+    int oc = sc[t] - nc, oa = sa[t] - na;
+    for (int c = c0; c < c1; ++c)
+        if (active[c]) {
+            live_new[oc] = live ? live[c] : c;
+            src[oc] = c;
+            start_new[oc] = oa;
+            oc += 1;
+            oa += cfg_start[c + 1] - cfg_start[c];
+        }
+    if (t == 1023) { start_new[sc[t]] = sa[t]; totals[0] = sc[t]; totals[1] = sa[t]; }
+}
+
+// chains of the CURRENT batch whose results are final (active == nullptr: all of them): positions and optimizer state to their
+// places in the ORIGINAL batch
+__global__ void __launch_bounds__(128)
+k_cmp_flush(const int *__restrict__ cfg_start, const unsigned char *__restrict__ active, const int *__restrict__ live,
+            const int *__restrict__ start0, const double *__restrict__ pos, const CgState *__restrict__ st,
+            double *__restrict__ final_pos, CgState *__restrict__ final_st) {
+    const int c = blockIdx.x;
+    if (active && active[c]) return;
+    const int o = live ? live[c] : c, a0 = cfg_start[c], n = 3 * (cfg_start[c + 1] - a0);
+    const size_t d0 = 3 * (size_t)start0[o], s0 = 3 * (size_t)a0;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) final_pos[d0 + k] = pos[s0 + k];
+    if (threadIdx.x == 0) final_st[o] = st[c];
+}
+
+__global__ void __launch_bounds__(128)
+k_cmp_gather(const int *__restrict__ src, const int *__restrict__ start_new, CmpView from, CmpView to, unsigned char *__restrict__ active_new) {
+    const int nc = blockIdx.x, c = src[nc], a0 = from.cfg_start[c], na = from.cfg_start[c + 1] - a0, b0 = start_new[nc];
+    for (int k = threadIdx.x; k < 3 * na; k += blockDim.x) {
+        to.pos[3 * (size_t)b0 + k] = from.pos[3 * (size_t)a0 + k];
+        to.x0[3 * (size_t)b0 + k] = from.x0[3 * (size_t)a0 + k];
+        to.hh[3 * (size_t)b0 + k] = from.hh[3 * (size_t)a0 + k];
+        to.gg[3 * (size_t)b0 + k] = from.gg[3 * (size_t)a0 + k];
+    }
+    for (int k = threadIdx.x; k < na; k += blockDim.x) {
+        to.Z[b0 + k] = from.Z[a0 + k];
+        to.atom_cfg[b0 + k] = nc;
+        if (from.fixed) to.fixed[b0 + k] = from.fixed[a0 + k];
+    }
+    if (threadIdx.x < 9) { to.cell[9 * (size_t)nc + threadIdx.x] = from.cell[9 * (size_t)c + threadIdx.x]; to.inv[9 * (size_t)nc + threadIdx.x] = from.inv[9 * (size_t)c + threadIdx.x]; }
+    if (threadIdx.x < 3) { to.nimg[3 * nc + threadIdx.x] = from.nimg[3 * c + threadIdx.x]; to.pbc[3 * nc + threadIdx.x] = from.pbc[3 * c + threadIdx.x]; }
+    if (threadIdx.x == 0) { to.st[nc] = from.st[c]; active_new[nc] = 1; }
+}
+
+// the gathered arrays back over the resident ones, one launch (13 small device-to-device copies cost more than the evaluation of a
+// small batch); live / start_new travel along
+__global__ void __launch_bounds__(256)
+k_cmp_copyback(int Bn, int Nn, CmpView to, CmpView from, int *__restrict__ live, const int *__restrict__ live_new,
+               const int *__restrict__ start_new) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = t; k < 3 * (size_t)Nn; k += step) { to.pos[k] = from.pos[k]; to.x0[k] = from.x0[k]; to.hh[k] = from.hh[k]; to.gg[k] = from.gg[k]; }
+    for (size_t k = t; k < (size_t)Nn; k += step) { to.Z[k] = from.Z[k]; to.atom_cfg[k] = from.atom_cfg[k]; if (from.fixed && to.fixed) to.fixed[k] = from.fixed[k]; }
+    for (size_t k = t; k < 9 * (size_t)Bn; k += step) { to.cell[k] = from.cell[k]; to.inv[k] = from.inv[k]; }
+    for (size_t k = t; k < 3 * (size_t)Bn; k += step) { to.nimg[k] = from.nimg[k]; to.pbc[k] = from.pbc[k]; }
+    for (size_t k = t; k < (size_t)Bn; k += step) { to.st[k] = from.st[k]; live[k] = live_new[k]; }
+    for (size_t k = t; k <= (size_t)Bn; k += step) to.cfg_start[k] = start_new[k];
+}
+
 __global__ void k_cg_report(int B, const CgState *__restrict__ st, int *__restrict__ out /*[B][3]*/) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -785,6 +880,97 @@ int relax_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host
     int *n_active_d = h->d_counters.as<int>() + 3;
     const int POLL = 8;
     int rc = VSSR_OK;
+    // ---- live-chain compaction (see k_cmp_plan): B_cur / N_cur = the resident batch the kernels see ------------------------
+    const char *cmp_env = getenv("VSSR_RELAX_COMPACT");   // (read per call: 0 switches the compaction off -- A/B runs, the equality test)
+    const bool cmp_enabled = !cmp_env || atoi(cmp_env) != 0;
+    const int cmp_min_atoms = cmp_env && atoi(cmp_env) > 1 ? atoi(cmp_env) : 65536;   // (VSSR_RELAX_COMPACT=n > 1: smallest resident batch, atoms)
+    int B_cur = B, N_cur = N;
+    bool compacted = false;
+    double *const x0v = h->d_vel.as<double>(), *const hv = x0v + 3 * (size_t)N, *const gv = x0v + 6 * (size_t)N;
+    // arena: [originals | parked finals | maps | gather targets]
+    struct Arena {
+        int *start0, *Z0, *cfg0, *nimg0, *live, *live_new, *src, *start_new, *totals;
+        double *cell0, *inv0, *final_pos;
+        uint8_t *pbc0, *fixed0;
+        CgState *final_st;
+        CmpView tmp;
+    } A{};
+    auto carve = [&]() -> int {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t Bz = (size_t)B, Nz = (size_t)N;
+        const size_t o_start0 = take(4 * (Bz + 1)), o_Z0 = take(4 * Nz), o_cfg0 = take(4 * Nz), o_nimg0 = take(12 * Bz), o_live = take(4 * Bz),
+                     o_live_new = take(4 * Bz), o_src = take(4 * Bz), o_start_new = take(4 * (Bz + 1)), o_tot = take(16),
+                     o_cell0 = take(72 * Bz), o_inv0 = take(72 * Bz), o_fpos = take(24 * Nz), o_pbc0 = take(3 * Bz), o_fixed0 = take(Nz),
+                     o_fst = take(sizeof(CgState) * Bz),
+                     t_start = take(4 * (Bz + 1)), t_Z = take(4 * Nz), t_cfg = take(4 * Nz), t_nimg = take(12 * Bz), t_pos = take(24 * Nz),
+                     t_cell = take(72 * Bz), t_inv = take(72 * Bz), t_x0 = take(24 * Nz), t_h = take(24 * Nz), t_g = take(24 * Nz),
+                     t_pbc = take(3 * Bz), t_fixed = take(Nz), t_st = take(sizeof(CgState) * Bz);
+        if (h->d_cmp.ensure(off)) return -1;
+        char *p = h->d_cmp.as<char>();
+        A.start0 = (int *)(p + o_start0); A.Z0 = (int *)(p + o_Z0); A.cfg0 = (int *)(p + o_cfg0); A.nimg0 = (int *)(p + o_nimg0);
+        A.live = (int *)(p + o_live); A.live_new = (int *)(p + o_live_new); A.src = (int *)(p + o_src);
+        A.start_new = (int *)(p + o_start_new); A.totals = (int *)(p + o_tot);
+        A.cell0 = (double *)(p + o_cell0); A.inv0 = (double *)(p + o_inv0); A.final_pos = (double *)(p + o_fpos);
+        A.pbc0 = (uint8_t *)(p + o_pbc0); A.fixed0 = (uint8_t *)(p + o_fixed0); A.final_st = (CgState *)(p + o_fst);
+        A.tmp = CmpView{(int *)(p + t_start), (int *)(p + t_Z), (int *)(p + t_cfg), (int *)(p + t_nimg), (double *)(p + t_pos),
+                        (double *)(p + t_cell), (double *)(p + t_inv), (double *)(p + t_x0), (double *)(p + t_h), (double *)(p + t_g),
+                        (uint8_t *)(p + t_pbc), (uint8_t *)(p + t_fixed), (CgState *)(p + t_st)};
+        return 0;
+    };
+    auto cur_view = [&]() {
+        return CmpView{h->d_cfg_start.as<int>(), h->d_Z.as<int>(), h->d_atom_cfg.as<int>(), h->d_nimg.as<int>(), h->d_pos.as<double>(),
+                       h->d_cell.as<double>(), h->d_invcell.as<double>(), x0v, hv, gv, h->d_pbc.as<uint8_t>(),
+                       const_cast<uint8_t *>(fixed), h->d_fire.as<CgState>()};
+    };
+#define CMP_COPY(dst, src_, bytes) VSSR_HIP(h, hipMemcpyAsync((dst), (src_), (bytes), hipMemcpyDeviceToDevice, st))
+    auto compact = [&]() -> int {
+        const CmpView cur = cur_view();
+        if (!compacted) {   // first time: keep the original batch
+            if (carve()) return set_err(h, VSSR_E_NOMEM, "compaction arena: out of device memory");
+            CMP_COPY(A.start0, cur.cfg_start, 4 * ((size_t)B + 1)); CMP_COPY(A.Z0, cur.Z, 4 * (size_t)N); CMP_COPY(A.cfg0, cur.atom_cfg, 4 * (size_t)N);
+            CMP_COPY(A.nimg0, cur.nimg, 12 * (size_t)B); CMP_COPY(A.cell0, cur.cell, 72 * (size_t)B); CMP_COPY(A.inv0, cur.inv, 72 * (size_t)B);
+            CMP_COPY(A.pbc0, cur.pbc, 3 * (size_t)B);
+            if (fixed) CMP_COPY(A.fixed0, fixed, (size_t)N);
+        }
+        const int *live = compacted ? A.live : nullptr;
+        hipLaunchKernelGGL(k_cmp_plan, dim3(1), dim3(1024), 0, st, B_cur, cur.cfg_start, active, live, A.live_new, A.src, A.start_new, A.totals);
+        hipLaunchKernelGGL(k_cmp_flush, dim3(B_cur), dim3(128), 0, st, cur.cfg_start, active, live, A.start0, cur.pos, cur.st, A.final_pos, A.final_st);
+        int tot[2] = {0, 0};
+        VSSR_HIP(h, hipMemcpyAsync(tot, A.totals, sizeof(tot), hipMemcpyDeviceToHost, st));
+        VSSR_HIP(h, hipStreamSynchronize(st));
+        const int Bn = tot[0], Nn = tot[1];
+        if (Bn <= 0 || Bn > B_cur || Nn <= 0 || Nn > N_cur) return set_err(h, VSSR_E_STATE, "live-chain compaction: inconsistent plan");
+        hipLaunchKernelGGL(k_cmp_gather, dim3(Bn), dim3(128), 0, st, A.src, A.start_new, cur, A.tmp, active);
+        // (the gather reads the resident arrays and writes the arena; one more launch copies the arena over the resident arrays)
+        {
+            CmpView from = A.tmp;
+            if (!fixed) from.fixed = nullptr;
+            const int blocks = (int)std::min<size_t>(1024, (3 * (size_t)Nn + 255) / 256);
+            hipLaunchKernelGGL(k_cmp_copyback, dim3(blocks), dim3(256), 0, st, Bn, Nn, cur, from, A.live, A.live_new, A.start_new);
+        }
+        compacted = true;
+        B_cur = Bn; N_cur = Nn;
+        h->n_cfg = Bn; h->n_atoms = Nn;
+        ++h->relax_compactions;
+        return VSSR_OK;
+    };
+    auto restore = [&]() -> int {   // park what is still resident, then bring the original batch back (positions = the final ones)
+        if (!compacted) return VSSR_OK;
+        const CmpView cur = cur_view();
+        hipLaunchKernelGGL(k_cmp_flush, dim3(B_cur), dim3(128), 0, st, cur.cfg_start, (const unsigned char *)nullptr, A.live, A.start0, cur.pos, cur.st,
+                           A.final_pos, A.final_st);
+        CMP_COPY(cur.cfg_start, A.start0, 4 * ((size_t)B + 1)); CMP_COPY(cur.Z, A.Z0, 4 * (size_t)N); CMP_COPY(cur.atom_cfg, A.cfg0, 4 * (size_t)N);
+        CMP_COPY(cur.nimg, A.nimg0, 12 * (size_t)B); CMP_COPY(cur.cell, A.cell0, 72 * (size_t)B); CMP_COPY(cur.inv, A.inv0, 72 * (size_t)B);
+        CMP_COPY(cur.pbc, A.pbc0, 3 * (size_t)B); CMP_COPY(cur.pos, A.final_pos, 24 * (size_t)N); CMP_COPY(cur.st, A.final_st, sizeof(CgState) * (size_t)B);
+        if (fixed) CMP_COPY(cur.fixed, A.fixed0, (size_t)N);
+        compacted = false;
+        B_cur = B; N_cur = N;
+        h->n_cfg = B; h->n_atoms = N;
+        return VSSR_OK;
+    };
+#undef CMP_COPY
+    h->relax_compactions = 0;
     // every launch is one evaluation; max_eval is tested between line searches, and a line search ends after at most ~60
     // halvings of alpha (fp64), so the launch budget is max_eval plus one line search plus setup / reset evaluations
     const long long max_launch = (long long)cp->max_eval + 72;
@@ -796,15 +982,19 @@ int relax_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host
     };
     long long it = 0;
     bool finished = false;
+    h->relax_lockstep = 0;
+    h->relax_chain_evals = 0;
     while (!rc && !finished) {
         for (; it < max_launch && !rc; ++it) {
             rc = h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : eam_run(h, want | VSSR_WANT_FORCES);
             if (rc) break;
+            ++h->relax_lockstep;
+            h->relax_chain_evals += B_cur;
             // the count of chains still running is read at the polls only: it is cleared and copied back in those iterations (the
             // step kernels in between add to a value nobody looks at) -- two dispatches less per evaluation, ~15 of them at 48 atoms
             const bool poll_it = (it + 1) % POLL == 0;
             if (poll_it) VSSR_HIP(h, hipMemsetAsync(n_active_d, 0, sizeof(int), st));
-            hipLaunchKernelGGL(k_cg_step, dim3(B), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
+            hipLaunchKernelGGL(k_cg_step, dim3(B_cur), dim3(256), 0, st, h->d_cfg_start.as<int>(), h->d_counters.as<int>(),
                                h->d_ters_e.as<double>(), h->d_ters_f.as<double>(), fixed, cp->max_iter, cp->max_eval, cp->etol,
                                cp->ftol, cp->dmax, h->d_pos.as<double>(), h->d_vel.as<double>(), h->d_vel.as<double>() + 3 * (size_t)N,
                                h->d_vel.as<double>() + 6 * (size_t)N, h->d_fire.as<CgState>(), active, n_active_d);
@@ -818,6 +1008,11 @@ int relax_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host
                     continue;
                 }
                 if (h->h_counters[3] == 0) { finished = true; break; }   // every chain has finished
+                // at most 3/4 of the resident chains are still running: continue on a compacted batch.  Only where the kernels are
+                // throughput-bound: below ~one round of workgroups (256 CUs x 3 x 64 centres = 49 k atoms) a launch costs the same
+                // whatever the live share, and the compaction (four launches + a host read) would only add to it (measured, 256
+                // chains x 48 atoms: -3 %; profiles/r05/NOTES_tersoff.md)
+                if (cmp_enabled && N_cur >= cmp_min_atoms && (long long)h->h_counters[3] * 4 <= (long long)B_cur * 3) rc = compact();
             }
         }
         if (rc || finished) break;
@@ -831,10 +1026,17 @@ int relax_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host
         finished = true;
     }
     h->active_mask = nullptr;
+    if (rc) {   // (a compacted batch is not handed back half-way: the caller uploads again)
+        if (compacted) { h->n_cfg = B; h->n_atoms = N; h->batch_valid = false; }
+        return rc;
+    }
+    rc = restore();
     if (rc) return rc;
     // results of the final positions for every chain (finished chains were switched off at different times)
     rc = h->kind == 2 ? tersoff_run(h, want | VSSR_WANT_FORCES) : eam_run(h, want | VSSR_WANT_FORCES);
     if (rc) return rc;
+    ++h->relax_lockstep;
+    h->relax_chain_evals += B;
     hipLaunchKernelGGL(k_cg_report, dim3((B + 127) / 128), dim3(128), 0, st, B, h->d_fire.as<CgState>(), h->d_relax_steps.as<int>());
     VSSR_HIP(h, hipGetLastError());
     h->ran = true;

@@ -289,6 +289,10 @@ struct vssr_handle {
     vssr::DevBuf d_vel, d_fire, d_fixed, d_relax_steps, d_relax_conv, d_active, d_bfgs_q, d_bfgs_b;
     const unsigned char *active_mask = nullptr;   // set by relax_run for the duration of a relaxation
     int relax_regrows = 0;
+    long long relax_lockstep = 0;   // lock-step evaluations of the batch launched by the last relaxation (vssr_batch_relax_counts)
+    int relax_compactions = 0;      // live-chain compactions of the last CG relaxation
+    vssr::DevBuf d_cmp;            // arena of the live-chain compaction (relax.hip)
+    long long relax_chain_evals = 0;   // chain-evaluations those launches actually dispatched (live-chain compaction: < lockstep x B)
     // trajectory recording of the lock-step relaxations (relax.hip k_traj_record): every traj_interval optimizer steps
     int traj_interval = 0, traj_records = 0, traj_B = 0, traj_N = 0;
     vssr::DevBuf d_traj_pos, d_traj_f, d_traj_e, d_traj_n;

@@ -104,6 +104,51 @@ def test_cg_gpu_follows_the_restatement(golden, oracle_mod):
 
 
 @pytest.mark.gpu
+def test_live_chain_compaction_changes_nothing_but_the_work(golden, monkeypatch):
+    """96 GaN chains (36 + 12 atoms, different rattles: 30 .. 150 evaluations each) minimised in lock step with and without the
+    live-chain compaction of the resident batch (``VSSR_RELAX_COMPACT``): positions, energies, per-atom energies, forces,
+    iteration / evaluation counts and stop reasons identical bit for bit; with it the driver dispatches far fewer
+    chain-evaluations for the same number of lock-step launches (``vssr_batch_relax_counts``).  A second relaxation and a plain
+    evaluation on the same handle afterwards see the original batch again."""
+    from surface_sampling_amd import backend
+
+    g = golden.structure("GaN_3x3_pristine")
+    ztop = g.positions[:, 2].max()
+    rng = np.random.default_rng(12)
+    types36 = np.array([0 if z == 31 else 1 for z in g.numbers], np.int32)
+    packs, mask = [], []
+    for b in range(96):
+        ads = np.array([(rng.uniform(), rng.uniform(), 0.0) for _ in range(12)]) @ g.cell
+        ads[:, 2] = ztop + rng.uniform(1.6, 2.4, 12)
+        pos = np.vstack([g.positions + rng.normal(0, 0.01 + 0.05 * rng.uniform(), g.positions.shape), ads])
+        packs.append((np.concatenate([types36, np.zeros(12, np.int32)]), pos, g.cell, np.ones(3, np.uint8)))
+        m = np.zeros(48, np.uint8)
+        m[:36][g.positions[:, 2] < ztop - 3.0] = 1
+        mask.append(m)
+    mask = np.concatenate(mask)
+    eng = backend.TersoffEngine(golden.tersoff_params, device=0)
+    runs = {}
+    for flag in ("0", "2"):      # off / for every batch size (the default compacts resident batches of >= 65 536 atoms only)
+        monkeypatch.setenv("VSSR_RELAX_COMPACT", flag)
+        out = eng.relax_cg_f64(packs, fixed=mask, max_iter=100)
+        runs[flag] = (out, eng.last_relax_counts)
+    (a, ca), (b, cb) = runs["0"], runs["2"]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    ev = a[5]
+    assert ev.min() < 0.6 * ev.max()                               # the chains really stop at different times
+    assert ca[0] == cb[0] and ca[1] == ca[0] * 96                    # same lock-step launches; without compaction every launch is full
+    needed = int(ev.sum()) + 96
+    assert needed <= cb[1] < 0.8 * ca[1], (needed, cb, ca)         # ... with it the dispatched chain-evaluations follow the live set
+    assert np.array_equal(a[3][mask.astype(bool)], np.concatenate([p[1] for p in packs])[mask.astype(bool)])   # held atoms did not move
+    # the handle holds the original batch again: a static evaluation of the relaxed geometries equals the returned results
+    n_atoms, T, pos, cell, pbc = backend.pack_batch(packs)
+    e2, ea2, f2 = eng.evaluate_arrays_f64(n_atoms, T, b[3], cell, pbc)
+    assert np.array_equal(e2, b[0]) and np.array_equal(f2, b[2])
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_cg_is_refused_for_the_fp32_painn_path(golden):
     """The line search compares energies at the 1e-8 level: only the fp64 potentials offer it (the reference uses the
     LAMMPS minimiser with LAMMPS calculators only)."""

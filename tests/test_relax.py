@@ -144,7 +144,7 @@ def test_stats_after_a_relaxation_need_a_full_run(golden):
     table, const = golden.offset_table()
     eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
     s = golden.structure("O36Sr12Ti12")
-    rattled = s.positions + np.random.default_rng(5).normal(0, 0.08, s.positions.shape)
+    rattled = s.positions + np.random.default_rng(5).normal(0, 0.15, s.positions.shape)
     packs = [(s.numbers, s.positions, s.cell, s.pbc), (s.numbers, rattled, s.cell, s.pbc)]
     eng.upload(packs)
     eng.run()
@@ -162,7 +162,7 @@ def test_stats_after_a_relaxation_need_a_full_run(golden):
     assert np.isfinite(st).all()
     # (ii) chain 0 is converged from the start, chain 1 keeps stepping: the mask goes in at the first poll
     eng.upload(packs)
-    info = eng.relax("FIRE", max_steps=8, fmax=1.5 * f_a)
+    info = eng.relax("FIRE", max_steps=8, fmax=1.05 * f_a)
     assert info["converged"][0] and info["n_steps"][0] == 0 and info["n_steps"][1] >= 4
     res = eng.download()                                                      # results stay available
     assert np.isfinite(res["energy"]).all()

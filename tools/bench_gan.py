@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--relax-steps", type=int, default=100)
     ap.add_argument("--sites", type=int, default=6, help="n x n adsorption-site grid above the slab")
     args = ap.parse_args()
-    from surface_sampling_amd import mc, structures
+    from surface_sampling_amd import backend, mc, structures
     from surface_sampling_amd.calculators import TersoffSurfCalc
 
     g = os.path.join(ROOT, "tests", "golden")
@@ -45,6 +45,26 @@ def main():
         assert (ens.num_adsorbates() == 12).all()
         ens.initialize()
         ens.step_canonical()                                        # warm-up (engine capacities settle)
+        # lock-step waste of the CG relaxations: chain-evaluations the chains NEEDED (their own n_eval + the final static one)
+        # against what the lock-step driver DISPATCHED (vssr_batch_relax_counts), and why the chains stopped
+        work = {"needed": 0, "dispatched": 0, "lockstep": 0, "relaxations": 0, "stop": {}, "evals": []}
+        inner = calc.evaluate_packed
+
+        def counted(*a, **k):
+            out = inner(*a, **k)
+            if "evaluations" in out:
+                ev = np.asarray(out["evaluations"], dtype=np.int64)
+                work["needed"] += int(ev.sum()) + len(ev)
+                work["dispatched"] += int(out["dispatched_chain_evaluations"])
+                work["lockstep"] += int(out["lockstep_evaluations"])
+                work["relaxations"] += len(ev)
+                work["evals"].append(ev)
+                for r, c in zip(*np.unique(out["stop"], return_counts=True)):
+                    name = backend.CG_STOP_REASONS.get(int(r), str(int(r)))
+                    work["stop"][name] = work["stop"].get(name, 0) + int(c)
+            return out
+
+        calc.evaluate_packed = counted
         n0 = ens.n_evaluations
         t0 = time.perf_counter()
         acc = [ens.step_canonical().mean() for _ in range(args.steps)]
@@ -54,6 +74,13 @@ def main():
                 "s_per_lockstep": dt / args.steps, "proposals_per_s": B * args.steps / dt, "acceptance": float(np.mean(acc)),
                 "mean_energy_eV": float(np.mean(ens.state.energy)), "relaxations": int(ens.n_evaluations - n0),
                 "reference": {"s_per_proposal": 32.667 / 1040, "where": "tutorials/GaN_0001.ipynb:6356 (one chain, CPU, in-process LAMMPS)"}}
+        ev = np.concatenate(work["evals"]) if work["evals"] else np.zeros(1, np.int64)
+        line["lockstep_waste"] = {"needed_chain_evaluations": work["needed"], "dispatched_chain_evaluations": work["dispatched"],
+                                  "dispatched_over_needed": work["dispatched"] / max(1, work["needed"]),
+                                  "lockstep_evaluations_per_proposal": work["lockstep"] / max(1, args.steps),
+                                  "evaluations_per_chain": {"min": int(ev.min()), "median": float(np.median(ev)), "mean": float(ev.mean()),
+                                                            "p90": float(np.percentile(ev, 90)), "max": int(ev.max())},
+                                  "stop_reasons": work["stop"]}
         line["speedup_vs_reference_per_proposal"] = line["proposals_per_s"] * line["reference"]["s_per_proposal"]
         print(json.dumps(line), flush=True)
         del ens, calc

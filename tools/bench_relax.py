@@ -41,9 +41,12 @@ def main():
             info = eng.relax(opt, fixed=mask, max_steps=args.relax_steps, fmax=fmax)
             dt = time.perf_counter() - t0
             need = int((info["n_steps"] + 1).sum())
+            lockstep, dispatched = eng.relax_counts()
             print(json.dumps({"optimizer": opt, "fmax": fmax, "chains": args.chains, "relax_steps": args.relax_steps,
                               "converged": int(info["converged"].sum()), "mean_steps": float(info["n_steps"].mean()),
-                              "chain_evaluations_needed": need, "wall_s": round(dt, 4),
+                              "chain_evaluations_needed": need, "lockstep_evaluations": lockstep,
+                              "chain_evaluations_dispatched": dispatched, "dispatched_over_needed": round(dispatched / max(1, need), 4),
+                              "wall_s": round(dt, 4),
                               "ms_per_256_chain_evaluations": round(1e3 * dt / need * 256, 3),
                               "full_batch_evaluation_ms": round(1e3 * t_eval, 3),
                               "wall_if_no_chain_dropped_s": round((args.relax_steps + 1) * t_eval, 4)}))
