@@ -468,7 +468,7 @@ void vssr_destroy(vssr_handle *h) {
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
                       &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_tile_sums, &h->d_erec, &h->d_rho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->d_zslot, &h->d_bundle, &h->d_excl, &h->d_hits, &h->wd16, &h->node16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv, &h->d_active, &h->d_bfgs_q, &h->d_bfgs_b,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
-                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_stress, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n, &h->d_chain_class, &h->d_class_list, &h->d_upd_save, &h->d_gpart, &h->d_energy64, &h->d_cmp};
+                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_stress, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n, &h->d_chain_class, &h->d_class_list, &h->d_upd_save, &h->d_gpart, &h->d_energy64, &h->d_cmp, &h->d_cm};
     for (DevBuf *b : bufs) b->release();
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -692,9 +692,13 @@ int vssr_batch_relax_cg(vssr_handle *h, const vssr_cg_params *params, const uint
     VSSR_HIP(h, hipSetDevice(h->device));
     h->relax_regrows = 0;
     h->last_want = want | VSSR_WANT_FORCES;
-    int rc = relax_cg(h, params, fixed, want);
+    // chains of <= 256 atoms on the Tersoff potential: one workgroup minimises one chain from start to stop (chain_min.hip); else
+    // the lock-step driver (relax.hip).  Same results bit for bit.
+    const bool resident = chain_min_supported(h);
+    int rc = resident ? chain_min_cg(h, params, fixed, want) : relax_cg(h, params, fixed, want);
     if (rc) return rc;
-    h->graph_partial = false;        // (the CG driver ends with a full evaluation of the final positions)
+    h->graph_partial = resident;     // (the lock-step driver ends with a full batch-wide evaluation of the final positions; the
+                                     //  chain-resident one numbers its rows per chain: introspection wants one plain run first)
     rc = sync_and_check(h);          // ... which may itself have overflowed the neighbor capacity: grow and repeat it
     if (rc) return rc;
     if (pos_out) VSSR_HIP(h, hipMemcpy(pos_out, h->d_pos.p, sizeof(double) * 3 * h->n_atoms, hipMemcpyDeviceToHost));

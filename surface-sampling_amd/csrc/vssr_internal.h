@@ -292,6 +292,7 @@ struct vssr_handle {
     long long relax_lockstep = 0;   // lock-step evaluations of the batch launched by the last relaxation (vssr_batch_relax_counts)
     int relax_compactions = 0;      // live-chain compactions of the last CG relaxation
     vssr::DevBuf d_cmp;            // arena of the live-chain compaction (relax.hip)
+    vssr::DevBuf d_cm;             // flags + per-chain evaluation counters of the chain-resident minimiser (chain_min.hip)
     long long relax_chain_evals = 0;   // chain-evaluations those launches actually dispatched (live-chain compaction: < lockstep x B)
     // trajectory recording of the lock-step relaxations (relax.hip k_traj_record): every traj_interval optimizer steps
     int traj_interval = 0, traj_records = 0, traj_B = 0, traj_N = 0;
@@ -359,6 +360,9 @@ int relax_run(vssr_handle *h, int method, const vssr_fire_params *fp, const vssr
               const uint8_t *fixed_host, uint32_t want);
 // LAMMPS-style conjugate gradients for the fp64 potentials (relax.hip); results in d_relax_steps [B][3] = {iterations, evaluations, stop reason}
 int relax_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host, uint32_t want);
+// chain_min.hip: the same minimisation with one workgroup per chain (Tersoff handles, chains of <= 256 atoms; VSSR_CG_FUSED=0 disables)
+bool chain_min_supported(const vssr_handle *h);
+int chain_min_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_host, uint32_t want);
 // MFMA node stages (painn_node_mfma.hip)
 int node_mfma_init(vssr_handle *h);
 void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,

@@ -112,21 +112,9 @@ def test_live_chain_compaction_changes_nothing_but_the_work(golden, monkeypatch)
     evaluation on the same handle afterwards see the original batch again."""
     from surface_sampling_amd import backend
 
-    g = golden.structure("GaN_3x3_pristine")
-    ztop = g.positions[:, 2].max()
-    rng = np.random.default_rng(12)
-    types36 = np.array([0 if z == 31 else 1 for z in g.numbers], np.int32)
-    packs, mask = [], []
-    for b in range(96):
-        ads = np.array([(rng.uniform(), rng.uniform(), 0.0) for _ in range(12)]) @ g.cell
-        ads[:, 2] = ztop + rng.uniform(1.6, 2.4, 12)
-        pos = np.vstack([g.positions + rng.normal(0, 0.01 + 0.05 * rng.uniform(), g.positions.shape), ads])
-        packs.append((np.concatenate([types36, np.zeros(12, np.int32)]), pos, g.cell, np.ones(3, np.uint8)))
-        m = np.zeros(48, np.uint8)
-        m[:36][g.positions[:, 2] < ztop - 3.0] = 1
-        mask.append(m)
-    mask = np.concatenate(mask)
+    packs, mask = _gan_mc_like_batch(golden, 96, 12)
     eng = backend.TersoffEngine(golden.tersoff_params, device=0)
+    monkeypatch.setenv("VSSR_CG_FUSED", "0")     # the lock-step driver (chains of this size take the chain-resident minimiser by default)
     runs = {}
     for flag in ("0", "2"):      # off / for every batch size (the default compacts resident batches of >= 65 536 atoms only)
         monkeypatch.setenv("VSSR_RELAX_COMPACT", flag)
@@ -145,6 +133,67 @@ def test_live_chain_compaction_changes_nothing_but_the_work(golden, monkeypatch)
     n_atoms, T, pos, cell, pbc = backend.pack_batch(packs)
     e2, ea2, f2 = eng.evaluate_arrays_f64(n_atoms, T, b[3], cell, pbc)
     assert np.array_equal(e2, b[0]) and np.array_equal(f2, b[2])
+    eng.close()
+
+
+def _gan_mc_like_batch(golden, n_chains, seed):
+    """GaN 3 x 3 slabs + 12 adatoms each, different rattles (chains need 20 .. 150 evaluations); bulk layers held."""
+    g = golden.structure("GaN_3x3_pristine")
+    ztop = g.positions[:, 2].max()
+    rng = np.random.default_rng(seed)
+    types36 = np.array([0 if z == 31 else 1 for z in g.numbers], np.int32)
+    packs, mask = [], []
+    for b in range(n_chains):
+        ads = np.array([(rng.uniform(), rng.uniform(), 0.0) for _ in range(12)]) @ g.cell
+        ads[:, 2] = ztop + rng.uniform(1.6, 2.4, 12)
+        pos = np.vstack([g.positions + rng.normal(0, 0.01 + 0.05 * rng.uniform(), g.positions.shape), ads])
+        packs.append((np.concatenate([types36, np.zeros(12, np.int32)]), pos, g.cell, np.ones(3, np.uint8)))
+        m = np.zeros(48, np.uint8)
+        m[:36][g.positions[:, 2] < ztop - 3.0] = 1
+        mask.append(m)
+    return packs, np.concatenate(mask)
+
+
+@pytest.mark.gpu
+def test_chain_resident_minimiser_equals_the_lock_step_driver(golden, monkeypatch):
+    """``chain_min.hip`` (one workgroup minimises one chain from its first evaluation to its stop criterion; the default for
+    Tersoff chains of <= 256 atoms) against the lock-step driver of ``relax.hip`` (``VSSR_CG_FUSED=0``) on 80 GaN chains of 48
+    atoms and a ragged batch (36 / 48 / 96-atom chains, a chain without held atoms): minimised positions, energies, per-atom
+    energies, forces, iteration / evaluation counts and stop reasons identical BIT FOR BIT; one launch instead of ~150 lock-step
+    evaluations, and exactly the chain-evaluations the chains need.  Also with a neighbor capacity that is too small at first
+    (the pools are enlarged and the chains continue where they stopped) and with the one-thread site kernel."""
+    from surface_sampling_amd import backend
+
+    packs, mask = _gan_mc_like_batch(golden, 80, 21)
+    g = golden.structure("GaN_3x3_pristine")
+    big = g.repeat((2, 1, 1))                                                # 72 atoms + 24 adatoms: two site tiles
+    rng = np.random.default_rng(3)
+    tb = np.array([0 if z == 31 else 1 for z in big.numbers], np.int32)
+    ads = np.array([(rng.uniform(), rng.uniform(), 0.0) for _ in range(24)]) @ big.cell
+    ads[:, 2] = big.positions[:, 2].max() + rng.uniform(1.6, 2.4, 24)
+    ragged = [packs[0], (tb[:36], g.positions + rng.normal(0, 0.04, g.positions.shape), g.cell, np.ones(3, np.uint8)),
+              (np.concatenate([tb, np.zeros(24, np.int32)]), np.vstack([big.positions + rng.normal(0, 0.03, big.positions.shape), ads]),
+               big.cell, np.ones(3, np.uint8)), packs[5]]
+    rmask = np.concatenate([mask[:48], np.zeros(36, np.uint8), np.zeros(96, np.uint8), mask[5 * 48:6 * 48]])
+    eng = backend.TersoffEngine(golden.tersoff_params, device=0)
+    for batch, fx in ((packs, mask), (ragged, rmask)):
+        out = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("VSSR_CG_FUSED", flag)
+            out[flag] = (eng.relax_cg_f64(batch, fixed=fx, max_iter=100), eng.last_relax_counts)
+        (a, ca), (b, cb) = out["0"], out["1"]
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), k
+        assert cb[0] == 1 and ca[0] > 20                                       # one launch against the lock-step evaluations
+        assert cb[1] == int(b[5].sum()) + len(batch) and cb[1] < ca[1]           # the chains' own evaluations (+ the setup one), nothing else
+        assert len(set(b[5].tolist())) > 2 and (b[6] > 0).all()
+    # slot pools too small at first: enlarged, the chains resume; same results
+    ref = out["1"][0]
+    eng.debug_capacity(slots_per_atom=4)
+    again = eng.relax_cg_f64(ragged, fixed=rmask, max_iter=100)
+    assert eng.debug_capacity() >= 1                                          # (regrows of the last relaxation)
+    for x, y in zip(ref, again):
+        assert np.array_equal(x, y)
     eng.close()
 
 
