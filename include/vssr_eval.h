@@ -123,6 +123,10 @@ int vssr_abi_version(void);
  *   VSSR_TERSOFF_SITE=1      Tersoff: the one-thread-per-centre kernel for every row (default: rows of <= 16 slots take the
  *                            four-lanes-per-centre kernel)
  * Read by every vssr_batch_relax_cg call:
+ *   VSSR_CG_FUSED=0|1        0: always the lock-step driver (one batch-wide evaluation per launch sequence); 1: the chain-resident
+ *                            minimiser (one workgroup relaxes one chain from start to stop, csrc/chain_min.hip) whenever it applies
+ *                            (Tersoff handles, chains of <= 256 atoms); unset: chain-resident for batches of <= 3 072 chains.  Same
+ *                            results bit for bit either way
  *   VSSR_RELAX_COMPACT=0     no live-chain compaction of the resident batch (default on for resident batches of >= 65 536 atoms: once
  *                            at most 3/4 of the chains are still minimising, the batch continues as a smaller one; same trajectories
  *                            bit for bit); n > 1: compact batches of >= n atoms (tests: 2 = always) */

@@ -23,6 +23,20 @@
 
 #include <vector>
 
+#ifdef CM_PHASE_TIMING   // debug build only (tools/gpu_cm_phase.py): 100 MHz wall-clock ticks per phase, workgroup 0
+__device__ unsigned long long g_cm_phase[16];
+#define CMP_INIT unsigned long long cmp_t = wall_clock64();
+#define CMP(k) { __syncthreads(); const unsigned long long cmp_n = wall_clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) g_cm_phase[k] += cmp_n - cmp_t; cmp_t = wall_clock64(); }
+extern "C" int vssr_debug_cm_phases(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cm_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_cm_phase), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define CMP_INIT
+#define CMP(k)
+#endif
+
 namespace vssr {
 
 struct ChainMinArgs {
@@ -73,8 +87,10 @@ k_cg_chain(const ChainMinArgs *__restrict__ Ap) {
 
     // one energy + force evaluation of the chain at its current positions; false: slot capacity exceeded (nothing was stepped)
     auto evaluate = [&]() -> bool {
+        CMP_INIT
         for (int i = a0 + tid; i < a1; i += CM_THREADS) wrap_atom(i, A.pos, A.atom_cfg, A.cell, A.invcell, A.pbc, A.wpos, A.wrap);
         __syncthreads();
+        CMP(0)
         for (int base = a0; base < a1; base += CM_THREADS / CM_LPC) {   // 16 lanes per centre, 16 centres per pass
             const int i = base + tid / CM_LPC;
             if (i < a1)
@@ -82,6 +98,7 @@ k_cg_chain(const ChainMinArgs *__restrict__ Ap) {
                                        A.hits, A.hits_stride, nullptr);
         }
         __syncthreads();
+        CMP(1)
         {   // rows of the chain: exclusive scan of the padded degrees (n <= 256: one atom per thread)
             const int pd = tid < n ? max((A.deg[a0 + tid] + 3) & ~3, 8) : 0;
             scan[tid] = pd;
@@ -100,6 +117,7 @@ k_cg_chain(const ChainMinArgs *__restrict__ Ap) {
             __syncthreads();
             if (s_over) return false;
         }
+        CMP(2)
         for (int base = a0; base < a1; base += CM_THREADS / CM_LPC) {
             const int i = base + tid / CM_LPC;
             if (i < a1)
@@ -107,11 +125,13 @@ k_cg_chain(const ChainMinArgs *__restrict__ Ap) {
                                       A.hits, A.hits_stride, nullptr);
         }
         __syncthreads();
+        CMP(3)
         for (int base = a0; base < a1; base += CM_THREADS / CM_LPC) {
             const int i = base + tid / CM_LPC;
             if (i < a1) rev_row<CM_LPC>(i, rs, A.edge, A.edge_S, A.rev);
         }
         __syncthreads();
+        CMP(4)
         if (A.fast) {
             for (int t0 = a0; t0 < a1; t0 += TS_CENTRES) {
                 const int i = t0 + (tid >> 2);
@@ -119,13 +139,17 @@ k_cg_chain(const ChainMinArgs *__restrict__ Ap) {
                 __syncthreads();
             }
         }
+        CMP(5)
         for (int i = a0 + tid; i < a1; i += CM_THREADS)
             tersoff_site_atom(i, A.n_types, A.P, A.type, A.atom_cfg, A.cell, A.wpos, rs, A.edge, A.edge_S, A.eps, A.gslot, A.fast ? TS_MAXD : -1);
         __syncthreads();
+        CMP(6)
         for (int i = a0 + tid; i < a1; i += CM_THREADS) tersoff_gather_atom(i, rs, A.rev, A.eps, A.gslot, A.e_atom, A.forces);
         __syncthreads();
+        CMP(7)
         tersoff_chain_energy(b, red, A.cfg_start, A.e_atom, A.energy);
         __syncthreads();
+        CMP(8)
         evals += 1;
         return true;
     };
@@ -139,9 +163,13 @@ k_cg_chain(const ChainMinArgs *__restrict__ Ap) {
             return;
         }
         if (it >= A.max_launch) break;   // launch budget of the lock-step driver exhausted (max_eval + 72 evaluations)
-        cg_step_chain(b, red, A.cfg_start, A.energy, A.forces, A.fixed, A.max_iter, A.max_eval, A.etol, A.ftol, A.dmax, A.pos, A.x0, A.hh, A.gg,
-                      A.st, A.active, A.flags + 1);
-        __syncthreads();
+        {
+            CMP_INIT
+            cg_step_chain(b, red, A.cfg_start, A.energy, A.forces, A.fixed, A.max_iter, A.max_eval, A.etol, A.ftol, A.dmax, A.pos, A.x0, A.hh, A.gg,
+                          A.st, A.active, A.flags + 1);
+            __syncthreads();
+            CMP(9)
+        }
         if (A.st[b].reason) break;   // (uniform: written by thread 0 in front of the barrier)
     }
     if (tid == 0) A.n_evals[b] += evals;
@@ -162,10 +190,16 @@ __global__ void k_cm_report(int B, const CgState *__restrict__ st, int *__restri
     out[3 * b] = st[b].niter; out[3 * b + 1] = st[b].neval; out[3 * b + 2] = st[b].reason;
 }
 
+// Which driver: the chain-resident kernel wins while the batch is small enough for launch latency and lock-step waste to dominate
+// (same-box A/B, GaN 48-atom chains, MC proposals/s, profiles/r05/NOTES_tersoff.md: 256 chains 20.9 k vs 15.9 k, 1 024: 45.0 k vs
+// 36.9 k, 4 096: 51.5 k vs 52 .. 56 k, 16 384: 63 k vs 70 .. 75 k): two 4-wave workgroups per CU cannot hide the fp64 latency chains
+// of the site terms as well as the batch-wide kernels do at 12 waves per CU once every CU has work for many rounds.
+// VSSR_CG_FUSED: 0 = always the lock-step driver, 1 = the chain-resident kernel whenever it applies, unset = by batch size.
 bool chain_min_supported(const vssr_handle *h) {
     if (h->kind != 2 || h->max_cfg_atoms > CM_MAX_ATOMS) return false;
-    const char *e = getenv("VSSR_CG_FUSED");   // (read per call: 0 = the lock-step driver -- A/B runs, the equality test)
-    return !e || atoi(e) != 0;
+    const char *e = getenv("VSSR_CG_FUSED");   // (read per call)
+    if (e) return atoi(e) != 0;
+    return h->n_cfg <= 3072;
 }
 
 // Same contract as relax_cg (relax.hip): afterwards the batch holds the minimised positions, d_ters_e / _ea / _f the static results of

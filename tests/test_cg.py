@@ -178,7 +178,7 @@ def test_chain_resident_minimiser_equals_the_lock_step_driver(golden, monkeypatc
     eng = backend.TersoffEngine(golden.tersoff_params, device=0)
     for batch, fx in ((packs, mask), (ragged, rmask)):
         out = {}
-        for flag in ("0", "1"):
+        for flag in ("0", "1"):      # lock-step driver / chain-resident minimiser
             monkeypatch.setenv("VSSR_CG_FUSED", flag)
             out[flag] = (eng.relax_cg_f64(batch, fixed=fx, max_iter=100), eng.last_relax_counts)
         (a, ca), (b, cb) = out["0"], out["1"]
@@ -193,6 +193,16 @@ def test_chain_resident_minimiser_equals_the_lock_step_driver(golden, monkeypatc
     again = eng.relax_cg_f64(ragged, fixed=rmask, max_iter=100)
     assert eng.debug_capacity() >= 1                                          # (regrows of the last relaxation)
     for x, y in zip(ref, again):
+        assert np.array_equal(x, y)
+    # crowded chains (adatoms pushed into the slab: rows of more than 16 slots): the one-thread site path inside the kernel
+    monkeypatch.setenv("VSSR_CG_FUSED", "1")
+    crowded = [(t.copy(), p.copy(), c, b_) for t, p, c, b_ in packs[:8]]
+    for k, (t, p, c, b_) in enumerate(crowded):
+        p[36:40] = p[20] + np.array([[0.9, 0.0, 0.3], [-0.9, 0.2, 0.4], [0.1, 0.95, -0.2], [0.2, -0.9, 0.5]]) * (1.0 + 0.05 * k)
+    got = eng.relax_cg_f64(crowded, fixed=mask[:8 * 48], max_iter=30)
+    monkeypatch.setenv("VSSR_CG_FUSED", "0")
+    want = eng.relax_cg_f64(crowded, fixed=mask[:8 * 48], max_iter=30)
+    for x, y in zip(want, got):
         assert np.array_equal(x, y)
     eng.close()
 
