@@ -22,7 +22,7 @@ The ONE JSON line carries, besides the contract fields:
                 executes on); `executed_pipe` = matrix-pipe occupancy (static MFMA count x 16x16x32x2 / launch time: ~4.9 x the
                 algorithmic flops because fp32 operands run as 3 fp16 products + padding -- occupancy, not useful work);
                 `views` gives the same launch against the fp32 vector peak and against HBM; `binding_resource` is built from the
-                committed PMC passes (profiles/r04/pmc_summary.json).  Launch times = HIP events on the engine's stream in a
+                committed PMC passes (profiles/r05/pmc_summary.json).  Launch times = HIP events on the engine's stream in a
                 SEPARATE single-stream pass after the timed region (with S > 1 launches of the two engines overlap, so
                 per-kernel durations inside the timed region are not clean);
   north_star    the BASELINE target ">= 40 % of HBM roofline on the neighbor-sum kernel" as an explicit field (not met: 15 %);
@@ -118,12 +118,14 @@ def executed_mfma_flops(which, n_slots, n_models):
     return n_models * 8 * (n_slots / 16.0) * MFMA_PER_STEP[which] * MFMA_FLOP
 
 
-PMC_SUMMARY = ("profiles", "r04", "pmc_summary.json")   # tools/gpu_pmc_r4.sh -> tools/pmc_summarize.py
+PMC_SUMMARY = ("profiles", "r05", "pmc_summary.json")   # tools/gpu_pmc_r5.sh -> tools/pmc_summarize.py
 
 
 def pmc_of(kernel):
     """Derived PMC figures of the (largest) instantiation of `kernel` from the committed summary, or None."""
     path = os.path.join(ROOT, *PMC_SUMMARY)
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r04", "pmc_summary.json")   # (the kernels of the PaiNN path did not change in round 5)
     if not os.path.exists(path):
         return None
     best = None
@@ -134,7 +136,7 @@ def pmc_of(kernel):
 
 
 def binding_resource(kernel):
-    """What binds the kernel, every number read from profiles/r04/pmc_summary.json (nothing hard-coded)."""
+    """What binds the kernel, every number read from the committed PMC summary (PMC_SUMMARY; nothing hard-coded)."""
     hit = pmc_of(kernel)
     if hit is None:
         return None
@@ -156,7 +158,7 @@ def binding_resource(kernel):
         parts.append(f"L1 address unit (TA) busy {d['ta_busy_pct']:.0f} %")
     out["summary"] = "; ".join(parts)
     out["instantiation"] = name
-    out["source"] = f"{src} (tools/gpu_pmc_r4.sh: rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1 --streams 1`)"
+    out["source"] = f"{src} (tools/gpu_pmc_r5.sh: rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1 --streams 1`)"
     return out
 
 

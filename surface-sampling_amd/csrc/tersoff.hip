@@ -18,9 +18,10 @@
 // kept for longer rows / more species) chased edge -> type -> parameters -> position through global memory for every (j, k)
 // and accumulated dE/dr_ik with global read-modify-writes: 882 us per evaluation of 4 096 x 48 atoms, all of it latency
 // (profiles/r04/NOTES_tersoff.md).  A lane owns the slots n = q, q + 4, ... of its centre in both passes:
-//   pass 1 (slot as j):  zeta_ij over all k, b_ij, the pair energy, dV/dr_ij and pref_j = 1/2 fc fA db/dzeta -> LDS
-//   pass 2 (slot n):     G_n = dV/dr_n rhat_n + sum_m [ pref_n dzeta_nm/dr_n + pref_m dzeta_mn/dr_n ]   (n as j, then n as k)
-// so every G is produced by one lane in registers and stored once.
+//   pass 1 (slot n as j): zeta_n over all k, b_ij, the pair energy, pref_n = 1/2 fc fA db/dzeta -> LDS, and the slot's own part of
+//                          G_n = dV/dr_n rhat_n + pref_n sum_m dzeta_nm/dr_n  (sums collected in the zeta walk, scaled afterwards)
+//   pass 2 (slot n as k): G_n += sum_m pref_m dzeta_mn/dr_n
+// so every G is produced by one lane (stored by pass 1, completed by pass 2), without atomics.
 #include "tersoff_dev.h"
 
 namespace vssr {

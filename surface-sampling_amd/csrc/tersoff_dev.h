@@ -306,27 +306,39 @@ __device__ __forceinline__ void tersoff_site4_tile(TersShared &sh, int i, bool m
     }
     __syncthreads();
     // ---- pass 1: the lane's slots as j ---------------------------------------------------------------------------
+    // zeta_n over all k, b_ij, the pair energy -- and, in the same walk over k, the sums that make up the slot's OWN three-body
+    // gradient d zeta_n / d r_n: it is linear in pref_n = 1/2 fc fA db/dzeta, which is only known once zeta_n is complete, so the
+    // unscaled sums Sa = sum_k fc dg ex (v_k - cs u) and Sb = sum_k fc g dex are collected first and scaled afterwards.  (Until
+    // round 5 pass 2 evaluated these factors a second time: three evaluations of the three-body factors per ordered pair (j, k),
+    // now two -- the site kernel is ~55 % of an evaluation of the GaN workloads, profiles/r05/NOTES_tersoff.md.)
     // (rolled loops: the body holds inlined fp64 exp / sin / cos / pow; four unrolled copies of both passes were 140 KB of code,
     // more than the instruction cache two CUs share)
 #pragma unroll 1
     for (int n = q; n < deg; n += TS_LANES) {
         const int tj = s_tp[n][cb];
-        double e_pair = 0.0, pref = 0.0, dVdr = 0.0;
+        double e_pair = 0.0, pref = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
         if (tj >= 0) {
             const int eij = (ti * nt + tj) * nt + tj;
             const TersL &pij = s_P[eij];
             const double r = s_r[n][cb];
             if (r <= pij.Rmax) {
                 const double ux = s_ux[n][cb], uy = s_uy[n][cb], uz = s_uz[n][cb];
-                double zeta = 0.0;
+                double zeta = 0.0, sax = 0.0, say = 0.0, saz = 0.0, sb = 0.0;
 #pragma unroll 1
                 for (int m = 0; m < deg; ++m) {
                     const int tk = s_tp[m][cb];
                     if (m == n || tk < 0) continue;
                     const double rk = s_r[m][cb];
-                    const double cs = ux * s_ux[m][cb] + uy * s_uy[m][cb] + uz * s_uz[m][cb];
+                    const double vx = s_ux[m][cb], vy = s_uy[m][cb], vz = s_uz[m][cb];
+                    const double cs = ux * vx + uy * vy + uz * vz;
                     TersTri t;
-                    if (t_tri(s_P[(ti * nt + tj) * nt + tk], r, rk, cs, t)) zeta += t.fc * t.g * t.ex;
+                    if (!t_tri(s_P[(ti * nt + tj) * nt + tk], r, rk, cs, t)) continue;
+                    zeta += t.fc * t.g * t.ex;
+                    const double a = t.fc * t.dg * t.ex;
+                    sax += a * (vx - cs * ux);
+                    say += a * (vy - cs * uy);
+                    saz += a * (vz - cs * uz);
+                    sb += t.fc * t.g * t.dex;
                 }
                 double fc, dfc;
                 t_fc_both(r, pij, fc, dfc);
@@ -334,53 +346,50 @@ __device__ __forceinline__ void tersoff_site4_tile(TersShared &sh, int i, bool m
                 double bij, dbij;
                 t_bij(zeta, pij, bij, dbij);
                 e_pair = 0.5 * fc * (fR + bij * fA);
-                dVdr = 0.5 * (dfc * (fR + bij * fA) + fc * (-pij.lam1 * fR - pij.lam2 * bij * fA));
+                const double dVdr = 0.5 * (dfc * (fR + bij * fA) + fc * (-pij.lam1 * fR - pij.lam2 * bij * fA));
                 pref = 0.5 * fc * fA * dbij;
+                // the slot as j, complete: dV/dr u + pref (Sa / r + Sb u)
+                const double pa = pref / r, su = dVdr + pref * sb;
+                gx = pa * sax + su * ux;
+                gy = pa * say + su * uy;
+                gz = pa * saz + su * uz;
             }
         }
         eps[e0 + n] = e_pair;
-        gslot[3 * (e0 + n)] = dVdr;   // parked for pass 2 (the same lane reads it back and overwrites the slot's record)
+        gslot[3 * (e0 + n)] = gx; gslot[3 * (e0 + n) + 1] = gy; gslot[3 * (e0 + n) + 2] = gz;   // pass 2 (the same lane) adds the rest
         s_pref[n][cb] = pref;
     }
     __syncthreads();
-    // ---- pass 2: G of the lane's slots -----------------------------------------------------------------------------
+    // ---- pass 2: the lane's slots as k of every other j (d zeta_m / d r_n, weighted with pref_m) --------------------------------
 #pragma unroll 1
     for (int n = q; n < deg; n += TS_LANES) {
         const int tn = s_tp[n][cb];
-        double gx = 0.0, gy = 0.0, gz = 0.0;
-        if (tn >= 0) {
-            const double dVdr = gslot[3 * (e0 + n)];
-            const double ux = s_ux[n][cb], uy = s_uy[n][cb], uz = s_uz[n][cb], r = s_r[n][cb], inv_r = 1.0 / r;
-            const double pref_n = s_pref[n][cb];
-            double su = 0.0;   // coefficient of u collected over all terms
+        if (tn < 0) continue;
+        const double ux = s_ux[n][cb], uy = s_uy[n][cb], uz = s_uz[n][cb], r = s_r[n][cb], inv_r = 1.0 / r;
+        double gx = 0.0, gy = 0.0, gz = 0.0, su = 0.0;   // su: coefficient of u collected over all terms
+        bool any = false;
 #pragma unroll 1
-            for (int m = 0; m < deg; ++m) {
-                const int tm = s_tp[m][cb];
-                if (m == n || tm < 0) continue;
-                const double pref_m = s_pref[m][cb];
-                if (pref_n == 0.0 && pref_m == 0.0) continue;
-                const double vx = s_ux[m][cb], vy = s_uy[m][cb], vz = s_uz[m][cb], rm = s_r[m][cb];
-                const double cs = ux * vx + uy * vy + uz * vz;
-                double a = 0.0;   // coefficient of (v - cs u) / r
-                // o = 0: n as j, m as k (d zeta_n / d r_n);  o = 1: m as j, n as k (d zeta_m / d r_n)
-#pragma unroll 1
-                for (int o = 0; o < 2; ++o) {
-                    const double pf = o ? pref_m : pref_n;
-                    if (pf == 0.0) continue;
-                    TersTri t;
-                    if (!t_tri(s_P[(ti * nt + (o ? tm : tn)) * nt + (o ? tn : tm)], o ? rm : r, o ? r : rm, cs, t)) continue;
-                    a += pf * t.fc * t.dg * t.ex;
-                    su += o ? pf * (t.dfc * t.g * t.ex - t.fc * t.g * t.dex) : pf * t.fc * t.g * t.dex;
-                }
-                a *= inv_r;
-                gx += a * (vx - cs * ux);
-                gy += a * (vy - cs * uy);
-                gz += a * (vz - cs * uz);
-            }
-            su += dVdr;
-            gx += su * ux; gy += su * uy; gz += su * uz;
+        for (int m = 0; m < deg; ++m) {
+            const int tm = s_tp[m][cb];
+            if (m == n || tm < 0) continue;
+            const double pf = s_pref[m][cb];
+            if (pf == 0.0) continue;
+            const double vx = s_ux[m][cb], vy = s_uy[m][cb], vz = s_uz[m][cb], rm = s_r[m][cb];
+            const double cs = ux * vx + uy * vy + uz * vz;
+            TersTri t;
+            if (!t_tri(s_P[(ti * nt + tm) * nt + tn], rm, r, cs, t)) continue;   // m as j, n as k
+            const double a = pf * t.fc * t.dg * t.ex * inv_r;
+            gx += a * (vx - cs * ux);
+            gy += a * (vy - cs * uy);
+            gz += a * (vz - cs * uz);
+            su += pf * (t.dfc * t.g * t.ex - t.fc * t.g * t.dex);
+            any = true;
         }
-        gslot[3 * (e0 + n)] = gx; gslot[3 * (e0 + n) + 1] = gy; gslot[3 * (e0 + n) + 2] = gz;
+        if (any) {
+            gslot[3 * (e0 + n)] += gx + su * ux;
+            gslot[3 * (e0 + n) + 1] += gy + su * uy;
+            gslot[3 * (e0 + n) + 2] += gz + su * uz;
+        }
     }
 }
 

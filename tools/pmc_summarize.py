@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 --pmc passes of tools/gpu_pmc_r4.sh: per kernel the per-launch mean of every raw counter and
+"""Summarise the rocprofv3 --pmc passes of tools/gpu_pmc_r4.sh (gpu_pmc_r5.sh): per kernel the per-launch mean of every raw counter and
 the derived figures bench.py quotes (`roofline.binding_resource`).  Units / corrections per /opt/skills/guides/MI355X_MICROARCH.md:
 SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed
 over SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE are in KB and FETCH_SIZE under-reports
