@@ -203,6 +203,10 @@ typedef struct {
     double etol, ftol; /* 1e-5, 1e-5 */
     double dmax;       /* 0.1 */
 } vssr_cg_params;
+/* Two drivers, same results bit for bit (csrc/chain_min.hip, csrc/relax.hip; VSSR_CG_FUSED / VSSR_RELAX_COMPACT above): Tersoff batches
+ * of <= 3 072 chains of <= 256 atoms are minimised by ONE workgroup per chain from the first evaluation to the stop criterion (no
+ * lock step: the GaN chains of the reference stop after 21 .. 159 evaluations each); everything else in lock step, with the resident
+ * batch compacted to the chains still minimising once it is large enough for that to pay. */
 int vssr_batch_relax_cg(vssr_handle *h, const vssr_cg_params *params, const uint8_t *fixed, uint32_t want,
                         double *pos_out, int32_t *n_iter, int32_t *n_eval, int32_t *stop_reason);
 
