@@ -113,6 +113,8 @@ int vssr_abi_version(void);
  *   VSSR_L0_FACTORISE=0      layer 0 runs the generic kernels instead of the species factorisation
  *   VSSR_EDGE_FS16_MAX=n, VSSR_EDGE_FS8_MAX=n, VSSR_EDGE_FS4_MAX=n   largest chain (atoms) served by the 16- / 8- / 4-feature-slice
  *                            kernels (lower = force a path)
+ *   VSSR_EDGE_FWD_2PASS=0    chains of the 4-feature class (788 .. 1 462 atoms) take the 4-feature forward kernel instead of the 8-feature
+ *                            kernel run twice over two neighbor sub-ranges (the default since round 5)
  *   VSSR_UPD_SAVE=1          update blocks store their forward intermediates for the reverse pass (measured: no gain)
  *   VSSR_GBAR_MODE=0|1|2     partial edge-gradient buffers: 0 shared float4 set with read-modify-write (round 2), 1 one float4 set per
  *                            layer, 2 (default) one compact 12-byte set per layer

@@ -322,14 +322,42 @@ __global__ void __launch_bounds__(64) k_edge_geom(int n_atoms, const int *__rest
 // {centre (chain-local), first slot, padded slot count, 0}.  Four consecutive entries form a "bundle" that one wave
 // walks in lock step (4 slots per centre and step), so the four centres finish within the same step and their results
 // are reduced / written with all lanes active.  One workgroup per chain, O(N^2) ranking on LDS broadcasts.
+// Ascending bitonic sort of 2048 keys in LDS by the whole workgroup (any power-of-two width up to 1024 threads x 1 exchange each): the
+// bundle tables rank a chain's centres by (length descending, index ascending) = ascending key ((4095 - len) << 11 | index); an
+// O(n^2) ranking was 0.2 .. 0.5 ms of the neighbor stage for 1 000 .. 1 400-atom chains.  Unused keys = 0xFFFFFFFF.
+constexpr int BSORT_N = 2048;
+__device__ __forceinline__ void lds_bitonic_sort(unsigned *keys) {
+    for (int k = 2; k <= BSORT_N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < BSORT_N / 2; t += blockDim.x) {
+                const int i = 2 * t - (t & (j - 1)), l = i + j;   // the pair (i, i + j) handled by exchange t
+                const unsigned a = keys[i], b2 = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > b2) == up) { keys[i] = b2; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+}
+
 __global__ void __launch_bounds__(256)
 k_bundle_sort(const int *__restrict__ cfg_start, const int *__restrict__ row_start, const int *__restrict__ counters,
-              int4 *__restrict__ bundle, const unsigned char *__restrict__ active) {
+              int4 *__restrict__ bundle, const unsigned char *__restrict__ active, int sort_keys) {
     extern __shared__ int sdeg[];
     if (counters[2] || (active && !active[blockIdx.x])) return;
     const int b = blockIdx.x, a0 = cfg_start[b], n = cfg_start[b + 1] - a0;
     for (int c = threadIdx.x; c < n; c += blockDim.x) sdeg[c] = row_start[a0 + c + 1] - row_start[a0 + c];
     __syncthreads();
+    if (n <= BSORT_N && sort_keys) {   // (same order as the ranking below: length descending, index ascending)
+        unsigned *keys = reinterpret_cast<unsigned *>(sdeg) + n;
+        for (int c = threadIdx.x; c < BSORT_N; c += blockDim.x) keys[c] = c < n ? ((unsigned)(4095 - min(sdeg[c], 4095)) << 11) | (unsigned)c : 0xFFFFFFFFu;
+        __syncthreads();
+        lds_bitonic_sort(keys);
+        for (int r = threadIdx.x; r < n; r += blockDim.x) {
+            const int c = (int)(keys[r] & 2047u);
+            bundle[a0 + r] = make_int4(c, row_start[a0 + c], sdeg[c], 0);
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < n; c += blockDim.x) {
         const int d = sdeg[c];
         int rank = 0;
@@ -338,6 +366,76 @@ k_bundle_sort(const int *__restrict__ cfg_start, const int *__restrict__ row_sta
             rank += (od > d || (od == d && o < c)) ? 1 : 0;
         }
         bundle[a0 + rank] = make_int4(c, row_start[a0 + c], d, 0);
+    }
+}
+
+// Per-pass bundle tables of the multi-pass neighbor sum (painn_edge_mfma.hip, k_edge_fwd_mfma<.., SUB>): chains of `list` only.  The
+// chain's atoms are cut into P = sub_passes(n) equal ranges; a row is sorted by neighbor, so the slots whose neighbor lies in range p
+// are a contiguous piece [k_p, k_{p+1}) of the row.  Windows are cut at quad boundaries -- quads [floor(k_p / 4), ceil(k_{p+1} / 4)) --
+// and the kernel sends slots of another range that fall into a window to its zero row.  A centre without a neighbor in range p gets
+// an empty window there.  Every table is ranked by window length like the full table by row length; n_entries[p - 1][chain] = centres
+// with a non-empty window in pass p >= 1 (the head of that table).  One workgroup per chain; LDS: SUB_MAX_PASSES x n ints.
+__global__ void __launch_bounds__(1024)
+k_bundle_sort_sub(const int *__restrict__ list, const int *__restrict__ cfg_start, const int *__restrict__ row_start,
+                  const float4 *__restrict__ edge, const int *__restrict__ counters, int N, int n_cfg, int chunk_max,
+                  int4 *__restrict__ bundle_sub, int *__restrict__ n_entries, const unsigned char *__restrict__ active) {
+    extern __shared__ int sdeg[];   // [P][n] window lengths, [P][n] first slots (relative to the row), 2 048 sort keys
+    const int b = list[blockIdx.x];
+    if (counters[2] || (active && !active[b])) return;
+    const int a0 = cfg_start[b], n = cfg_start[b + 1] - a0;
+    const int P = sub_passes(n, chunk_max), chunk = sub_chunk(n, chunk_max);
+    int *len = sdeg, *first = sdeg + SUB_MAX_PASSES * n;
+    __shared__ int cnt[SUB_MAX_PASSES];   // (LDS counters: thousands of global atomics on one address cost more than the rest of the kernel)
+    if (threadIdx.x < SUB_MAX_PASSES) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // 16 lanes per centre (one DPP row): every lane counts, over its slots, the neighbors below each range boundary; the row is sorted
+    // by neighbor, so the count IS the index k_p of the first slot of range p (a binary search per boundary was ten dependent L2 round
+    // trips per centre and boundary: most of this kernel's time)
+    const int lane = threadIdx.x & 15;
+    for (int c = threadIdx.x >> 4; c < n; c += blockDim.x >> 4) {
+        const int rs = row_start[a0 + c], re = row_start[a0 + c + 1];
+        int below[SUB_MAX_PASSES];   // [p]: real slots with neighbor < (p + 1) chunk; [P - 1]: all real slots
+#pragma unroll
+        for (int p = 0; p < SUB_MAX_PASSES; ++p) below[p] = 0;
+        for (int e = rs + lane; e < re; e += 16) {
+            const int j = __float_as_int(edge[e].w);
+            if (j < 0) continue;
+            const int jl = j - a0;
+#pragma unroll
+            for (int p = 0; p < SUB_MAX_PASSES; ++p) below[p] += (p + 1 >= P || jl < (p + 1) * chunk) ? 1 : 0;
+        }
+#pragma unroll
+        for (int p = 0; p < SUB_MAX_PASSES; ++p) {   // sum over the 16 lanes of the row (every lane ends with the total)
+            int x = below[p];
+            x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+            below[p] = x;
+        }
+        if (lane == 0) {
+            int kprev = 0;
+            for (int p = 0; p < P; ++p) {
+                const int k = below[p];                          // first slot (relative) beyond range p
+                const bool any = k > kprev;
+                const int f = kprev & ~3, last = p + 1 < P ? min((k + 3) & ~3, re - rs) : re - rs;   // (the last window ends with the row: pads carry zero entries)
+                len[p * n + c] = any ? last - f : 0;
+                first[p * n + c] = f;
+                if (any && p > 0) atomicAdd(&cnt[p], 1);
+                kprev = k;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x < SUB_MAX_PASSES) n_entries[(size_t)(threadIdx.x - 1) * n_cfg + b] = cnt[threadIdx.x];
+    unsigned *keys = reinterpret_cast<unsigned *>(sdeg + 2 * SUB_MAX_PASSES * n);
+    for (int p = 0; p < P; ++p) {
+        const int *lp = len + p * n;
+        __syncthreads();   // (the previous pass is done reading the keys)
+        for (int c = threadIdx.x; c < BSORT_N; c += blockDim.x) keys[c] = c < n ? ((unsigned)(4095 - min(lp[c], 4095)) << 11) | (unsigned)c : 0xFFFFFFFFu;
+        __syncthreads();
+        lds_bitonic_sort(keys);
+        for (int r = threadIdx.x; r < n; r += blockDim.x) {
+            const int c = (int)(keys[r] & 2047u);
+            bundle_sub[(size_t)p * N + a0 + r] = make_int4(c, row_start[a0 + c] + first[p * n + c], lp[c], 0);
+        }
     }
 }
 
@@ -442,10 +540,42 @@ int build_neighbors(vssr_handle *h, double cutoff) {
             default: LAUNCH_GEOM(0); break;
         }
 #undef LAUNCH_GEOM
-        if ((size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024)   // chains of the MFMA edge kernels (LDS slices) are far smaller
-            hipLaunchKernelGGL(k_bundle_sort, dim3(h->n_cfg), dim3(256), (size_t)h->max_cfg_atoms * sizeof(int), st,
+        if ((size_t)h->max_cfg_atoms * sizeof(int) <= 48 * 1024) {   // chains of the MFMA edge kernels (LDS slices) are far smaller
+            // (large chains: key sort in LDS instead of the O(n^2) ranking -- the same table; rows longer than 4 095 slots do not occur)
+            const int sort_keys = h->max_cfg_atoms > 512 && h->max_cfg_atoms <= BSORT_N;
+            hipLaunchKernelGGL(k_bundle_sort, dim3(h->n_cfg), dim3(256),
+                               (size_t)h->max_cfg_atoms * sizeof(int) + (sort_keys ? BSORT_N * sizeof(unsigned) : 0), st,
                                h->d_cfg_start.as<int>(), h->d_row_start.as<int>(), h->d_counters.as<int>(),
-                               h->d_bundle.as<int4>(), h->active_mask);
+                               h->d_bundle.as<int4>(), h->active_mask, sort_keys);
+            // chains of the 4-feature class (788 .. 1 462 atoms): per-pass tables of the two-pass 8-feature forward kernel
+            // per-pass bundle tables of the multi-pass forms: forward (chains of the 4-feature class) and reverse (class FS16P); the two
+            // cut the chain into ranges of different size, so each has its own tables
+            auto sub_tables = [&](vssr::DevBuf &buf, const int *list, int n_list, int max_atoms, int chunk) -> int {
+                if (sub_passes(max_atoms, chunk) > SUB_MAX_PASSES) return set_err(h, VSSR_E_BADARG, "neighbor sub-range too small for this chain");
+                if (buf.ensure(sizeof(int4) * SUB_MAX_PASSES * (size_t)n + sizeof(int) * (SUB_MAX_PASSES - 1) * (size_t)h->n_cfg))
+                    return set_err(h, VSSR_E_NOMEM, "bundle tables: out of device memory");
+                hipLaunchKernelGGL(k_bundle_sort_sub, dim3(n_list), dim3(1024),
+                                   2 * SUB_MAX_PASSES * (size_t)max_atoms * sizeof(int) + BSORT_N * sizeof(unsigned), st, list,
+                                   h->d_cfg_start.as<int>(), h->d_row_start.as<int>(), h->d_edge.as<float4>(), h->d_counters.as<int>(), n, h->n_cfg,
+                                   chunk, buf.as<int4>(), reinterpret_cast<int *>(buf.as<int4>() + SUB_MAX_PASSES * (size_t)n), h->active_mask);
+                return VSSR_OK;
+            };
+            if (h->fwd_two_pass && h->n_class[EDGE_CLASS_FS4] > 0) {
+                int off = 0;
+                for (int c = 0; c < EDGE_CLASS_FS4; ++c) off += h->n_class[c];
+                const int rc2 = sub_tables(h->d_bundle_sub, h->d_class_list.as<int>() + off, h->n_class[EDGE_CLASS_FS4], h->max_class_atoms[EDGE_CLASS_FS4],
+                                           h->sub_chunk_fwd ? h->sub_chunk_fwd : sub_chunk_max(h->fwd_two_pass));
+                if (rc2) return rc2;
+            }
+            if (h->n_bclass[EDGE_BCLASS_FS16P] > 0) {
+                int off = 0;
+                for (int c = 0; c < EDGE_MFMA_CLASSES; ++c) off += h->n_class[c];
+                for (int c = 0; c < EDGE_BCLASS_FS16P; ++c) off += h->n_bclass[c];
+                const int rc2 = sub_tables(h->d_bundle_subb, h->d_class_list.as<int>() + off, h->n_bclass[EDGE_BCLASS_FS16P],
+                                           h->max_bclass_atoms[EDGE_BCLASS_FS16P], h->sub_chunk_bwd ? h->sub_chunk_bwd : sub_chunk_max_bwd());
+                if (rc2) return rc2;
+            }
+        }
     }
     h->prof.end(st);
     VSSR_HIP(h, hipMemcpyAsync(h->h_counters, h->d_counters.as<int>(), sizeof(int) * 4,

@@ -564,7 +564,7 @@ int painn_gbar_groups(const vssr_handle *h) {
     if (h->num_conv < 2) return 1;
     const int per_set = h->n_bclass[EDGE_BCLASS_FS4] ? edge_class_groups(EDGE_BCLASS_FS4)
                         : h->n_bclass[EDGE_BCLASS_FS8] ? edge_class_groups(EDGE_BCLASS_FS8)
-                        : h->n_bclass[EDGE_BCLASS_FS16] ? edge_class_groups(EDGE_BCLASS_FS16) : 1;
+                        : (h->n_bclass[EDGE_BCLASS_FS16] || h->n_bclass[EDGE_BCLASS_FS16P]) ? edge_class_groups(EDGE_BCLASS_FS16) : 1;
     return per_set > 1 ? per_set * gbar_layer_sets(h) : 1;
 }
 
@@ -701,7 +701,9 @@ int painn_run(vssr_handle *h, uint32_t want) {
         else {
             for (int cls = 0; cls < EDGE_MFMA_CLASSES; ++cls)
                 launch_edge_fwd_mfma(st, cls, N, cls_list[cls], h->n_class[cls], M, l, h->max_class_atoms[cls], MW, G, counters,
-                                     (int)(h->slot_cap - 1), sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l], sv.v_msg[l]);
+                                     (int)(h->slot_cap - 1), sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l], sv.v_msg[l],
+                                     (cls == EDGE_CLASS_FS4 && h->fwd_two_pass) ? h->d_bundle_sub.as<int4>() : (const int4 *)nullptr,
+                                     h->fwd_two_pass, h->sub_chunk_fwd ? h->sub_chunk_fwd : sub_chunk_max(h->fwd_two_pass));
             if (n_gather)
                 hipLaunchKernelGGL(k_edge_fwd<false>, g_atom, blk, 0, st, N, l, MW, G, counters, h->cutoff, h->excl_vol,
                                    h->excl_sigma, h->excl_power, sv.s_in[l], sv.v_in[l], sv.phi[l], sv.s_msg[l],
@@ -765,7 +767,9 @@ int painn_run(vssr_handle *h, uint32_t want) {
                                          h->max_bclass_atoms[cls], MW, G, counters, (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l],
                                          sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar,
                                          compact ? h->d_gpart.as<float>() : reinterpret_cast<float *>(sv.gbar), (long long)h->slot_cap,
-                                         n_groups, layer_sets > 1 ? (L - 1 - l) * (n_groups / layer_sets) : 0, compact ? 3 : 4);
+                                         n_groups, layer_sets > 1 ? (L - 1 - l) * (n_groups / layer_sets) : 0, compact ? 3 : 4,
+                                         cls == EDGE_BCLASS_FS16P ? h->d_bundle_subb.as<int4>() : (const int4 *)nullptr,
+                                         h->sub_chunk_bwd ? h->sub_chunk_bwd : sub_chunk_max_bwd());
                 if (n_gather)   // partial buffer 0 of every model
                     hipLaunchKernelGGL(k_edge_bwd<false>, g_atom, blk, 0, st, N, l, accumulate, MW, G, counters,
                                        h->cutoff, h->excl_vol, h->excl_sigma, h->excl_power, sv.v_in[l], sv.phi[l],
@@ -788,13 +792,13 @@ int painn_run(vssr_handle *h, uint32_t want) {
 #else
         if (compact) {
 #endif
-            const int uni = h->active_mask ? 0 : h->n_bclass[EDGE_BCLASS_FS16] == h->n_cfg ? 8 : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? 16
+            const int uni = h->active_mask ? 0 : h->n_bclass[EDGE_BCLASS_FS16] + h->n_bclass[EDGE_BCLASS_FS16P] == h->n_cfg ? 8 : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? 16
                             : h->n_bclass[EDGE_BCLASS_FS4] == h->n_cfg ? 32 : 0;
             const dim3 grid = uni ? dim3((unsigned)((h->slot_cap + 255) / 256), 1) : dim3(h->n_cfg, 12);
             hipLaunchKernelGGL(k_reduce_gpart, grid, dim3(256), 0, st, M, n_groups, layer_sets, G, counters, h->d_gpart.as<float>(),
                                sv.gbar, (long long)h->slot_cap, uni);
         } else if (n_groups > 1) {
-            const int cls_only = h->n_bclass[EDGE_BCLASS_FS16] == h->n_cfg ? EDGE_BCLASS_FS16
+            const int cls_only = h->n_bclass[EDGE_BCLASS_FS16] + h->n_bclass[EDGE_BCLASS_FS16P] == h->n_cfg ? EDGE_BCLASS_FS16
                                  : h->n_bclass[EDGE_BCLASS_FS8] == h->n_cfg ? EDGE_BCLASS_FS8
                                  : h->n_bclass[EDGE_BCLASS_FS4] == h->n_cfg ? EDGE_BCLASS_FS4 : -1;
             if (cls_only >= 0 && !h->active_mask && (layer_sets == 1 || n_gather == 0))   // (switched-off chains keep their reduced gradients: the per-chain form skips them)

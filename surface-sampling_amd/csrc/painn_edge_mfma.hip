@@ -39,6 +39,10 @@ extern "C" int vssr_debug_edge_phases(unsigned long long *out, int reset) {
 #define EPH_FLUSH(base)
 #endif
 
+#ifndef SUB16_WAVES
+#define SUB16_WAVES 12   // waves per workgroup of the 16-feature multi-pass forward form (144 registers: 3 waves per SIMD; 8 waves: +6 %)
+#endif
+
 namespace vssr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -390,14 +394,28 @@ __device__ __forceinline__ int chain_of_workgroup(const GraphView &G, const int 
     return G.act.chain(b) ? b : -1;
 }
 
-template <int NF, bool SLDS, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// SUB (chains whose slice does not fit LDS at this width: one launch per `pass`): the chain's atoms are cut into P = ceil(n / chunk_max)
+// equal ranges (sub_passes / sub_chunk below); the workgroup of pass p stages only the neighbors [lo, lo + ns) of range p plus an
+// all-zero row, and walks, for every centre, the window of its (neighbor-sorted) row that holds those neighbors (`bundle_tab`:
+// per-pass bundle tables, nbr.hip k_bundle_sort_sub).  Windows are cut at quad boundaries, so a window may contain slots of another
+// range: their neighbor index is redirected to the zero row and they contribute exactly nothing.  Pass 0 walks every centre and adds
+// the residual (s_in, v_in of the centre, from memory) like the SLDS = false form; a later pass walks the centres that have
+// neighbors in its range (`n_entries`: the head of its length-sorted table) and adds to what the passes before it wrote (s_msg,
+// v_msg): same code, other base pointers.  Why wider slices in several passes beat narrower slices in one: every (slice, model)
+// workgroup streams the chain's per-slot tables once, so the table stream per atom grows with the number of slices -- the bound of
+// the 8- and 4-feature kernels on large chains (profiles/r05/NOTES_large_chains.md).
+// (registers: 4 waves per SIMD = 128 everywhere, except the 16-feature multi-pass form, whose extra residual registers need the
+//  256 of an 8-wave workgroup)
+template <int NF, bool SLDS, int WAVES, bool SUB = false>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu((SUB && NF == 4) ? WAVES / 4 : 4, (SUB && NF == 4) ? WAVES / 4 : 4)))
 k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *__restrict__ counters,
                 int zero_slot, int n_models, int max_atoms, const int *__restrict__ list, int n_list,
                 const float *__restrict__ s_in, const float *__restrict__ v_in, const float *__restrict__ phi,
-                float *__restrict__ s_msg, float *__restrict__ v_msg) {
+                float *s_msg, float *v_msg, const int4 *__restrict__ bundle_tab, const int *__restrict__ n_entries_tab, int pass,
+                int chunk_max) {
     using LY = EdgeGeo<NF>;
     constexpr int FS = LY::FS, NSLICE = LY::NSLICE, NT = LY::NT, EDGE_THREADS = 64 * WAVES;
+    static_assert(!SUB || !SLDS, "the sub-range form takes its residuals from memory");
     extern __shared__ __attribute__((aligned(16))) float tile[];
     if (counters[2]) return;
     int t;
@@ -407,6 +425,15 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     const int a0 = G.cfg_start[b], Nc = G.cfg_start[b + 1] - a0;
     const size_t mN = (size_t)m * N;
     const int tid = threadIdx.x;
+    // staged neighbors: all atoms of the chain, or (SUB) range `pass` of its sub_passes(Nc) ranges
+    int lo = 0, ns = Nc;
+    if constexpr (SUB) {
+        if (pass >= sub_passes(Nc, chunk_max)) return;   // (uniform; this chain needs fewer passes than the launch's largest)
+        const int chunk = sub_chunk(Nc, chunk_max);
+        lo = pass * chunk;
+        ns = min(chunk, Nc - lo);
+    }
+    const float *res_s = (SUB && pass) ? s_msg : s_in, *res_v = (SUB && pass) ? v_msg : v_in;   // what a centre's sums are added to
 
     // ---- stage the chain's feature slice: tile[atom][f][seg] ---------------------------------------------------------
     // NSEG * FS / 4 float4 per atom; loads are issued in batches of 4 per thread before any LDS store so that
@@ -415,10 +442,13 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     {
         constexpr int Q4 = FS / 4;                          // float4 per slice segment
         constexpr int PER_ATOM = (LY::NSEG + (SLDS ? 1 : 0)) * Q4;   // float4 per atom
-        const int total = Nc * PER_ATOM;
+        const int total = ns * PER_ATOM;
+        if constexpr (SUB) {   // the all-zero row behind the staged ones: where slots of the other half point
+            for (int k = tid; k < LY::ROW; k += EDGE_THREADS) tile[(size_t)ns * LY::ROW + k] = 0.f;
+        }
         auto src_of = [&](int idx) -> const float * {
             int atom = idx / PER_ATOM, rem = idx - atom * PER_ATOM, seg = rem / Q4, q4 = rem % Q4;
-            const size_t ga = mN + a0 + atom;
+            const size_t ga = mN + a0 + lo + atom;
             if (seg == LY::NSEG) return s_in + ga * F + fs * FS + q4 * 4;                  // s slice
             if (seg < 3) return phi + ga * F3 + seg * F + fs * FS + q4 * 4;                // sections a, b, c
             return v_in + (ga * 3 + (seg - 3)) * F + fs * FS + q4 * 4;                     // v_x, v_y, v_z
@@ -462,7 +492,11 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 
     // ---- work list: bundles of 4 centres of (nearly) equal slot count, see BundleWalk --------------------------------
     BundleWalk<EDGE_THREADS / 64> bw;
-    bw.init(G.bundle + a0, Nc, __builtin_amdgcn_readfirstlane(wave), p >> 2);
+    // (SUB, pass >= 1: only the centres with neighbors in that range -- the head of the length-sorted table; the others keep what
+    //  the earlier passes wrote)
+    const int n_entries = (SUB && pass) ? n_entries_tab[(size_t)(pass - 1) * G.n_cfg + b] : Nc;
+    if (n_entries <= 0) return;   // (no barrier below)
+    bw.init((SUB ? bundle_tab : G.bundle) + a0, n_entries, __builtin_amdgcn_readfirstlane(wave), p >> 2);
     if (bw.nj == 0) return;   // (no barrier below)
 #ifdef ABL_STAGE_ONLY   // ablation: staging + prologue only (results wrong)
     if (bw.nj > 0) return;
@@ -474,11 +508,19 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     // scalar residual of this stream's centre: requested when the wave switches to a bundle (for the bundle after it), used
     // when that bundle completes -- always a load (clamped row for streams without a centre), like the bundle entries
     typedef typename FeatVec<NF>::type fres;
-    fres sres_cur, sres_nxt;
+    fres sres_cur, sres_nxt, vres_cur[SUB ? 3 : 1];   // (SUB: the vector residual is requested when its bundle STARTS -- one set of
+                                                       //  registers; a window is several steps long, enough for an L2 round trip)
     auto load_residual = [&](int cc) {
-        return *reinterpret_cast<const fres *>(s_in + (mN + a0 + min(max(cc, 0), Nc - 1)) * F + fcol);
+        return *reinterpret_cast<const fres *>(res_s + (mN + a0 + min(max(cc, 0), Nc - 1)) * F + fcol);
+    };
+    auto load_residual_v = [&](int cc, int x) {   // (SUB: the centre's own v row may not be among the staged ones)
+        return *reinterpret_cast<const fres *>(res_v + ((mN + a0 + min(max(cc, 0), Nc - 1)) * 3 + x) * F + fcol);
     };
     if (!SLDS) { sres_cur = load_residual(bw.cur.x); sres_nxt = load_residual(bw.nxt.x); }
+    if constexpr (SUB) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x) vres_cur[x] = load_residual_v(bw.cur.x, x);
+    }
 
     // quad-interleaved table (nbr.hip f16_unit): unit = quad * 32 + piece * 16 + fq * 4 + e -> the 4 slot lanes of a quad read
     // 64 contiguous bytes; exhausted streams read the reserved all-zero quad (filter = 0)
@@ -522,9 +564,9 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 #pragma unroll
             for (int r = 0; r < NF; ++r) {
                 so[r] = ds[r] + (SLDS ? sr[r] : sres_cur[r]);
-                xo[r] = dvx[r] + vc[r * LY::NSEG + 3];
-                yo[r] = dvy[r] + vc[r * LY::NSEG + 4];
-                zo[r] = dvz[r] + vc[r * LY::NSEG + 5];
+                xo[r] = dvx[r] + (SUB ? vres_cur[0][r] : vc[r * LY::NSEG + 3]);
+                yo[r] = dvy[r] + (SUB ? vres_cur[SUB ? 1 : 0][r] : vc[r * LY::NSEG + 4]);
+                zo[r] = dvz[r] + (SUB ? vres_cur[SUB ? 2 : 0][r] : vc[r * LY::NSEG + 5]);
             }
             store_feat<NF>(s_msg + ga * F + fcol, so);
             store_feat<NF>(v_msg + (ga * 3 + 0) * F + fcol, xo);
@@ -546,7 +588,11 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 #ifdef ABL_LDS_BCAST   // ablation: every gather reads row 0 or 1 (no LDS bank conflicts; results wrong)
             const int jn = (int)(rq[ph][0][3] >> 16) & 1;
 #else
-            const int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
+            int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
+            if constexpr (SUB) {   // staged row of the neighbor, or the zero row for a neighbor of the other half
+                const unsigned jl = (unsigned)(jn - lo);
+                jn = jl < (unsigned)ns ? (int)jl : ns;
+            }
 #endif
             if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
                 flush_bundle();
@@ -555,6 +601,10 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                     sres_cur = sres_nxt;
                     __builtin_amdgcn_sched_barrier(0);   // the old value leaves its registers before the load that refills them
                     sres_nxt = load_residual(bw.nxt.x);
+                    if constexpr (SUB) {
+#pragma unroll
+                        for (int x = 0; x < 3; ++x) vres_cur[x] = load_residual_v(bw.cur.x, x);
+                    }
                 }
                 EPH(2)   // bundle completion
             }
@@ -656,14 +706,20 @@ size_t edge_bwd_lds_bytes_t(int max_atoms) { return sizeof(float) * ((size_t)max
 // (The narrow slices need fewer registers -- 145 / 110 with 8- / 4-feature slices -- but wider workgroups, 12 resp. 16 waves when one
 // workgroup owns the CU, changed nothing: 9.08 vs 9.01 .. 9.22 ms at 700 atoms, 37.1 vs 36.9 at 1 400, profiles/r04/ab_bwd_wide.txt;
 // these launches are bound by the L2 -> L1 stream of the per-slot tables, which every slice re-reads, not by latency.)
-template <int NF, bool FIRST, int WAVES>
+// SUB: the multi-pass form of the forward kernel (see there) for the reverse pass: pass p stages [sbar, vbar] of the neighbors of
+// range p plus a zero row and walks the windows of its per-pass bundle table; a slot whose neighbor is outside the range gathers
+// zeros (every term of its contribution carries sbar_n / vbar_n) and sends its gradient record to the spare entry, so the record of
+// a slot is written by exactly one pass.  Pass 0 writes phibar_c / vbar_c (+ the residual vbar_msg_c, from memory); a later pass
+// adds to what is there.
+template <int NF, bool FIRST, int WAVES, bool SUB = false>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 2 waves per SIMD either way: use the 256 VGPRs
 k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms,
                 const int *__restrict__ list, int n_list,
                 const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
-                const float *__restrict__ vbar_msg, float *__restrict__ phibar, float *__restrict__ vbar_in,
-                float *__restrict__ gbar, long long gbar_stride, int n_groups, int group_off, int rec) {
+                const float *__restrict__ vbar_msg, float *phibar, float *vbar_in,
+                float *__restrict__ gbar, long long gbar_stride, int n_groups, int group_off, int rec,
+                const int4 *__restrict__ bundle_tab, const int *__restrict__ n_entries_tab, int pass, int chunk_max) {
     using LY = EdgeGeo<NF>;
     constexpr int FS = LY::FS, NSG = LY::NSLICE, NT = LY::NT, ROWB = LY::ROWB, BWD_THREADS = 64 * WAVES;
     typedef typename FeatVec<NF>::type fvx;   // the lane's NF features (ext vectors: arrays of HIP float4 stay in scratch memory)
@@ -676,6 +732,13 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     const int a0 = G.cfg_start[b], Nc = G.cfg_start[b + 1] - a0;
     const size_t mN = (size_t)m * N;
     const int tid = threadIdx.x;
+    int lo = 0, ns = Nc;   // staged neighbors: all atoms of the chain, or (SUB) range `pass`
+    if constexpr (SUB) {
+        if (pass >= sub_passes(Nc, chunk_max)) return;   // (uniform)
+        const int chunk = sub_chunk(Nc, chunk_max);
+        lo = pass * chunk;
+        ns = min(chunk, Nc - lo);
+    }
     const int lane = tid & 63, wave = tid >> 6, p = lane & 15, fq = lane >> 4, e = p & 3;
     const int last_slot = max(G.row_start[a0 + Nc] - 1, 0);
     const u32x4 sel = {0u, 0u, 0u, fq == (p & 3) ? 0x3C00u : 0u};   // selector tile (filter_tiles_sel): 1.0 at K entry 6
@@ -704,14 +767,17 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     // ---- stage [atom][f][sbar, vbar_x, vbar_y, vbar_z] of this slice ------------------------------------------
     {
         constexpr int Q4 = FS / 4;           // float4 per segment
-        const int total = Nc * 4 * Q4;       // 4 segments per atom
+        const int total = ns * 4 * Q4;       // 4 segments per atom
+        if constexpr (SUB) {   // the all-zero row behind the staged ones
+            for (int k = tid; k < ROWB; k += BWD_THREADS) tile[(size_t)ns * ROWB + k] = 0.f;
+        }
         for (int base = tid; base < total; base += STAGE_BATCH * BWD_THREADS) {
             float4 v4[STAGE_BATCH];
 #pragma unroll
             for (int u = 0; u < STAGE_BATCH; ++u) {
                 const int idx = min(base + u * BWD_THREADS, total - 1);
                 const int atom = idx / (4 * Q4), seg = (idx / Q4) & 3, q4 = idx % Q4;
-                const size_t ga = mN + a0 + atom;
+                const size_t ga = mN + a0 + lo + atom;
                 const float *src = seg == 0 ? sbar_msg + ga * F + fs * FS + q4 * 4
                                             : vbar_msg + (ga * 3 + (seg - 1)) * F + fs * FS + q4 * 4;
                 v4[u] = *reinterpret_cast<const float4 *>(src);
@@ -745,7 +811,9 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     __syncthreads();
 
     BundleWalk<BWD_THREADS / 64> bw;   // work list: bundles of 4 centres, see the forward kernel
-    bw.init(G.bundle + a0, Nc, __builtin_amdgcn_readfirstlane(wave), p >> 2);
+    const int n_entries = (SUB && pass) ? n_entries_tab[(size_t)(pass - 1) * G.n_cfg + b] : Nc;
+    if (n_entries <= 0) return;   // (no barrier below)
+    bw.init((SUB ? bundle_tab : G.bundle) + a0, n_entries, __builtin_amdgcn_readfirstlane(wave), p >> 2);
     if (bw.nj == 0) return;   // (no barrier below)
 #ifdef ABL_STAGE_ONLY   // ablation: staging + prologue only (results wrong)
     if (bw.nj > 0) return;
@@ -776,6 +844,20 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     load_centre(bw.cur.x);
     park_centre();
     load_centre(bw.nxt.x);
+    // (SUB) what the centre's sums are added to, requested when its bundle starts: vbar_msg_c (pass 0: the residual, the centre's own
+    // row may not be staged) resp. the phibar_c / vbar_c the earlier passes wrote
+    fvx rres[SUB ? 6 : 1];
+    auto load_rres = [&](int cc) {
+        const size_t ga = mN + a0 + min(max(cc, 0), Nc - 1);
+        const float *vsrc = pass ? vbar_in : vbar_msg;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) rres[SUB ? 3 + x : 0] = *reinterpret_cast<const fvx *>(vsrc + (ga * 3 + x) * F + fcol);
+        if (pass) {   // (uniform)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rres[SUB ? q : 0] = *reinterpret_cast<const fvx *>(phibar + ga * F3 + q * F + fcol);
+        }
+    };
+    if constexpr (SUB) load_rres(bw.cur.x);
     float accb[NF], accc[NF], accx[NF], accy[NF], accz[NF];
 #pragma unroll
     for (int r = 0; r < NF; ++r) { accb[r] = 0.f; accc[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; accz[r] = 0.f; }
@@ -801,14 +883,23 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 #pragma unroll
             for (int r = 0; r < NF; ++r) {
                 a_[r] = fmaf(cv[5][r], tz[r], fmaf(cv[4][r], ty[r], cv[3][r] * tx[r]));
-                x_[r] = fmaf(cv[0][r], tx[r], res[4 * r + 1]);
-                y_[r] = fmaf(cv[0][r], ty[r], res[4 * r + 2]);
-                z_[r] = fmaf(cv[0][r], tz[r], res[4 * r + 3]);
+                x_[r] = fmaf(cv[0][r], tx[r], SUB ? rres[SUB ? 3 : 0][r] : res[4 * r + 1]);
+                y_[r] = fmaf(cv[0][r], ty[r], SUB ? rres[SUB ? 4 : 0][r] : res[4 * r + 2]);
+                z_[r] = fmaf(cv[0][r], tz[r], SUB ? rres[SUB ? 5 : 0][r] : res[4 * r + 3]);
             }
             float *pbp = phibar + ga * F3 + fcol;
+            if (SUB && pass) {   // (uniform) add to what the earlier passes wrote
+                float b_[NF], c_[NF];
+#pragma unroll
+                for (int r = 0; r < NF; ++r) { a_[r] += rres[0][r]; b_[r] = tb[r] + rres[SUB ? 1 : 0][r]; c_[r] = tc[r] + rres[SUB ? 2 : 0][r]; }
+                store_feat<NF>(pbp, a_);
+                store_feat<NF>(pbp + F, b_);
+                store_feat<NF>(pbp + 2 * F, c_);
+            } else {
             store_feat<NF>(pbp, a_);
             store_feat<NF>(pbp + F, tb);
             store_feat<NF>(pbp + 2 * F, tc);
+            }
             store_feat<NF>(vbar_in + (ga * 3 + 0) * F + fcol, x_);
             store_feat<NF>(vbar_in + (ga * 3 + 1) * F + fcol, y_);
             store_feat<NF>(vbar_in + (ga * 3 + 2) * F + fcol, z_);
@@ -857,10 +948,16 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         for (int ph = 0; ph < 2; ++ph) {
             arrival_fence(rq[ph][0], rq[ph][1], dq[ph][0], dq[ph][1], gold[ph]);
             EPH(1)
+            bool in_range = true;
 #ifdef ABL_LDS_BCAST   // ablation: every gather reads row 0 or 1 (no LDS bank conflicts; results wrong)
             const int jn = (int)(rq[ph][0][3] >> 16) & 1;
 #else
-            const int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
+            int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
+            if constexpr (SUB) {   // staged row of the neighbor, or the zero row for a neighbor of another range
+                const unsigned jl = (unsigned)(jn - lo);
+                in_range = jl < (unsigned)ns;
+                jn = in_range ? (int)jl : ns;
+            }
 #endif
             const float gold_cur = FIRST ? 0.f : take(gold[ph]);
             if (bw.t == bw.Lc) {   // wave-uniform: the bundle is complete
@@ -869,6 +966,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 park_centre();                       // centre data of the bundle that starts now
                 __builtin_amdgcn_sched_barrier(0);   // the old values leave their registers before the loads that refill them are issued
                 load_centre(bw.nxt.x);
+                if constexpr (SUB) load_rres(bw.cur.x);
                 EPH(2)
             }
             bool real_slot;
@@ -961,7 +1059,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 const float gsum = __uint_as_float(q[0]) + __uint_as_float(q[1]);
                 // three rows of a real slot write one component each; every other lane writes the spare entry, so the
                 // store is unconditional and the memory-operation count of a step does not depend on the path
-                const bool real = gcomp_id < 3 && real_slot && invd > 0.f;
+                const bool real = gcomp_id < 3 && real_slot && invd > 0.f && (!SUB || in_range);
 #if defined(ABL_LDS_FORCE)
                 gown += real ? gsum : 0.f;
                 atomicAdd(&facc[real ? 3 * jn + gcomp_id : 3 * Nc], (unsigned long long)__float2ll_rn(-gsum * 4294967296.f));
@@ -996,13 +1094,14 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 
 int edge_mfma_init(vssr_handle *h) {
 #define SET_LDS(K) VSSR_HIP(h, hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-    SET_LDS((k_edge_fwd_mfma<4, true, 16>)); SET_LDS((k_edge_fwd_mfma<4, false, 16>)); SET_LDS((k_edge_fwd_mfma<2, false, 16>));
+    SET_LDS((k_edge_fwd_mfma<4, true, 16>)); SET_LDS((k_edge_fwd_mfma<4, false, 16>)); SET_LDS((k_edge_fwd_mfma<2, false, 16>)); SET_LDS((k_edge_fwd_mfma<2, false, 16, true>)); SET_LDS((k_edge_fwd_mfma<4, false, SUB16_WAVES, true>));
     SET_LDS((k_edge_fwd_mfma<4, true, 8>)); SET_LDS((k_edge_fwd_mfma<4, true, 4>)); SET_LDS((k_edge_fwd_mfma<1, false, 16>));
     SET_LDS((k_edge_bwd_mfma<1, true, 4>)); SET_LDS((k_edge_bwd_mfma<1, false, 4>));
     SET_LDS((k_edge_bwd_mfma<1, true, 8>)); SET_LDS((k_edge_bwd_mfma<1, false, 8>));
     SET_LDS((k_edge_bwd_mfma<4, true, 4>)); SET_LDS((k_edge_bwd_mfma<4, false, 4>));
     SET_LDS((k_edge_bwd_mfma<2, true, 4>)); SET_LDS((k_edge_bwd_mfma<2, false, 4>));
     SET_LDS((k_edge_bwd_mfma<4, true, 8>)); SET_LDS((k_edge_bwd_mfma<4, false, 8>));
+    SET_LDS((k_edge_bwd_mfma<4, true, 8, true>)); SET_LDS((k_edge_bwd_mfma<4, false, 8, true>));
     SET_LDS((k_edge_bwd_mfma<2, true, 8>)); SET_LDS((k_edge_bwd_mfma<2, false, 8>));
 #undef SET_LDS
     return VSSR_OK;
@@ -1032,15 +1131,33 @@ static_assert(edge_bclass_slices(EDGE_BCLASS_FS16) == EdgeGeo<4>::NSLICE && edge
 
 // layers >= 1 only (layer 0: painn_l0.hip or the gather kernels, see painn_run).  cls: EDGE_BCLASS_FS16 / _FS8 (reverse) resp.
 // EDGE_CLASS_FS16 / _FS16M / _FS8 (forward); list / n_list: the chains of that class; max_atoms: the largest of them.
+// bundle_sub != nullptr: the multi-pass 16-feature form (per-pass bundle tables of these chains, cut for the reverse chunk size; the
+// partial edge-gradient buffers are then those of the 16-feature class: 8 slices)
 void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
-                          float *phibar, float *vbar_in, float *gbar, long long gbar_stride, int n_groups, int group_off, int rec) {
+                          float *phibar, float *vbar_in, float *gbar, long long gbar_stride, int n_groups, int group_off, int rec,
+                          const int4 *bundle_sub, int sub_chunk) {
     if (n_list <= 0) return;
+    if (cls == EDGE_BCLASS_FS16P) {
+        const int chunk_max = sub_chunk, passes = sub_passes(max_atoms, chunk_max), staged = min(chunk_max, max_atoms) + 1;
+        const int *n_entries = reinterpret_cast<const int *>(bundle_sub + (size_t)SUB_MAX_PASSES * N);
+        for (int pass = 0; pass < passes; ++pass) {
+#define LAUNCH_BWD_SUB(FIRST)                                                                                                    \
+    hipLaunchKernelGGL((k_edge_bwd_mfma<4, FIRST, 8, true>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<4>::NSLICE * M), dim3(64 * 8),   \
+                       (edge_bwd_lds_bytes_t<4, 8>(staged)), st, N, l, MW, G, counters, zero_slot, M, staged, list, n_list, v_in, phi, \
+                       sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups, group_off, rec, bundle_sub + (size_t)pass * N, \
+                       n_entries, pass, chunk_max)
+            if (layer_first) LAUNCH_BWD_SUB(true); else LAUNCH_BWD_SUB(false);
+#undef LAUNCH_BWD_SUB
+        }
+        return;
+    }
 #define LAUNCH_BWD(NF, FIRST, WAVES)                                                                                             \
     hipLaunchKernelGGL((k_edge_bwd_mfma<NF, FIRST, WAVES>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), dim3(64 * WAVES), \
                        (edge_bwd_lds_bytes_t<NF, WAVES>(max_atoms)), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, \
-                       v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups, group_off, rec)
+                       v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups, group_off, rec,                \
+                       (const int4 *)nullptr, (const int *)nullptr, 0, 0)
     // 4-wave workgroups when two of them can share a CU (LDS) AND there are enough workgroups to give every CU two; a small batch (a
     // single chain = 24 workgroups) takes 8 waves so that a lone workgroup still fills its CU's SIMDs: the per-workgroup walk is the
     // latency of the launch (1 chain of 260 atoms: 103 -> 55 us).  The width never changes a result (a centre's sums run in slot order
@@ -1058,14 +1175,17 @@ void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
 #undef LAUNCH_BWD
 }
 
+// bundle_sub: the per-pass bundle tables (nbr.hip k_bundle_sort_sub: [SUB_MAX_PASSES][N] entries, then [SUB_MAX_PASSES - 1][n_cfg] entry
+// counts) of the chains of the 4-feature class (788 .. 1 462 atoms), or nullptr: those chains take the 4-feature kernel.  sub_width:
+// 16 or 8 = slice width of the multi-pass form.
 void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int max_atoms, const ModelW *MW,
                           const GraphView &G, const int *counters, int zero_slot, const float *s_in, const float *v_in,
-                          const float *phi, float *s_msg, float *v_msg) {
+                          const float *phi, float *s_msg, float *v_msg, const int4 *bundle_sub, int sub_width, int sub_chunk) {
     if (n_list <= 0) return;
 #define LAUNCH_FWD(NF, SLDS, WAVES)                                                                                                \
     hipLaunchKernelGGL((k_edge_fwd_mfma<NF, SLDS, WAVES>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<NF>::NSLICE * M), dim3(64 * WAVES), \
                        (edge_fwd_lds_bytes_t<NF, SLDS>(max_atoms)), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, \
-                       s_in, v_in, phi, s_msg, v_msg)
+                       s_in, v_in, phi, s_msg, v_msg, (const int4 *)nullptr, (const int *)nullptr, 0, 0)
     if (cls == EDGE_CLASS_FS16) {   // workgroups per CU that the launch's largest slice allows -> waves per workgroup
         // (a launch with fewer workgroups than CUs -- a single chain -- takes the widest form: its latency is one workgroup's walk)
         const size_t lds = edge_fwd_lds_bytes_t<4, true>(max_atoms);
@@ -1075,7 +1195,22 @@ void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
         else LAUNCH_FWD(4, true, 16);
     } else if (cls == EDGE_CLASS_FS16M) LAUNCH_FWD(4, false, 16);
     else if (cls == EDGE_CLASS_FS8) LAUNCH_FWD(2, false, 16);
-    else LAUNCH_FWD(1, false, 16);
+    else if (bundle_sub) {
+        // wider slices over P neighbor sub-ranges: pass 0 (range 0 staged; writes sums + residual), then the passes that add to it
+        const int chunk_max = sub_chunk, passes = sub_passes(max_atoms, chunk_max);
+        const int staged = min(chunk_max, max_atoms) + 1;   // rows of the LDS tile: the largest range + the zero row
+        const int *n_entries = reinterpret_cast<const int *>(bundle_sub + (size_t)SUB_MAX_PASSES * N);
+        for (int pass = 0; pass < passes; ++pass) {
+            if (sub_width == 16)
+                hipLaunchKernelGGL((k_edge_fwd_mfma<4, false, SUB16_WAVES, true>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<4>::NSLICE * M), dim3(64 * SUB16_WAVES),
+                                   (edge_fwd_lds_bytes_t<4, false>(staged)), st, N, l, MW, G, counters, zero_slot, M, staged, list, n_list,
+                                   s_in, v_in, phi, s_msg, v_msg, bundle_sub + (size_t)pass * N, n_entries, pass, chunk_max);
+            else
+                hipLaunchKernelGGL((k_edge_fwd_mfma<2, false, 16, true>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<2>::NSLICE * M), dim3(64 * 16),
+                                   (edge_fwd_lds_bytes_t<2, false>(staged)), st, N, l, MW, G, counters, zero_slot, M, staged, list, n_list,
+                                   s_in, v_in, phi, s_msg, v_msg, bundle_sub + (size_t)pass * N, n_entries, pass, chunk_max);
+        }
+    } else LAUNCH_FWD(1, false, 16);
 #undef LAUNCH_FWD
 }
 

@@ -320,6 +320,9 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     if (const char *e = getenv("VSSR_EDGE_FS16_MAX")) h->fs16_max_atoms = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_FS8_MAX")) h->fs8_max_atoms = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_FS4_MAX")) h->fs4_max_atoms = atoi(e);
+    if (const char *e = getenv("VSSR_EDGE_BWD_MPASS")) h->bwd_multi_pass = atoi(e);
+    if (const char *e = getenv("VSSR_EDGE_SUB_CHUNK")) { const int c = atoi(e); if (c >= 8) { h->sub_chunk_fwd = c; h->sub_chunk_bwd = c; } }
+    if (const char *e = getenv("VSSR_EDGE_FWD_2PASS")) { const int w = atoi(e); h->fwd_two_pass = (w == 8 || w == 16) ? w : w ? 16 : 0; }
     if (!rc && cfg->offset_per_z) {
         h->has_offset = true;
         h->offset_const = cfg->offset_const;
@@ -468,7 +471,7 @@ void vssr_destroy(vssr_handle *h) {
                       &h->d_wrap, &h->d_Z, &h->d_atom_cfg, &h->d_cfg_start, &h->d_cell, &h->d_invcell, &h->d_nimg,
                       &h->d_pbc, &h->d_deg, &h->d_row_start, &h->d_edge, &h->d_edge_S, &h->d_rev, &h->d_counters, &h->d_tile_sums, &h->d_erec, &h->d_rho, &h->d_dist, &h->d_rho16, &h->d_drho16, &h->d_zslot, &h->d_bundle, &h->d_excl, &h->d_hits, &h->wd16, &h->node16, &h->d_l0A, &h->d_l0At, &h->d_zmap, &h->d_zlist, &h->d_l0T, &h->d_l0Q, &h->d_vel, &h->d_fire, &h->d_fixed, &h->d_relax_steps, &h->d_relax_conv, &h->d_active, &h->d_bfgs_q, &h->d_bfgs_b,
                       &h->d_state, &h->d_gbar, &h->d_energy, &h->d_energy_std, &h->d_energy_models, &h->d_forces,
-                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_stress, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n, &h->d_chain_class, &h->d_class_list, &h->d_upd_save, &h->d_gpart, &h->d_energy64, &h->d_cmp, &h->d_cm};
+                      &h->d_forces_std, &h->d_e_atoms, &h->d_ters_e, &h->d_ters_ea, &h->d_ters_f, &h->d_sat, &h->d_sat_out, &h->d_stress, &h->d_traj_pos, &h->d_traj_f, &h->d_traj_e, &h->d_traj_n, &h->d_chain_class, &h->d_class_list, &h->d_upd_save, &h->d_gpart, &h->d_energy64, &h->d_cmp, &h->d_cm, &h->d_bundle_sub, &h->d_bundle_subb};
     for (DevBuf *b : bufs) b->release();
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -555,6 +558,10 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
             if (bc == EDGE_BCLASS_FS16 && h->fs16_max_atoms >= 0 && n_atoms[b] > h->fs16_max_atoms) bc = EDGE_BCLASS_FS8;
             if (c == EDGE_CLASS_FS8 && h->fs8_max_atoms >= 0 && n_atoms[b] > h->fs8_max_atoms) { c = EDGE_CLASS_FS4; bc = EDGE_BCLASS_FS4; }
             if (c == EDGE_CLASS_FS4 && h->fs4_max_atoms >= 0 && n_atoms[b] > h->fs4_max_atoms) { c = EDGE_CLASS_GATHER; bc = EDGE_BCLASS_GATHER; }
+            // reverse pass of chains beyond the single-pass 16-feature form (by the chain's OWN size, not by a test knob that moved it):
+            // the same kernel in several passes over neighbor sub-ranges
+            if (bc != EDGE_BCLASS_GATHER && ((h->bwd_multi_pass == 1 && edge_bclass_of(n_atoms[b]) != EDGE_BCLASS_FS16) || h->bwd_multi_pass == 2))
+                bc = EDGE_BCLASS_FS16P;
             bcls[b] = (unsigned char)bc;
             h->n_class[c] += 1;
             h->n_bclass[bc] += 1;

@@ -246,7 +246,7 @@ struct vssr_handle {
     // the chain lists of the matrix-pipe classes (concatenated in class order), counts and largest chain per class
     vssr::DevBuf d_chain_class, d_class_list;
     int n_class[5] = {0, 0, 0, 0, 0}, max_class_atoms[5] = {0, 0, 0, 0, 0};   // forward classes (EDGE_CLASS_*)
-    int n_bclass[4] = {0, 0, 0, 0}, max_bclass_atoms[4] = {0, 0, 0, 0};       // reverse classes (EDGE_BCLASS_*); lists follow the forward lists
+    int n_bclass[5] = {0, 0, 0, 0, 0}, max_bclass_atoms[5] = {0, 0, 0, 0, 0};   // reverse classes (EDGE_BCLASS_*); lists follow the forward lists
     int fs16_max_atoms = -1, fs8_max_atoms = -1, fs4_max_atoms = -1;   // test knobs (VSSR_EDGE_FS16_MAX / _FS8_MAX / _FS4_MAX): lower the class limits
     int max_images = 0;          // largest number of periodic images any configuration of the batch scans per pair
 
@@ -278,6 +278,13 @@ struct vssr_handle {
     vssr::DevBuf d_pos, d_wpos, d_wrap, d_Z, d_atom_cfg, d_cfg_start, d_cell, d_invcell, d_nimg, d_pbc;
     vssr::DevBuf d_deg, d_row_start, d_edge, d_edge_S, d_rev, d_counters, d_tile_sums;
     vssr::DevBuf d_erec, d_rho, d_dist, d_rho16, d_drho16, d_zslot, d_bundle, d_excl;
+    vssr::DevBuf d_bundle_sub;   // [2][n_atoms] per-pass bundle tables of the two-pass forward neighbor sum (chains of the 4-feature class)
+    int bwd_multi_pass = 1;      // VSSR_EDGE_BWD_MPASS=0: chains of > 557 atoms take the 8- / 4-feature reverse kernels (round 4) instead of the
+                                 // 16-feature kernel in several passes; 2: every chain of the matrix-pipe classes takes the multi-pass form (tests)
+    int sub_chunk_fwd = 0, sub_chunk_bwd = 0;   // VSSR_EDGE_SUB_CHUNK=n (tests): atoms per neighbor sub-range instead of what LDS holds
+    vssr::DevBuf d_bundle_subb;  // per-pass bundle tables of the reverse multi-pass form (its ranges are larger than the forward's)
+    int fwd_two_pass = 16;       // VSSR_EDGE_FWD_2PASS = 0 | 8 | 16: chains of 788 .. 1 462 atoms take the 4-feature forward kernel, or the 8- / 16-feature
+                                 // kernel in several passes over neighbor sub-ranges
     vssr::DevBuf d_hits;         // neighbor search: per (centre, candidate) 64-bit hit masks of the counting pass
     // layer-0 species factorisation (painn_l0.hip)
     int l0_enabled = 1, l0_nz = 0;
@@ -397,18 +404,27 @@ int edge_mfma_init(vssr_handle *h);
 enum { EDGE_CLASS_FS16 = 0, EDGE_CLASS_FS16M = 1, EDGE_CLASS_FS8 = 2, EDGE_CLASS_FS4 = 3, EDGE_CLASS_GATHER = 4, EDGE_CLASSES = 5,
        EDGE_MFMA_CLASSES = 4 };
 // reverse paths (the reverse tile is smaller: 16-feature slices serve chains up to 557 atoms): what GraphView::chain_class holds
-enum { EDGE_BCLASS_FS16 = 0, EDGE_BCLASS_FS8 = 1, EDGE_BCLASS_FS4 = 2, EDGE_BCLASS_GATHER = 3, EDGE_BCLASSES = 4, EDGE_MFMA_BCLASSES = 3 };
+// (FS16P: 16-feature slices in several passes over neighbor sub-ranges -- chains beyond the 557 atoms of the single-pass form, round 5)
+enum { EDGE_BCLASS_FS16 = 0, EDGE_BCLASS_FS8 = 1, EDGE_BCLASS_FS4 = 2, EDGE_BCLASS_FS16P = 3, EDGE_BCLASS_GATHER = 4, EDGE_BCLASSES = 5,
+       EDGE_MFMA_BCLASSES = 4 };
 // partial edge-gradient buffers (feature slices) a chain of reverse class c writes per layer set and model
-__host__ __device__ constexpr int edge_bclass_slices(int c) { return c == EDGE_BCLASS_FS16 ? 8 : c == EDGE_BCLASS_FS8 ? 16 : c == EDGE_BCLASS_FS4 ? 32 : 1; }
+__host__ __device__ constexpr int edge_bclass_slices(int c) { return (c == EDGE_BCLASS_FS16 || c == EDGE_BCLASS_FS16P) ? 8 : c == EDGE_BCLASS_FS8 ? 16 : c == EDGE_BCLASS_FS4 ? 32 : 1; }
 int edge_bclass_of(int n_atoms);
 int edge_class_of(int n_atoms);       // path of a chain by its own atom count
+// multi-pass forward neighbor sum (chains of the 4-feature class): the chain's atoms in P equal ranges of at most chunk_max atoms
+constexpr int SUB_MAX_PASSES = 4;
+__host__ __device__ constexpr int sub_chunk_max(int width) { return width == 16 ? 400 : 784; }   // staged rows that fit 160 KB (400 / 208 B per row) minus the zero row
+__host__ __device__ constexpr int sub_chunk_max_bwd() { return 550; }   // reverse tile: 272 B per row + the current-centre records (12 KB) in 160 KB, minus the zero row
+__host__ __device__ constexpr int sub_passes(int n_atoms, int chunk_max) { return (n_atoms + chunk_max - 1) / chunk_max; }
+__host__ __device__ constexpr int sub_chunk(int n_atoms, int chunk_max) { return (n_atoms + sub_passes(n_atoms, chunk_max) - 1) / sub_passes(n_atoms, chunk_max); }
 int edge_class_groups(int cls);       // partial edge-gradient buffers a chain of that class writes per model
 void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int layer_first, int max_atoms,
                           const ModelW *MW, const GraphView &G, const int *counters, int zero_slot,
                           const float *v_in, const float *phi, const float *sbar_msg, const float *vbar_msg,
-                          float *phibar, float *vbar_in, float *gbar, long long gbar_stride, int n_groups, int group_off, int rec);
+                          float *phibar, float *vbar_in, float *gbar, long long gbar_stride, int n_groups, int group_off, int rec,
+                          const int4 *bundle_sub, int sub_chunk);
 void launch_edge_fwd_mfma(hipStream_t st, int cls, int N, const int *list, int n_list, int M, int l, int max_atoms, const ModelW *MW,
                           const GraphView &G, const int *counters, int zero_slot, const float *s_in, const float *v_in,
-                          const float *phi, float *s_msg, float *v_msg);
+                          const float *phi, float *s_msg, float *v_msg, const int4 *bundle_sub, int sub_width, int sub_chunk);
 
 }  // namespace vssr

@@ -745,12 +745,21 @@ def test_mixed_chain_sizes_take_their_own_path(golden, oracle_mod, engine):
     assert np.array_equal(rev["energy"][::-1], res["energy"])
 
 
-@pytest.mark.parametrize("knobs", [{"VSSR_EDGE_FS16_MAX": "0"}, {"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0"}],
-                         ids=["8-feature", "4-feature"])
+@pytest.mark.parametrize("knobs", [{"VSSR_EDGE_FS16_MAX": "0"}, {"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0"},
+                                   {"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0", "VSSR_EDGE_FWD_2PASS": "8"},
+                                   {"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0", "VSSR_EDGE_FWD_2PASS": "0"},
+                                   {"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0", "VSSR_EDGE_BWD_MPASS": "2", "VSSR_EDGE_SUB_CHUNK": "100"},
+                                   {"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0", "VSSR_EDGE_BWD_MPASS": "2", "VSSR_EDGE_SUB_CHUNK": "70",
+                                    "VSSR_EDGE_FWD_2PASS": "8"}],
+                         ids=["8-feature", "4-feature-class-forward-16-feature-multi-pass", "4-feature-class-forward-8-feature-multi-pass",
+                              "4-feature-both-ways", "multi-pass-both-ways-ranges-of-100", "multi-pass-both-ways-ranges-of-70-forward-8-feature"])
 def test_narrow_feature_slices_match_the_oracle_on_the_small_structures(golden, oracle_mod, monkeypatch, knobs):
     """The 8- and the 4-feature-slice kernels on inputs every other test sends through the 16-feature ones (VSSR_EDGE_FS16_MAX=0
-    moves every chain to the next class, VSSR_EDGE_FS8_MAX=0 one further: 4-feature slices in both directions -- the class of
-    788 .. 1 462-atom chains): reference KAT structure, per-layer intermediates, a ragged batch; results agree with the
+    moves every chain to the next class, VSSR_EDGE_FS8_MAX=0 one further: the class of 788 .. 1 462-atom chains -- reverse pass on
+    4-feature slices, forward pass as several launches of the 16- (or, VSSR_EDGE_FWD_2PASS=8, 8-) feature kernel over sub-ranges of
+    the chain's neighbors (round 5), or with VSSR_EDGE_FWD_2PASS=0 on 4-feature slices as in round 4; VSSR_EDGE_BWD_MPASS=2 +
+    VSSR_EDGE_SUB_CHUNK=n: forward AND reverse pass in several passes over neighbor ranges of n atoms -- what chains of more than
+    557 atoms take in the reverse pass -- with up to four ranges on these 76 .. 270-atom structures): reference KAT structure, per-layer intermediates, a ragged batch; results agree with the
     default path to fp32 rounding (different summation tree inside a slot quad is NOT involved: same order, other slices)."""
     from surface_sampling_amd import backend, structures
 
@@ -814,7 +823,8 @@ def test_stored_forward_intermediates_give_identical_results(golden, monkeypatch
 
 
 def test_repeatability_of_every_neighbor_sum_path():
-    """Short form of tools/gpu_stress_classes.py (the builder-run soak: 8 configurations incl. the 4-feature slices of round 4,
+    """Short form of tools/gpu_stress_classes.py (the builder-run soak: 9 configurations incl. the 4-feature slices of round 4 and the
+    two-pass forward form of round 5,
     profiles/r03/NOTES_soak.md): every slice width / workgroup width of the edge kernels, three fresh engines each, every
     evaluation bit-identical to the first (MFMA operand hazards show up as isolated run-to-run differences)."""
     import subprocess
@@ -825,7 +835,7 @@ def test_repeatability_of_every_neighbor_sum_path():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_stress_classes.py")], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("mismatches 0") == 8, r.stdout
+    assert r.stdout.count("mismatches 0") == 10, r.stdout
 
 
 def test_large_chain_takes_four_feature_slices_in_both_directions(golden, oracle_mod, engine):

@@ -7,8 +7,11 @@ three fresh engines, energies and forces compared bit for bit with the first eva
   fs8      490-atom chains     -> forward 8-feature slices, reverse 16-feature slices / 8 waves
   fs8all   VSSR_EDGE_FS16_MAX=0 on 260-atom chains -> 8-feature slices in both directions (4-wave reverse)
   big8     735-atom chains     -> 8-feature slices both directions, 8-wave reverse
-  fs4all   VSSR_EDGE_FS16_MAX=0 VSSR_EDGE_FS8_MAX=0 on 260-atom chains -> 4-feature slices in both directions (round 4)
-  big4     975-atom chains     -> forward 4-feature, reverse 8-feature slices (round 4)"""
+  fs4all   VSSR_EDGE_FS16_MAX=0 VSSR_EDGE_FS8_MAX=0 on 260-atom chains -> the class of 788 .. 1 462-atom chains: reverse 4-feature slices,
+           forward two passes of the 8-feature kernel (round 5)
+  fs4k     the same with VSSR_EDGE_FWD_2PASS=0 -> 4-feature slices in both directions (round 4)
+  mpass    260-atom chains, VSSR_EDGE_BWD_MPASS=2 VSSR_EDGE_SUB_CHUNK=100 -> multi-pass 16-feature kernels in both directions (3 ranges)
+  big4     975-atom chains     -> multi-pass 16-feature kernels in both directions by the chains' own size (forward 3, reverse 2 ranges)"""
 import os, sys
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,6 +31,9 @@ cfgs = {
     "fs8all": ({"VSSR_EDGE_FS16_MAX": "0"}, [structures.synth_chain(s60.repeat((2, 2, 1)), c) for c in range(n)]),
     "big8": ({}, [structures.synth_chain(s80.repeat((3, 3, 1)), c, grid=(12, 12)) for c in range(max(n // 2, 8))]),
     "fs4all": ({"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0"}, [structures.synth_chain(s60.repeat((2, 2, 1)), c) for c in range(n)]),
+    "fs4k": ({"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0", "VSSR_EDGE_FWD_2PASS": "0"}, [structures.synth_chain(s60.repeat((2, 2, 1)), c) for c in range(n)]),
+    "mpass": ({"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0", "VSSR_EDGE_BWD_MPASS": "2", "VSSR_EDGE_SUB_CHUNK": "100"},
+              [structures.synth_chain(s60.repeat((2, 2, 1)), c) for c in range(n)]),
     "big4": ({}, [structures.synth_chain(s80.repeat((4, 3, 1)), c, grid=(16, 12)) for c in range(max(n // 3, 8))]),
 }
 only = os.environ.get("ONLY")
