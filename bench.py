@@ -278,6 +278,10 @@ def main():
         import datetime
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node, loopback rendezvous: keep RCCL's bootstrap off interfaces that do not exist in the container (on one of the
+        # boxes seen, communicator set-up took 7 min instead of 10 s; xGMI / shared-memory transports are unaffected)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
         # a group that cannot form (a rank missing, RCCL refusing the device set) ends the run with the rank named and a
         # non-zero exit instead of hanging: finite timeout on the rendezvous and on every collective
         try:

@@ -111,10 +111,13 @@ int vssr_abi_version(void);
 /* Environment variables read once by vssr_create -- test / measurement hooks, none is needed in production:
  *   VSSR_EDGE_IMPL=gather    every chain takes the gather neighbor kernels (reference path of the parity tests)
  *   VSSR_L0_FACTORISE=0      layer 0 runs the generic kernels instead of the species factorisation
- *   VSSR_EDGE_FS16_MAX=n, VSSR_EDGE_FS8_MAX=n, VSSR_EDGE_FS4_MAX=n   largest chain (atoms) served by the 16- / 8- / 4-feature-slice
+ *   VSSR_EDGE_FS16_MAX=n, VSSR_EDGE_FS8_MAX=n, VSSR_EDGE_FS4_MAX=n   largest chain (atoms) served by the single-pass 16- / 8- / 4-feature-slice
  *                            kernels (lower = force a path)
- *   VSSR_EDGE_FWD_2PASS=0    chains of the 4-feature class (788 .. 1 462 atoms) take the 4-feature forward kernel instead of the 8-feature
- *                            kernel run twice over two neighbor sub-ranges (the default since round 5)
+ *   VSSR_EDGE_FWD_2PASS=0|8|16, VSSR_EDGE_FWD_MPASS_FS8=0, VSSR_EDGE_BWD_MPASS=0|1|2, VSSR_EDGE_SUB_CHUNK=n
+ *                            large chains (forward: > 405 atoms, reverse: > 557): 16-feature slices in several passes over sub-ranges of
+ *                            the chain's neighbors (the default since round 5) instead of the narrower single-pass kernels of round 4
+ *                            (FWD_2PASS=0 / FWD_MPASS_FS8=0 / BWD_MPASS=0); 8: the forward multi-pass form on 8-feature slices;
+ *                            BWD_MPASS=2 + SUB_CHUNK=n (tests): every chain takes the multi-pass forms, ranges of n atoms
  *   VSSR_UPD_SAVE=1          update blocks store their forward intermediates for the reverse pass (measured: no gain)
  *   VSSR_GBAR_MODE=0|1|2     partial edge-gradient buffers: 0 shared float4 set with read-modify-write (round 2), 1 one float4 set per
  *                            layer, 2 (default) one compact 12-byte set per layer

@@ -321,6 +321,7 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     if (const char *e = getenv("VSSR_EDGE_FS8_MAX")) h->fs8_max_atoms = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_FS4_MAX")) h->fs4_max_atoms = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_BWD_MPASS")) h->bwd_multi_pass = atoi(e);
+    if (const char *e = getenv("VSSR_EDGE_FWD_MPASS_FS8")) h->fwd_mpass_fs8 = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_SUB_CHUNK")) { const int c = atoi(e); if (c >= 8) { h->sub_chunk_fwd = c; h->sub_chunk_bwd = c; } }
     if (const char *e = getenv("VSSR_EDGE_FWD_2PASS")) { const int w = atoi(e); h->fwd_two_pass = (w == 8 || w == 16) ? w : w ? 16 : 0; }
     if (!rc && cfg->offset_per_z) {
@@ -558,6 +559,8 @@ int vssr_batch_upload(vssr_handle *h, int32_t n_cfg, const int32_t *n_atoms, con
             if (bc == EDGE_BCLASS_FS16 && h->fs16_max_atoms >= 0 && n_atoms[b] > h->fs16_max_atoms) bc = EDGE_BCLASS_FS8;
             if (c == EDGE_CLASS_FS8 && h->fs8_max_atoms >= 0 && n_atoms[b] > h->fs8_max_atoms) { c = EDGE_CLASS_FS4; bc = EDGE_BCLASS_FS4; }
             if (c == EDGE_CLASS_FS4 && h->fs4_max_atoms >= 0 && n_atoms[b] > h->fs4_max_atoms) { c = EDGE_CLASS_GATHER; bc = EDGE_BCLASS_GATHER; }
+            // the 8-feature forward class (406 .. 787 atoms by the chain's own size) also takes the 16-feature multi-pass form
+            if (h->fwd_mpass_fs8 && h->fwd_two_pass == 16 && c == EDGE_CLASS_FS8 && edge_class_of(n_atoms[b]) == EDGE_CLASS_FS8) c = EDGE_CLASS_FS4;
             // reverse pass of chains beyond the single-pass 16-feature form (by the chain's OWN size, not by a test knob that moved it):
             // the same kernel in several passes over neighbor sub-ranges
             if (bc != EDGE_BCLASS_GATHER && ((h->bwd_multi_pass == 1 && edge_bclass_of(n_atoms[b]) != EDGE_BCLASS_FS16) || h->bwd_multi_pass == 2))

@@ -281,6 +281,8 @@ struct vssr_handle {
     vssr::DevBuf d_bundle_sub;   // [2][n_atoms] per-pass bundle tables of the two-pass forward neighbor sum (chains of the 4-feature class)
     int bwd_multi_pass = 1;      // VSSR_EDGE_BWD_MPASS=0: chains of > 557 atoms take the 8- / 4-feature reverse kernels (round 4) instead of the
                                  // 16-feature kernel in several passes; 2: every chain of the matrix-pipe classes takes the multi-pass form (tests)
+    int fwd_mpass_fs8 = 1;       // VSSR_EDGE_FWD_MPASS_FS8=0: chains of 406 .. 787 atoms take the single-pass 8-feature forward kernel (round 4) instead of
+                                 // the 16-feature multi-pass form (-9 % on that kernel, profiles/r05/NOTES_large_chains.md)
     int sub_chunk_fwd = 0, sub_chunk_bwd = 0;   // VSSR_EDGE_SUB_CHUNK=n (tests): atoms per neighbor sub-range instead of what LDS holds
     vssr::DevBuf d_bundle_subb;  // per-pass bundle tables of the reverse multi-pass form (its ranges are larger than the forward's)
     int fwd_two_pass = 16;       // VSSR_EDGE_FWD_2PASS = 0 | 8 | 16: chains of 788 .. 1 462 atoms take the 4-feature forward kernel, or the 8- / 16-feature

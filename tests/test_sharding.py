@@ -292,6 +292,8 @@ def test_device_results_reach_torch_and_rccl_without_a_host_copy():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # (loopback rendezvous, like bench.py: no interface probing in the container)
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         # the step path itself through RCCL: the staging tensor goes to all_gather_into_tensor as it is (even blocks), the
