@@ -335,7 +335,7 @@ struct BundleWalk {
     __device__ __forceinline__ int4 load(int jj, bool &ok) const {
         const int idx = 4 * bundle_of(jj) + st;
         ok = jj < nj && idx < Nc;
-        return tab[min(idx, Nc - 1)];
+        return tab[max(min(idx, Nc - 1), 0)];
     }
     __device__ __forceinline__ static int4 select(const int4 &v, bool ok) { return ok ? v : make_int4(-1, 0, 0, 0); }
     __device__ __forceinline__ static int steps(const int4 &q) { return max(__builtin_amdgcn_readfirstlane(q.z) >> 2, 2); }
@@ -404,6 +404,11 @@ __device__ __forceinline__ int chain_of_workgroup(const GraphView &G, const int 
 // v_msg): same code, other base pointers.  Why wider slices in several passes beat narrower slices in one: every (slice, model)
 // workgroup streams the chain's per-slot tables once, so the table stream per atom grows with the number of slices -- the bound of
 // the 8- and 4-feature kernels on large chains (profiles/r05/NOTES_large_chains.md).
+// Output pointers: __restrict__ (the single-pass forms never read what they write), plain in the multi-pass forms, whose later passes
+// add to the output of the earlier ones.  (Dropping the qualifier everywhere cost the single-pass reverse kernel 5 %: other schedule.)
+template <bool ALIASED> struct EdgeOut { typedef float *__restrict__ ptr; };
+template <> struct EdgeOut<true> { typedef float *ptr; };
+
 // (registers: 4 waves per SIMD = 128 everywhere, except the 16-feature multi-pass form, whose extra residual registers need the
 //  256 of an 8-wave workgroup)
 template <int NF, bool SLDS, int WAVES, bool SUB = false>
@@ -411,8 +416,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const int *__restrict__ counters,
                 int zero_slot, int n_models, int max_atoms, const int *__restrict__ list, int n_list,
                 const float *__restrict__ s_in, const float *__restrict__ v_in, const float *__restrict__ phi,
-                float *s_msg, float *v_msg, const int4 *__restrict__ bundle_tab, const int *__restrict__ n_entries_tab, int pass,
-                int chunk_max) {
+                typename EdgeOut<SUB>::ptr s_msg, typename EdgeOut<SUB>::ptr v_msg, const int4 *__restrict__ bundle_tab,
+                const int *__restrict__ n_entries_tab, int pass, int chunk_max) {
     using LY = EdgeGeo<NF>;
     constexpr int FS = LY::FS, NSLICE = LY::NSLICE, NT = LY::NT, EDGE_THREADS = 64 * WAVES;
     static_assert(!SUB || !SLDS, "the sub-range form takes its residuals from memory");
@@ -494,8 +499,11 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     BundleWalk<EDGE_THREADS / 64> bw;
     // (SUB, pass >= 1: only the centres with neighbors in that range -- the head of the length-sorted table; the others keep what
     //  the earlier passes wrote)
-    const int n_entries = (SUB && pass) ? n_entries_tab[(size_t)(pass - 1) * G.n_cfg + b] : Nc;
-    if (n_entries <= 0) return;   // (no barrier below)
+    int n_entries = Nc;   // (an extra early exit here changes the compiler's memory-wait merge at the loop header: measured +5 % on the
+                          //  single-pass reverse kernel; a pass without entries leaves through `bw.nj == 0` like an empty chain)
+    if constexpr (SUB) {
+        if (pass) n_entries = n_entries_tab[(size_t)(pass - 1) * G.n_cfg + b];
+    }
     bw.init((SUB ? bundle_tab : G.bundle) + a0, n_entries, __builtin_amdgcn_readfirstlane(wave), p >> 2);
     if (bw.nj == 0) return;   // (no barrier below)
 #ifdef ABL_STAGE_ONLY   // ablation: staging + prologue only (results wrong)
@@ -717,7 +725,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 const int *__restrict__ counters, int zero_slot, int n_models, int max_atoms,
                 const int *__restrict__ list, int n_list,
                 const float *__restrict__ v_in, const float *__restrict__ phi, const float *__restrict__ sbar_msg,
-                const float *__restrict__ vbar_msg, float *phibar, float *vbar_in,
+                const float *__restrict__ vbar_msg, typename EdgeOut<SUB>::ptr phibar, typename EdgeOut<SUB>::ptr vbar_in,
                 float *__restrict__ gbar, long long gbar_stride, int n_groups, int group_off, int rec,
                 const int4 *__restrict__ bundle_tab, const int *__restrict__ n_entries_tab, int pass, int chunk_max) {
     using LY = EdgeGeo<NF>;
@@ -811,8 +819,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     __syncthreads();
 
     BundleWalk<BWD_THREADS / 64> bw;   // work list: bundles of 4 centres, see the forward kernel
-    const int n_entries = (SUB && pass) ? n_entries_tab[(size_t)(pass - 1) * G.n_cfg + b] : Nc;
-    if (n_entries <= 0) return;   // (no barrier below)
+    int n_entries = Nc;   // (an extra early exit here changes the compiler's memory-wait merge at the loop header: measured +5 % on the
+                          //  single-pass reverse kernel; a pass without entries leaves through `bw.nj == 0` like an empty chain)
+    if constexpr (SUB) {
+        if (pass) n_entries = n_entries_tab[(size_t)(pass - 1) * G.n_cfg + b];
+    }
     bw.init((SUB ? bundle_tab : G.bundle) + a0, n_entries, __builtin_amdgcn_readfirstlane(wave), p >> 2);
     if (bw.nj == 0) return;   // (no barrier below)
 #ifdef ABL_STAGE_ONLY   // ablation: staging + prologue only (results wrong)
