@@ -134,6 +134,44 @@ def test_relax_batch_records_the_trajectory_like_the_reference_observer(golden, 
 
 
 @pytest.mark.gpu
+def test_multi_pass_neighbor_sums_inside_a_relaxation_with_regrow_and_drop_out(golden, monkeypatch):
+    """The multi-pass forms of the neighbor-sum kernels (what chains of more than 405 / 557 atoms take; here forced onto 260-atom
+    chains with ranges of 100 atoms) inside the lock-step BFGS driver: a neighbor capacity that is too small at first (buffers and
+    per-pass bundle tables are rebuilt), a chain that converges early and drops out (activity mask), FixAtoms -- same relaxed
+    geometries and energies as the default single-pass kernels to fp32 rounding, identical when repeated."""
+    from surface_sampling_amd import backend, structures
+
+    table, const = golden.offset_table()
+    big = golden.structure("SrTiO3_2x2_pristine").repeat((2, 2, 1))
+    chains = [structures.synth_chain(big, 5), structures.synth_chain(big, 9), structures.synth_chain(big, 13)]
+    packs = [(c.numbers, c.positions, c.cell, c.pbc) for c in chains]
+    mask = np.concatenate([(c.positions[:, 2] < c.positions[:240, 2].max() - 4.0).astype(np.uint8) for c in chains])
+    mask[len(chains[0]):len(chains[0]) + len(chains[1])] = 1          # chain 1: everything held -> converged from the start, drops out
+    runs = []
+    for knobs in ({}, {"VSSR_EDGE_FS16_MAX": "0", "VSSR_EDGE_FS8_MAX": "0", "VSSR_EDGE_BWD_MPASS": "2", "VSSR_EDGE_SUB_CHUNK": "100"}):
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        eng = backend.PainnEngine(golden.blobs, device=0, offset_per_z=table, offset_const=const)
+        for k in knobs:
+            monkeypatch.delenv(k)
+        out = []
+        for rep in range(2):
+            eng.debug_capacity(slots_per_atom=16, tight=1)           # too small: the relaxation has to regrow
+            eng.upload(packs)
+            info = eng.relax_bfgs(fixed=mask, max_steps=6, fmax=0.01)
+            res = eng.download()
+            out.append((info["positions"].copy(), res["energy_f64"].copy(), res["forces"].copy(), info["n_steps"].copy()))
+            assert eng.debug_capacity() >= 1
+        assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
+        runs.append(out[0])
+        eng.close()
+    (p0, e0, f0, n0), (p1, e1, f1, n1) = runs
+    assert np.array_equal(n0, n1) and n0[1] == 0 and n0[0] == 6 and n0[2] == 6
+    assert np.abs(p0 - p1).max() < 2e-4 and np.abs(e0 - e1).max() < 2e-4 and np.abs(f0 - f1).max() < 2e-3
+    assert np.array_equal(p0[mask.astype(bool)], np.concatenate([c.positions for c in chains])[mask.astype(bool)])
+
+
+@pytest.mark.gpu
 def test_stats_after_a_relaxation_need_a_full_run(golden):
     """A lock-step relaxation in which a chain converged EARLY leaves a resident graph that covers only the chains of its last
     iteration: the introspection calls say so instead of returning partial data (advisor finding, round 2); one full run makes
