@@ -206,6 +206,30 @@ def cpu_baseline(blobs, chains, table, const, budget_s=12.0):
     n_c, dt_c = timed(lambda s: oracle.ensemble(blobs, s.numbers, s.positions, s.cell, s.pbc, 32, table, const))
     out = {"value": n_c / dt_c, "unit": "evaluations/s", "cores": threads, "kind": "port",
            "sample": f"{n_c} chains of the same workload, one at a time (C oracle, fp32, OpenMP, {dt_c:.1f} s)"}
+    # the same port the way a CPU would run MANY chains: one chain per core (threads inside a chain scale poorly: 3.0 vs 4.8
+    # evaluations/s on the 8 cores of the build container)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+
+        oracle.set_threads(1)
+        one = lambda s: oracle.ensemble(blobs, s.numbers, s.positions, s.cell, s.pbc, 32, table, const)
+        one(chains[0])
+        n_p, t0 = 0, time.perf_counter()
+        with ThreadPoolExecutor(cores) as pool:      # (ctypes releases the GIL inside the C call)
+            while n_p < len(chains) and (time.perf_counter() - t0 < budget_s or n_p == 0):
+                part = chains[n_p:n_p + cores]
+                list(pool.map(one, part))
+                n_p += len(part)
+        dt_p = time.perf_counter() - t0
+        par = {"value": n_p / dt_p, "unit": "evaluations/s", "cores": cores, "kind": "port",
+               "sample": f"{n_p} chains of the same workload, {cores} at a time on one thread each (C oracle, fp32, {dt_p:.1f} s)"}
+        if par["value"] > out["value"]:
+            out, par = par, out
+        out["chain_parallel_or_threaded"] = par
+    except Exception as exc:
+        out["chain_parallel_or_threaded"] = {"error": str(exc)}
+    finally:
+        oracle.set_threads(cores)
     try:
         import torch
 
@@ -217,7 +241,10 @@ def cpu_baseline(blobs, chains, table, const, budget_s=12.0):
         alt = {"value": n_t / dt_t, "unit": "evaluations/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"{n_t} chains of the same workload, one at a time (torch-CPU fp32 forward + autograd, {dt_t:.1f} s)"}
         if alt["value"] > out["value"]:
+            extra = out.pop("chain_parallel_or_threaded", None)
             out, alt = alt, out
+            if extra is not None:
+                out["chain_parallel_or_threaded"] = extra
         out["other_port"] = alt
     except Exception as exc:   # torch CPU threading problems must not cost the bench line
         out["other_port"] = {"error": str(exc)}
