@@ -291,6 +291,10 @@ def main():
     result_path = os.environ.get("VSSR_RESULT_PATH", "auto")
     init_timeout_s = float(os.environ.get("VSSR_DIST_TIMEOUT_S", "600"))
 
+    # the host driver of this pool only supports dmabuf IPC (already exported by the image; kept here so that a bare environment
+    # cannot make RCCL's P2P set-up fail with `hipIpcGetMemHandle: invalid argument`) -- before anything initialises HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     import torch
 
     from surface_sampling_amd import backend
