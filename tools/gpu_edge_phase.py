@@ -23,6 +23,15 @@ lib.vssr_debug_edge_phases(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
 names = ["(clock start)", "wait for the step's table entries", "bundle completion (1 step in ~11)", "gather issue + LDS wait",
          "matrix instructions issued", "matrix results + first feature", "prefetch issue + remaining features", "reduce-scatter + store"]
+if os.environ.get("VSSR_EDGE_BWD_32", "0") != "0":   # the 32x32x16 reverse kernel marks other phases
+    names32 = ["", "wait for the step's table entries", "bundle completion", "group 0: gathers + matrix instructions issued",
+               "group 0: matrix results + vector work", "group 1: gathers + matrix instructions issued",
+               "group 1: matrix results + refill issue + vector work", "reduce-scatter + store"]
+    tot = v[9:16].sum()
+    print("k_edge_bwd_mfma32")
+    for k in range(1, 8):
+        print(f"   {names32[k]:52s} {100 * v[8 + k] / tot:6.1f} %")
+    sys.exit(0)
 for lo, kern in ((0, "k_edge_fwd_mfma"), (8, "k_edge_bwd_mfma")):
     tot = v[lo + 1:lo + 8].sum()
     print(kern)
