@@ -19,6 +19,12 @@
 // owns the fixed slot range [cfg_start[b], cfg_start[b + 1]) x cap_per_atom instead of a place in a batch-wide scan.
 #include "cg_dev.h"
 #include "nbr_dev.h"
+#ifdef CM_PHASE_TIMING   // sub-phases of the site tile: slots 10 .. 12 of g_cm_phase
+#include <hip/hip_runtime.h>
+extern __device__ unsigned long long g_cm_phase[16];
+#define TS_MARK_INIT unsigned long long ts_t = wall_clock64();
+#define TS_MARK(k) { __syncthreads(); const unsigned long long ts_n = wall_clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) g_cm_phase[10 + (k)] += ts_n - ts_t; ts_t = wall_clock64(); }
+#endif
 #include "tersoff_dev.h"
 
 #include <vector>

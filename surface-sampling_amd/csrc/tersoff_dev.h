@@ -188,6 +188,11 @@ __device__ inline void tersoff_site_atom(int i, int nt, const TersP *__restrict_
 }
 
 
+#ifndef TS_MARK   // phase clocks of the chain-resident minimiser's debug build (chain_min.hip, -DCM_PHASE_TIMING)
+#define TS_MARK_INIT
+#define TS_MARK(k)
+#endif
+
 constexpr int TS_MAXD = 16, TS_CENTRES = 64, TS_LANES = 4, TS_MAXP = 64;   // slots per row in LDS; centres / workgroup; lanes / centre; 4^3 entries
 
 // A parameter entry as k_tersoff_site4 keeps it in LDS: what every three-body term would otherwise recompute from the file's
@@ -279,6 +284,7 @@ __device__ __forceinline__ void tersoff_site4_tile(TersShared &sh, int i, bool m
     auto &s_ux = sh.ux; auto &s_uy = sh.uy; auto &s_uz = sh.uz; auto &s_r = sh.r; auto &s_pref = sh.pref; auto &s_tp = sh.tp; auto &s_P = sh.P;
     const int tid = threadIdx.x, cb = tid >> 2, q = tid & 3;
     int e0 = 0, deg = 0, ti = 0;
+    TS_MARK_INIT
     if (mine) {
         e0 = row_start[i];
         deg = row_start[i + 1] - e0;
@@ -305,6 +311,7 @@ __device__ __forceinline__ void tersoff_site4_tile(TersShared &sh, int i, bool m
         }
     }
     __syncthreads();
+    TS_MARK(0)
     // ---- pass 1: the lane's slots as j ---------------------------------------------------------------------------
     // zeta_n over all k, b_ij, the pair energy -- and, in the same walk over k, the sums that make up the slot's OWN three-body
     // gradient d zeta_n / d r_n: it is linear in pref_n = 1/2 fc fA db/dzeta, which is only known once zeta_n is complete, so the
@@ -360,6 +367,7 @@ __device__ __forceinline__ void tersoff_site4_tile(TersShared &sh, int i, bool m
         s_pref[n][cb] = pref;
     }
     __syncthreads();
+    TS_MARK(1)
     // ---- pass 2: the lane's slots as k of every other j (d zeta_m / d r_n, weighted with pref_m) --------------------------------
 #pragma unroll 1
     for (int n = q; n < deg; n += TS_LANES) {
@@ -391,6 +399,7 @@ __device__ __forceinline__ void tersoff_site4_tile(TersShared &sh, int i, bool m
             gslot[3 * (e0 + n) + 2] += gz + su * uz;
         }
     }
+    TS_MARK(2)
 }
 
 // row_start: indexed [c], [c + 1]

@@ -25,4 +25,6 @@ for form in ("1",):
     print(f"chain-resident minimiser, {n} chains, chain 0: {ev} evaluations, {tot / 100 / ev:.1f} us per evaluation")
     for k, nm in enumerate(names):
         print(f"   {nm:18s} {buf[k] / 100 / ev:7.2f} us  {100 * buf[k] / tot:5.1f} %")
+    for k, nm in enumerate(["site4: neighborhood -> LDS", "site4: pass 1 (zeta, b_ij, pair terms)", "site4: pass 2 (cross three-body gradients)"]):
+        print(f"      {nm:44s} {buf[10 + k] / 100 / ev:7.2f} us")
 eng.close()
