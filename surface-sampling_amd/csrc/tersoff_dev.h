@@ -223,8 +223,29 @@ __device__ __forceinline__ void t_fc_both(double r, const TersL &p, double &fc, 
     dfc = -0.5 * p.piD2 * cs;
 }
 struct TersTri { double g, dg, ex, dex, fc, dfc; };
+// The three-body fields of an entry as a register copy.  The (j, k) loops of the site tile read everything an iteration may need
+// from LDS in ONE batch in front of its branches (tri_fields + pin): with the reads left behind the early-outs the compiler emitted
+// five to six dependent LDS round trips per iteration (type -> pref -> vectors -> Rmax -> shape fields -> cutoff fields, ~130 cycles
+// each at one or two waves per SIMD), more than the arithmetic of the term (profiles/r05/NOTES_tersoff.md section 5).
+struct TersL3 { double Rmax, Rmin, R, piD2, g0, g1, d2, h, lam3; int m3; };
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(int &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ TersL3 tri_fields(const TersL &e) {
+    TersL3 p = {e.Rmax, e.Rmin, e.R, e.piD2, e.g0, e.g1, e.d2, e.h, e.lam3, e.m3};
+    pin(p.Rmax); pin(p.Rmin); pin(p.R); pin(p.piD2); pin(p.g0); pin(p.g1); pin(p.d2); pin(p.h); pin(p.lam3); pin(p.m3);
+    return p;
+}
+__device__ __forceinline__ void t_fc_both(double r, const TersL3 &p, double &fc, double &dfc) {
+    if (r < p.Rmin) { fc = 1.0; dfc = 0.0; return; }
+    if (r > p.Rmax) { fc = 0.0; dfc = 0.0; return; }
+    double sn, cs;
+    t_sincos_half_pi(p.piD2 * (r - p.R), sn, cs);
+    fc = 0.5 * (1.0 - sn);
+    dfc = -0.5 * p.piD2 * cs;
+}
 // three-body factors of (i, j, k) with entry p: false when k is outside the entry's cutoff
-__device__ __forceinline__ bool t_tri(const TersL &p, double rj, double rk, double cs, TersTri &o) {
+template <class ENTRY>
+__device__ __forceinline__ bool t_tri(const ENTRY &p, double rj, double rk, double cs, TersTri &o) {
     if (rk > p.Rmax) return false;
     const double hc = p.h - cs, inv = 1.0 / (p.d2 + hc * hc);
     o.g = p.g0 - p.g1 * inv;
@@ -333,13 +354,16 @@ __device__ __forceinline__ void tersoff_site4_tile(TersShared &sh, int i, bool m
                 double zeta = 0.0, sax = 0.0, say = 0.0, saz = 0.0, sb = 0.0;
 #pragma unroll 1
                 for (int m = 0; m < deg; ++m) {
-                    const int tk = s_tp[m][cb];
+                    // every LDS operand of the (n, m) term in one batch, in front of the branches (a padding slot reads entry .. 0)
+                    int tk = s_tp[m][cb];
+                    double rk = s_r[m][cb];
+                    double vx = s_ux[m][cb], vy = s_uy[m][cb], vz = s_uz[m][cb];
+                    const TersL3 pk = tri_fields(s_P[(ti * nt + tj) * nt + max(tk, 0)]);
+                    pin(tk); pin(rk); pin(vx); pin(vy); pin(vz);
                     if (m == n || tk < 0) continue;
-                    const double rk = s_r[m][cb];
-                    const double vx = s_ux[m][cb], vy = s_uy[m][cb], vz = s_uz[m][cb];
                     const double cs = ux * vx + uy * vy + uz * vz;
                     TersTri t;
-                    if (!t_tri(s_P[(ti * nt + tj) * nt + tk], r, rk, cs, t)) continue;
+                    if (!t_tri(pk, r, rk, cs, t)) continue;
                     zeta += t.fc * t.g * t.ex;
                     const double a = t.fc * t.dg * t.ex;
                     sax += a * (vx - cs * ux);
@@ -378,14 +402,16 @@ __device__ __forceinline__ void tersoff_site4_tile(TersShared &sh, int i, bool m
         bool any = false;
 #pragma unroll 1
         for (int m = 0; m < deg; ++m) {
-            const int tm = s_tp[m][cb];
+            int tm = s_tp[m][cb];
+            double pf = s_pref[m][cb];
+            double vx = s_ux[m][cb], vy = s_uy[m][cb], vz = s_uz[m][cb], rm = s_r[m][cb];
+            const TersL3 pm = tri_fields(s_P[(ti * nt + max(tm, 0)) * nt + tn]);
+            pin(tm); pin(pf); pin(vx); pin(vy); pin(vz); pin(rm);
             if (m == n || tm < 0) continue;
-            const double pf = s_pref[m][cb];
             if (pf == 0.0) continue;
-            const double vx = s_ux[m][cb], vy = s_uy[m][cb], vz = s_uz[m][cb], rm = s_r[m][cb];
             const double cs = ux * vx + uy * vy + uz * vz;
             TersTri t;
-            if (!t_tri(s_P[(ti * nt + tm) * nt + tn], rm, r, cs, t)) continue;   // m as j, n as k
+            if (!t_tri(pm, rm, r, cs, t)) continue;   // m as j, n as k
             const double a = pf * t.fc * t.dg * t.ex * inv_r;
             gx += a * (vx - cs * ux);
             gy += a * (vy - cs * uy);
