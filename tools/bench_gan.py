@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--relax-steps", type=int, default=100)
     ap.add_argument("--sites", type=int, default=6, help="n x n adsorption-site grid above the slab")
+    ap.add_argument("--groups", type=int, default=1, help="chains in G mc.ConcurrentChains groups (own calculators / engines / host threads): "
+                                                          "the slowest chain of one group's relaxation no longer idles the GPU")
     args = ap.parse_args()
     from surface_sampling_amd import backend, mc, structures
     from surface_sampling_amd.calculators import TersoffSurfCalc
@@ -33,25 +35,51 @@ def main():
     coords = np.array([(i + 0.5) / n * base.cell[0] + (j + 0.5) / n * base.cell[1] for i in range(n) for j in range(n)], float)
     coords[:, 2] = ztop + 1.8
     fixed = np.flatnonzero(base.positions[:, 2] < ztop - 3.0)
+    def composed(ens, B):                                           # the tutorial's composition: 12 Ga adatoms per chain, evenly spread
+        state = ens.state
+        for site in ens.even_adsorption_sites(12):
+            state = ens.apply(state, np.full(B, int(site), np.int64), np.zeros(B, np.int64))
+        ens.state = state
+        assert (ens.num_adsorbates() == 12).all()
+
+    if args.groups > 1:
+        for B in [int(x) for x in args.chains.split(",")]:
+            calcs = [TersoffSurfCalc(params, ["Ga", "N"], device="cuda:0") for _ in range(args.groups)]
+            for c in calcs:
+                c.set(relax_steps=args.relax_steps)
+            cc = mc.ConcurrentChains.build(base, coords, ("Ga",), B, calcs, seed=4, relax=True, relax_steps=args.relax_steps,
+                                           fixed_indices=fixed, temperature=0.3, optimizer="LAMMPS")
+            for grp in cc.groups:
+                composed(grp, len(grp.chain_ids))
+            cc.initialize()
+            cc.steps(1, canonical=True)                             # warm-up
+            n0 = cc.n_evaluations
+            t0 = time.perf_counter()
+            acc = cc.steps(args.steps, canonical=True)
+            dt = time.perf_counter() - t0
+            print(json.dumps({"metric": "batched canonical MC proposals/s, GaN(0001) 3x3 Tersoff, every proposal CG-relaxed (<= %d iterations)" % args.relax_steps,
+                              "chains": B, "groups": len(cc.groups), "mc_steps": args.steps, "s_per_lockstep": dt / args.steps,
+                              "proposals_per_s": B * args.steps / dt, "acceptance": float(acc.mean() / args.steps),
+                              "mean_energy_eV": float(np.mean(cc.energy)), "relaxations": int(cc.n_evaluations - n0)}), flush=True)
+            del cc, calcs
+        return
     for B in [int(x) for x in args.chains.split(",")]:
         calc = TersoffSurfCalc(params, ["Ga", "N"], device="cuda:0")
         calc.set(relax_steps=args.relax_steps)
         ens = mc.ChainEnsemble(base, coords, ("Ga",), B, calc, seed=4, relax=True, relax_steps=args.relax_steps,
                                fixed_indices=fixed, temperature=0.3, optimizer="LAMMPS")
-        state = ens.state                                           # the tutorial's composition: 12 Ga adatoms per chain, evenly spread
-        for site in ens.even_adsorption_sites(12):
-            state = ens.apply(state, np.full(B, int(site), np.int64), np.zeros(B, np.int64))
-        ens.state = state
-        assert (ens.num_adsorbates() == 12).all()
+        composed(ens, B)
         ens.initialize()
         ens.step_canonical()                                        # warm-up (engine capacities settle)
         # lock-step waste of the CG relaxations: chain-evaluations the chains NEEDED (their own n_eval + the final static one)
         # against what the lock-step driver DISPATCHED (vssr_batch_relax_counts), and why the chains stopped
-        work = {"needed": 0, "dispatched": 0, "lockstep": 0, "relaxations": 0, "stop": {}, "evals": []}
+        work = {"needed": 0, "dispatched": 0, "lockstep": 0, "relaxations": 0, "stop": {}, "evals": [], "calc_s": 0.0}
         inner = calc.evaluate_packed
 
         def counted(*a, **k):
+            tc = time.perf_counter()
             out = inner(*a, **k)
+            work["calc_s"] += time.perf_counter() - tc
             if "evaluations" in out:
                 ev = np.asarray(out["evaluations"], dtype=np.int64)
                 work["needed"] += int(ev.sum()) + len(ev)
@@ -81,6 +109,7 @@ def main():
                                   "evaluations_per_chain": {"min": int(ev.min()), "median": float(np.median(ev)), "mean": float(ev.mean()),
                                                             "p90": float(np.percentile(ev, 90)), "max": int(ev.max())},
                                   "stop_reasons": work["stop"]}
+        line["calculator_share"] = work["calc_s"] / dt   # time inside calc.evaluate_packed (upload, relaxation, download) / wall time
         line["speedup_vs_reference_per_proposal"] = line["proposals_per_s"] * line["reference"]["s_per_proposal"]
         print(json.dumps(line), flush=True)
         del ens, calc
