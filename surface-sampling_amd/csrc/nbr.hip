@@ -146,13 +146,11 @@ k_rev(int n, const int *__restrict__ row_start, const float4 *__restrict__ edge,
 // stored in the order the MFMA operand wants them: table[slot][kq][ks] = rho_{kq + 4 ks}  (kq = lane >> 4, ks < 5);
 // entry ks = 5 of every quarter holds the envelope fc (resp. its derivative).
 // One thread per (slot, kq).  sin/cos of the multiples come from one sincos + a rotation recurrence.
-// Operand-ready record of one (slot, quarter) for v_mfma_f32_16x16x32_f16.  The quarter contributes 8 of the 32 K
-// entries of the filter contraction: its 5 radial values (k = kq + 4 kk), the envelope fc (partner of the bias column,
-// which the weight side carries in quarter 0 only) and two zeros.  Every value is split into two fp16 pieces
-// x = h + l (h = fp16(x), l = fp16(x - h); 22 mantissa bits, fp16 subnormals are honoured by the matrix core --
-// tools/micro/mfma_f16_denorm.hip); each piece of the 8 entries is one complete 16-byte MFMA operand, stored H | L
-// (32 bytes).  The edge kernels issue Wh.L + Wl.H + Wh.H: the dropped product is 2^-22 relative, and measured against
-// fp64 the 3-product result is as accurate as a plain fp32 dot product (max 2.0e-7 vs 1.9e-7 on the real weights).
+// Operand-ready record of one (slot, quarter) for v_mfma_f32_16x16x32_f16 (write_f16_record).  Every value is split into
+// two fp16 pieces x = h + l (h = fp16(x), l = fp16(x - h); 22 mantissa bits, fp16 subnormals are honoured by the matrix
+// core -- tools/micro/mfma_f16_denorm.hip).  The edge kernels accumulate Wh.L + Wl.H + Wh.H: the dropped product is 2^-22
+// relative, and measured against fp64 the 3-product result is as accurate as a plain fp32 dot product (max 2.0e-7 vs
+// 1.9e-7 on the real weights).
 __device__ __forceinline__ void split2_f16(float x, unsigned &h, unsigned &l) {
     const _Float16 hh = (_Float16)x;
     const _Float16 ll = (_Float16)(x - (float)hh);
@@ -166,10 +164,14 @@ __device__ __forceinline__ void split2_f16(float x, unsigned &h, unsigned &l) {
 __device__ __forceinline__ size_t f16_unit(size_t slot, int kq, int piece) {
     return (slot >> 2) * 32 + (size_t)piece * 16 + (size_t)kq * 4 + (slot & 3);
 }
-// The two spare K entries of a quarter (the weight side is zero there) carry the per-slot scalars of the edge kernels:
-// entry 6 = one of {u_x, u_y, u_z, 1/d} (quarter 0..3) as fp16 pieces h | l -- a selector tile on the matrix pipe hands all
-// four to every lane of the slot (painn_edge_mfma.hip, 22-bit values) -- and entry 7 of the H piece = the chain-local
-// neighbor index as a raw 16-bit integer (a finite fp16 pattern below 0x7C00).  No separate record loads in the hot loops.
+// Record of one (slot, quarter), 32 bytes = two 16-byte units.  The quarter owns the radial indices k = kq + 4 t (t < 5): their
+// three products per index (15) and one of the three envelope / bias products fill the 16 K entries a lane holds in TWO matrix
+// instructions (painn_edge_mfma.hip, build_wd16 has the weight side):
+//   unit 0 = [l0 l1 l2 l3 l4 env h0 h1]                    the first B operand as it stands (env: fc_l | fc_h | fc_h | 0 by quarter)
+//   unit 1 = [h2 h3 h4 h4 | scalar (fp32) | neighbor]      the second operand [h2 h3 h4 h4 h0 h1 h2 h3] is put together from both
+//                                                          units in registers (two moves)
+// scalar = one of {u_x, u_y, u_z, 1 / d} (quarter 0 .. 3) as a plain fp32 word -- an all-gather on the row swaps hands all four to
+// every lane of the slot -- and the last word = the chain-local neighbor index.  No separate record loads in the hot loops.
 __device__ __forceinline__ void write_f16_record(const float (&v)[5], float env, uint4 *__restrict__ tab, size_t slot, int kq,
                                                  float spare, unsigned jbits) {
     unsigned h[6], l[6];
@@ -177,10 +179,9 @@ __device__ __forceinline__ void write_f16_record(const float (&v)[5], float env,
     for (int k = 0; k < 5; ++k) split2_f16(v[k], h[k], l[k]);
     split2_f16(env, h[5], l[5]);
     auto pk = [](unsigned lo, unsigned hi) { return lo | (hi << 16); };
-    unsigned sh, sl;
-    split2_f16(spare, sh, sl);
-    tab[f16_unit(slot, kq, 0)] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), pk(sh, jbits));
-    tab[f16_unit(slot, kq, 1)] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), pk(sl, 0u));
+    const unsigned env_piece = kq == 0 ? l[5] : kq == 3 ? 0u : h[5];   // partners: bd_h | bd_l | bd_h | 0 (build_wd16)
+    tab[f16_unit(slot, kq, 0)] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], env_piece), pk(h[0], h[1]));
+    tab[f16_unit(slot, kq, 1)] = make_uint4(pk(h[2], h[3]), pk(h[4], h[4]), __float_as_uint(spare), jbits);
 }
 
 // sum over the 16 lanes of a wave that share lane & 3 (the threads of one table quarter), result in all of them: two

@@ -9,10 +9,11 @@
 // atoms of its chain in LDS once (exactly the compulsory HBM bytes of SURVEY §8(d): every phi/v element is read by one
 // workgroup only), then walks the chain's padded CSR in steps of 16 slots per wave: 4 streams x 4 slots, the 4 streams
 // being the 4 centres of a "bundle" of (nearly) equal slot count (BundleWalk below).  The filter tile
-// D[16 features][16 slots] = Wd_ext . rho runs on v_mfma_f32_16x16x32_f16 (fp16 2-way split, three products): weights are
-// the A operand (resident in registers), rho the B operand, read as operand-ready pieces from the quad-interleaved
-// per-slot table that k_edge_geom (nbr.hip) writes once per evaluation; the slot's unit vector, 1 / d and neighbor index
-// ride in the spare K entries of the same table (selector tile, filter_tiles_sel).  Lane (p, fq) owns slot p and features
+// D[16 features][16 slots] = Wd_ext . rho runs on v_mfma_f32_16x16x32_f16 (fp16 2-way split, three products packed densely
+// into the K dimension: two instructions per tile): weights are the A operand (resident in registers), rho the B operand,
+// read as operand-ready pieces from the quad-interleaved per-slot table that k_edge_geom (nbr.hip) writes once per
+// evaluation; the slot's unit vector, 1 / d and neighbor index ride in the same records as plain 32-bit words (slot_scalars):
+// no other per-slot load in the hot loops.  Lane (p, fq) owns slot p and features
 // 4 fq .. 4 fq + 3: it gathers the neighbor's values from the LDS tile, forms the messages in registers and accumulates
 // them; a centre is written once, after a 4-lane DPP reduction.  No atomics; the summation order per centre is the CSR
 // order regardless of batching.  What bounds these kernels and what was tried: DESIGN.md section 5,
@@ -51,12 +52,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // fp32 MFMA shares the FP32 datapath with the VALU (measured: worse than additive), the 16-bit MFMAs do not.  Both
 // operands are split into two fp16 pieces x = h + l (22 mantissa bits) and three products are kept, Wh rl + Wl rh + Wh rh;
 // the dropped Wl rl is 2^-22 relative.  Measured on the real weights against fp64 this is as accurate as a plain fp32 dot
-// product (nbr.hip).  The K = 32 entries of one v_mfma_f32_16x16x32_f16 are, per lane quarter kq: the 5 radial indices
-// k = kq + 4 kk, the bias column (weights: bd in quarter 0, zero elsewhere; rho side: the envelope fc) and two zeros.
-// Every piece is a complete 16-byte operand, so a tile costs three matrix-pipe instructions fed directly from loaded
-// registers.  Pieces of rho are pre-split once per evaluation (k_edge_geom, nbr.hip), pieces of the weights once per
-// handle (build_wd16): nothing is split, shuffled or bias-multiplied in the hot loop.  (An exact 3-way bf16 split with
-// six products was used first: same accuracy, twice the matrix work and 1.5x the table bytes.)
+// product (nbr.hip).  K layout (round 6): a lane quarter kq owns the 5 radial indices k = kq + 4 t; their 3 x 5 products and
+// one of the three envelope / bias products (bd_h fc_l | bd_l fc_h | bd_h fc_h in quarters 0 .. 2) are exactly the 16 K entries
+// the lane holds in TWO matrix instructions -- 63 of the 64 K entries carry a product.  (Rounds 1-5 issued the three products
+// as three instructions with 23 of 32 K entries used each, plus a two-instruction selector tile that handed out the per-slot
+// scalars from the spare entries: 11 / 20 matrix instructions per 16 slots in the forward / reverse kernel instead of 6 / 12;
+// same-box A/B profiles/r06/ab_kdense.txt.)  The first B operand is unit 0 of the slot's table record as loaded; the second is
+// put together from both units with two register moves (dense_b2): rho_h is stored once, the freed words carry the quarter's
+// per-slot scalar as fp32 and the neighbor index.  Pieces of rho are pre-split once per evaluation (k_edge_geom, nbr.hip),
+// pieces of the weights once per handle (build_wd16): nothing is split or bias-multiplied in the hot loop.  (An exact 3-way
+// bf16 split with six products was used first: same accuracy, twice the matrix work and 1.5x the table bytes.)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one MFMA operand: 8 x fp16
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -93,6 +98,11 @@ __device__ __forceinline__ float take(float src) {
     asm("v_mov_b32 %0, %1" : "=v"(d) : "v"(src));
     return d;
 }
+__device__ __forceinline__ unsigned take_u(unsigned src) {
+    unsigned d;
+    asm("v_mov_b32 %0, %1" : "=v"(d) : "v"(src));
+    return d;
+}
 __device__ __forceinline__ void mfma_load_fence(int &index, float &a, float &b, float &c) {
     asm volatile("; mfma_load_fence" : "+v"(index), "+v"(a), "+v"(b), "+v"(c));
 }
@@ -118,77 +128,64 @@ __device__ __forceinline__ u32x4 gload_u32x4(const u32x4 *p) {
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
-// Filter tiles of one step.  The three partial products of a tile form a dependent accumulator chain, and dependent MFMAs
+// Filter tiles of one step.  The two products of a tile form a dependent accumulator chain, and dependent MFMAs
 // issued back to back stall INSIDE the matrix pipe: everything queued behind them reads its source registers much later
 // than the compiler's wait-state model assumes, while the compiler already reuses those registers (observed: VALU and
-// LDS writes into MFMA sources a few wait states after issue -> wrong forces).  So the products are issued in rounds
-// across all NT tiles, smallest product first: an MFMA's predecessor in its chain is NT instructions back and has
-// retired when it reaches the pipe, nothing queues up, and the compiler's model holds.  The scheduling barriers pin
-// the issue order (without them the scheduler re-serialises the chains to save registers, or ends one round and starts
-// the next on the same tile).
-// The same rounds plus the selector tile: sel has a single 1.0 per lane (K entry 6 of quarter fq on feature row i with
-// i % 4 == fq), so D_sel[4 q + r][slot] = entry 6 of quarter r of the slot's record = {u_x, u_y, u_z, 1/d}[r]: lane (slot p,
-// any quarter) receives the four per-slot scalars in its 4 accumulator registers, h piece + l piece (22 bits), without
-// a record load and without cross-lane traffic.  Two products (round 0: l, round 2: h).
+// LDS writes into MFMA sources a few wait states after issue -> wrong forces).  So the products are issued in two rounds
+// across all NT tiles: with three or more tiles the producer of an accumulator is at least three matrix instructions back and
+// has retired when its consumer reaches the pipe; with one or two tiles every product starts its own chain (zero accumulator)
+// and the two partial sums are added on the vector unit.  The scheduling barriers pin the issue order (without them the
+// scheduler re-serialises the chains to save registers).  Unit 0 of the slot's table record is the first B operand as loaded,
+// dense_b2 puts the second together from both units.
+__device__ __forceinline__ u32x4 dense_b2(const u32x4 &u0, const u32x4 &u1) { return (u32x4){u1[0], u1[1], u0[3], u1[0]}; }
 template <int NT>
-__device__ __forceinline__ void filter_tiles_sel(const u32x4 (*const (&w)[NT])[2], const u32x4 (*const (&r)[NT])[2], f32x4 (&acc)[NT],
-                                                 const u32x4 &sel, const u32x4 (&rs)[2], f32x4 &accsel) {
-    if constexpr (NT == 1) {
-        // One filter tile (4-feature slices, forward): five matrix instructions in three chains -- (Wh rl, Wl rh) | Wh rh | selector
-        // (l, h) -- ordered so that every product's predecessor in its chain is three instructions back; the two filter partial sums
-        // are added on the vector unit.
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 a = mfma_f16((*w[0])[0], (*r[0])[1], z);
-        __builtin_amdgcn_sched_barrier(0);
-        accsel = mfma_f16(sel, rs[1], z);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4 b = mfma_f16((*w[0])[0], (*r[0])[0], z);
-        __builtin_amdgcn_sched_barrier(0);
-        a = mfma_f16((*w[0])[1], (*r[0])[0], a);
-        __builtin_amdgcn_sched_barrier(0);
-        accsel = mfma_f16(sel, rs[0], accsel);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("; mfma operands live" : : "v"((*r[0])[0]), "v"((*r[0])[1]), "v"(rs[0]), "v"(rs[1]));   // (see below)
-        acc[0] = a + b;
-        return;
-    }
-    constexpr int wi[3] = {0, 1, 0}, ri[3] = {1, 0, 0};   // Wh rl, Wl rh, Wh rh
+__device__ __forceinline__ void filter_tiles_dense(const u32x4 (*const (&w)[NT])[2], const u32x4 *const (&b1)[NT], const u32x4 *const (&b2)[NT],
+                                                   f32x4 (&acc)[NT]) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NT >= 3) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    accsel = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifdef ABL_THIRD_MFMA   // ablation: only the first of the three products (results wrong)
-    constexpr int NPROD = 1;
-#else
-    constexpr int NPROD = 3;
-#endif
-#pragma unroll
-    for (int k = 0; k < NPROD; ++k) {
-        if (NT < 3 && k == 2) {   // two tiles: the selector's second product goes in FRONT of the last round, so that every
-            accsel = mfma_f16(sel, rs[ri[k]], accsel);   // product's predecessor in its chain stays three instructions back
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = mfma_f16((*w[t])[0], *b1[t], z);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            acc[t] = mfma_f16((*w[t])[wi[k]], (*r[t])[ri[k]], acc[t]);
-            __builtin_amdgcn_sched_barrier(0);       // fixed tile order inside the round as well
-        }
-        if (k == 0 || (k == 2 && NT >= 3)) {
-            accsel = mfma_f16(sel, rs[ri[k]], accsel);
+            acc[t] = mfma_f16((*w[t])[1], *b2[t], acc[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
-    if constexpr (NT == 2) {
-        // The B operands stay live past the block: with few tiles the register allocator otherwise places the destination of a chain's
-        // LAST product over its (dying) B operand while the accumulator input is another register -- the pattern that produced
-        // run-to-run differences in round 3 (lint rule 4, tools/check_mfma_loads.py; seen again in the 4-feature reverse kernel).
+        // the second operands stay live past the block: otherwise the register allocator places the destination of a chain's last
+        // product over its dying B operand while the accumulator input is another register (lint rule 4, tools/check_mfma_loads.py)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) asm volatile("; mfma operands live" : : "v"((*r[t])[0]), "v"((*r[t])[1]));
-        asm volatile("; mfma operands live" : : "v"(rs[0]), "v"(rs[1]));
+        for (int t = 0; t < NT; ++t) asm volatile("; mfma operands live" : : "v"(*b2[t]));
+    } else {
+        f32x4 part[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = mfma_f16((*w[t])[0], *b1[t], z);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            part[t] = mfma_f16((*w[t])[1], *b2[t], z);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("; mfma operands live" : : "v"(*b1[t]), "v"(*b2[t]));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] += part[t];
     }
 }
+// The per-slot scalars {u_x, u_y, u_z, 1 / d}: lane (slot, quarter r) loaded scalar r as a plain fp32 word with its table record;
+// an all-gather over the four 16-lane rows on the gfx950 row swaps hands all four to every lane of the slot (three swaps):
+// swap32 (x, x) -> (x0 x1 x0 x1), (x2 x3 x2 x3) by rows; swap16 of each with itself -> x0, x1 resp. x2, x3 in every row.
+__device__ __forceinline__ void slot_scalars(unsigned x, float &s0, float &s1, float &s2, float &s3) {
+    const auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    const auto lo = __builtin_amdgcn_permlane16_swap(a[0], a[0], false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(a[1], a[1], false, false);
+    s0 = __uint_as_float(lo[0]); s1 = __uint_as_float(lo[1]); s2 = __uint_as_float(hi[0]); s3 = __uint_as_float(hi[1]);
+}
 
-// host: weight pieces in A-operand order.  dst[row][kq][piece h, l][4 dwords]: entries 0..4 = W[row][kq + 4 kk],
-// entry 5 = bd[row] in quarter 0 (pairs with the envelope entry written by write_f16_record, nbr.hip), rest zero.
+// host: weight pieces in A-operand order, dst[row][kq][operand 1, 2][4 dwords]
 void build_wd16(const float *Wd, const float *bd, unsigned *dst) {
     auto split2 = [](float x, unsigned (&p)[2]) {
         const _Float16 h = (_Float16)x;
@@ -198,18 +195,27 @@ void build_wd16(const float *Wd, const float *bd, unsigned *dst) {
         memcpy(&lb, &l, 2);
         p[0] = hb; p[1] = lb;
     };
+    // the partners of the two B operands the edge kernels form from a table record (nbr.hip write_f16_record),
+    //   B1 = [l0 l1 l2 l3 l4 env h0 h1]   A1 = [Wh0 Wh1 Wh2 Wh3 Wh4 bias Wl0 Wl1]   (bias / env: bd_h fc_l | bd_l fc_h | bd_h fc_h | 0 0
+    //   B2 = [h2 h3 h4 h4 h0 h1 h2 h3]    A2 = [Wl2 Wl3 Wl4 Wh4 Wh0 Wh1 Wh2 Wh3]      in quarters 0 .. 3)
+    // index t of quarter kq = radial index kq + 4 t: per quarter Wh.rho_l + Wl.rho_h + Wh.rho_h of its five radial functions.
     for (int row = 0; row < F3; ++row)
         for (int kq = 0; kq < 4; ++kq) {
-            unsigned half[2][8] = {};
-            for (int t = 0; t < 6; ++t) {
-                if (t == 5 && kq != 0) continue;
+            unsigned wh[5], wl[5], bp[2];
+            for (int t = 0; t < 5; ++t) {
                 unsigned p2[2];
-                split2(t < 5 ? Wd[(size_t)row * 20 + kq + 4 * t] : bd[row], p2);
-                for (int pc = 0; pc < 2; ++pc) half[pc][t] = p2[pc];
+                split2(Wd[(size_t)row * 20 + kq + 4 * t], p2);
+                wh[t] = p2[0]; wl[t] = p2[1];
             }
+            split2(bd[row], bp);
+            const unsigned bias = kq == 1 ? bp[1] : kq == 3 ? 0u : bp[0];
+            const unsigned a1[8] = {wh[0], wh[1], wh[2], wh[3], wh[4], bias, wl[0], wl[1]};
+            const unsigned a2[8] = {wl[2], wl[3], wl[4], wh[4], wh[0], wh[1], wh[2], wh[3]};
             unsigned *o = dst + ((size_t)row * 4 + kq) * 8;
-            for (int pc = 0; pc < 2; ++pc)
-                for (int q = 0; q < 4; ++q) o[pc * 4 + q] = half[pc][2 * q] | (half[pc][2 * q + 1] << 16);
+            for (int q = 0; q < 4; ++q) {
+                o[q] = a1[2 * q] | (a1[2 * q + 1] << 16);
+                o[4 + q] = a2[2 * q] | (a2[2 * q + 1] << 16);
+            }
         }
 }
 
@@ -534,7 +540,6 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
     // 64 contiguous bytes; exhausted streams read the reserved all-zero quad (filter = 0)
     const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;
     const int zero_quad = (zero_slot + 1) / 4 - 1;   // zero_slot = capacity - 1; the last complete quad is all zero
-    const u32x4 sel = {0u, 0u, 0u, fq == (p & 3) ? 0x3C00u : 0u};   // selector tile (filter_tiles_sel): 1.0 at K entry 6
 
     // Two table buffers (rho pieces; they also carry the unit vector and the neighbor id of the slot), one per step parity:
     // buffer ph is consumed by the step of parity ph and refilled right after that step's MFMAs for the step after next,
@@ -596,7 +601,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 #ifdef ABL_LDS_BCAST   // ablation: every gather reads row 0 or 1 (no LDS bank conflicts; results wrong)
             const int jn = (int)(rq[ph][0][3] >> 16) & 1;
 #else
-            int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
+            int jn = (int)rq[ph][1][3];           // chain-local neighbor of this lane's slot (last word of the record's unit 1)
             if constexpr (SUB) {   // staged row of the neighbor, or the zero row for a neighbor of the other half
                 const unsigned jl = (unsigned)(jn - lo);
                 jn = jl < (unsigned)ns ? (int)jl : ns;
@@ -635,19 +640,22 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
                     }
                 }
             }
-            mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
+            // unit vector of this lane's slot: the record's scalar words, all-gathered over the slot's four lanes (slot_scalars)
+            float ux, uy, uz, invd_unused;
+            slot_scalars(take_u(rq[ph][1][2]), ux, uy, uz, invd_unused);   // (moved out first: the buffer must be dead at its refill, see take())
+            u32x4 rb2 = dense_b2(rq[ph][0], rq[ph][1]);   // second B operand
+            mfma_pre_fence(rq[ph][0], rb2);          // gathers are issued before the first MFMA
             EPH(3)   // gather issue (+ the LDS wait the clock read implies)
-            // ---- filter GEMM  D[tile row][slot] = Wd_ext[row][k] rho[k][slot]  (bias . fc included) ---------------------
-            f32x4 acc[NT], usel;
+            // ---- filter GEMM  D[tile row][slot] = Wd_ext[row][k] rho[k][slot]  (bias . fc included): 2 instructions per tile ------
+            f32x4 acc[NT];
             {
-                const u32x4 (*wp[NT])[2], (*rp3[NT])[2];
+                const u32x4 (*wp[NT])[2], *bp1[NT], *bp2[NT];
 #pragma unroll
-                for (int s2 = 0; s2 < NT; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; }
-                filter_tiles_sel<NT>(wp, rp3, acc, sel, rq[ph], usel);
+                for (int s2 = 0; s2 < NT; ++s2) { wp[s2] = &wA[s2]; bp1[s2] = &rq[ph][0]; bp2[s2] = &rb2; }
+                filter_tiles_dense<NT>(wp, bp1, bp2, acc);
             }
             __builtin_amdgcn_sched_barrier(0);
             EPH(4)   // matrix instructions issued
-            const float ux = usel[0], uy = usel[1], uz = usel[2];   // unit vector of this lane's slot
             // ---- messages of this lane's slot for its NF features (filter = 0 exactly for pads / foreign slots) ----------
             auto message = [&](int r) {
                 const float *tr = tv + r * LY::NSEG;
@@ -749,7 +757,6 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     }
     const int lane = tid & 63, wave = tid >> 6, p = lane & 15, fq = lane >> 4, e = p & 3;
     const int last_slot = max(G.row_start[a0 + Nc] - 1, 0);
-    const u32x4 sel = {0u, 0u, 0u, fq == (p & 3) ? 0x3C00u : 0u};   // selector tile (filter_tiles_sel): 1.0 at K entry 6
     const LayerW &W = MW[m].layer[l];
     // partial edge-gradient buffer of this (model, layer set, slice): rec floats per slot -- 4 (float4 records, group 0 doubles
     // as the final buffer) or 3 (compact per-layer buffers, reduced into the separate final buffer by k_reduce_gpart)
@@ -963,7 +970,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 #ifdef ABL_LDS_BCAST   // ablation: every gather reads row 0 or 1 (no LDS bank conflicts; results wrong)
             const int jn = (int)(rq[ph][0][3] >> 16) & 1;
 #else
-            int jn = (int)(rq[ph][0][3] >> 16);   // chain-local neighbor of this lane's slot (K entry 7 of the h piece)
+            int jn = (int)rq[ph][1][3];           // chain-local neighbor of this lane's slot (last word of the record's unit 1)
             if constexpr (SUB) {   // staged row of the neighbor, or the zero row for a neighbor of another range
                 const unsigned jl = (unsigned)(jn - lo);
                 in_range = jl < (unsigned)ns;
@@ -1002,21 +1009,27 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 #pragma unroll
                 for (int q = 0; q < 6; ++q) cv[q] = cr[q];
             }
-            mfma_pre_fence(rq[ph][0], rq[ph][1]);   // gathers are issued before the first MFMA
-            mfma_pre_fence(dq[ph][0], dq[ph][1]);
+            // unit vector c -> n (edge (n -> c) has -u) and 1 / d: the record's scalar words, all-gathered over the slot's four lanes
+            float ux, uy, uz, invd;
+            slot_scalars(take_u(rq[ph][1][2]), ux, uy, uz, invd);   // (moved out first: the buffer must be dead at its refill, see take())
+            u32x4 rb2 = dense_b2(rq[ph][0], rq[ph][1]), db2 = dense_b2(dq[ph][0], dq[ph][1]);   // second B operands
+            mfma_pre_fence(rq[ph][0], rb2);          // gathers are issued before the first MFMA
+            mfma_pre_fence(dq[ph][0], db2);
             EPH(3)
-            // filter and its radial derivative for this lane's slot and NF features (bias . fc / bias . fc' included)
-            f32x4 awd[2 * NT], usel;   // tiles [0, NT): filter w, [NT, 2 NT): radial derivative dw; usel: per-slot scalars
+            // filter and its radial derivative for this lane's slot and NF features (bias . fc / bias . fc' included): 2 instructions per tile
+            f32x4 awd[2 * NT];   // tiles [0, NT): filter w, [NT, 2 NT): radial derivative dw
             {
-                const u32x4 (*wp[2 * NT])[2], (*rp3[2 * NT])[2];
+                const u32x4 (*wp[2 * NT])[2], *bp1[2 * NT], *bp2[2 * NT];
 #pragma unroll
-                for (int s2 = 0; s2 < NT; ++s2) { wp[s2] = &wA[s2]; rp3[s2] = &rq[ph]; wp[NT + s2] = &wA[s2]; rp3[NT + s2] = &dq[ph]; }
-                filter_tiles_sel<2 * NT>(wp, rp3, awd, sel, rq[ph], usel);
+                for (int s2 = 0; s2 < NT; ++s2) {
+                    wp[s2] = &wA[s2]; bp1[s2] = &rq[ph][0]; bp2[s2] = &rb2;
+                    wp[NT + s2] = &wA[s2]; bp1[NT + s2] = &dq[ph][0]; bp2[NT + s2] = &db2;
+                }
+                filter_tiles_dense<2 * NT>(wp, bp1, bp2, awd);
             }
             const f32x4 *aw = awd, *ad = awd + NT;
             __builtin_amdgcn_sched_barrier(0);
             EPH(4)
-            const float ux = usel[0], uy = usel[1], uz = usel[2], invd = usel[3];   // unit vector c -> n (edge (n -> c) has -u), 1 / d
             float dpart = 0.f, ub0 = 0.f, ub1 = 0.f, ub2 = 0.f;
             auto feature = [&](int r) {
                 const float sbn = tb[4 * r], vb0 = tb[4 * r + 1], vb1 = tb[4 * r + 2], vb2 = tb[4 * r + 3];

@@ -33,7 +33,7 @@ struct LayerW {
     // W1, W2, U, V, W3, W4 (forward) and W1^T, W2^T, W4^T, W3^T, [U;V]^T (reverse) as 2-way fp16 pieces in
     // v_mfma_f32_16x16x32_f16 B-fragment order (pack_mfma_tiles16), 16-column tiles
     const uint4 *qW1, *qW2, *qU, *qV, *qW3, *qW4, *qW1t, *qW2t, *qW4t, *qW3t, *qUVt;
-    const uint4 *wd16;           // radial-filter weights, 2-way fp16 split in MFMA A-operand order: [3F rows][4 quarters][h, l]
+    const uint4 *wd16;           // radial-filter weights, 2-way fp16 split in MFMA A-operand order: [3F rows][4 quarters][operand 1, 2] (build_wd16)
 };
 struct ModelW {
     const float *embed;  // [n_embed][F]
@@ -72,7 +72,7 @@ struct GraphView {  // neighbor multigraph of the resident batch (padded CSR by 
     // per-slot geometry tables, computed once per evaluation and shared by every layer / model / feature slice
     const float4 *erec;      // [slots] {u_x, u_y, u_z, bitcast(j local to its chain)} ; pads: u = 0, j = 0 (same condition as rho, else null)
     const float *rho;        // [slots][4][6]  radial basis * envelope, [kq][ks] = rho_{kq+4ks}: only for the layer-0 kernel of batches with > 4 species (else null)
-    const uint4 *rho16;      // operand-ready 2-way fp16 split of rho, quad-interleaved: [slot / 4][piece h, l][quarter][slot % 4] x 16 B (nbr.hip f16_unit)
+    const uint4 *rho16;      // operand-ready 2-way fp16 split of rho + the slot's scalars, quad-interleaved: [slot / 4][unit 0, 1][quarter][slot % 4] x 16 B (nbr.hip f16_unit, write_f16_record)
     const uint4 *drho16;     // same for d rho / d d
     const unsigned char *zslot;   // [slots] species index (zmap) of the neighbor, 255 for pads / unmapped
     const float2 *dist2;     // [slots] {1 / edge length (pads: -1), excluded-volume dE/dd = -p (sigma/d)^p / d (pads: 0)}

@@ -7,7 +7,8 @@ closes a block: the fragment loads of the next chunk group legitimately follow i
 kernels): inside a dense block an MFMA never accumulates into the destination of one of the two MFMAs in front of it -- the
 producer of its accumulator is at least three matrix instructions back (dependent MFMAs issued closer stall inside the pipe
 and read their other sources late; profiles/r01/NOTES_mfma_hazards.md).  Rule 4 (same files): a product that is not the first of its
-chain never overwrites its own A / B operand.  Rule 5 (every file): no FLAT memory instructions.  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
+chain never overwrites its own A / B operand.  Rule 5 (every file): no FLAT memory instructions.  Rule 6 (edge kernels): the static count
+of matrix instructions per 16-slot step is printed and checked against the K-dense form's 2 per tile.  Usage: check_mfma_loads.py [file.hip ...]  (exit 1 on violation)."""
 import os, re, subprocess, sys, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -131,6 +132,35 @@ def check(hip):
         if re.match(r"^\s*flat_(load|store|atomic)", l):
             bad += 1
             print(f"VIOLATION in {kernel}: FLAT memory instruction at line {i}: {l.strip()}")
+    # rule 6 (edge kernels): matrix instructions per 16-slot step of the hot loops = v_mfma between two '; arrival_fence' markers.
+    # The K-dense radial filter (round 6) issues 2 per tile: 6 / 4 / 2 in the forward kernels with 16- / 8- / 4-feature slices,
+    # 12 / 8 / 4 in the reverse kernels (filter + radial derivative); more means a product fell back to its own instruction.
+    if groups:
+        kernel, count, steps = None, None, {}
+        for l in lines:
+            m = re.match(r"^(_ZN\w+):", l)
+            if m:
+                kernel, count = m.group(1), None
+            t = l.strip()
+            if "; arrival_fence" in t:
+                if count:
+                    steps.setdefault(kernel, set()).add(count)
+                count = 0
+            elif t.startswith("v_mfma") and count is not None:
+                count += 1
+            elif t.startswith("s_endpgm"):
+                if count:
+                    steps.setdefault(kernel, set()).add(count)
+                count = None
+        for k, v in steps.items():
+            is_bwd = "k_edge_bwd" in k
+            nf = int(re.search(r"mfmaILi(\d)E", k).group(1))
+            limit = (4 if is_bwd else 2) * {4: 3, 2: 2, 1: 1}[nf]   # 2 per tile; tiles per table: 3 / 2 / 1 (EdgeGeo::NT)
+            tag = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.split("(")[0].replace("void vssr::", "")
+            print(f"    {tag:44s} matrix instructions per 16-slot step: {sorted(v)} (limit {limit})")
+            if max(v) > limit:
+                bad += 1
+                print(f"VIOLATION in {k}: {max(v)} matrix instructions per step, expected <= {limit}")
     print(f"{os.path.basename(hip)}: {groups} MFMA groups checked, {dense_blocks} dense MFMA pairs, {bad} violations")
     return bad
 
