@@ -211,7 +211,12 @@ typedef struct {
 /* Two drivers, same results bit for bit (csrc/chain_min.hip, csrc/relax.hip; VSSR_CG_FUSED / VSSR_RELAX_COMPACT above): Tersoff batches
  * of <= 3 072 chains of <= 256 atoms are minimised by ONE workgroup per chain from the first evaluation to the stop criterion (no
  * lock step: the GaN chains of the reference stop after 21 .. 159 evaluations each); everything else in lock step, with the resident
- * batch compacted to the chains still minimising once it is large enough for that to pay. */
+ * batch compacted to the chains still minimising once it is large enough for that to pay.  The automatic choice takes the
+ * chain-resident driver for batches of <= 3 072 chains of <= 64 atoms (the measured regime); VSSR_CG_FUSED=1 / 0 forces one.
+ * State of the handle afterwards: positions, energies, per-atom energies and forces are those of the minimised geometries with
+ * either driver.  The resident neighbor GRAPH differs: the lock-step driver leaves the batch-wide graph of the final evaluation
+ * (vssr_batch_stats / vssr_batch_neighbors work at once), the chain-resident driver numbers its rows per chain and leaves no
+ * batch-wide graph -- those two calls return VSSR_E_STATE until one vssr_batch_run has been made. */
 int vssr_batch_relax_cg(vssr_handle *h, const vssr_cg_params *params, const uint8_t *fixed, uint32_t want,
                         double *pos_out, int32_t *n_iter, int32_t *n_eval, int32_t *stop_reason);
 

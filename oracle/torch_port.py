@@ -48,7 +48,7 @@ class TorchEnsemble:
         self.dtype = dtype
         self.models = [{k: v.to(dtype) for k, v in _fields(b).items()} for b in blobs]
 
-    def model_energy(self, W, Z, ej, r, mask, N, D):
+    def model_energy(self, W, Z, ej, r, mask, N, D, per_atom=False):
         """Energy (model units) of one structure.  Edge rows are padded per centre to D slots: ``r`` [N D, 3] (requires
         grad), ``ej`` [N D] neighbor of every slot, ``mask`` [N D] 1 for real edges."""
         d = torch.sqrt((r * r).sum(dim=1))
@@ -71,8 +71,10 @@ class TorchEnsemble:
             a_vv, a_sv, a_ss = torch.split(g, F, dim=1)
             v = v + a_vv[:, None, :] * Uv
             s = s + a_sv * (Uv * Vv).sum(dim=1) + a_ss
-        e = (swish(s @ W["readout.W5"].T + W["readout.b5"]) @ W["readout.w6"].T + W["readout.b6"]).sum()
-        return e + (((SIGMA / d) ** POWER) * mask).sum()
+        e_atom = (swish(s @ W["readout.W5"].T + W["readout.b5"]) @ W["readout.w6"].T + W["readout.b6"])[:, 0]
+        if per_atom:   # (evaluate_batch: per-atom energies incl. the excluded volume of the atom's own slots)
+            return e_atom + (((SIGMA / d) ** POWER) * mask).reshape(N, D).sum(dim=1)
+        return e_atom.sum() + (((SIGMA / d) ** POWER) * mask).sum()
 
     def evaluate(self, Z, pos, cell, pbc, offset_per_z=None, offset_const=0.0, units_per_ev=oracle.EV_TO_KCAL_MOL):
         """dict(energy, energy_std, forces, forces_std, energy_models) in eV, like ``oracle.ensemble``."""
@@ -109,3 +111,44 @@ class TorchEnsemble:
         fs = np.stack(fs)
         return {"energy": es.mean(), "energy_std": es.std(), "forces": fs.mean(0), "forces_std": fs.std(0),
                 "energy_models": es}
+
+    def evaluate_batch(self, structs, offset_per_z=None, offset_const=0.0, units_per_ev=oracle.EV_TO_KCAL_MOL):
+        """Several independent structures ``(Z, pos, cell, pbc)`` as ONE graph (atoms concatenated, neighbor indices shifted): the
+        dense layers see all atoms of the batch in one GEMM, which is how a CPU runs this model at its best (bench.py's
+        ``cpu_baseline`` times it).  Returns per-structure ``energy`` / ``energy_std`` [B] and ``forces`` of the concatenated
+        atoms, like ``evaluate`` does for one structure."""
+        parts, n_at = [], []
+        for Z, pos, cell, pbc in structs:
+            parts.append(oracle.neighbors(pos, cell, pbc, CUTOFF))
+            n_at.append(len(Z))
+        first = np.concatenate([[0], np.cumsum(n_at)])
+        N = int(first[-1])
+        D = int(max(max(np.bincount(p[0], minlength=n).max() for p, n in zip(parts, n_at)), 1))
+        r_pad = np.zeros((N * D, 3)); r_pad[:, 0] = 1.0
+        ej_pad = np.zeros(N * D, np.int64); m = np.zeros(N * D)
+        for (ei, ej, eS, er), n, a0 in zip(parts, n_at, first[:-1]):
+            deg = np.bincount(ei, minlength=n)
+            start = np.concatenate([[0], np.cumsum(deg)])[:-1]
+            slot = (ei.astype(np.int64) + a0) * D + (np.arange(len(ei)) - start[ei])
+            r_pad[slot] = er; ej_pad[slot] = ej.astype(np.int64) + a0; m[slot] = 1.0
+        ei_pad = np.repeat(np.arange(N, dtype=np.int64), D)
+        Zall = np.concatenate([np.asarray(s[0], dtype=np.int64) for s in structs])
+        Zt, ej_t, ei_t = torch.from_numpy(Zall), torch.from_numpy(ej_pad), torch.from_numpy(ei_pad)
+        mask = torch.from_numpy(m).to(self.dtype)
+        chain_of = torch.from_numpy(np.repeat(np.arange(len(structs)), n_at))
+        es, fs = [], []
+        for W in self.models:
+            r = torch.from_numpy(r_pad).to(self.dtype).requires_grad_(True)
+            e_atoms = self.model_energy(W, Zt, ej_t, r, mask, N, D, per_atom=True)
+            (g,) = torch.autograd.grad(e_atoms.sum(), r)
+            g = g * mask[:, None]
+            grad = torch.zeros(N, 3, dtype=self.dtype).index_add_(0, ej_t, g).index_add_(0, ei_t, -g)
+            e_chain = torch.zeros(len(structs), dtype=torch.float64).index_add_(0, chain_of, e_atoms.detach().double())
+            es.append(e_chain.numpy() / units_per_ev)
+            fs.append(-(grad.double().numpy()) / units_per_ev)
+        es = np.stack(es, axis=1)     # [B, M]
+        if offset_per_z is not None:
+            table = np.asarray(offset_per_z)
+            es = es + np.array([table[np.asarray(s[0])].sum() + offset_const for s in structs])[:, None]
+        fs = np.stack(fs)
+        return {"energy": es.mean(1), "energy_std": es.std(1), "forces": fs.mean(0), "forces_std": fs.std(0), "energy_models": es}

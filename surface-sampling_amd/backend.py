@@ -303,10 +303,12 @@ class _Handle:
         res["cfg_start"] = self._cfg_start
         res["saturated"] = self.saturated()
         # the same energies without the float32 output word (vssr_batch_energy_f64): what acceptance tests and relaxation
-        # drivers compare; "energy" keeps the reference's float32 type
-        e64, s64, m64 = np.zeros(B), np.zeros(B), np.zeros((B, M))
-        self._check(self._lib.vssr_batch_energy_f64(self._h, _ptr(e64, C.c_double), _ptr(s64, C.c_double), _ptr(m64, C.c_double)))
-        res["energy_f64"], res["energy_std_f64"], res["energy_models_f64"] = e64, s64, m64
+        # drivers compare; "energy" keeps the reference's float32 type.  Only when energies were asked for (a second call with
+        # three blocking copies otherwise bought nothing).
+        if int(want) & WANT_ENERGY:
+            e64, s64, m64 = np.zeros(B), np.zeros(B), np.zeros((B, M))
+            self._check(self._lib.vssr_batch_energy_f64(self._h, _ptr(e64, C.c_double), _ptr(s64, C.c_double), _ptr(m64, C.c_double)))
+            res["energy_f64"], res["energy_std_f64"], res["energy_models_f64"] = e64, s64, m64
         return res
 
     def embedding(self, model=None):

@@ -222,6 +222,11 @@ class EnsembleNFFSurface(_Base):
         model_units / prediction_units / offset_units: as in the reference (``"kcal/mol"``, ``"eV"``,
             ``"atomic"``).
         cutoff: neighbor cutoff in Å (the reference passes it through ``get_atoms_batch``).
+        position_dtype: ``"float64"`` (default: the caller's positions as they are) or ``"float32"``: positions are rounded to
+            float32 before an evaluation, the way nff's ``AtomsBatch`` holds them (``nxyz`` is a float32 tensor, reference
+            ``mcmc/utils/misc.py:34-42``) -- single-point results then reproduce the reference's prints to the last printed
+            digit of fmax (1e-5 eV/A).  Applies to ``calculate``, ``calculate_batch`` and the
+            single-point form of ``evaluate_packed``; relaxations move fp64 positions on the device either way.
         properties: like nff's ``NeuralFF(properties=[...])``; with ``"embedding"`` in it ``results["embedding"]`` holds the
             per-atom latent features ``[N, 128]`` (final scalar state) of the first model -- the reference computes them
             with ``NeuralFF(models[0], properties=["energy", "forces", "embedding"])`` -- and ``results["embedding_models"]``
@@ -234,7 +239,8 @@ class EnsembleNFFSurface(_Base):
     name = "ensemble_nff_surface_mi355x"
 
     def __init__(self, models, device="cuda", model_units="kcal/mol", prediction_units="eV",
-                 offset_units="atomic", cutoff=5.0, hparams=None, logger=None, properties=("energy", "forces"), **kwargs):
+                 offset_units="atomic", cutoff=5.0, hparams=None, logger=None, properties=("energy", "forces"),
+                 position_dtype="float64", **kwargs):
         # a single model is accepted as well: the reference's NFFPourbaix is a NeuralFF and is constructed with ONE module,
         # NFFPourbaix(models[0], device=..., model_units=..., prediction_units="eV") (scripts/sample_pourbaix_surface.py:253-258)
         if isinstance(models, (str, bytes)) or hasattr(models, "__fspath__") or hasattr(models, "state_dict") \
@@ -249,6 +255,9 @@ class EnsembleNFFSurface(_Base):
         self.prediction_units = prediction_units
         self.offset_units = offset_units
         self.cutoff = float(cutoff)
+        if str(np.dtype(position_dtype)) not in ("float64", "float32"):
+            raise ValueError(f"position_dtype must be float64 or float32, not {position_dtype!r}")
+        self.position_dtype = str(np.dtype(position_dtype))
         self.hparams = dict(hparams or {})
         self.chem_pots: dict = {}
         self.offset_data: dict = {}
@@ -365,6 +374,13 @@ class EnsembleNFFSurface(_Base):
                                           self._require(self.chem_pots, "chemical potentials"),
                                           self._require(self.offset_data, "offset data"), self.offset_units)
 
+    def _arrays(self, atoms):
+        """(numbers, positions, cell, pbc) of an Atoms-like for the ABI, positions rounded as ``position_dtype`` says."""
+        Z, pos, cell, pbc = structures.as_arrays(atoms)
+        if self.__dict__.get("position_dtype", "float64") == "float32":
+            pos = np.asarray(pos, dtype=np.float64).astype(np.float32).astype(np.float64)
+        return Z, pos, cell, pbc
+
     def _fill_results(self, res, b=0):
         a0, a1 = int(res["cfg_start"][b]), int(res["cfg_start"][b + 1])
         return {
@@ -391,7 +407,7 @@ class EnsembleNFFSurface(_Base):
             atoms = self.atoms
         _Base.calculate(self, atoms, properties, system_changes)
         eng = self._get_engine()
-        res = eng.evaluate([structures.as_arrays(atoms)])
+        res = eng.evaluate([self._arrays(atoms)])
         # a fresh dict per calculation, like nff's NeuralFF / EnsembleNFF.calculate: entries of an earlier structure that this
         # call does not produce (surface_energy, stress, embedding) must not survive a direct calculate() on another one
         self.results = dict(self._fill_results(res, 0))
@@ -422,7 +438,7 @@ class EnsembleNFFSurface(_Base):
         """Evaluate B independent configurations at once; returns one results dict per configuration
         (``want_embedding``: default = ``"embedding" in self.properties``; ``want_stress``: also ``stress`` / ``stress_std``)."""
         eng = self._get_engine()
-        res = eng.evaluate([structures.as_arrays(a) for a in atoms_list])
+        res = eng.evaluate([self._arrays(a) for a in atoms_list])
         stress = eng.stress() if want_stress else None
         if want_embedding is None:
             want_embedding = "embedding" in self.properties
@@ -500,6 +516,8 @@ class EnsembleNFFSurface(_Base):
             return eng.download(), inf
 
         pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
+        if not relax and self.__dict__.get("position_dtype", "float64") == "float32":
+            pos = pos.astype(np.float32).astype(np.float64)   # single points on nff's float32 nxyz (see the class docstring)
         cell, pbc = np.asarray(cell, dtype=np.float64).reshape(B, 9), np.asarray(pbc).reshape(B, 3)
         # (a single lock-step evaluation is too short to pay for the second host thread: measured 15.4 vs 15.0 ms per MC step)
         n_str = self.streams if (relax and B >= 2 * self.MIN_CHAINS_PER_STREAM) else 1

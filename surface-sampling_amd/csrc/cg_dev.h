@@ -65,6 +65,10 @@ __device__ __forceinline__ void cg_step_chain(int b, double *red, const int *__r
           double *__restrict__ gall, CgState *__restrict__ st, unsigned char *__restrict__ active, int *__restrict__ n_active) {
     const int tid = threadIdx.x, nt = blockDim.x;
     CgState S = st[b];
+    // every wave has its copy of the state before thread 0 can store the advanced one: several exits below (a back-tracked trial,
+    // the reset paths, stop right behind PH_PROJ) store without a barrier in front of them, and a wave that loaded late would take
+    // another branch than the rest of its workgroup and wait alone at a block_sum barrier (advisor r5)
+    __syncthreads();
     if (S.reason) return;
     const int a0 = cfg_start[b], n = 3 * (cfg_start[b + 1] - a0);
     double *x = pos + 3 * (size_t)a0, *x0 = x0all + 3 * (size_t)a0, *h = hall + 3 * (size_t)a0, *g = gall + 3 * (size_t)a0;

@@ -17,6 +17,7 @@
 // reductions), so rows, energies, forces, iteration / evaluation counts and stop reasons equal the lock-step driver's bit for
 // bit (tests/test_cg.py::test_chain_resident_minimiser_equals_the_lock_step_driver).  Only the slot numbering differs: a chain
 // owns the fixed slot range [cfg_start[b], cfg_start[b + 1]) x cap_per_atom instead of a place in a batch-wide scan.
+#include <algorithm>
 #include "cg_dev.h"
 #include "nbr_dev.h"
 #ifdef CM_PHASE_TIMING   // sub-phases of the site tile: slots 10 .. 12 of g_cm_phase
@@ -205,7 +206,10 @@ bool chain_min_supported(const vssr_handle *h) {
     if (h->kind != 2 || h->max_cfg_atoms > CM_MAX_ATOMS) return false;
     const char *e = getenv("VSSR_CG_FUSED");   // (read per call)
     if (e) return atoi(e) != 0;
-    return h->n_cfg <= 3072;
+    // the automatic choice covers the regime that was measured: chains of <= 64 atoms (one site tile per workgroup).  A 200-atom
+    // chain runs its 64-centre site tiles one after another inside one workgroup; that regime has no A/B, so it takes the lock-step
+    // kernels unless VSSR_CG_FUSED=1 asks for the chain-resident one (advisor r5)
+    return h->n_cfg <= 3072 && h->max_cfg_atoms <= 64;
 }
 
 // Same contract as relax_cg (relax.hip): afterwards the batch holds the minimised positions, d_ters_e / _ea / _f the static results of
@@ -235,7 +239,10 @@ int chain_min_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_
     h->relax_compactions = 0;
     static const bool one_thread = [] { const char *e = getenv("VSSR_TERSOFF_SITE"); return e && atoi(e) == 1; }();
     const double rc = h->ters_cutmax;
-    int cap = h->cap_per_atom;
+    // slots per atom of the per-chain pools: the handle's capacity, or what an earlier chain-resident relaxation had to grow to.  The
+    // grown value stays with THIS driver (cm_cap_per_atom): the batch-wide runs size their buffers from cap_per_atom and repair an
+    // overflow exactly, they must not inherit up to 64x from a pool that doubles (advisor r5)
+    int cap = std::max(h->cap_per_atom, h->cm_cap_per_atom);
     for (int attempt = 0;; ++attempt) {
         // slot pools: every chain owns n_atoms x cap slots
         const long long slots = (long long)N * cap + 64;
@@ -282,7 +289,7 @@ int chain_min_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_
         cap *= 2;
         ++h->relax_regrows;
     }
-    h->cap_per_atom = cap;
+    h->cm_cap_per_atom = cap;
     hipLaunchKernelGGL(k_cm_report, dim3((B + 127) / 128), dim3(128), 0, st, B, h->d_fire.as<CgState>(), h->d_relax_steps.as<int>());
     std::vector<int> ne(B);
     VSSR_HIP(h, hipMemcpyAsync(ne.data(), n_evals, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, st));

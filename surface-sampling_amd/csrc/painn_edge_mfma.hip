@@ -941,7 +941,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 #endif
         const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
+#ifdef ABL_3LOADS   // ablation: three table loads per step instead of four (results wrong)
+        dq[buf][0] = dp[0]; dq[buf][1] = dq[buf][0];
+#else
         dq[buf][0] = dp[0]; dq[buf][1] = dp[16];
+#endif
 #ifdef ABL_NO_GBAR   // ablation build (tools/build_variant.sh): same instruction stream, the partial edge-gradient buffers stay in L2
         if (!FIRST) gold[buf] = gcomp[(size_t)min((quad_first_slot + e) & 1023, last_slot) * rec];
 #else

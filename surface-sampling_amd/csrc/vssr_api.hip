@@ -985,6 +985,7 @@ int vssr_debug_capacity(vssr_handle *h, int32_t slots_per_atom, int32_t tight, i
     if (!h) return VSSR_E_BADARG;
     if (slots_per_atom > 0) {
         h->cap_per_atom = slots_per_atom;
+        h->cm_cap_per_atom = 0;   // (the chain-resident minimiser's pools start from the new value as well)
         h->slot_cap = 0;   // re-derived at the next neighbor build
     }
     if (tight >= 0) h->cap_tight = tight != 0;

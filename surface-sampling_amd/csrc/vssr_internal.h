@@ -311,6 +311,7 @@ struct vssr_handle {
     int64_t zero_entry_cap = -1;  // capacity / table addresses for which the all-zero table entries were last cleared
     const void *zero_entry_tab[2] = {nullptr, nullptr};
     int cap_per_atom = 64;        // initial neighbor capacity (slots per atom); vssr_debug_capacity
+    int cm_cap_per_atom = 0;      // slots per atom the chain-resident CG minimiser's per-chain pools grew to (chain_min.hip)
     bool cap_tight = false;       // regrow to the exact need only (tests: forces repeated overflows)
     uint32_t last_want = 0;                       // outputs produced by the last run
     int64_t slot_cap = 0;

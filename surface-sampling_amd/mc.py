@@ -395,7 +395,14 @@ class ChainEnsemble:
                  reference_groupby: bool = False, require_per_atom_energies: bool = False,
                  require_distance_decay: bool = False, distance_decay_factor: float = 1.0,
                  exchange_by_group_key: bool = False, filter_distance: float = 0.0,
-                 distance_adsorbate_types=("Sr", "Ti"), testing: bool = False):
+                 distance_adsorbate_types=("Sr", "Ti"), testing: bool = False, acceptance_energy: str = "f64"):
+        # Which word of the device's ensemble energy the acceptance test compares: "f64" (default) = the mean as the device forms
+        # it, before the narrowing to the float32 result word; "f32" = results["energy"], the float32 word the reference's
+        # Metropolis test sees (mcmc/calculators/calculators.py:484) -- for runs that want the reference's accept / reject decisions
+        # reproduced even where |dE| is of the order of the float32 spacing at keV energies (1e-4 .. 5e-4 eV).
+        if acceptance_energy not in ("f64", "f32"):
+            raise ValueError('acceptance_energy must be "f64" or "f32"')
+        self.acceptance_energy = acceptance_energy
         self.base = base
         self.ads_coords = np.asarray(ads_coords, float).reshape(-1, 3)
         self.adsorbates = list(adsorbates)
@@ -697,7 +704,8 @@ class ChainEnsemble:
         self._last_pae = [ea[start[k]:start[k + 1]] for k in range(b)]
         # the acceptance energy is the device's fp64 value where the backend returns it (vssr_batch_energy_f64); "energy"
         # keeps the reference's float32 result word
-        raw = np.asarray(out["energy_f64"] if "energy_f64" in out else out["energy"], dtype=np.float64)
+        raw = np.asarray(out["energy_f64"] if ("energy_f64" in out and self.acceptance_energy == "f64") else out["energy"],
+                         dtype=np.float64)
         if mode[0] == "plain":
             energies = raw
         else:
@@ -747,7 +755,8 @@ class ChainEnsemble:
             self._last_pae = [o[4].get("per_atom_energies") if len(o) > 4 and isinstance(o[4], dict) else None for o in out]
         else:
             out = self.calc.calculate_batch(slabs)
-            raw = [float(o["energy_f64"]) if "energy_f64" in o else float(np.ravel(o["energy"])[0]) for o in out]
+            raw = [float(o["energy_f64"]) if ("energy_f64" in o and self.acceptance_energy == "f64")
+                   else float(np.ravel(o["energy"])[0]) for o in out]
             relaxed = slabs
             self._last_pae = [o.get("per_atom_energies") for o in out]
         self.n_evaluations += len(slabs)
@@ -766,12 +775,11 @@ class ChainEnsemble:
             pass
         return self.calc.relax_batch(slabs, **kw)
 
-    @staticmethod
-    def _final_energy(relax_out) -> float:
+    def _final_energy(self, relax_out) -> float:
         """Energy of the relaxed slab from a ``relax_batch`` tuple: the results of its final evaluation when the backend
         returns them, else the tuple's energy field."""
         res = relax_out[4] if len(relax_out) > 4 else None
-        if isinstance(res, dict) and "energy_f64" in res:
+        if isinstance(res, dict) and "energy_f64" in res and self.acceptance_energy == "f64":
             return float(res["energy_f64"])
         if isinstance(res, dict) and "energy" in res:
             return float(np.ravel(res["energy"])[0])

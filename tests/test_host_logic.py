@@ -95,6 +95,17 @@ def test_calculator_surface_without_gpu(golden):
         calcs.EnsembleNFFSurface(golden.blobs, device="cpu")._get_engine()
     with pytest.raises(ValueError):
         calcs.EnsembleNFFSurface([golden.blobs[0][:100]])
+    # position_dtype="float32": the input geometry as nff's AtomsBatch holds it (float32 nxyz, reference mcmc/utils/misc.py:34-42)
+    s = golden.structure("SrTiO3_2x2_pristine")
+    pos64 = calc._arrays(s)[1]
+    assert calc.position_dtype == "float64" and np.array_equal(pos64, s.positions)
+    c32 = calcs.EnsembleNFFSurface(golden.blobs, position_dtype="float32")
+    pos32 = c32._arrays(s)[1]
+    assert pos32.dtype == np.float64 and np.array_equal(pos32, s.positions.astype(np.float32).astype(np.float64))
+    assert not np.array_equal(pos32, s.positions) and np.abs(pos32 - s.positions).max() < 2e-6
+    assert copy.deepcopy(c32).position_dtype == "float32"
+    with pytest.raises(ValueError):
+        calcs.EnsembleNFFSurface(golden.blobs, position_dtype="float16")
 
 
 def test_mini_calculator_caching():

@@ -586,6 +586,31 @@ class PackedLatticeGasCalc(LatticeGasCalc):
                 "n_steps": np.zeros(len(e), np.int32), "converged": np.ones(len(e), bool)}
 
 
+def test_acceptance_energy_word_is_selectable():
+    """``acceptance_energy="f64"`` (default) compares the fp64 word of the backend, ``"f32"`` the float32 result word the
+    reference's Metropolis test sees (mcmc/calculators/calculators.py:484)."""
+    class TwoWordCalc(PackedLatticeGasCalc):
+        def evaluate_packed(self, *a, **k):
+            out = super().evaluate_packed(*a, **k)
+            out["energy_f64"] = out["energy"] + 1000.0      # (distinguishable words)
+            out["energy"] = out["energy"].astype(np.float32)
+            return out
+
+    Z = structures.ATOMIC_NUMBERS
+    base = structures.Structure(np.array([Z["Ti"], Z["Ti"]], np.int32), np.array([[0, 0, 0], [2.0, 0, 0]], float),
+                                np.diag([20.0, 20.0, 20.0]), np.array([True, True, False]))
+    coords = np.array([[1.0 * s, 0.0, 2.0] for s in range(4)], float)
+    got = {}
+    for word in ("f64", "f32"):
+        calc = TwoWordCalc(2, {Z["Sr"]: -0.05, Z["O"]: 0.02}, J=0.03)
+        ens = mc.ChainEnsemble(base, coords, ("Sr", "O"), 8, calc, seed=1, relax=False, acceptance_energy=word)
+        ens.initialize()
+        got[word] = ens.state.energy.copy()
+    assert np.all(got["f64"] - got["f32"] > 999.0)
+    with pytest.raises(ValueError):
+        mc.ChainEnsemble(base, coords, ("Sr", "O"), 8, PackedLatticeGasCalc(2, {}, J=0.0), acceptance_energy="f16")
+
+
 def test_batch_arrays_equal_the_per_chain_structures():
     """``batch_arrays`` builds what ``structure(b)`` builds for every chain -- atoms, groups ("HO", "H2O"), adsorption order."""
     ens, _ = _group_ensemble(48)

@@ -176,3 +176,45 @@ def test_torch_port_matches_oracle(golden, oracle_mod):
         assert np.abs(r["forces"] - o["forces"]).max() < 1e-10
         assert np.abs(r["energy_models"] - o["energy_models"]).max() < 1e-10
         assert np.abs(r["forces_std"] - o["forces_std"]).max() < 1e-10
+    # the batched form (several structures as one graph: bench.py's chain-parallel CPU baseline) = the structures one by one
+    ss = [golden.structure(n) for n in ("SrTiO3_2x2_pristine", "O40Sr16Ti12", "O44Sr12Ti16")]
+    rb = te.evaluate_batch([(s.numbers, s.positions, s.cell, s.pbc) for s in ss], table, const)
+    a0 = 0
+    for b, s in enumerate(ss):
+        o = oracle_mod.ensemble(golden.blobs, s.numbers, s.positions, s.cell, s.pbc, 64, table, const)
+        assert abs(rb["energy"][b] - o["energy"]) < 1e-9 and abs(rb["energy_std"][b] - o["energy_std"]) < 1e-9
+        assert np.abs(rb["forces"][a0:a0 + len(s)] - o["forces"]).max() < 1e-9
+        a0 += len(s)
+
+
+def test_bench_batch_vectors_are_the_oracles_answers(golden, oracle_mod):
+    """tests/golden/bench_batch_fp64.npz (tools/make_bench_golden.py: all 256 chains of the benchmark batch, the reference of
+    the GPU suite's whole-batch parity test) against the oracle that generated it, on three chains, and its input checksum
+    against the chains bench.py builds today."""
+    import hashlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    G = np.load(os.path.join(root, "tests", "golden", "bench_batch_fp64.npz"))
+    chains = bench.build_chains(golden.structures, 0, 256)
+    h = hashlib.sha256()
+    for s in chains:
+        h.update(np.ascontiguousarray(s.numbers, dtype=np.int32).tobytes())
+        h.update(np.ascontiguousarray(s.positions, dtype=np.float64).tobytes())
+        h.update(np.ascontiguousarray(s.cell, dtype=np.float64).tobytes())
+    assert h.hexdigest() == str(G["inputs_sha256"])
+    cs = G["cfg_start"]
+    assert cs[-1] == sum(len(s.numbers) for s in chains) == len(G["forces"])
+    table, const = golden.offset_table()
+    for b in (0, 131, 255):
+        s = chains[b]
+        r = oracle_mod.ensemble(golden.blobs, s.numbers, s.positions, s.cell, s.pbc, 64, table, const)
+        assert abs(r["energy"] - G["energy"][b]) < 1e-8 and abs(r["energy_std"] - G["energy_std"][b]) < 1e-8
+        assert np.abs(r["forces"] - G["forces"][cs[b]:cs[b + 1]]).max() < 1e-8
+    # what plain fp32 arithmetic of the same algorithm gives on this batch (the yardstick the device is printed against)
+    assert np.abs(G["energy_fp32mode"] - G["energy"]).max() < 5e-4
+    assert np.abs(G["forces_fp32mode"].astype(np.float64) - G["forces"]).max() < 1e-3

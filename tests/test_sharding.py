@@ -102,6 +102,11 @@ def _bench_worker(rank, world, port, per_gpu, out_dir):
         g = g.cpu().numpy() if hasattr(g, "cpu") else np.asarray(g)
         want = np.array([float(np.sum(c[1])) + (k + 1) for c in chains], dtype=np.float32)
         ok = ok and g.shape == (world * per_gpu, 2) and np.array_equal(g[:, 0], want) and np.array_equal(g[:, 1], 0.25 * want)
+    # first-contact diagnostics of bench.py for N > 1 (per-rank clocks, compute-only and gather-only probes), same group
+    d = bench.rank_diagnostics(sh, dist, 0.010 * (rank + 1), 5, backend.WANT_ENERGY, "cpu", k=2)
+    ok = ok and len(d["ms_per_step"]) == len(d["compute_only_ms_per_step"]) == len(d["gather_only_ms"]) == world
+    ok = ok and np.allclose(d["ms_per_step"], [2.0 * (r + 1) for r in range(world)]) and d["slowest_rank"] == world - 1
+    ok = ok and d["fastest_rank"] == 0 and all(x >= 0 for x in d["gather_only_ms"]) and d["spread_pct"] > 0
     np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array([ok]))
     dist.barrier()
     dist.destroy_process_group()
@@ -403,6 +408,10 @@ def test_bench_entry_point_eight_ranks_on_one_gpu(tmp_path):
     assert abs(line["value"] - 8 * 8 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
     gv = line["gather_verified"]
     assert gv["bit_exact"] and len(gv["ranks"]) == 2 and 0 not in gv["ranks"] and gv["chains"] >= 8
+    pr = line["per_rank"]      # a first multi-GPU run explains itself: every rank's clock, compute-only and gather-only probes
+    assert len(pr["ms_per_step"]) == len(pr["compute_only_ms_per_step"]) == len(pr["gather_only_ms"]) == 8
+    assert max(pr["ms_per_step"]) <= line["ms_per_step"] * (1 + 1e-9) and min(pr["ms_per_step"]) > 0
+    assert 0 <= pr["slowest_rank"] < 8 and 0 <= pr["fastest_rank"] < 8 and all(x > 0 for x in pr["gather_only_ms"])
     assert gathered.shape == (64, 3) and not gathered[:, 2].any()
     full = _one_engine_reference(64)
     assert np.array_equal(gathered[:, 0], full["energy_f64"]) and np.array_equal(gathered[:, 1], full["energy_std_f64"])

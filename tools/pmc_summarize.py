@@ -1,5 +1,5 @@
-"""Summarise the rocprofv3 --pmc passes of tools/gpu_pmc_r4.sh (gpu_pmc_r5.sh): per kernel the per-launch mean of every raw counter and
-the derived figures bench.py quotes (`roofline.binding_resource`).  Units / corrections per /opt/skills/guides/MI355X_MICROARCH.md:
+"""Summarise the rocprofv3 --pmc passes of tools/gpu_pmc.sh: per kernel the per-launch mean of every raw counter and
+the derived figures bench.py quotes (`roofline.from_committed_profile`).  Units / corrections per /opt/skills/guides/MI355X_MICROARCH.md:
 SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed
 over SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE are in KB and FETCH_SIZE under-reports
 16-B/lane streams 2x on gfx950 (doubled here, as in profiles/r02-r03).  Usage: python tools/pmc_summarize.py <dir> -> text;
@@ -46,6 +46,12 @@ def main():
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
             e["hbm_traffic_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
         out[k] = e
+    # which kernels the counters belong to: a digest of the kernel sources the profiled library was built from (bench.csrc_digest);
+    # bench.py quotes these figures only while the tree's digest is still this one
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["_meta"] = {"csrc_sha256": bench.csrc_digest(), "collected_by": "tools/gpu_pmc.sh (rocprofv3 --pmc passes of "
+                    "`bench.py --steps 1 --warmup 1 --streams 1`, one pass per counter set, no tracing flags)"}
     json.dump(out, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     cols = ("cycles_per_launch", "matrix_pipe_busy_pct_of_simd_cycles", "valu_active_pct_of_simd_cycles", "wait_inst_any_pct_of_wave_cycles",
             "wait_any_pct_of_wave_cycles", "ta_busy_pct", "l1_accesses_per_cu_cycle", "hbm_traffic_bytes_per_launch")
