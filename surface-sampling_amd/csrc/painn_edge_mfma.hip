@@ -1121,9 +1121,6 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
 }
 
 
-#ifdef EDGE_BWD_MFMA32   // experiment of round 5 (measured and dropped, profiles/r05/NOTES_mfma32_reverse.md): tools/build_variant.sh bwd32 -DEDGE_BWD_MFMA32
-#include "experimental/edge_bwd_mfma32.inc"
-#endif
 
 int edge_mfma_init(vssr_handle *h) {
 #define SET_LDS(K) VSSR_HIP(h, hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
@@ -1136,9 +1133,6 @@ int edge_mfma_init(vssr_handle *h) {
     SET_LDS((k_edge_bwd_mfma<4, true, 8>)); SET_LDS((k_edge_bwd_mfma<4, false, 8>));
     SET_LDS((k_edge_bwd_mfma<4, true, 8, true>)); SET_LDS((k_edge_bwd_mfma<4, false, 8, true>));
     SET_LDS((k_edge_bwd_mfma<2, true, 8>)); SET_LDS((k_edge_bwd_mfma<2, false, 8>));
-#ifdef EDGE_BWD_MFMA32
-    SET_LDS((k_edge_bwd_mfma32<4>)); SET_LDS((k_edge_bwd_mfma32<8>));
-#endif
 #undef SET_LDS
     return VSSR_OK;
 }
@@ -1204,20 +1198,6 @@ void launch_edge_bwd_mfma(hipStream_t st, int cls, int N, const int *list, int n
         const bool many = (long long)n_list * EdgeGeo<NF>::NSLICE * M > 256;                                                     \
         if (two_fit && many) LAUNCH_BWD(NF, FIRST, 4); else LAUNCH_BWD(NF, FIRST, 8);                                            \
     } while (0)
-#ifdef EDGE_BWD_MFMA32
-    static const int use32 = [] { const char *e = getenv("VSSR_EDGE_BWD_32"); return e ? atoi(e) : 0; }();
-    if (cls == EDGE_BCLASS_FS16 && layer_first && use32) {   // the 32x32x16 form (first write of a partial-gradient set only)
-        const bool two_fit = 2 * edge_bwd_lds_bytes_t<4, 4>(max_atoms) <= 160 * 1024;
-        const bool many = (long long)n_list * EdgeGeo<4>::NSLICE * M > 256;
-#define LAUNCH_BWD32(WAVES)                                                                                                      \
-    hipLaunchKernelGGL((k_edge_bwd_mfma32<WAVES>), dim3(((n_list + 7) / 8) * 8 * EdgeGeo<4>::NSLICE * M), dim3(64 * WAVES),       \
-                       (edge_bwd_lds_bytes_t<4, WAVES>(max_atoms)), st, N, l, MW, G, counters, zero_slot, M, max_atoms, list, n_list, \
-                       v_in, phi, sbar_msg, vbar_msg, phibar, vbar_in, gbar, gbar_stride, n_groups, group_off, rec)
-        if (two_fit && many) LAUNCH_BWD32(4); else LAUNCH_BWD32(8);
-#undef LAUNCH_BWD32
-        return;
-    }
-#endif
     if (cls == EDGE_BCLASS_FS4) { if (layer_first) LAUNCH_BWD_W(1, true); else LAUNCH_BWD_W(1, false); }
     else if (cls == EDGE_BCLASS_FS8) { if (layer_first) LAUNCH_BWD_W(2, true); else LAUNCH_BWD_W(2, false); }
     else { if (layer_first) LAUNCH_BWD_W(4, true); else LAUNCH_BWD_W(4, false); }

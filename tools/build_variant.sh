@@ -7,7 +7,6 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 d=$root/build/variants/src_$name
 mkdir -p $d/surface-sampling_amd/csrc $d/include
 cp $root/surface-sampling_amd/csrc/*.hip $root/surface-sampling_amd/csrc/*.h $root/surface-sampling_amd/csrc/Makefile $d/surface-sampling_amd/csrc/
-[ -d $root/surface-sampling_amd/csrc/experimental ] && cp -r $root/surface-sampling_amd/csrc/experimental $d/surface-sampling_amd/csrc/
 cp $root/include/*.h $d/include/
 make -C $d/surface-sampling_amd/csrc -j8 -s XFLAGS="$*" OUT=$root/build/variants/lib_$name.so
 ls -la $root/build/variants/lib_$name.so
