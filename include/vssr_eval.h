@@ -108,30 +108,25 @@ typedef struct {
 
 /* ---- PaiNN ensemble ------------------------------------------------------------------- */
 int vssr_abi_version(void);
-/* Environment variables read once by vssr_create -- test / measurement hooks, none is needed in production:
+/* Environment variables -- test / measurement hooks, none is needed in production (eleven; the knobs of experiments that were
+ * measured and dropped are gone with their code: profiles/EXPERIMENTS.md).  Read once by vssr_create:
  *   VSSR_EDGE_IMPL=gather    every chain takes the gather neighbor kernels (reference path of the parity tests)
  *   VSSR_L0_FACTORISE=0      layer 0 runs the generic kernels instead of the species factorisation
- *   VSSR_EDGE_FS16_MAX=n, VSSR_EDGE_FS8_MAX=n, VSSR_EDGE_FS4_MAX=n   largest chain (atoms) served by the single-pass 16- / 8- / 4-feature-slice
- *                            kernels (lower = force a path)
- *   VSSR_EDGE_FWD_2PASS=0|8|16, VSSR_EDGE_FWD_MPASS_FS8=0, VSSR_EDGE_BWD_MPASS=0|1|2, VSSR_EDGE_SUB_CHUNK=n
+ *   VSSR_EDGE_FS16_MAX=n, VSSR_EDGE_FS8_MAX=n   largest chain (atoms) served by the single-pass 16- / 8-feature-slice kernels
+ *                            (tests: lower = force the path of larger chains onto small structures)
+ *   VSSR_EDGE_FWD_2PASS=0|8|16, VSSR_EDGE_BWD_MPASS=0|1|2, VSSR_EDGE_SUB_CHUNK=n
  *                            large chains (forward: > 405 atoms, reverse: > 557): 16-feature slices in several passes over sub-ranges of
- *                            the chain's neighbors (the default since round 5) instead of the narrower single-pass kernels of round 4
- *                            (FWD_2PASS=0 / FWD_MPASS_FS8=0 / BWD_MPASS=0); 8: the forward multi-pass form on 8-feature slices;
- *                            BWD_MPASS=2 + SUB_CHUNK=n (tests): every chain takes the multi-pass forms, ranges of n atoms
- *   VSSR_UPD_SAVE=1          update blocks store their forward intermediates for the reverse pass (measured: no gain)
- *   VSSR_GBAR_MODE=0|1|2     partial edge-gradient buffers: 0 shared float4 set with read-modify-write (round 2), 1 one float4 set per
- *                            layer, 2 (default) one compact 12-byte set per layer
+ *                            the chain's neighbors (the default) instead of the narrower single-pass kernels (FWD_2PASS=0 /
+ *                            BWD_MPASS=0); 8: the forward multi-pass form on 8-feature slices; BWD_MPASS=2 + SUB_CHUNK=n (tests):
+ *                            every chain takes the multi-pass forms, ranges of n atoms
+ *   VSSR_UPD_SAVE=1          update blocks store their forward intermediates for the reverse pass (measured: no gain; kept because
+ *                            the parity tests use it as an independent second path through the reverse update kernel)
  *   VSSR_DEBUG_KEEP=1        materialise buffers that only vssr_debug_read consumes (the last block's vector output)
- * Read once per process by the first evaluation (every kind of handle):
- *   VSSR_NBR_LPC=16|32|64, VSSR_REV_LPC=16|32|64   lanes per centre atom in the neighbor search / the reverse-slot search (default 16;
- *                            reverse-slot search 32 for PaiNN handles); the neighbor list is the same bit for bit in every form
- *   VSSR_TERSOFF_SITE=1      Tersoff: the one-thread-per-centre kernel for every row (default: rows of <= 16 slots take the
- *                            four-lanes-per-centre kernel)
  * Read by every vssr_batch_relax_cg call:
  *   VSSR_CG_FUSED=0|1        0: always the lock-step driver (one batch-wide evaluation per launch sequence); 1: the chain-resident
  *                            minimiser (one workgroup relaxes one chain from start to stop, csrc/chain_min.hip) whenever it applies
- *                            (Tersoff handles, chains of <= 256 atoms); unset: chain-resident for batches of <= 3 072 chains.  Same
- *                            results bit for bit either way
+ *                            (Tersoff handles, chains of <= 256 atoms); unset: chain-resident for batches of <= 3 072 chains of <= 64
+ *                            atoms.  Same results bit for bit either way
  *   VSSR_RELAX_COMPACT=0     no live-chain compaction of the resident batch (default on for resident batches of >= 65 536 atoms: once
  *                            at most 3/4 of the chains are still minimising, the batch continues as a smaller one; same trajectories
  *                            bit for bit); n > 1: compact batches of >= n atoms (tests: 2 = always) */

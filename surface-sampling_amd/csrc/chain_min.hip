@@ -237,7 +237,6 @@ int chain_min_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_
     h->relax_lockstep = 0;
     h->relax_chain_evals = 0;
     h->relax_compactions = 0;
-    static const bool one_thread = [] { const char *e = getenv("VSSR_TERSOFF_SITE"); return e && atoi(e) == 1; }();
     const double rc = h->ters_cutmax;
     // slots per atom of the per-chain pools: the handle's capacity, or what an earlier chain-resident relaxation had to grow to.  The
     // grown value stays with THIS driver (cm_cap_per_atom): the batch-wide runs size their buffers from cap_per_atom and repair an
@@ -258,7 +257,7 @@ int chain_min_cg(vssr_handle *h, const vssr_cg_params *cp, const uint8_t *fixed_
         VSSR_HIP(h, hipMemsetAsync(flags, 0, sizeof(int) * 8, st));
         ChainMinArgs A{};
         A.n_types = h->n_types;
-        A.fast = (!one_thread && h->n_types * h->n_types * h->n_types <= TS_MAXP) ? 1 : 0;
+        A.fast = (h->n_types * h->n_types * h->n_types <= TS_MAXP) ? 1 : 0;
         A.P = h->ters_params.as<TersP>();
         A.type = h->d_Z.as<int>(); A.atom_cfg = h->d_atom_cfg.as<int>(); A.cfg_start = h->d_cfg_start.as<int>(); A.nimg = h->d_nimg.as<int>();
         A.cell = h->d_cell.as<double>(); A.invcell = h->d_invcell.as<double>();

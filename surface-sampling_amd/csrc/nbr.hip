@@ -465,11 +465,8 @@ int build_neighbors(vssr_handle *h, double cutoff) {
     // lanes per centre.  Measured on the PaiNN bench (profiles/r04/ab_nbr_lanes_per_centre.txt) and the GaN workload: 16-lane rows
     // beat one wave per centre in the search at every chain size (260-atom chains: 4 full chunks of 64 + one with 4 lanes; 48-atom
     // chains: 48 of 64 lanes, once), the reverse-slot search likes 32 lanes on PaiNN rows (~41 slots) and 16 on the 8-slot rows of
-    // the analytic potentials.  VSSR_NBR_LPC / VSSR_REV_LPC = 16 | 32 | 64 force a form (tests run the suite with each).
-    static const int lpc_env = [] { const char *e = getenv("VSSR_NBR_LPC"); return e ? atoi(e) : 0; }();
-    static const int rev_env = [] { const char *e = getenv("VSSR_REV_LPC"); return e ? atoi(e) : 0; }();
-    const int lpc_nbr = lpc_env ? lpc_env : 16;
-    const int lpc_rev = rev_env ? rev_env : lpc_env ? lpc_env : (h->kind != 1 ? 16 : 32);
+    // the analytic potentials.  (The 32- and 64-lane search forms gave the same list bit for bit and are not built any more.)
+    const int lpc_rev = h->kind != 1 ? 16 : 32;
     dim3 wblk(256);
     auto grid_for = [&](int lpc) { return dim3((n + 256 / lpc - 1) / (256 / lpc)); };
 #define NBR_ARGS(FILLING) n, h->d_wpos.as<double>(), h->d_atom_cfg.as<int>(), h->d_cfg_start.as<int>(), h->d_cell.as<double>(),          \
@@ -480,24 +477,19 @@ int build_neighbors(vssr_handle *h, double cutoff) {
     hipLaunchKernelGGL(k_wrap, grd, blk, 0, st, n, h->d_pos.as<double>(), h->d_atom_cfg.as<int>(),
                        h->d_cell.as<double>(), h->d_invcell.as<double>(), h->d_pbc.as<uint8_t>(),
                        h->d_wpos.as<double>(), h->d_wrap.as<int>());
-    if (lpc_nbr == 16) hipLaunchKernelGGL((k_nbr<false, 16>), grid_for(16), wblk, 0, st, NBR_ARGS(false));
-    else if (lpc_nbr == 32) hipLaunchKernelGGL((k_nbr<false, 32>), grid_for(32), wblk, 0, st, NBR_ARGS(false));
-    else hipLaunchKernelGGL((k_nbr<false, 64>), grid_for(64), wblk, 0, st, NBR_ARGS(false));
+    hipLaunchKernelGGL((k_nbr<false, 16>), grid_for(16), wblk, 0, st, NBR_ARGS(false));
     const int n_tiles = n > 0 ? (n + 4095) / 4096 : 1;   // (an empty batch still writes its counters)
     if (n_tiles > 1)
         hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(1024), 0, st, n, h->d_deg.as<int>(), h->d_tile_sums.as<int>());
     hipLaunchKernelGGL(k_scan_rows, dim3(n_tiles), dim3(1024), 0, st, n, h->d_deg.as<int>(),
                        h->d_row_start.as<int>(), h->d_counters.as<int>(), (long long)h->slot_cap,
                        n_tiles > 1 ? h->d_tile_sums.as<int>() : (const int *)nullptr);
-    if (lpc_nbr == 16) hipLaunchKernelGGL((k_nbr<true, 16>), grid_for(16), wblk, 0, st, NBR_ARGS(true));
-    else if (lpc_nbr == 32) hipLaunchKernelGGL((k_nbr<true, 32>), grid_for(32), wblk, 0, st, NBR_ARGS(true));
-    else hipLaunchKernelGGL((k_nbr<true, 64>), grid_for(64), wblk, 0, st, NBR_ARGS(true));
+    hipLaunchKernelGGL((k_nbr<true, 16>), grid_for(16), wblk, 0, st, NBR_ARGS(true));
 #undef NBR_ARGS
     const ActiveView rev_av{h->active_mask, h->d_atom_cfg.as<int>()};
 #define REV_ARGS n, h->d_row_start.as<int>(), h->d_edge.as<float4>(), h->d_edge_S.as<int>(), h->d_rev.as<int>(), h->d_counters.as<int>(), rev_av
     if (lpc_rev == 16) hipLaunchKernelGGL(k_rev<16>, grid_for(16), wblk, 0, st, REV_ARGS);
-    else if (lpc_rev == 32) hipLaunchKernelGGL(k_rev<32>, grid_for(32), wblk, 0, st, REV_ARGS);
-    else hipLaunchKernelGGL(k_rev<64>, grid_for(64), wblk, 0, st, REV_ARGS);
+    else hipLaunchKernelGGL(k_rev<32>, grid_for(32), wblk, 0, st, REV_ARGS);
 #undef REV_ARGS
     if (h->kind == 1) {   // PaiNN: per-slot geometry tables shared by all layers / models / slices
         // layer-0 factorisation with at most 4 species: its T blocks are accumulated by k_edge_geom (h->l0T_by_geom); with more species

@@ -234,7 +234,7 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NRT][NCT]) {
 
 // ---- message MLP forward: phi = W2 swish(W1 s + b1) + b2 ---------------------------------------------------
 // RT = 16-row tiles per wave: 2 = the 32-atom tile of every node kernel; 4 = 64 atoms per workgroup (the weight stream per atom
-// halves; VSSR_MSG_MLP_RT=4, the row-scaling experiment of round 4, profiles/r04/NOTES_node_rows.md).  The saturation watch
+// halves: the row-scaling experiment of round 4, profiles/r04/NOTES_node_rows.md; only RT = 2 is instantiated).  The saturation watch
 // attributes rows modulo 32 (mfma16.h), exact for RT = 2 only: the RT = 4 form is an experiment, never the default.
 template <int RT, int PF>
 __global__ void __launch_bounds__(NTHREADS)
@@ -1119,9 +1119,6 @@ bool readout_mfma_supported(int hidden) { return hidden == RH; }
 
 int node_mfma_init(vssr_handle *h) {
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_mfma<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_msg_mlp_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)node_mfma_lds_bytes(1)));
     VSSR_HIP(h, hipFuncSetAttribute((const void *)k_update_fwd_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1146,17 +1143,10 @@ int node_mfma_init(vssr_handle *h) {
 
 void launch_msg_mlp_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
                          float *phi) {
-    // VSSR_MSG_MLP_RT = 4 / VSSR_MSG_MLP_PF = 1: row-scaling experiment (64-atom tiles / pipelined GEMMs); default 2 / 0
-    static const int rt = [] { const char *e = getenv("VSSR_MSG_MLP_RT"); return e ? atoi(e) : 2; }();
-    static const int pf = [] { const char *e = getenv("VSSR_MSG_MLP_PF"); return e ? atoi(e) : 0; }();
-    // VSSR_MSG_MLP_ONE_WG=1: request 96 KB of LDS so that ONE workgroup fits a CU (the occupancy of the fused update kernels)
-    static const int one_wg = [] { const char *e = getenv("VSSR_MSG_MLP_ONE_WG"); return e ? atoi(e) : 0; }();
-#define LAUNCH_MLP(RT_, PF_)                                                                                                  \
-    hipLaunchKernelGGL((k_msg_mlp_mfma<RT_, PF_>), dim3((N + 16 * RT_ - 1) / (16 * RT_), M), dim3(NTHREADS),                      \
-                       one_wg ? (size_t)96 * 1024 : (RT_ / 2) * node_mfma_lds_bytes(0), st, N, l, av, MW, s_in, phi)
-    if (rt == 4) { if (pf) LAUNCH_MLP(4, 1); else LAUNCH_MLP(4, 0); }
-    else { if (pf) LAUNCH_MLP(2, 1); else LAUNCH_MLP(2, 0); }
-#undef LAUNCH_MLP
+    // (64-atom tiles and pipelined GEMMs were measured here in round 4 -- the row-scaling experiment, profiles/r04/NOTES_node_rows.md:
+    //  -3.3 % on this kernel -- and are not built any more)
+    hipLaunchKernelGGL((k_msg_mlp_mfma<2, 0>), dim3((N + TA - 1) / TA, M), dim3(NTHREADS), node_mfma_lds_bytes(0), st, N, l, av, MW,
+                       s_in, phi);
 }
 void launch_msg_mlp_bwd_mfma(hipStream_t st, int N, int M, int l, const ActiveView &av, const ModelW *MW, const float *s_in,
                              const float *phibar, const float *sbar_msg, float *sbar_in) {

@@ -84,9 +84,8 @@ int tersoff_run(vssr_handle *h, uint32_t want) {
     dim3 blk(64), grd((N + 63) / 64);
     const ActiveView av{h->active_mask, h->d_atom_cfg.as<int>()};
     // rows of <= TS_MAXD slots: four lanes per centre from LDS; longer rows (and potentials of more than 4 species): one thread per
-    // centre.  VSSR_TERSOFF_SITE=1 forces the one-thread form for every row (A/B, tests).
-    static const bool one_thread = [] { const char *e = getenv("VSSR_TERSOFF_SITE"); return e && atoi(e) == 1; }();
-    const bool fast = !one_thread && h->n_types * h->n_types * h->n_types <= TS_MAXP;
+    // centre.
+    const bool fast = h->n_types * h->n_types * h->n_types <= TS_MAXP;
     if (fast)
         hipLaunchKernelGGL(k_tersoff_site4, dim3((N + TS_CENTRES - 1) / TS_CENTRES), dim3(TS_CENTRES * TS_LANES), 0, st, N, h->n_types,
                            h->ters_params.as<TersP>(), h->d_Z.as<int>(), h->d_atom_cfg.as<int>(), h->d_cell.as<double>(),

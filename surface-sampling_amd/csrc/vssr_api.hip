@@ -315,13 +315,10 @@ int vssr_create(const vssr_painn_config *cfg, vssr_handle **out) {
     if (const char *e = getenv("VSSR_L0_FACTORISE")) h->l0_enabled = atoi(e);
     if (const char *e = getenv("VSSR_UPD_SAVE")) h->upd_save = atoi(e);
     if (const char *e = getenv("VSSR_DEBUG_KEEP")) h->debug_keep = atoi(e);
-    if (const char *e = getenv("VSSR_GBAR_MODE")) h->gbar_mode = atoi(e);
     // test knobs: send chains above these atom counts to the next class (8-feature slices / gather kernels) although they fit
     if (const char *e = getenv("VSSR_EDGE_FS16_MAX")) h->fs16_max_atoms = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_FS8_MAX")) h->fs8_max_atoms = atoi(e);
-    if (const char *e = getenv("VSSR_EDGE_FS4_MAX")) h->fs4_max_atoms = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_BWD_MPASS")) h->bwd_multi_pass = atoi(e);
-    if (const char *e = getenv("VSSR_EDGE_FWD_MPASS_FS8")) h->fwd_mpass_fs8 = atoi(e);
     if (const char *e = getenv("VSSR_EDGE_SUB_CHUNK")) { const int c = atoi(e); if (c >= 8) { h->sub_chunk_fwd = c; h->sub_chunk_bwd = c; } }
     if (const char *e = getenv("VSSR_EDGE_FWD_2PASS")) { const int w = atoi(e); h->fwd_two_pass = (w == 8 || w == 16) ? w : w ? 16 : 0; }
     if (!rc && cfg->offset_per_z) {
