@@ -267,7 +267,7 @@ def cpu_baseline(blobs, chains, table, const, budget_s=12.0):
         modes.append(alt)
         # the same port the way a CPU runs this model at its best: `cores` chains as ONE graph, so that every dense layer is one
         # GEMM over all their atoms on the host BLAS (the chain-parallel form of the torch path)
-        nb = min(cores, len(chains))
+        nb = min(8, cores, len(chains))   # (32 chains as one graph thrash the caches: 1.4 evaluations/s on the 32-core host of round 6)
         pack = lambda lo: [(s.numbers, s.positions, s.cell, s.pbc) for s in chains[lo:lo + nb]]
         te.evaluate_batch(pack(0), table, const)
         n_b, t0 = 0, time.perf_counter()

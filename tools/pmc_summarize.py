@@ -56,7 +56,8 @@ def main():
     cols = ("cycles_per_launch", "matrix_pipe_busy_pct_of_simd_cycles", "valu_active_pct_of_simd_cycles", "wait_inst_any_pct_of_wave_cycles",
             "wait_any_pct_of_wave_cycles", "ta_busy_pct", "l1_accesses_per_cu_cycle", "hbm_traffic_bytes_per_launch")
     print(f"{'kernel':40s} {'n':>3s} " + " ".join(f"{c[:14]:>14s}" for c in cols))
-    for k, e in sorted(out.items(), key=lambda kv: -kv[1].get("cycles_per_launch", 0) * kv[1]["launches_seen"]):
+    rows = [(k, e) for k, e in out.items() if not k.startswith("_")]
+    for k, e in sorted(rows, key=lambda kv: -kv[1].get("cycles_per_launch", 0) * kv[1]["launches_seen"]):
         print(f"{k[:40]:40s} {e['launches_seen']:3d} " + " ".join(f"{e.get(c, float('nan')):14.4g}" for c in cols))
 
 
