@@ -13,7 +13,7 @@ import os, re, subprocess, sys, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "surface-sampling_amd", "csrc")
-LOAD = re.compile(r"^\s*(ds_read|ds_load|global_load|buffer_load|scratch_load|flat_load)")
+LOAD = re.compile(r"^\s*(ds_read|ds_load|ds_bpermute|ds_permute|ds_swizzle|global_load|buffer_load|scratch_load|flat_load)")
 DENSE_GAP = 6
 DEFAULT_FILES = ("painn_edge_mfma.hip", "painn_node_mfma.hip", "painn_l0.hip")
 
