@@ -247,7 +247,7 @@ struct vssr_handle {
     vssr::DevBuf d_chain_class, d_class_list;
     int n_class[5] = {0, 0, 0, 0, 0}, max_class_atoms[5] = {0, 0, 0, 0, 0};   // forward classes (EDGE_CLASS_*)
     int n_bclass[5] = {0, 0, 0, 0, 0}, max_bclass_atoms[5] = {0, 0, 0, 0, 0};   // reverse classes (EDGE_BCLASS_*); lists follow the forward lists
-    int fs16_max_atoms = -1, fs8_max_atoms = -1, fs4_max_atoms = -1;   // test knobs (VSSR_EDGE_FS16_MAX / _FS8_MAX / _FS4_MAX): lower the class limits
+    int fs16_max_atoms = -1, fs8_max_atoms = -1, fs4_max_atoms = -1;   // test knobs (VSSR_EDGE_FS16_MAX / _FS8_MAX): lower the class limits (fs4: no knob, always the LDS limit)
     int max_images = 0;          // largest number of periodic images any configuration of the batch scans per pair
 
     // configuration
@@ -281,8 +281,8 @@ struct vssr_handle {
     vssr::DevBuf d_bundle_sub;   // [2][n_atoms] per-pass bundle tables of the two-pass forward neighbor sum (chains of the 4-feature class)
     int bwd_multi_pass = 1;      // VSSR_EDGE_BWD_MPASS=0: chains of > 557 atoms take the 8- / 4-feature reverse kernels (round 4) instead of the
                                  // 16-feature kernel in several passes; 2: every chain of the matrix-pipe classes takes the multi-pass form (tests)
-    int fwd_mpass_fs8 = 1;       // VSSR_EDGE_FWD_MPASS_FS8=0: chains of 406 .. 787 atoms take the single-pass 8-feature forward kernel (round 4) instead of
-                                 // the 16-feature multi-pass form (-9 % on that kernel, profiles/r05/NOTES_large_chains.md)
+    int fwd_mpass_fs8 = 1;       // chains of 406 .. 787 atoms take the 16-feature multi-pass forward form (-9 % against the single-pass
+                                 // 8-feature kernel of round 4, profiles/r05/NOTES_large_chains.md; 0 = that kernel, no knob any more)
     int sub_chunk_fwd = 0, sub_chunk_bwd = 0;   // VSSR_EDGE_SUB_CHUNK=n (tests): atoms per neighbor sub-range instead of what LDS holds
     vssr::DevBuf d_bundle_subb;  // per-pass bundle tables of the reverse multi-pass form (its ranges are larger than the forward's)
     int fwd_two_pass = 16;       // VSSR_EDGE_FWD_2PASS = 0 | 8 | 16: chains of 788 .. 1 462 atoms take the 4-feature forward kernel, or the 8- / 16-feature
@@ -322,7 +322,8 @@ struct vssr_handle {
     vssr::StateView sv;
     vssr::DevBuf d_gbar;
     vssr::DevBuf d_upd_save;     // forward intermediates of every update block for the reverse pass (update_save_bytes per layer)
-    // Partial edge gradients of the reverse neighbor pass (VSSR_GBAR_MODE):
+    // Partial edge gradients of the reverse neighbor pass (fixed to mode 2 since round 6; modes 0 / 1 are what rounds 2 / 3 measured,
+    // profiles/r03/NOTES_edge_traffic.md, and still serve the gather kernels' float4 records):
     //   0  one set of float4 buffers per model, the second reverse layer adds to it (read-modify-write), group 0 is reduced in place
     //   1  one set per reverse layer (no read-modify-write: TA relief in the second launch), float4 records
     //   2  one set per reverse layer, 12-byte records in a separate buffer, reduced into the final float4 buffer  (default)
