@@ -444,3 +444,31 @@ def test_packed_path_helpers_of_the_calculators(golden):
     with pytest.raises(ValueError, match="Z=38"):
         t._types_of([31, 38])
     assert t._engine is None
+
+
+def test_bench_quotes_counter_profiles_only_for_the_kernels_they_measured(tmp_path, monkeypatch):
+    """`roofline.from_committed_profile`: PMC-derived figures are not measurable inside a bench run; the committed summary is quoted
+    only while the digest of the kernel sources equals the one recorded with the profile."""
+    import json
+
+    import bench
+
+    prof = tmp_path / "pmc_summary.json"
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "PMC_SUMMARY", ("pmc_summary.json",))
+    monkeypatch.setattr(bench, "csrc_digest", lambda: "abc")
+    assert bench.committed_profile()["stale"]                                   # no profile at all
+    data = {"_meta": {"csrc_sha256": "abc", "collected_by": "x"},
+            "vssr::k_edge_bwd_mfma<4, true, 4, false>": {"cycles_per_launch": 10.0, "ta_busy_pct": 80.0, "hbm_traffic_bytes_per_launch": 5.0},
+            "vssr::k_edge_bwd_mfma<4, false, 4, false>": {"cycles_per_launch": 3.0, "ta_busy_pct": 70.0}}
+    prof.write_text(json.dumps(data))
+    got = bench.committed_profile()
+    assert not got["stale"] and got["kernels"]["k_edge_bwd_mfma"]["instantiation"].endswith("<4, true, 4, false>")
+    assert got["kernels"]["k_edge_bwd_mfma"]["hbm_traffic_bytes_per_launch"] == 5.0 and "k_edge_fwd_mfma" not in got["kernels"]
+    monkeypatch.setattr(bench, "csrc_digest", lambda: "other")                  # a kernel source changed after the profile
+    stale = bench.committed_profile()
+    assert stale["stale"] and "kernels" not in stale and stale["profile_csrc_sha256"] == "abc"
+    # the real digest covers the kernel sources and moves with them
+    monkeypatch.undo()
+    d = bench.csrc_digest()
+    assert len(d) == 64 and d == bench.csrc_digest()
