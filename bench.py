@@ -102,8 +102,6 @@ def rank_diagnostics(sharded, dist, elapsed_local, steps, want, collective_devic
     collective, or host jitter."""
     import torch
 
-    from surface_sampling_amd import backend
-
     def sync():
         sharded.engine.synchronize()
         if torch.cuda.is_available() and str(collective_device) != "cpu":
@@ -118,7 +116,7 @@ def rank_diagnostics(sharded, dist, elapsed_local, steps, want, collective_devic
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(k):
-        g = sharded._gather_local(sharded._local_scalars(backend.WANT_ENERGY | backend.WANT_STD))
+        g = sharded.gather_only()
         if hasattr(g, "is_cuda") and g.is_cuda:
             torch.cuda.synchronize(g.device)
     gather_ms = 1e3 * (time.perf_counter() - t0) / k

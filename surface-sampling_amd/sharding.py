@@ -339,6 +339,14 @@ class ShardedEnsemble:
         self._steps_since_check += 1
         return self.gathered
 
+    def gather_only(self):
+        """The exchange step alone, on the results of the last evaluation: this rank's per-chain (E, sigma_E[, overflow flag]) ->
+        every rank.  What ``step()`` does after ``engine.run``; ``bench.rank_diagnostics`` times it separately."""
+        from . import backend
+
+        self.gathered = self._gather_local(self._local_scalars(backend.WANT_ENERGY | backend.WANT_STD))
+        return self.gathered
+
     def check(self) -> bool:
         """Device result path: did any rank's LAST gathered evaluation overflow its neighbor capacity?  If so every rank
         repairs (``engine.synchronize()`` reruns with grown buffers) and gathers again; returns True when that happened.
