@@ -762,6 +762,10 @@ int painn_run(vssr_handle *h, uint32_t want) {
                                    sbar_msg_l, sv.vbar_msg, sv.phibar, sv.vbar, sv.gbar,
                                    (long long)h->slot_cap * fin_groups, -1, (int)compact);
             else {
+                // (a launch that writes a partial-gradient set for the first time writes compact records: k_edge_bwd_mfma<.., FIRST = true>
+                //  has their stride compiled in)
+                if ((l == L - 1 || layer_sets > 1) && !compact && h->n_cfg > n_gather)
+                    return set_err(h, VSSR_E_STATE, "matrix-pipe reverse kernels need the compact partial-gradient records");
                 for (int cls = 0; cls < EDGE_MFMA_BCLASSES; ++cls)
                     launch_edge_bwd_mfma(st, cls, N, bcls_list[cls], h->n_bclass[cls], M, l, (int)(l == L - 1 || layer_sets > 1),
                                          h->max_bclass_atoms[cls], MW, G, counters, (int)(h->slot_cap - 1), sv.v_in[l], sv.phi[l],

@@ -277,6 +277,25 @@ size_t edge_fwd_lds_bytes_t(int max_atoms) {
     return sizeof(float) * ((size_t)max_atoms * (EdgeGeo<NF>::ROW + (SLDS ? EdgeGeo<NF>::FS : 0)) + 4);
 }
 
+// Gather rows of the LDS tiles: the row offset is formed with the 24-bit multiply-add (full rate) on a 32-bit LDS address.  Written
+// on a generic `float *` the same arithmetic is 64-bit -- v_mad_u64_u32, a quarter-rate instruction, once per step and lane.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+__device__ __forceinline__ lds_cfloat *lds_base(const float *p) { return (lds_cfloat *)p; }
+__device__ __forceinline__ lds_cfloat *lds_row(lds_cfloat *base, int row, int row_floats) {
+    return base + __umul24((unsigned)row, (unsigned)row_floats);
+}
+__device__ __forceinline__ f32x4 lds_read4(lds_cfloat *p) { return *reinterpret_cast<__attribute__((address_space(3))) const f32x4 *>(p); }
+__device__ __forceinline__ f32x2v lds_read2(lds_cfloat *p) { return *reinterpret_cast<__attribute__((address_space(3))) const f32x2v *>(p); }
+#else   // (host pass of the single-source compile: address spaces do not exist there)
+typedef const float lds_cfloat;
+__host__ __device__ inline lds_cfloat *lds_base(const float *p) { return p; }
+__host__ __device__ inline lds_cfloat *lds_row(lds_cfloat *base, int row, int row_floats) { return base + row * row_floats; }
+__host__ __device__ inline f32x4 lds_read4(lds_cfloat *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__host__ __device__ inline f32x2v lds_read2(lds_cfloat *p) { return *reinterpret_cast<const f32x2v *>(p); }
+#endif
+
 // sum over the 4 lanes of a quad (lanes 4q..4q+3), result in every lane: two DPP quad_perm adds
 __device__ __forceinline__ float quad_sum(float x) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
@@ -549,7 +568,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
 #ifdef ABL_TABLE_L2   // ablation: every table read hits a 256 KB window (results wrong)
         const u32x4 *rp = rho_lane + (size_t)(valid ? ((quad_first_slot >> 2) & 511) : zero_quad) * 32;
 #else
-        const u32x4 *rp = rho_lane + (size_t)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;
+        const u32x4 *rp = rho_lane + (size_t)(unsigned)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;   // (unsigned: no sign extension, one shift-add)
 #endif
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
     };
@@ -590,7 +609,7 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
         for (int r = 0; r < NF; ++r) { ds[r] = 0.f; dvx[r] = 0.f; dvy[r] = 0.f; dvz[r] = 0.f; }
     };
 
-    const float *trow = tile + (NF * fq) * LY::NSEG;
+    lds_cfloat *trow = lds_base(tile) + (NF * fq) * LY::NSEG;
     EPH_INIT
     EPH(0)   // (the prologue is not timed: the clock starts here)
     while (bw.j < bw.nj) {
@@ -625,18 +644,18 @@ k_edge_fwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G, const 
             float tv[NF * LY::NSEG];
             {
                 if constexpr ((NF * LY::NSEG) % 4 == 0) {
-                    const float4 *row = reinterpret_cast<const float4 *>(trow + jn * LY::ROW);
+                    lds_cfloat *row = lds_row(trow, jn, LY::ROW);
 #pragma unroll
                     for (int q = 0; q < NF * LY::NSEG / 4; ++q) {
-                        const float4 t4 = row[q];
-                        tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
+                        const f32x4 t4 = lds_read4(row + 4 * q);
+                        tv[4 * q] = t4[0]; tv[4 * q + 1] = t4[1]; tv[4 * q + 2] = t4[2]; tv[4 * q + 3] = t4[3];
                     }
                 } else {   // 4-feature slices: the lane's six values start 24 fq bytes into the row (8-byte aligned)
-                    const float2 *row = reinterpret_cast<const float2 *>(trow + jn * LY::ROW);
+                    lds_cfloat *row = lds_row(trow, jn, LY::ROW);
 #pragma unroll
                     for (int q = 0; q < NF * LY::NSEG / 2; ++q) {
-                        const float2 t2 = row[q];
-                        tv[2 * q] = t2.x; tv[2 * q + 1] = t2.y;
+                        const f32x2v t2 = lds_read2(row + 2 * q);
+                        tv[2 * q] = t2[0]; tv[2 * q + 1] = t2[1];
                     }
                 }
             }
@@ -760,7 +779,10 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     const LayerW &W = MW[m].layer[l];
     // partial edge-gradient buffer of this (model, layer set, slice): rec floats per slot -- 4 (float4 records, group 0 doubles
     // as the final buffer) or 3 (compact per-layer buffers, reduced into the separate final buffer by k_reduce_gpart)
-    float *gb = gbar + (size_t)(m * n_groups + group_off + fs) * gbar_stride * rec;
+    // records of a FIRST launch are the compact 12-byte ones (painn.hip launches FIRST only onto them): a constant stride lets the
+    // per-step store address be a shift-add instead of a quarter-rate 64-bit multiply-add
+    const int rec_c = FIRST ? 3 : rec;
+    float *gb = gbar + (size_t)(m * n_groups + group_off + fs) * gbar_stride * rec_c;
     const u32x4 *rho_lane = reinterpret_cast<const u32x4 *>(G.rho16) + fq * 4 + e;   // quad-interleaved tables, see forward
     const u32x4 *drho_lane = reinterpret_cast<const u32x4 *>(G.drho16) + fq * 4 + e;
     const int zero_quad = (zero_slot + 1) / 4 - 1;
@@ -930,14 +952,14 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
     // buffer ph is consumed by the step of parity ph and refilled right after that step's MFMAs for the step after next
     // (~1.6 steps for a load to arrive).  The old partial edge gradient of the slot (written by the previous layer for
     // this lane's slot; a slot is visited once per launch, so the early read is safe) travels with the tables.
-    float *gcomp = gb + min(gcomp_id, rec - 1);   // component this row ends up with (id 3: none -- that row only ever writes the spare entry)
+    float *gcomp = gb + min(gcomp_id, rec_c - 1);   // component this row ends up with (id 3: none -- that row only ever writes the spare entry)
     u32x4 rq[2][2], dq[2][2];
     float gold[2] = {0.f, 0.f};
     auto fetch = [&](int buf, int quad_first_slot, bool valid) {
 #ifdef ABL_TABLE_L2
         const size_t off = (size_t)(valid ? ((quad_first_slot >> 2) & 511) : zero_quad) * 32;
 #else
-        const size_t off = (size_t)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;
+        const size_t off = (size_t)(unsigned)(valid ? (quad_first_slot >> 2) : zero_quad) * 32;   // (unsigned: no sign extension, one shift-add)
 #endif
         const u32x4 *rp = rho_lane + off, *dp = drho_lane + off;
         rq[buf][0] = rp[0]; rq[buf][1] = rp[16];
@@ -947,9 +969,9 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         dq[buf][0] = dp[0]; dq[buf][1] = dp[16];
 #endif
 #ifdef ABL_NO_GBAR   // ablation build (tools/build_variant.sh): same instruction stream, the partial edge-gradient buffers stay in L2
-        if (!FIRST) gold[buf] = gcomp[(size_t)min((quad_first_slot + e) & 1023, last_slot) * rec];
+        if (!FIRST) gold[buf] = gcomp[(size_t)min((quad_first_slot + e) & 1023, last_slot) * rec_c];
 #else
-        if (!FIRST) gold[buf] = gcomp[(size_t)min(quad_first_slot + e, last_slot) * rec];
+        if (!FIRST) gold[buf] = gcomp[(size_t)min(quad_first_slot + e, last_slot) * rec_c];
 #endif
     };
     {
@@ -962,7 +984,7 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
         __builtin_amdgcn_sched_barrier(0);
         fetch(1, q1, v1);
     }
-    const float *trow = tile + (NF * fq) * 4;
+    lds_cfloat *trow = lds_base(tile) + (NF * fq) * 4;
     EPH_INIT
     EPH(0)
     while (bw.j < bw.nj) {
@@ -995,11 +1017,11 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
             const int my_slot = bw.quad_ahead(0, real_slot) + e;
             float tb[4 * NF];
             {
-                const float4 *row = reinterpret_cast<const float4 *>(trow + jn * ROWB);
+                lds_cfloat *row = lds_row(trow, jn, ROWB);
 #pragma unroll
                 for (int q = 0; q < NF; ++q) {
-                    const float4 t4 = row[q];
-                    tb[4 * q] = t4.x; tb[4 * q + 1] = t4.y; tb[4 * q + 2] = t4.z; tb[4 * q + 3] = t4.w;
+                    const f32x4 t4 = lds_read4(row + 4 * q);
+                    tb[4 * q] = t4[0]; tb[4 * q + 1] = t4[1]; tb[4 * q + 2] = t4[2]; tb[4 * q + 3] = t4[3];
                 }
             }
             // (the record's index passes through an empty asm: otherwise the compiler forwards the parked registers to these
@@ -1092,18 +1114,18 @@ k_edge_bwd_mfma(int N, int l, const ModelW *__restrict__ MW, GraphView G,
                 gown += real ? gsum : 0.f;
                 atomicAdd(&facc[real ? 3 * jn + gcomp_id : 3 * Nc], (unsigned long long)__float2ll_rn(-gsum * 4294967296.f));
 #elif defined(ABL_NO_GSTORE)   // ablation: the store only happens for a value the arithmetic never produces
-                if (gsum == 1.2345e33f) gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;
+                if (gsum == 1.2345e33f) gcomp[(size_t)(real ? my_slot : zero_slot) * rec_c] = gsum + gold_cur;
 #elif defined(ABL_STORE4)   // ablation: one 16-byte store every fourth step instead of a dword store per step (same bytes, results wrong)
                 if ((bw.t & 3) == 3) {
-                    float *dst = gcomp + (size_t)(real ? my_slot : zero_slot) * rec;
+                    float *dst = gcomp + (size_t)(real ? my_slot : zero_slot) * rec_c;
                     asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"((f32x4){gsum, gsum, gsum, gsum}) : "memory");
                 }
 #elif defined(ABL_ROW3_NO_GSTORE)   // ablation: the row without a component does not store
-                if (gcomp_id < 3) gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;
+                if (gcomp_id < 3) gcomp[(size_t)(real ? my_slot : zero_slot) * rec_c] = gsum + gold_cur;
 #elif defined(ABL_NO_GBAR)
-                gcomp[(size_t)(real ? (my_slot & 1023) : zero_slot) * rec] = gsum + gold_cur;
+                gcomp[(size_t)(real ? (my_slot & 1023) : zero_slot) * rec_c] = gsum + gold_cur;
 #else
-                gcomp[(size_t)(real ? my_slot : zero_slot) * rec] = gsum + gold_cur;
+                gcomp[(unsigned)(real ? my_slot : zero_slot) * (unsigned)rec_c] = gsum + gold_cur;   // (32-bit index: shift-add for the constant stride)
 #endif
             }
             ++bw.t;
