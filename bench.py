@@ -333,7 +333,8 @@ def main():
     dist_backend = os.environ.get("VSSR_DIST_BACKEND", "nccl")
     device_ordinal = int(os.environ.get("VSSR_LOCAL_DEVICE", local_rank))
     result_path = os.environ.get("VSSR_RESULT_PATH", "auto")
-    init_timeout_s = float(os.environ.get("VSSR_DIST_TIMEOUT_S", "1500")   # (RCCL device code paged in slowly on one box of the pool: 12 min until the first communicator))
+    # (RCCL's device code paged in slowly on one box of the pool: 12 min until the first communicator)
+    init_timeout_s = float(os.environ.get("VSSR_DIST_TIMEOUT_S", "1500"))
 
     # the host driver of this pool only supports dmabuf IPC (already exported by the image; kept here so that a bare environment
     # cannot make RCCL's P2P set-up fail with `hipIpcGetMemHandle: invalid argument`) -- before anything initialises HIP
