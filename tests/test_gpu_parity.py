@@ -298,6 +298,33 @@ def test_tersoff_gpu_vs_oracle(golden, oracle_mod):
     eng.close()
 
 
+def test_tersoff_silicon_literature_values_on_the_device(oracle_mod):
+    """Tersoff's published Si(C) set (n = 0.78734, beta = 1.1e-6: the b_ij branch GaN.tersoff never takes) on the device: the
+    diamond lattice at the published a0 = 5.432 A gives the published cohesive energy of 4.63 eV per atom, the lattice-constant scan
+    has its minimum there, and a rattled 64-atom supercell agrees with the fp64 oracle (tests/test_oracle_kat.py pins the oracle on
+    the same values)."""
+    from conftest import SI_T3, SI_T3_A0, SI_T3_ECOH, diamond_cell
+    from surface_sampling_amd import backend
+
+    eng = backend.TersoffEngine(SI_T3, device=0)
+    scan_a = (5.430, 5.431, 5.432, 5.433, 5.434)
+    batch = [diamond_cell(a) + ([1, 1, 1],) for a in scan_a]
+    rng = np.random.default_rng(8)
+    t, x, c = diamond_cell(SI_T3_A0)
+    X = np.concatenate([x + np.array([i, j, k]) * SI_T3_A0 for i in range(2) for j in range(2) for k in range(2)])
+    X = X + rng.normal(0, 0.08, X.shape)
+    batch.append((np.zeros(len(X), np.int32), X, c * 2, [1, 1, 1]))
+    e, ea, F = eng.evaluate_f64(batch)
+    per_atom = e[:5] / 8
+    assert abs(per_atom[2] - SI_T3_ECOH) <= 5e-4, per_atom
+    assert int(np.argmin(per_atom)) == 2, per_atom
+    assert np.abs(F[:40]).max() < 1e-9
+    E0, ea0, F0 = oracle_mod.tersoff(SI_T3, *batch[5])
+    assert abs(e[5] - E0) <= 1e-9 * abs(E0)
+    assert np.abs(ea[40:] - ea0).max() <= 1e-9 and np.abs(F[40:] - F0).max() <= 1e-8
+    eng.close()
+
+
 from conftest import synthetic_tersoff as _synthetic_tersoff  # noqa: E402
 
 

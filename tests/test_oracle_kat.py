@@ -111,6 +111,41 @@ def test_tersoff_oracle_branches_beyond_gan_are_self_consistent(oracle_mod):
             assert abs(fd - F[i, x]) <= 2e-6 * max(1.0, abs(F[i, x])), (nt, i, x, fd, F[i, x])
 
 
+def test_tersoff_silicon_literature_values(oracle_mod):
+    """A known answer for the b_ij branch GaN.tersoff never takes (n != 1, beta << 1), from the literature instead of the reference
+    (which holds none): Tersoff's Si(C) parameters (PRB 38, 9902 (1988); LAMMPS' Si.tersoff) were fitted to diamond-cubic silicon
+    with a0 = 5.432 A and a cohesive energy of 4.63 eV per atom.  The restated formulas give -4.6296 eV per atom, the energy
+    minimum of the lattice-constant scan sits at 5.432 A to the third decimal, and no force acts on the perfect lattice.  (By hand:
+    4 neighbors at 2.3521 A, zeta = 3 g(-1/3) = 3.067e4, b = 0.95831, E = 2 (1830.8 e^{-5.8330} - 0.95831 x 471.18 e^{-4.0743}).)"""
+    from conftest import SI_T3, SI_T3_A0, SI_T3_ECOH, diamond_cell
+
+    def e_atom(a):
+        t, x, c = diamond_cell(a)
+        E, ea, F = oracle_mod.tersoff(SI_T3, t, x, c, [1, 1, 1])
+        assert np.abs(F).max() < 1e-10 and np.abs(ea - E / 8).max() < 1e-12
+        return E / 8
+
+    e0 = e_atom(SI_T3_A0)
+    assert abs(e0 - SI_T3_ECOH) <= 5e-4, e0                      # -4.629595: the published 4.63 eV
+    assert abs(e0 - (-4.629595012655)) <= 1e-9                    # (regression value of this restatement)
+    scan = {a: e_atom(a) for a in (5.430, 5.431, 5.432, 5.433, 5.434)}
+    assert min(scan, key=scan.get) == SI_T3_A0, scan              # the published lattice constant is the minimum
+    # a rattled 64-atom supercell: forces = -dE/dx on this parameter set too
+    rng = np.random.default_rng(8)
+    t, x, c = diamond_cell(SI_T3_A0)
+    X = np.concatenate([x + np.array([i, j, k]) * SI_T3_A0 for i in range(2) for j in range(2) for k in range(2)])
+    X = X + rng.normal(0, 0.08, X.shape)
+    T, C = np.zeros(len(X), np.int32), c * 2
+    E, ea, F = oracle_mod.tersoff(SI_T3, T, X, C, [1, 1, 1])
+    h = 1e-5
+    for i, ax in [(0, 0), (21, 1), (63, 2)]:
+        p = X.copy(); p[i, ax] += h
+        Ep, _, _ = oracle_mod.tersoff(SI_T3, T, p, C, [1, 1, 1], False)
+        p[i, ax] -= 2 * h
+        Em, _, _ = oracle_mod.tersoff(SI_T3, T, p, C, [1, 1, 1], False)
+        assert abs(-(Ep - Em) / (2 * h) - F[i, ax]) <= 1e-6, (i, ax)
+
+
 def test_neighbor_multigraph_properties(golden, oracle_mod):
     """in the 60-atom slab (cell < 2*cutoff) pairs repeat through several images."""
     s = golden.structure("SrTiO3_2x2_pristine")
